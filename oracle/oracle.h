@@ -1,0 +1,105 @@
+/*
+ * oracle.h -- CPU restatement ("oracle") of the per-frame front-end of
+ * whwh747/A-Low-Texture-Robust-Hybrid-Feature-Based-Visual-Odometry.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The shipped path is the HIP library in
+ * a-low-texture-robust-hybrid-feature-based-visual-odometry_amd/csrc (libhvo.so).
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path
+ *  and cannot be compiled here (needs OpenCV 3.2 + contrib, Eigen,
+ * PCL).  Every routine cites the reference file:line it follows; arithmetic that lives in
+ * un-vendored OpenCV 3.2.0 / Eigen is restated from their published algorithms and marked
+ * "ASSUMED".  The pins we do have are the known-answer constants derivable from the
+ * reference text (tests/test_oracle_known_answers.py).
+ *
+ * Plain C11, no dependencies.  Build: make -C oracle  (gcc -O3 -march=native -ffp-contract=off)
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* == cv::KeyPoint, 28 bytes */
+typedef struct { float x, y, size, angle, response; int32_t octave, class_id; } orc_keypoint;
+
+/* == cv::line_descriptor::KeyLine, 68 bytes
+ * (Thirdparty/line_descriptor/include/line_descriptor/descriptor_custom.hpp:105-144) */
+typedef struct {
+    float angle; int32_t class_id, octave; float pt_x, pt_y, response, size;
+    float sx, sy, ex, ey, sox, soy, eox, eoy, length; int32_t num_pixels;
+} orc_keyline;
+
+typedef struct { double normal[3], center[3], mse; int32_t n_points, rid; } orc_plane;
+
+/* ---------------- assumed OpenCV 3.2.0 primitives (cvsem.c) ---------------- */
+int   orc_cvround_f(float v);
+int   orc_cvround_d(double v);
+float orc_fast_atan2(float y, float x);
+/* cv::resize(u8, INTER_LINEAR) */
+void  orc_resize_linear_u8_factor(const uint8_t *src, int sw, int sh, int sstride,
+                                  uint8_t *dst, int dw, int dh, int dstride, double fx, double fy);
+void  orc_resize_linear_u8(const uint8_t *src, int sw, int sh, int sstride,
+                           uint8_t *dst, int dw, int dh, int dstride);
+/* fixed-point (x256) 1-D Gaussian kernel as cv::GaussianBlur builds it for CV_8U; returns sum */
+int   orc_gaussian_kernel_q8(int ksize, double sigma, int *k);
+/* cv::GaussianBlur(u8, ksize x ksize, sigma, BORDER_REFLECT_101) */
+void  orc_gaussian_blur_u8(const uint8_t *src, int w, int h, int sstride,
+                           uint8_t *dst, int dstride, int ksize, double sigma);
+/* cv::Sobel(u8 -> CV_16S, dx,dy, ksize 3, BORDER_REFLECT_101) */
+void  orc_sobel3_u8_s16(const uint8_t *src, int w, int h, int sstride,
+                        int16_t *dst, int dstride_elems, int dx, int dy);
+/* cv::FAST(view, kps, threshold, nonmax=true), TYPE_9_16. Writes (x,y,score) int triples in
+ * raster order; returns count (never more than cap). */
+int   orc_fast9_16(const uint8_t *img, int stride, int vw, int vh, int threshold,
+                   int *xys, int cap);
+/* FAST corner score of a single pixel (cornerScore<16>), independent of the threshold that
+ * admitted it: max over the 16 arcs of 9 of max(min(d), -max(d)) - 1. */
+int   orc_fast_score(const uint8_t *p, int stride);
+/* cv::LineIterator(img, p1, p2).count for float end points (8-connected) */
+int   orc_line_iterator_count(int w, int h, float x1, float y1, float x2, float y2);
+
+/* ---------------- ORB (orb.c): src/ORBextractor.cc ---------------- */
+typedef struct {
+    int   nfeatures;      /* ORBextractor.nFeatures  (TUM3.yaml:41) */
+    float scale_factor;   /* ORBextractor.scaleFactor */
+    int   nlevels;        /* ORBextractor.nLevels     */
+    int   ini_th_fast;    /* ORBextractor.iniThFAST   */
+    int   min_th_fast;    /* ORBextractor.minThFAST   */
+} orc_orb_params;
+
+typedef struct orc_orb orc_orb;
+orc_orb *orc_orb_create(const orc_orb_params *p);
+void     orc_orb_destroy(orc_orb *o);
+/* ORBextractor::operator() (ORBextractor.cc:1041-1103). Returns 0, *n = #keypoints. */
+int      orc_orb_extract(orc_orb *o, const uint8_t *gray, int w, int h, int stride,
+                         orc_keypoint *kps, uint8_t *desc32, int cap, int *n);
+/* table / intermediate accessors for known-answer and per-stage parity tests */
+int         orc_orb_umax(const orc_orb *o, int *umax16);                 /* 16 ints */
+int         orc_orb_features_per_level(const orc_orb *o, int *out);     /* nlevels ints */
+float       orc_orb_scale(const orc_orb *o, int level);
+const int8_t *orc_orb_pattern(void);                                    /* 256*4 */
+int         orc_orb_level(const orc_orb *o, int level, int *w, int *h, int *stride,
+                          const uint8_t **data);       /* mvImagePyramid[level] (no apron) */
+int         orc_orb_level_blurred(const orc_orb *o, int level, const uint8_t **data, int *stride);
+int         orc_orb_grid(const orc_orb *o, int level, int *ncols, int *nrows, int *wcell, int *hcell);
+/* candidates fed to DistributeOctTree at `level`: n triples (x,y,response), cell-major order */
+int         orc_orb_candidates(const orc_orb *o, int level, const int **xys);
+int         orc_orb_level_count(const orc_orb *o, int level);            /* kps kept at level */
+
+/* ---------------- Hamming (match.c): src/ORBmatcher.cc:1676, LSDmatcher.cpp:803-863,1137 ---- */
+int  orc_descriptor_distance(const uint8_t *a, const uint8_t *b);
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, 2): idx2/dist2 are nq*2, -1/INT_MAX padded */
+void orc_hamming_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx2, int32_t *dist2);
+void orc_hamming_matrix(const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *d);
+/* LSDmatcher::matchNNR */
+int  orc_match_nnr(const uint8_t *d1, int n1, const uint8_t *d2, int n2, float nnr, int32_t *m12);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

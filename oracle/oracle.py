@@ -1,0 +1,210 @@
+"""ctypes loader for the CPU oracle (liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package.  Parity unpinned (see oracle.h).
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KEYPOINT_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                        ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+KEYLINE_DT = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"),
+                       ("pt_x", "<f4"), ("pt_y", "<f4"), ("response", "<f4"), ("size", "<f4"),
+                       ("sx", "<f4"), ("sy", "<f4"), ("ex", "<f4"), ("ey", "<f4"),
+                       ("sox", "<f4"), ("soy", "<f4"), ("eox", "<f4"), ("eoy", "<f4"),
+                       ("length", "<f4"), ("num_pixels", "<i4")])
+PLANE_DT = np.dtype([("normal", "<f8", 3), ("center", "<f8", 3), ("mse", "<f8"),
+                     ("n_points", "<i4"), ("rid", "<i4")])
+assert KEYPOINT_DT.itemsize == 28 and KEYLINE_DT.itemsize == 68 and PLANE_DT.itemsize == 64
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        L = _LIB
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_cvround_f.argtypes = [C.c_float]
+        L.orc_cvround_d.argtypes = [C.c_double]
+        L.orc_orb_create.restype = C.c_void_p
+        L.orc_orb_create.argtypes = [C.POINTER(OrbParams)]
+        L.orc_orb_destroy.argtypes = [C.c_void_p]
+        L.orc_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.orc_orb_umax.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_orb_features_per_level.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_orb_scale.restype = C.c_float
+        L.orc_orb_scale.argtypes = [C.c_void_p, C.c_int]
+        L.orc_orb_pattern.restype = C.POINTER(C.c_int8)
+        L.orc_orb_level.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                    C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+        L.orc_orb_level_blurred.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        L.orc_orb_grid.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_int)] * 4
+        L.orc_orb_candidates.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.orc_orb_level_count.argtypes = [C.c_void_p, C.c_int]
+        L.orc_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_hamming_knn2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_hamming_matrix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_match_nnr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+        L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_gaussian_kernel_q8.argtypes = [C.c_int, C.c_double, C.c_void_p]
+        L.orc_gaussian_blur_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double]
+        L.orc_sobel3_u8_s16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_fast9_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast_score.argtypes = [C.c_void_p, C.c_int]
+        L.orc_line_iterator_count.argtypes = [C.c_int, C.c_int] + [C.c_float] * 4
+        _bind_optional(L)
+    return _LIB
+
+
+def _bind_optional(L):
+    """bindings for the LSD/LBD/PEAC oracles (present once those files are built)"""
+    if hasattr(L, "orc_peac_run"):
+        L.orc_peac_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                   C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.POINTER(C.c_int)]
+    if hasattr(L, "orc_lsd_detect"):
+        L.orc_lsd_detect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                     C.POINTER(C.c_int)]
+    if hasattr(L, "orc_line_extract"):
+        L.orc_line_extract.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    if hasattr(L, "orc_lbd_compute"):
+        L.orc_lbd_compute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Orb:
+    """ORBextractor oracle (src/ORBextractor.cc)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.p = OrbParams(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        self.h = lib().orc_orb_create(C.byref(self.p))
+        self.nlevels = nlevels
+        self.cap = max(nfeatures * 2, 64)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_orb_destroy(self.h)
+            self.h = None
+
+    def extract(self, gray):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        h, w = gray.shape
+        kp = np.zeros(self.cap, dtype=KEYPOINT_DT)
+        desc = np.zeros((self.cap, 32), dtype=np.uint8)
+        n = C.c_int(0)
+        rc = lib().orc_orb_extract(self.h, _p(gray), w, h, gray.strides[0], _p(kp), _p(desc), self.cap, C.byref(n))
+        assert rc == 0
+        return kp[: n.value].copy(), desc[: n.value].copy()
+
+    def umax(self):
+        a = np.zeros(16, dtype=np.int32); lib().orc_orb_umax(self.h, _p(a)); return a
+
+    def features_per_level(self):
+        a = np.zeros(self.nlevels, dtype=np.int32); lib().orc_orb_features_per_level(self.h, _p(a)); return a
+
+    def level(self, l, blurred=False):
+        w, h, s, d = C.c_int(), C.c_int(), C.c_int(), C.c_void_p()
+        lib().orc_orb_level(self.h, l, C.byref(w), C.byref(h), C.byref(s), C.byref(d))
+        if blurred:
+            lib().orc_orb_level_blurred(self.h, l, C.byref(d), C.byref(s))
+        buf = (C.c_uint8 * (s.value * h.value)).from_address(d.value)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(h.value, s.value)[:, : w.value].copy()
+
+    def grid(self, l):
+        v = [C.c_int() for _ in range(4)]
+        lib().orc_orb_grid(self.h, l, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)
+
+    def candidates(self, l):
+        d = C.c_void_p()
+        n = lib().orc_orb_candidates(self.h, l, C.byref(d))
+        if n == 0:
+            return np.zeros((0, 3), dtype=np.int32)
+        buf = (C.c_int32 * (3 * n)).from_address(d.value)
+        return np.frombuffer(buf, dtype=np.int32).reshape(n, 3).copy()
+
+    def level_count(self, l):
+        return lib().orc_orb_level_count(self.h, l)
+
+
+def pattern():
+    return np.ctypeslib.as_array(lib().orc_orb_pattern(), shape=(1024,)).copy()
+
+
+def hamming_knn2(q, t):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    idx = np.zeros((len(q), 2), np.int32); dist = np.zeros((len(q), 2), np.int32)
+    lib().orc_hamming_knn2(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
+    return idx, dist
+
+
+def hamming_matrix(q, t):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    d = np.zeros((len(q), len(t)), np.uint16)
+    lib().orc_hamming_matrix(_p(q), len(q), _p(t), len(t), _p(d))
+    return d
+
+
+def match_nnr(d1, d2, nnr):
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    m = np.zeros(len(d1), np.int32)
+    n = lib().orc_match_nnr(_p(d1), len(d1), _p(d2), len(d2), nnr, _p(m))
+    return n, m
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8); h, w = src.shape
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), w, h, src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def gaussian_blur(src, ksize, sigma):
+    src = np.ascontiguousarray(src, np.uint8); h, w = src.shape
+    dst = np.zeros((h, w), np.uint8)
+    lib().orc_gaussian_blur_u8(_p(src), w, h, src.strides[0], _p(dst), w, ksize, sigma)
+    return dst
+
+
+def gaussian_kernel_q8(ksize, sigma):
+    k = np.zeros(ksize, np.int32)
+    lib().orc_gaussian_kernel_q8(ksize, sigma, _p(k))
+    return k
+
+
+def sobel3(src, dx, dy):
+    src = np.ascontiguousarray(src, np.uint8); h, w = src.shape
+    dst = np.zeros((h, w), np.int16)
+    lib().orc_sobel3_u8_s16(_p(src), w, h, src.strides[0], _p(dst), w, dx, dy)
+    return dst
+
+
+def fast9_16(view, threshold, cap=4096):
+    view = np.ascontiguousarray(view, np.uint8); h, w = view.shape
+    out = np.zeros((cap, 3), np.int32)
+    n = lib().orc_fast9_16(_p(view), view.strides[0], w, h, threshold, _p(out), cap)
+    return out[:n].copy()
