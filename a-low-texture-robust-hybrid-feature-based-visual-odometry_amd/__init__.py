@@ -1,0 +1,324 @@
+"""MI355X-native RGB-D front-end (ORB + LSD/LBD + PEAC planes + Hamming matching).
+
+Thin ctypes binding over libhvo.so (csrc/, C ABI in include/hvo.h) plus host-side mirrors
+of the reference's operator interfaces so parity tests read like the reference's call sites:
+
+    ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)(image)
+        -> reference include/ORBextractor.h:53-61, src/ORBextractor.cc:1041
+    LINEextractor(numOctaves, scale, nLSDFeature)(image)
+        -> reference include/LineExtractor.h:186-193, src/LineExtractor.cpp:329
+    PlaneDetection(K, depthMapFactor).run(depth_u16)
+        -> reference include/PlaneExtractor.h:36-56, src/PlaneExtractor.cpp:26-66
+    ORBmatcher.DescriptorDistance / LSDmatcher.match
+        -> reference src/ORBmatcher.cc:1676, src/LSDmatcher.cpp:828
+
+There is no CPU path: if libhvo.so is missing or no gfx950 device is present every call
+raises HvoError.  This package never imports the oracle.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_LIBPATH = os.path.join(_CSRC, "libhvo.so")
+_LIB = None
+
+HVO_OK = 0
+STAGE_ORB, STAGE_LSD, STAGE_PLANES, STAGE_ALL = 1, 2, 4, 7
+
+KEYPOINT_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                        ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+KEYLINE_DT = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"),
+                       ("pt_x", "<f4"), ("pt_y", "<f4"), ("response", "<f4"), ("size", "<f4"),
+                       ("sx", "<f4"), ("sy", "<f4"), ("ex", "<f4"), ("ey", "<f4"),
+                       ("sox", "<f4"), ("soy", "<f4"), ("eox", "<f4"), ("eoy", "<f4"),
+                       ("length", "<f4"), ("num_pixels", "<i4")])
+PLANE_DT = np.dtype([("normal", "<f8", 3), ("center", "<f8", 3), ("mse", "<f8"),
+                     ("n_points", "<i4"), ("rid", "<i4")])
+assert KEYPOINT_DT.itemsize == 28 and KEYLINE_DT.itemsize == 68 and PLANE_DT.itemsize == 64
+
+EXPORTS = [
+    "hvo_abi_version", "hvo_default_params", "hvo_create", "hvo_destroy", "hvo_strerror", "hvo_last_error",
+    "hvo_extract_orb", "hvo_extract_lsd", "hvo_compute_planes",
+    "hvo_hamming_matrix", "hvo_hamming_knn2", "hvo_match_nnr",
+    "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch",
+    "hvo_profile_last", "hvo_profile_enable",
+]
+
+
+class HvoError(RuntimeError):
+    def __init__(self, status, what=""):
+        self.status = status
+        msg = _LIB.hvo_strerror(status).decode() if _LIB is not None else "libhvo.so unavailable"
+        super().__init__("hvo status %d (%s) %s" % (status, msg, what))
+
+
+class Params(C.Structure):
+    _fields_ = [("orb_nfeatures", C.c_int32), ("orb_scale_factor", C.c_float), ("orb_nlevels", C.c_int32),
+                ("orb_ini_th_fast", C.c_int32), ("orb_min_th_fast", C.c_int32),
+                ("lsd_num_octaves", C.c_int32), ("lsd_scale", C.c_float), ("lsd_nfeatures", C.c_int32),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("depth_map_factor", C.c_float), ("device", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class FrameIn(C.Structure):
+    _fields_ = [("gray", C.c_void_p), ("gray_stride", C.c_int),
+                ("depth", C.c_void_p), ("depth_stride", C.c_int)]
+
+
+class FrameOut(C.Structure):
+    _fields_ = [("kp", C.c_void_p), ("desc", C.c_void_p), ("kp_cap", C.c_int), ("n_kp", C.c_int),
+                ("kl", C.c_void_p), ("ldesc", C.c_void_p), ("linefn", C.c_void_p), ("kl_cap", C.c_int), ("n_kl", C.c_int),
+                ("labels", C.c_void_p), ("planes", C.c_void_p), ("pl_cap", C.c_int), ("n_planes", C.c_int),
+                ("status", C.c_int)]
+
+
+def build(force=False):
+    """compile libhvo.so in-tree with hipcc --offload-arch=gfx950 (cross-compiles without a GPU)"""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", _CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", _CSRC])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_LIBPATH):
+            raise HvoError(-3, "libhvo.so not built (run __graft_entry__.build())")
+        L = C.CDLL(_LIBPATH)
+        L.hvo_strerror.restype = C.c_char_p
+        L.hvo_strerror.argtypes = [C.c_int]
+        L.hvo_last_error.restype = C.c_char_p
+        L.hvo_last_error.argtypes = [C.c_void_p]
+        L.hvo_default_params.argtypes = [C.POINTER(Params)]
+        L.hvo_default_params.restype = None
+        L.hvo_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_void_p)]
+        L.hvo_destroy.argtypes = [C.c_void_p]
+        L.hvo_destroy.restype = None
+        L.hvo_extract_orb.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.POINTER(C.c_int)]
+        L.hvo_extract_lsd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.hvo_compute_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.POINTER(C.c_int)]
+        L.hvo_hamming_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.hvo_hamming_knn2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.hvo_match_nnr.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
+                                    C.POINTER(C.c_int)]
+        L.hvo_batch_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameIn), C.c_int, C.c_int]
+        L.hvo_batch_run.argtypes = [C.c_void_p, C.c_uint]
+        L.hvo_batch_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameOut)]
+        L.hvo_extract_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameIn), C.POINTER(FrameOut), C.c_int, C.c_int, C.c_uint]
+        L.hvo_profile_last.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+        L.hvo_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_params(**kw):
+    p = Params()
+    lib().hvo_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise TypeError("unknown hvo_params field " + k)
+        setattr(p, k, v)
+    return p
+
+
+class Context:
+    """One hvo_ctx: one HIP stream + device slabs.  Not thread-safe (like ORBextractor)."""
+
+    def __init__(self, params=None, **kw):
+        self.params = params if params is not None else default_params(**kw)
+        h = C.c_void_p()
+        rc = lib().hvo_create(C.byref(self.params), C.byref(h))
+        if rc != HVO_OK:
+            raise HvoError(rc, "hvo_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().hvo_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc, what):
+        if rc != HVO_OK:
+            raise HvoError(rc, what + ": " + lib().hvo_last_error(self.h).decode())
+
+    # ---- single frame ----
+    def extract_orb(self, gray):
+        if gray is None or gray.size == 0:
+            return np.zeros(0, KEYPOINT_DT), np.zeros((0, 32), np.uint8)
+        if gray.dtype != np.uint8 or gray.ndim != 2:
+            raise HvoError(-6, "ORB input must be CV_8UC1 (ORBextractor.cc:1048)")
+        gray = np.ascontiguousarray(gray)
+        h, w = gray.shape
+        cap = self.params.orb_nfeatures + 8 * self.params.orb_nlevels + 64
+        kp = np.zeros(cap, KEYPOINT_DT); desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        self._chk(lib().hvo_extract_orb(self.h, _p(gray), w, h, gray.strides[0], _p(kp), _p(desc), cap, C.byref(n)), "extract_orb")
+        return kp[: n.value].copy(), desc[: n.value].copy()
+
+    def extract_lsd(self, gray, cap=None):
+        if gray is None or gray.size == 0:
+            return np.zeros(0, KEYLINE_DT), np.zeros((0, 32), np.uint8), np.zeros((0, 3))
+        if gray.dtype != np.uint8 or gray.ndim != 2:
+            raise HvoError(-6, "LSD input must be CV_8UC1 (LineExtractor.cpp:335)")
+        gray = np.ascontiguousarray(gray)
+        h, w = gray.shape
+        cap = cap or max(self.params.lsd_nfeatures, 1)
+        kl = np.zeros(cap, KEYLINE_DT); desc = np.zeros((cap, 32), np.uint8); fn = np.zeros((cap, 3), np.float64)
+        n = C.c_int(0)
+        self._chk(lib().hvo_extract_lsd(self.h, _p(gray), w, h, gray.strides[0], _p(kl), _p(desc), _p(fn), cap, C.byref(n)), "extract_lsd")
+        return kl[: n.value].copy(), desc[: n.value].copy(), fn[: n.value].copy()
+
+    def compute_planes(self, depth, cap=64):
+        if depth.dtype != np.uint16 or depth.ndim != 2:
+            raise HvoError(-6, "depth must be CV_16UC1 (PlaneExtractor.cpp:34-38)")
+        depth = np.ascontiguousarray(depth)
+        h, w = depth.shape
+        labels = np.zeros((h, w), np.int32); planes = np.zeros(cap, PLANE_DT)
+        n = C.c_int(0)
+        self._chk(lib().hvo_compute_planes(self.h, _p(depth), w, h, depth.strides[0], _p(labels), _p(planes), cap, C.byref(n)), "compute_planes")
+        return labels, planes[: n.value].copy()
+
+    # ---- matching ----
+    def hamming_matrix(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        d = np.zeros((len(q), len(t)), np.uint16)
+        self._chk(lib().hvo_hamming_matrix(self.h, _p(q), len(q), _p(t), len(t), _p(d)), "hamming_matrix")
+        return d
+
+    def hamming_knn2(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        idx = np.zeros((len(q), 2), np.int32); dist = np.zeros((len(q), 2), np.int32)
+        self._chk(lib().hvo_hamming_knn2(self.h, _p(q), len(q), _p(t), len(t), _p(idx), _p(dist)), "hamming_knn2")
+        return idx, dist
+
+    def match_nnr(self, d1, d2, nnr):
+        d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+        m = np.full(len(d1), -1, np.int32); n = C.c_int(0)
+        self._chk(lib().hvo_match_nnr(self.h, _p(d1), len(d1), _p(d2), len(d2), nnr, _p(m), C.byref(n)), "match_nnr")
+        return n.value, m
+
+    # ---- batch ----
+    def batch_upload(self, gray, depth=None):
+        """gray: (B,H,W) u8; depth: (B,H,W) u16 or None"""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        B, h, w = gray.shape
+        if depth is not None:
+            depth = np.ascontiguousarray(depth, np.uint16)
+        fi = (FrameIn * B)()
+        for b in range(B):
+            fi[b].gray = gray[b].ctypes.data; fi[b].gray_stride = gray.strides[1]
+            if depth is not None:
+                fi[b].depth = depth[b].ctypes.data; fi[b].depth_stride = depth.strides[1]
+        self._chk(lib().hvo_batch_upload(self.h, B, fi, w, h), "batch_upload")
+        self._B, self._w, self._h = B, w, h
+
+    def batch_run(self, stages=STAGE_ALL):
+        self._chk(lib().hvo_batch_run(self.h, stages), "batch_run")
+
+    def batch_download(self, stages=STAGE_ALL, pl_cap=64):
+        B, w, h = self._B, self._w, self._h
+        kcap = self.params.orb_nfeatures + 8 * self.params.orb_nlevels + 64
+        lcap = max(self.params.lsd_nfeatures, 1)
+        fo = (FrameOut * B)()
+        res = []
+        for b in range(B):
+            r = {}
+            if stages & STAGE_ORB:
+                r["kp"] = np.zeros(kcap, KEYPOINT_DT); r["desc"] = np.zeros((kcap, 32), np.uint8)
+                fo[b].kp = r["kp"].ctypes.data; fo[b].desc = r["desc"].ctypes.data; fo[b].kp_cap = kcap
+            if stages & STAGE_LSD:
+                r["kl"] = np.zeros(lcap, KEYLINE_DT); r["ldesc"] = np.zeros((lcap, 32), np.uint8); r["linefn"] = np.zeros((lcap, 3))
+                fo[b].kl = r["kl"].ctypes.data; fo[b].ldesc = r["ldesc"].ctypes.data; fo[b].linefn = r["linefn"].ctypes.data
+                fo[b].kl_cap = lcap
+            if stages & STAGE_PLANES:
+                r["labels"] = np.zeros((h, w), np.int32); r["planes"] = np.zeros(pl_cap, PLANE_DT)
+                fo[b].labels = r["labels"].ctypes.data; fo[b].planes = r["planes"].ctypes.data; fo[b].pl_cap = pl_cap
+            res.append(r)
+        self._chk(lib().hvo_batch_download(self.h, B, fo), "batch_download")
+        for b, r in enumerate(res):
+            r["status"] = fo[b].status
+            if "kp" in r:
+                r["kp"] = r["kp"][: fo[b].n_kp]; r["desc"] = r["desc"][: fo[b].n_kp]
+            if "kl" in r:
+                r["kl"] = r["kl"][: fo[b].n_kl]; r["ldesc"] = r["ldesc"][: fo[b].n_kl]; r["linefn"] = r["linefn"][: fo[b].n_kl]
+            if "planes" in r:
+                r["planes"] = r["planes"][: fo[b].n_planes]
+        return res
+
+    def profile_enable(self, on=True):
+        self._chk(lib().hvo_profile_enable(self.h, 1 if on else 0), "profile_enable")
+
+    def profile_last(self):
+        names = (C.c_char_p * 32)(); ms = (C.c_float * 32)()
+        n = lib().hvo_profile_last(self.h, names, ms, 32)
+        return {names[i].decode(): ms[i] for i in range(n)}
+
+
+# ---------------------------------------------------------------------------------------
+# host-side mirrors of the reference's operator interfaces
+# ---------------------------------------------------------------------------------------
+class ORBextractor:
+    """ORB_SLAM2::ORBextractor (include/ORBextractor.h:53-61).  operator()(image) -> (keypoints, descriptors)."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, device=0):
+        self.ctx = Context(orb_nfeatures=nfeatures, orb_scale_factor=scaleFactor, orb_nlevels=nlevels,
+                           orb_ini_th_fast=iniThFAST, orb_min_th_fast=minThFAST, device=device)
+
+    def __call__(self, image, mask=None):
+        return self.ctx.extract_orb(image)     # mask is ignored, as in the reference (ORBextractor.h:58)
+
+
+class LINEextractor:
+    """ORB_SLAM2::LINEextractor (include/LineExtractor.h:186-193)."""
+
+    def __init__(self, numOctaves=1, scale=1.2, nLSDFeature=200, min_line_length=0, device=0):
+        self.ctx = Context(lsd_num_octaves=numOctaves, lsd_scale=scale, lsd_nfeatures=nLSDFeature, device=device)
+
+    def __call__(self, image, mask=None):
+        return self.ctx.extract_lsd(image)
+
+
+class PlaneDetection:
+    """PlaneDetection (include/PlaneExtractor.h:36-56): readDepthImage + runPlaneDetection."""
+
+    def __init__(self, K=None, depthMapFactor=1.0 / 5000.0, device=0):
+        kw = dict(depth_map_factor=depthMapFactor, device=device)
+        if K is not None:
+            kw.update(fx=K[0][0], fy=K[1][1], cx=K[0][2], cy=K[1][2])
+        self.ctx = Context(**kw)
+
+    def run(self, depth_u16):
+        return self.ctx.compute_planes(depth_u16)
+
+
+class ORBmatcher:
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30      # src/ORBmatcher.cc:37-39
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or Context()
+
+    def DescriptorDistance(self, a, b):
+        return int(self.ctx.hamming_matrix(np.asarray(a).reshape(1, 32), np.asarray(b).reshape(1, 32))[0, 0])
+
+
+class LSDmatcher:
+    TH_HIGH, TH_LOW = 80, 50                          # src/LSDmatcher.cpp:12-14
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or Context()
+
+    def match(self, desc1, desc2, nnr):
+        """LSDmatcher::match -> matchNNR (src/LSDmatcher.cpp:828-863, 803-826): (n, matches_12)"""
+        return self.ctx.match_nnr(desc1, desc2, nnr)

@@ -1,0 +1,254 @@
+// api.hip -- the extern "C" boundary of libhvo.so (include/hvo.h).  No compute here: argument
+// checks, device selection, staging, and dispatch to the per-subsystem batch runners.
+// There is deliberately no CPU path: without a usable gfx950 device every call fails.
+#include "hvo_internal.hpp"
+#include <string.h>
+#include <new>
+
+extern "C" {
+
+int hvo_abi_version(void) { return HVO_ABI_VERSION; }
+
+void hvo_default_params(hvo_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    // Examples/RGB-D/TUM3.yaml:41-54, 60-63, 8-11, 34
+    p->orb_nfeatures = 1000; p->orb_scale_factor = 1.2f; p->orb_nlevels = 8;
+    p->orb_ini_th_fast = 20; p->orb_min_th_fast = 7;
+    p->lsd_num_octaves = 1; p->lsd_scale = 1.2f; p->lsd_nfeatures = 200;
+    p->fx = 535.4f; p->fy = 539.2f; p->cx = 320.1f; p->cy = 247.6f;
+    p->depth_map_factor = 1.0f / 5000.0f;      // Tracking.cc:156-160
+    p->device = 0; p->max_batch = 1;
+}
+
+const char *hvo_strerror(int s)
+{
+    switch (s) {
+    case HVO_OK: return "ok";
+    case HVO_ERR_INVALID_ARG: return "invalid argument";
+    case HVO_ERR_NO_DEVICE: return "no usable HIP device (gfx950 required; there is no CPU fallback)";
+    case HVO_ERR_HIP: return "HIP runtime error";
+    case HVO_ERR_UNSUPPORTED: return "unsupported configuration or image geometry";
+    case HVO_ERR_CAPACITY: return "internal capacity exceeded, results truncated";
+    case HVO_ERR_BAD_DTYPE: return "wrong image type";
+    default: return "unknown status";
+    }
+}
+
+const char *hvo_last_error(const hvo_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int hvo_create(const hvo_params *p, hvo_ctx **out)
+{
+    if (!p || !out) return HVO_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HVO_ERR_NO_DEVICE;
+    if (p->device < 0 || p->device >= ndev) return HVO_ERR_NO_DEVICE;
+    if (p->max_batch < 1) return HVO_ERR_INVALID_ARG;
+    if (p->lsd_num_octaves != 1) return HVO_ERR_UNSUPPORTED;
+    hvo_ctx *ctx = new (std::nothrow) hvo_ctx();
+    if (!ctx) return HVO_ERR_INVALID_ARG;
+    ctx->p = *p; ctx->device = p->device;
+    for (auto &r : ctx->prof) { r.name = nullptr; r.e0 = r.e1 = nullptr; r.ms = 0; r.used = false; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { delete ctx; return HVO_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) { delete ctx; return HVO_ERR_NO_DEVICE; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete ctx; return HVO_ERR_NO_DEVICE; }   // code object is gfx950 only
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HVO_ERR_HIP; }
+    int rc = orb_init_tables(ctx);
+    if (rc) { hvo_destroy(ctx); return rc; }
+    *out = ctx;
+    return HVO_OK;
+}
+
+void hvo_destroy(hvo_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    orb_free_plan(ctx);
+    match_free(ctx);
+    peac_free(ctx);
+    lsd_free(ctx);
+    if (ctx->d_pattern) (void)hipFree(ctx->d_pattern);
+    if (ctx->d_umax) (void)hipFree(ctx->d_umax);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    for (auto &r : ctx->prof) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int hvo_profile_enable(hvo_ctx *ctx, int on)
+{
+    if (!ctx) return HVO_ERR_INVALID_ARG;
+    ctx->profile = on != 0;
+    return HVO_OK;
+}
+
+int hvo_profile_last(const hvo_ctx *ctx, const char **names, float *ms, int cap)
+{
+    if (!ctx) return HVO_ERR_INVALID_ARG;
+    int n = 0;
+    for (int i = 0; i < ctx->nprof && n < cap; i++) {
+        if (!ctx->prof[i].used) continue;
+        if (names) names[n] = ctx->prof[i].name;
+        if (ms) ms[n] = ctx->prof[i].ms;
+        n++;
+    }
+    return n;
+}
+
+int hvo_batch_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h)
+{
+    if (!ctx || !in || n < 1) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    int rc = orb_upload(ctx, n, in, w, h);
+    if (rc) return rc;
+    ctx->have_depth = true;
+    for (int f = 0; f < n; f++) if (!in[f].depth) ctx->have_depth = false;
+    if (ctx->have_depth) { rc = peac_upload(ctx, n, in, w, h); if (rc) return rc; }
+    ctx->batch_n = n; ctx->batch_w = w; ctx->batch_h = h;
+    return HVO_OK;
+}
+
+int hvo_batch_run(hvo_ctx *ctx, unsigned stages)
+{
+    if (!ctx || ctx->batch_n < 1) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    for (int i = 0; i < ctx->nprof; i++) ctx->prof[i].used = false;
+    int rc;
+    if (stages & HVO_STAGE_ORB) { rc = orb_run(ctx, ctx->batch_n); if (rc) return rc; }
+    if (stages & HVO_STAGE_PLANES) {
+        if (!ctx->have_depth) return HVO_ERR_INVALID_ARG;
+        rc = peac_run(ctx, ctx->batch_n); if (rc) return rc;
+    }
+    if (stages & HVO_STAGE_LSD) { rc = lsd_run(ctx, ctx->batch_n); if (rc) return rc; }
+    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->profile)
+        for (int i = 0; i < ctx->nprof; i++)
+            if (ctx->prof[i].used) HVO_HIP(hipEventElapsedTime(&ctx->prof[i].ms, ctx->prof[i].e0, ctx->prof[i].e1));
+    return HVO_OK;
+}
+
+int hvo_batch_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
+{
+    if (!ctx || !out || n < 1 || n > ctx->batch_n) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    for (int f = 0; f < n; f++) { out[f].status = HVO_OK; out[f].n_kp = out[f].n_kl = out[f].n_planes = 0; }
+    int rc = orb_download(ctx, n, out);
+    if (rc) return rc;
+    bool want_pl = false, want_kl = false;
+    for (int f = 0; f < n; f++) { want_pl |= (out[f].labels || out[f].planes); want_kl |= (out[f].kl != nullptr); }
+    if (want_pl) { rc = peac_download(ctx, n, out); if (rc) return rc; }
+    if (want_kl) { rc = lsd_download(ctx, n, out); if (rc) return rc; }
+    return HVO_OK;
+}
+
+int hvo_extract_batch(hvo_ctx *ctx, int n, const hvo_frame_in *in, hvo_frame_out *out, int w, int h, unsigned stages)
+{
+    int rc = hvo_batch_upload(ctx, n, in, w, h);
+    if (rc) return rc;
+    if ((rc = hvo_batch_run(ctx, stages))) return rc;
+    return hvo_batch_download(ctx, n, out);
+}
+
+int hvo_extract_orb(hvo_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
+                    hvo_keypoint *kp, uint8_t *desc32, int cap, int *n)
+{
+    if (!ctx || !n) return HVO_ERR_INVALID_ARG;
+    *n = 0;
+    if (!gray || w <= 0 || h <= 0) return HVO_OK;        // ORBextractor.cc:1044
+    if (!kp || !desc32 || cap < 0 || stride < w) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    hvo_frame_in in; memset(&in, 0, sizeof(in));
+    in.gray = gray; in.gray_stride = stride;
+    int rc = orb_upload(ctx, 1, &in, w, h);
+    if (rc) return rc;
+    for (int i = 0; i < ctx->nprof; i++) ctx->prof[i].used = false;
+    if ((rc = orb_run(ctx, 1))) return rc;
+    hvo_frame_out out; memset(&out, 0, sizeof(out));
+    out.kp = kp; out.desc = desc32; out.kp_cap = cap;
+    if ((rc = orb_download(ctx, 1, &out))) return rc;
+    *n = out.n_kp;
+    return out.status;
+}
+
+int hvo_hamming_matrix(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *d)
+{
+    if (!ctx || nq < 0 || nt < 0) return HVO_ERR_INVALID_ARG;
+    if (nq == 0 || nt == 0) return HVO_OK;
+    if (!q || !t || !d) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    return match_matrix(ctx, q, nq, t, nt, d);
+}
+
+int hvo_hamming_knn2(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx2, int32_t *dist2)
+{
+    if (!ctx || nq < 0 || nt < 0) return HVO_ERR_INVALID_ARG;
+    if (nq == 0) return HVO_OK;
+    if (!q || !idx2 || !dist2 || (nt > 0 && !t)) return HVO_ERR_INVALID_ARG;
+    if (nt == 0) {
+        for (int i = 0; i < 2 * nq; i++) { idx2[i] = -1; dist2[i] = INT32_MAX; }
+        return HVO_OK;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    return match_knn2(ctx, q, nq, t, nt, idx2, dist2);
+}
+
+int hvo_match_nnr(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float nnr,
+                  int32_t *m12, int *n_matches)
+{
+    // LSDmatcher::matchNNR (LSDmatcher.cpp:803-826): the Hamming search runs on the GPU, the
+    // n1 ratio tests are the host-side epilogue (they read 2*n1 ints).
+    if (!ctx || !m12 || !n_matches || n1 < 0 || n2 < 0) return HVO_ERR_INVALID_ARG;
+    *n_matches = 0;
+    if (n1 == 0) return HVO_OK;
+    int32_t *idx = (int32_t *)hvo_stage_host(ctx, (size_t)n1 * 4 * sizeof(int32_t));
+    if (!idx) return HVO_ERR_HIP;
+    int32_t *dist = idx + (size_t)n1 * 2;
+    int rc = hvo_hamming_knn2(ctx, d1, n1, d2, n2, idx, dist);
+    if (rc) return rc;
+    int m = 0;
+    for (int i = 0; i < n1; i++) {
+        m12[i] = -1;
+        if (n2 >= 2 && (float)dist[2 * i] < (float)dist[2 * i + 1] * nnr) { m12[i] = idx[2 * i]; m++; }
+    }
+    *n_matches = m;
+    return HVO_OK;
+}
+
+}  // extern "C"
+
+// ---- helpers shared by the subsystem files ----
+int hvo_prof_begin(hvo_ctx *ctx, const char *name)
+{
+    if (!ctx->profile) return -1;
+    int id = -1;
+    for (int i = 0; i < ctx->nprof; i++) if (ctx->prof[i].name == name) id = i;
+    if (id < 0) {
+        if (ctx->nprof >= HVO_MAX_PROFILE) return -1;
+        id = ctx->nprof++;
+        ctx->prof[id].name = name;
+        (void)hipEventCreate(&ctx->prof[id].e0);
+        (void)hipEventCreate(&ctx->prof[id].e1);
+    }
+    ctx->prof[id].used = true;
+    (void)hipEventRecord(ctx->prof[id].e0, ctx->stream);
+    return id;
+}
+
+void hvo_prof_end(hvo_ctx *ctx, int id)
+{
+    if (id >= 0) (void)hipEventRecord(ctx->prof[id].e1, ctx->stream);
+}
+
+void *hvo_stage_host(hvo_ctx *ctx, size_t bytes)
+{
+    if (ctx->h_stage_cap >= bytes) return ctx->h_stage;
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    ctx->h_stage = nullptr; ctx->h_stage_cap = 0;
+    if (hipHostMalloc(&ctx->h_stage, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    ctx->h_stage_cap = bytes;
+    return ctx->h_stage;
+}

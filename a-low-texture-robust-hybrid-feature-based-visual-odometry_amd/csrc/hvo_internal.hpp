@@ -1,0 +1,126 @@
+// hvo_internal.hpp -- shared declarations of libhvo.so (not part of the ABI).
+//
+// One hvo_ctx owns one HIP stream and every device slab of a batch ("plan") for a given image
+// geometry.  Stages are written as batch kernels: grid.y (or a flattened index) walks the frames
+// of the resident batch so that launch latency is amortised over the batch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/hvo.h"
+
+#define HVO_MAX_LEVELS 16
+#define HVO_EDGE_THRESHOLD 19      // ORBextractor.cc:72
+#define HVO_CELL_TILE 72           // largest FAST cell view (wCell+6) the LDS tile holds
+#define HVO_CELL_CAP 256           // max NMS survivors kept per cell
+#define HVO_MAX_PROFILE 32
+
+struct LevelGeom {
+    int w, h, pitch;
+    int minBX, minBY, maxBX, maxBY;     // ORBextractor.cc:771-774
+    int nCols, nRows, wCell, hCell;     // ORBextractor.cc:782-785
+    int cell_off, ncells;               // into the per-frame cell table
+    int nfeat;                          // mnFeaturesPerLevel
+    int cand_off, cand_cap;             // per-frame candidate scratch (entries)
+    int node_off, node_cap;             // per-frame quadtree node scratch (entries)
+    int kp_off, kp_cap;                 // per-frame per-level selected keypoints
+    int scaled_patch;                   // (int)(31*scale)
+    float scale;
+    unsigned long long img_off;         // byte offset of this level inside a frame's pyramid slab
+    int rs_off;                         // offset into resize tables (x entries), y at ry_off
+    int ry_off;
+    int tile_off, ntx, nty;             // blur tiles
+};
+
+struct CellDesc {   // one FAST cell view (ORBextractor.cc:787-806)
+    short level, x0, y0, vw, vh, ox, oy, pad;
+};
+
+struct OrbPlan {
+    int w = 0, h = 0, nlevels = 0, batch = 0;
+    LevelGeom lev[HVO_MAX_LEVELS];
+    int ncells = 0, cand_total = 0, node_total = 0, kp_total = 0, ntiles = 0;
+    size_t pyr_bytes = 0;               // per frame
+    int kp_cap = 0;                     // output capacity per frame
+    // device
+    LevelGeom *d_lev = nullptr;
+    CellDesc *d_cells = nullptr;
+    int *d_rs_xofs = nullptr; int *d_rs_xalpha = nullptr;   // per level: dw entries
+    int *d_rs_yofs = nullptr; int *d_rs_ybeta = nullptr;    // per level: dh entries (yofs packs sy0|sy1<<16)
+    int4 *d_tiles = nullptr;            // blur tiles (level, tx, ty, 0)
+    uint8_t *d_pyr = nullptr, *d_blur = nullptr;            // batch * pyr_bytes
+    uint32_t *d_cell_kp = nullptr; int *d_cell_cnt = nullptr;
+    uint32_t *d_cand = nullptr; int *d_keys = nullptr, *d_keys_tmp = nullptr;
+    int4 *d_nodeA = nullptr, *d_nodeB = nullptr; int2 *d_vs = nullptr, *d_vp = nullptr; int *d_order = nullptr;
+    uint32_t *d_lvl_kp = nullptr; int *d_lvl_cnt = nullptr;
+    hvo_keypoint *d_kp = nullptr; uint8_t *d_desc = nullptr; int *d_nkp = nullptr;
+    int *d_flags = nullptr;             // per frame error flags
+};
+
+struct ProfileRec { const char *name; hipEvent_t e0, e1; float ms; bool used; };
+
+struct hvo_ctx {
+    hvo_params p;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    OrbPlan orb;
+    // ORB tables
+    int umax[16];
+    float scale[HVO_MAX_LEVELS], inv_scale[HVO_MAX_LEVELS];
+    int nfeat[HVO_MAX_LEVELS];
+    int8_t *d_pattern = nullptr; int *d_umax = nullptr;
+    // resident batch
+    int batch_n = 0, batch_w = 0, batch_h = 0;
+    bool have_depth = false;
+    // matcher scratch
+    uint8_t *d_mq = nullptr, *d_mt = nullptr; size_t mq_cap = 0, mt_cap = 0;
+    void *d_mout = nullptr; size_t mout_cap = 0;
+    // host staging (pinned)
+    void *h_stage = nullptr; size_t h_stage_cap = 0;
+    // profiling
+    bool profile = false;
+    ProfileRec prof[HVO_MAX_PROFILE]; int nprof = 0;
+    // opaque per-subsystem state (peac.hip / lsd.hip own these)
+    void *peac = nullptr;
+    void *lsd = nullptr;
+};
+
+#define HVO_HIP(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ctx->last_error = std::string(#call) + ": " + hipGetErrorString(e_);            \
+            return HVO_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+// profiling scope helpers (api.hip)
+int  hvo_prof_begin(hvo_ctx *ctx, const char *name);
+void hvo_prof_end(hvo_ctx *ctx, int id);
+void *hvo_stage_host(hvo_ctx *ctx, size_t bytes);
+
+// orb.hip
+int orb_init_tables(hvo_ctx *ctx);
+int orb_ensure_plan(hvo_ctx *ctx, int w, int h, int batch);
+void orb_free_plan(hvo_ctx *ctx);
+int orb_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h);
+int orb_run(hvo_ctx *ctx, int n);
+int orb_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
+
+// match.hip
+int match_matrix(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *d);
+int match_knn2(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx2, int32_t *dist2);
+void match_free(hvo_ctx *ctx);
+
+// peac.hip
+int peac_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h);
+int peac_run(hvo_ctx *ctx, int n);
+int peac_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
+void peac_free(hvo_ctx *ctx);
+
+// lsd.hip (+ lbd)
+int lsd_run(hvo_ctx *ctx, int n);
+int lsd_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
+void lsd_free(hvo_ctx *ctx);

@@ -1,0 +1,856 @@
+// orb.hip -- batched ORB extraction for gfx950 (MI355X).
+//
+// Replaces ORBextractor::operator() (reference src/ORBextractor.cc:1041-1103) for a batch of
+// independent frames.  Kernels (one launch covers every frame of the batch):
+//   k_resize        ComputePyramid                    ORBextractor.cc:1105-1130  (cv::resize u8 bilinear)
+//   k_fast_cells    per-cell cv::FAST + fallback      ORBextractor.cc:787-827
+//   k_octree        DistributeOctTree / DivideNode    ORBextractor.cc:537-761, 479-535
+//   k_orient        IC_Angle + fastAtan2              ORBextractor.cc:75-102, 470-477
+//   k_blur7         GaussianBlur 7x7 sigma 2          ORBextractor.cc:1083-1084
+//   k_brief         computeOrbDescriptor              ORBextractor.cc:106-145
+//
+// Data layout in HBM (per frame): one pyramid slab holding the nlevels u8 images back to back
+// (row pitch = width rounded up to 64 B, no apron: REFLECT_101 is applied by index reflection
+// where the reference reads its 19-px apron), a second slab of the same shape for the blurred
+// levels, fixed-capacity candidate slabs per FAST cell, and the output keypoint / descriptor
+// slabs (cap x 28 B, cap x 32 B).
+//
+// Bit-exactness notes: all image arithmetic is integer; float steps (fastAtan2 polynomial,
+// steered-BRIEF coordinate rotation) use __f*_rn intrinsics so no FMA contraction can occur.
+#include "hvo_internal.hpp"
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+
+// =====================================================================================
+// device helpers
+// =====================================================================================
+static __device__ __forceinline__ int reflect101(int p, int n)
+{
+    if (p < 0) p = -p;
+    if (p >= n) p = 2 * (n - 1) - p;
+    return p < 0 ? 0 : p;
+}
+
+static __device__ __forceinline__ unsigned long long lanemask_lt()
+{
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+// =====================================================================================
+// K1: pyramid level l from level l-1 (cv::resize INTER_LINEAR u8, 11-bit fixed point)
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, size_t frame_stride,
+                                                LevelGeom S, LevelGeom D,
+                                                const int *__restrict__ xofs, const int *__restrict__ xalpha,
+                                                const int *__restrict__ yofs, const int *__restrict__ ybeta)
+{
+    const int dy = blockIdx.y * blockDim.y + threadIdx.y;
+    const int dx0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (dy >= D.h || dx0 >= D.w) return;
+    uint8_t *base = pyr + (size_t)blockIdx.z * frame_stride;
+    const uint8_t *src = base + S.img_off;
+    uint8_t *dst = base + D.img_off;
+    const int yo = yofs[dy];
+    const int sy0 = yo & 0xFFFF, sy1 = yo >> 16;
+    const int yb = ybeta[dy];
+    const int b0 = (short)(yb & 0xFFFF), b1 = (short)(yb >> 16);
+    const uint8_t *r0 = src + (size_t)sy0 * S.pitch, *r1 = src + (size_t)sy1 * S.pitch;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int dx = dx0 + i;
+        if (dx < D.w) {
+            int sx = xofs[dx];
+            int xa = xalpha[dx];
+            int a0 = (short)(xa & 0xFFFF), a1 = (short)(xa >> 16);
+            int sx1 = min(sx + 1, S.w - 1);       // a1 == 0 whenever sx+1 is outside
+            int t0 = r0[sx] * a0 + r0[sx1] * a1;
+            int t1 = r1[sx] * a0 + r1[sx1] * a1;
+            int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+            out |= (uint32_t)(v & 0xFF) << (8 * i);
+        }
+    }
+    // pitch is a multiple of 64 so a full dword store stays inside the row
+    *reinterpret_cast<uint32_t *>(dst + (size_t)dy * D.pitch + dx0) = out;
+}
+
+// =====================================================================================
+// K2: FAST-9-16 per cell, strict 3x3 NMS inside the cell view, threshold fallback
+// =====================================================================================
+// FAST corner score (cornerScore<16> of OpenCV): with d[k] = v - ring[k],
+//   S = max over the 16 arcs of 9 contiguous ring pixels of max(min d, -max d) - 1
+// A pixel is a corner at threshold t  <=>  S >= t, so one threshold-free score map serves both
+// the iniThFAST pass and the minThFAST fallback; NMS survivors at t are the strict 8-neighbour
+// local maxima of S with S >= t.
+static __device__ __forceinline__ int fast_score(const uint8_t *tile, int tp, int x, int y, int v)
+{
+    const uint8_t *p = tile + y * tp + x;
+    int d[16];
+    d[0] = v - p[3 * tp];          d[1] = v - p[3 * tp + 1];   d[2] = v - p[2 * tp + 2];   d[3] = v - p[tp + 3];
+    d[4] = v - p[3];               d[5] = v - p[-tp + 3];      d[6] = v - p[-2 * tp + 2];  d[7] = v - p[-3 * tp + 1];
+    d[8] = v - p[-3 * tp];         d[9] = v - p[-3 * tp - 1];  d[10] = v - p[-2 * tp - 2]; d[11] = v - p[-tp - 3];
+    d[12] = v - p[-3];             d[13] = v - p[tp - 3];      d[14] = v - p[2 * tp - 2];  d[15] = v - p[3 * tp - 1];
+    int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn8[k] = min(mn4[k], mn4[(k + 4) & 15]); mx8[k] = max(mx4[k], mx4[(k + 4) & 15]); }
+    int best = -1000;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int mn9 = min(mn8[k], d[(k + 8) & 15]);
+        int mx9 = max(mx8[k], d[(k + 8) & 15]);
+        best = max(best, max(mn9, -mx9));
+    }
+    return best - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, size_t frame_stride,
+                                                    const LevelGeom *__restrict__ lev,
+                                                    const CellDesc *__restrict__ cells, int ncells,
+                                                    uint32_t *__restrict__ cell_kp, int *__restrict__ cell_cnt,
+                                                    int iniTh, int minTh, int *__restrict__ flags)
+{
+    constexpr int TP = HVO_CELL_TILE + 8;
+    __shared__ uint8_t tile[HVO_CELL_TILE * TP];
+    __shared__ uint8_t sc[HVO_CELL_TILE * TP];
+    __shared__ int wsum[4];
+    __shared__ int s_cnt_ini;
+    const int cell = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    const CellDesc c = cells[cell];
+    const LevelGeom L = lev[c.level];
+    const uint8_t *img = pyr + (size_t)frame * frame_stride + L.img_off;
+    const int vw = c.vw, vh = c.vh;
+    for (int i = tid; i < vw * vh; i += 256) {
+        int y = i / vw, x = i - y * vw;
+        tile[y * TP + x] = img[(size_t)(c.y0 + y) * L.pitch + c.x0 + x];
+        sc[y * TP + x] = 0;
+    }
+    if (tid == 0) s_cnt_ini = 0;
+    __syncthreads();
+    const int iw = vw - 6, ih = vh - 6;
+    const int P = iw * ih;
+    for (int p = tid; p < P; p += 256) {
+        int y = 3 + p / iw, x = 3 + p % iw;
+        const uint8_t *q = tile + y * TP + x;
+        int v = q[0];
+        // necessary condition for a 9-arc at threshold minTh: one of ring pixels 0 / 8 differs by
+        // more than minTh (every arc of 9 contains pixel 0 or pixel 8), likewise 4 / 12.
+        int lo = v - minTh, hi = v + minTh;
+        int a = q[3 * TP], b = q[-3 * TP], e = q[3], f = q[-3];
+        bool c0 = (a < lo) | (a > hi) | (b < lo) | (b > hi);
+        bool c1 = (e < lo) | (e > hi) | (f < lo) | (f > hi);
+        if (c0 & c1) {
+            int s = fast_score(tile, TP, x, y, v);
+            sc[y * TP + x] = (uint8_t)(s >= minTh ? s : 0);
+        }
+    }
+    __syncthreads();
+    // NMS + ordered emission.  Thread t owns the raster-contiguous pixels [t*chunk, (t+1)*chunk).
+    const int chunk = (P + 255) / 256;
+    const int p0 = tid * chunk, p1 = min(P, p0 + chunk);
+    unsigned long long keep = 0;   // chunk <= 64 given HVO_CELL_TILE (66*66/256 = 18)
+    int n_ini = 0, n_min = 0;
+    for (int p = p0; p < p1; p++) {
+        int y = 3 + p / iw, x = 3 + p % iw;
+        const uint8_t *s = sc + y * TP + x;
+        int v = s[0];
+        if (v == 0) continue;
+        // neighbours outside the interior region are never written -> 0, like the zeroed score
+        // rows/columns of the reference's per-view FAST call
+        bool ok = v > s[-1] && v > s[1] && v > s[-TP - 1] && v > s[-TP] && v > s[-TP + 1] &&
+                  v > s[TP - 1] && v > s[TP] && v > s[TP + 1];
+        if (ok) { keep |= 1ull << (p - p0); n_min++; n_ini += (v >= iniTh); }
+    }
+    if (n_ini) atomicAdd(&s_cnt_ini, n_ini);
+    __syncthreads();
+    const bool use_ini = s_cnt_ini > 0;
+    const int th = use_ini ? iniTh : minTh;
+    int mine = use_ini ? n_ini : n_min;
+    // block exclusive scan of `mine`
+    const int lane = tid & 63, wv = tid >> 6;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int i = 0; i < 4; i++) { if (i < wv) base += wsum[i]; total += wsum[i]; }
+    int pos = base + incl - mine;
+    uint32_t *out = cell_kp + ((size_t)frame * ncells + cell) * HVO_CELL_CAP;
+    for (int p = p0; p < p1; p++) {
+        if (!((keep >> (p - p0)) & 1)) continue;
+        int y = 3 + p / iw, x = 3 + p % iw;
+        int v = sc[y * TP + x];
+        if (v < th) continue;
+        if (pos < HVO_CELL_CAP) out[pos] = (uint32_t)(x + c.ox) | ((uint32_t)(y + c.oy) << 12) | ((uint32_t)v << 24);
+        pos++;
+    }
+    if (tid == 0) {
+        if (total > HVO_CELL_CAP) { atomicOr(&flags[frame], 1); total = HVO_CELL_CAP; }
+        cell_cnt[(size_t)frame * ncells + cell] = total;
+    }
+}
+
+// =====================================================================================
+// K3: quadtree distribution -- one wave per (frame, level), serial semantics
+// =====================================================================================
+// Node record: A = {ulx, uly, brx, bry}, B = {koff, nk, prev, next}.  bNoMore <=> nk == 1.
+// Keys are indices into the level's candidate array; a node's keys live in keys[koff, koff+nk)
+// and its children re-use that range (stable 4-way partition), so no pool growth.
+// Tie rule for the (size, node*) sort of ORBextractor.cc:682: node creation order.
+struct OctArgs {
+    const LevelGeom *lev;
+    const uint32_t *cell_kp; const int *cell_cnt; int ncells;
+    uint32_t *cand; int *keys; int *keys_tmp; int4 *nodeA; int4 *nodeB; int2 *vs; int2 *vp; int *order;
+    uint32_t *lvl_kp; int *lvl_cnt; int *flags;
+    int cand_total, node_total, kp_total, nlevels;
+};
+
+static __device__ __forceinline__ int cand_x(uint32_t c) { return c & 0xFFF; }
+static __device__ __forceinline__ int cand_y(uint32_t c) { return (c >> 12) & 0xFFF; }
+static __device__ __forceinline__ int cand_s(uint32_t c) { return c >> 24; }
+
+__global__ __launch_bounds__(64) void k_octree(OctArgs a)
+{
+    const int level = blockIdx.x, frame = blockIdx.y, lane = threadIdx.x;
+    const LevelGeom L = a.lev[level];
+    uint32_t *cand = a.cand + (size_t)frame * a.cand_total + L.cand_off;
+    int *keys = a.keys + (size_t)frame * a.cand_total + L.cand_off;
+    int *ktmp = a.keys_tmp + (size_t)frame * a.cand_total + L.cand_off;
+    int4 *nA = a.nodeA + (size_t)frame * a.node_total + L.node_off;
+    int4 *nB = a.nodeB + (size_t)frame * a.node_total + L.node_off;
+    int2 *vs = a.vs + (size_t)frame * a.node_total + L.node_off;
+    int2 *vp = a.vp + (size_t)frame * a.node_total + L.node_off;
+    int *order = a.order + (size_t)frame * a.node_total + L.node_off;
+    uint32_t *outkp = a.lvl_kp + (size_t)frame * a.kp_total + L.kp_off;
+    int *outcnt = a.lvl_cnt + (size_t)frame * a.nlevels + level;
+    const unsigned long long lt = lanemask_lt();
+
+    // ---- gather the cells' candidates in cell order (vToDistributeKeys) ----
+    int nc = 0;
+    bool overflow = false;
+    for (int ci = 0; ci < L.ncells; ci++) {
+        const size_t cidx = (size_t)frame * a.ncells + L.cell_off + ci;
+        int cnt = a.cell_cnt[cidx];
+        const uint32_t *src = a.cell_kp + cidx * HVO_CELL_CAP;
+        if (nc + cnt > L.cand_cap) { cnt = L.cand_cap - nc; overflow = true; }
+        for (int i = lane; i < cnt; i += 64) cand[nc + i] = src[i];
+        nc += cnt;
+    }
+    if (overflow && lane == 0) atomicOr(&a.flags[frame], 2);
+    if (nc == 0 || L.nCols < 1 || L.nRows < 1) { if (lane == 0) *outcnt = 0; return; }
+    __syncthreads();
+
+    const int N = L.nfeat;
+    const int bw = L.maxBX - L.minBX, bh = L.maxBY - L.minBY;
+    const int nIni = (int)roundf(__fdiv_rn((float)bw, (float)bh));
+    if (nIni < 1) { if (lane == 0) *outcnt = 0; return; }
+    const float hX = __fdiv_rn((float)bw, (float)nIni);
+
+    int nn = 0;               // nodes created
+    int head = -1, tail = -1, size = 0;
+    bool nodes_full = false;
+
+    // ---- initial nodes: stable filter of candidates by (int)(x / hX) ----
+    {
+        int koff = 0;
+        for (int i = 0; i < nIni; i++) {
+            int cnt = 0;
+            for (int b = 0; b < nc; b += 64) {
+                int k = b + lane;
+                bool in = false;
+                if (k < nc) in = ((int)__fdiv_rn((float)cand_x(cand[k]), hX)) == i;
+                unsigned long long m = __ballot(in);
+                if (in) keys[koff + cnt + __popcll(m & lt)] = k;
+                cnt += __popcll(m);
+            }
+            if (cnt > 0) {   // empty initial nodes are erased right away (ORBextractor.cc:580-581)
+                if (lane == 0) {
+                    nA[nn] = make_int4((int)(hX * (float)i), 0, (int)(hX * (float)(i + 1)), bh);
+                    nB[nn] = make_int4(koff, cnt, tail, -1);
+                    if (tail >= 0) nB[tail].w = nn;
+                }
+                if (head < 0) head = nn;
+                tail = nn; nn++; size++;
+            }
+            koff += cnt;
+        }
+    }
+    __syncthreads();
+
+    int nvs = 0;
+    // divide node `ni`: partitions its keys, creates the non-empty children, pushes them to the
+    // front of the list in order n1..n4 and unlinks `ni`.  Everything below is wave-uniform.
+    auto divide = [&](int ni) {
+        const int4 A = nA[ni];
+        const int4 B = nB[ni];
+        const int halfX = (int)ceilf((float)(A.z - A.x) * 0.5f);
+        const int halfY = (int)ceilf((float)(A.w - A.y) * 0.5f);
+        const int mx = A.x + halfX, my = A.y + halfY;
+        const int koff = B.x, nk = B.y;
+        int cnt[4] = { 0, 0, 0, 0 };
+        for (int b = 0; b < nk; b += 64) {
+            int i = b + lane;
+            int cls = -1;
+            if (i < nk) { uint32_t cd = cand[keys[koff + i]]; cls = (cand_x(cd) < mx ? 0 : 1) + (cand_y(cd) < my ? 0 : 2); }
+#pragma unroll
+            for (int q = 0; q < 4; q++) cnt[q] += __popcll(__ballot(cls == q));
+        }
+        int off[4] = { 0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2] };
+        int run[4] = { 0, 0, 0, 0 };
+        for (int b = 0; b < nk; b += 64) {
+            int i = b + lane;
+            int cls = -1, k = 0;
+            if (i < nk) { k = keys[koff + i]; uint32_t cd = cand[k]; cls = (cand_x(cd) < mx ? 0 : 1) + (cand_y(cd) < my ? 0 : 2); }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                unsigned long long m = __ballot(cls == q);
+                if (cls == q) ktmp[koff + off[q] + run[q] + __popcll(m & lt)] = k;
+                run[q] += __popcll(m);
+            }
+        }
+        __syncthreads();
+        for (int i = lane; i < nk; i += 64) keys[koff + i] = ktmp[koff + i];
+        int nchild = (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0) + (cnt[3] > 0);
+        if (nn + nchild > L.node_cap) { nodes_full = true; __syncthreads(); return false; }
+        if (lane == 0) {
+            const int bx[4][4] = { { A.x, A.y, mx, my }, { mx, A.y, A.z, my }, { A.x, my, mx, A.w }, { mx, my, A.z, A.w } };
+            int h = head, id = nn;
+            for (int q = 0; q < 4; q++) {
+                if (!cnt[q]) continue;
+                nA[id] = make_int4(bx[q][0], bx[q][1], bx[q][2], bx[q][3]);
+                nB[id] = make_int4(koff + off[q], cnt[q], -1, h);
+                nB[h].z = id;          // h is never -1 here: `ni` is still linked
+                if (cnt[q] > 1) vs[nvs + (q > 0 && cnt[0] > 1) + (q > 1 && cnt[1] > 1) + (q > 2 && cnt[2] > 1)] = make_int2(cnt[q], id);
+                h = id; id++;
+            }
+            // unlink ni
+            int4 Bn = nB[ni];
+            if (Bn.z >= 0) nB[Bn.z].w = Bn.w;
+            if (Bn.w >= 0) nB[Bn.w].z = Bn.z;
+        }
+        // uniform bookkeeping
+        {
+            // `ni` can only be the head if no child was pushed before it -- children are pushed first
+            int last_child = nn + nchild - 1;
+            if (B.w < 0) tail = (B.z >= 0) ? B.z : ((nchild > 0) ? nn : -1);   // ni was the tail
+            // prev of ni may be a just-created child when ni was head:
+            if (B.z < 0 && B.w < 0 && nchild > 0) tail = nn;   // single-element list: first child becomes tail
+            head = (nchild > 0) ? last_child : ((B.z < 0) ? B.w : head);
+            nvs += (cnt[0] > 1) + (cnt[1] > 1) + (cnt[2] > 1) + (cnt[3] > 1);
+            nn += nchild;
+            size += nchild - 1;
+        }
+        __syncthreads();
+        return true;
+    };
+
+    bool finish = false;
+    while (!finish) {
+        int prevSize = size;
+        nvs = 0;
+        int nToExpand = 0;
+        int it = head;
+        while (it >= 0) {
+            const int4 B = nB[it];
+            if (B.y == 1) { it = B.w; continue; }
+            int before = nvs;
+            int nxt = B.w;
+            if (!divide(it)) { finish = true; break; }
+            nToExpand += nvs - before;
+            it = nxt;
+        }
+        if (finish) break;
+        if (size >= N || size == prevSize) {
+            finish = true;
+        } else if (size + nToExpand * 3 > N) {
+            while (!finish) {
+                prevSize = size;
+                const int nvp = nvs;
+                // rank sort of (size, node) ascending; keys are unique
+                for (int i = lane; i < nvp; i += 64) {
+                    int2 me = vs[i];
+                    int r = 0;
+                    for (int j = 0; j < nvp; j++) { int2 o = vs[j]; r += (o.x < me.x) || (o.x == me.x && o.y < me.y); }
+                    vp[r] = me;
+                }
+                __syncthreads();
+                nvs = 0;
+                for (int j = nvp - 1; j >= 0; j--) {
+                    if (!divide(vp[j].y)) { finish = true; break; }
+                    if (size >= N) break;
+                }
+                if (size >= N || size == prevSize) finish = true;
+            }
+        }
+    }
+    if (nodes_full && lane == 0) atomicOr(&a.flags[frame], 4);
+
+    // ---- retain the best point of each node, list order (ORBextractor.cc:737-758) ----
+    int cntn = 0;
+    for (int it = head; it >= 0 && cntn < L.kp_cap; it = nB[it].w) { if (lane == 0) order[cntn] = it; cntn++; }
+    __syncthreads();
+    for (int i = lane; i < cntn; i += 64) {
+        const int4 B = nB[order[i]];
+        uint32_t best = cand[keys[B.x]];
+        for (int k = 1; k < B.y; k++) { uint32_t c = cand[keys[B.x + k]]; if (cand_s(c) > cand_s(best)) best = c; }
+        outkp[i] = best;
+    }
+    if (lane == 0) *outcnt = cntn;
+}
+
+// =====================================================================================
+// K4: orientation (IC_Angle) + keypoint records.  One wave per keypoint.
+// =====================================================================================
+static __device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    // cv::fastAtan2 (OpenCV 3.2) -- float polynomial, evaluated without contraction
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float eps = (float)2.2204460492503131e-16;
+    float ax = fabsf(x), ay = fabsf(y), r, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        r = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        r = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) r = __fsub_rn(180.f, r);
+    if (y < 0) r = __fsub_rn(360.f, r);
+    return r;
+}
+
+// maps a per-frame keypoint index to (level, index inside the level); returns false past the end
+static __device__ __forceinline__ bool locate_kp(const int *lvl_cnt, int nlevels, int cap, int idx, int &level, int &k, int &total)
+{
+    int acc = 0; level = -1; k = 0;
+    for (int l = 0; l < nlevels; l++) {
+        int c = lvl_cnt[l];
+        if (level < 0 && idx < acc + c) { level = l; k = idx - acc; }
+        acc += c;
+    }
+    total = min(acc, cap);
+    return level >= 0 && idx < total;
+}
+
+__global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr, size_t frame_stride,
+                                                const LevelGeom *__restrict__ lev, int nlevels,
+                                                const uint32_t *__restrict__ lvl_kp, const int *__restrict__ lvl_cnt, int kp_total,
+                                                const int *__restrict__ umax,
+                                                hvo_keypoint *__restrict__ kp_out, int *__restrict__ nkp, int cap)
+{
+    const int frame = blockIdx.y, lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int level, k, total;
+    bool ok = locate_kp(lvl_cnt + (size_t)frame * nlevels, nlevels, cap, idx, level, k, total);
+    if (blockIdx.x == 0 && threadIdx.x == 0) nkp[frame] = total;
+    if (!ok) return;
+    const LevelGeom L = lev[level];
+    const uint32_t c = lvl_kp[(size_t)frame * kp_total + L.kp_off + k];
+    const int x = cand_x(c) + L.minBX, y = cand_y(c) + L.minBY;
+    const uint8_t *img = pyr + (size_t)frame * frame_stride + L.img_off;
+    // lanes 0..61: row v = (lane>>1) - 15 in [-15, 15], half = lane & 1 (u < 0 / u >= 0)
+    int m10 = 0, m01 = 0;
+    const int v = (lane >> 1) - 15;
+    if (lane < 62) {
+        const int d = umax[v < 0 ? -v : v];
+        const uint8_t *row = img + (size_t)(y + v) * L.pitch + x;
+        int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
+        int s = 0, su = 0;
+        for (int u = u0; u <= u1; u++) { int p = row[u]; s += p; su += u * p; }
+        m10 = su; m01 = v * s;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
+    if (lane == 0) {
+        hvo_keypoint kp;
+        kp.x = (float)x; kp.y = (float)y;           // level coordinates; k_brief rescales
+        kp.size = (float)L.scaled_patch;
+        kp.angle = fast_atan2_deg((float)m01, (float)m10);
+        kp.response = (float)cand_s(c);
+        kp.octave = level; kp.class_id = -1;
+        kp_out[(size_t)frame * cap + idx] = kp;
+    }
+}
+
+// =====================================================================================
+// K5a: 7x7 Gaussian blur, sigma 2, u8 -> u8 (OpenCV 3.2 fixed-point path)
+// =====================================================================================
+// Row pass with integer taps {18,34,49,55,49,34,18} (sum 257) fits u16; column pass in int32,
+// then: columns x < (w & ~3) round-half-to-even of s/65536 (the SSE2 float path of
+// SymmColumnVec_32s8u -- exact in float here), the last w%4 columns (s + 32768) >> 16.
+#define BLUR_TW 64
+#define BLUR_TH 32
+__global__ __launch_bounds__(256) void k_blur7(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, size_t frame_stride,
+                                               const LevelGeom *__restrict__ lev, const int4 *__restrict__ tiles,
+                                               int k0, int k1, int k2, int k3)
+{
+    __shared__ uint8_t in[(BLUR_TH + 6) * (BLUR_TW + 8)];
+    __shared__ uint16_t hb[(BLUR_TH + 6) * BLUR_TW];
+    const int4 t = tiles[blockIdx.x];
+    const LevelGeom L = lev[t.x];
+    const uint8_t *src = pyr + (size_t)blockIdx.y * frame_stride + L.img_off;
+    uint8_t *dst = blur + (size_t)blockIdx.y * frame_stride + L.img_off;
+    const int x0 = t.y * BLUR_TW, y0 = t.z * BLUR_TH, tid = threadIdx.x;
+    constexpr int IP = BLUR_TW + 8;
+    for (int i = tid; i < (BLUR_TH + 6) * (BLUR_TW + 6); i += 256) {
+        int r = i / (BLUR_TW + 6), c = i - r * (BLUR_TW + 6);
+        int yy = reflect101(y0 + r - 3, L.h), xx = reflect101(x0 + c - 3, L.w);
+        in[r * IP + c] = src[(size_t)yy * L.pitch + xx];
+    }
+    __syncthreads();
+    for (int i = tid; i < (BLUR_TH + 6) * BLUR_TW; i += 256) {
+        int r = i / BLUR_TW, c = i - r * BLUR_TW;
+        const uint8_t *p = in + r * IP + c;
+        int s = k0 * (p[0] + p[6]) + k1 * (p[1] + p[5]) + k2 * (p[2] + p[4]) + k3 * p[3];
+        hb[i] = (uint16_t)s;
+    }
+    __syncthreads();
+    const int c = tid & 63, rg = tid >> 6;     // 4 row groups of 8 rows
+    const int x = x0 + c;
+    if (x >= L.w) return;
+    const bool vec = x < (L.w & ~3);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        int r = rg * 8 + j, y = y0 + r;
+        if (y >= L.h) break;
+        const uint16_t *p = hb + r * BLUR_TW + c;
+        int s = k0 * (p[0] + p[6 * BLUR_TW]) + k1 * (p[BLUR_TW] + p[5 * BLUR_TW]) +
+                k2 * (p[2 * BLUR_TW] + p[4 * BLUR_TW]) + k3 * p[3 * BLUR_TW];
+        int q;
+        if (vec) { q = s >> 16; int rem = s & 0xFFFF; if (rem > 32768 || (rem == 32768 && (q & 1))) q++; }
+        else q = (s + 32768) >> 16;
+        dst[(size_t)y * L.pitch + x] = (uint8_t)min(q, 255);
+    }
+}
+
+// =====================================================================================
+// K5b: steered BRIEF-256.  One wave per keypoint; lane l produces descriptor bits 4l..4l+3.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_brief(const uint8_t *__restrict__ blur, size_t frame_stride,
+                                               const LevelGeom *__restrict__ lev,
+                                               const int8_t *__restrict__ pattern,
+                                               hvo_keypoint *__restrict__ kps, const int *__restrict__ nkp, int cap,
+                                               uint8_t *__restrict__ desc)
+{
+    const int frame = blockIdx.y, lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= nkp[frame]) return;
+    hvo_keypoint *kp = kps + (size_t)frame * cap + idx;
+    const float kx = kp->x, ky = kp->y, ang = kp->angle;
+    const int level = kp->octave;
+    const LevelGeom L = lev[level];
+    const uint8_t *img = blur + (size_t)frame * frame_stride + L.img_off;
+    // float angle = kpt.angle * factorPI; a = (float)cos(angle), b = (float)sin(angle)
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float angle = __fmul_rn(ang, factorPI);
+    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    const int cx = __float2int_rn(kx), cy = __float2int_rn(ky);
+    const int4 praw = *reinterpret_cast<const int4 *>(pattern + 16 * lane);
+    const int8_t *pp = reinterpret_cast<const int8_t *>(&praw);
+    unsigned nib = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        int t[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            float x = (float)pp[4 * q + 2 * e], y = (float)pp[4 * q + 2 * e + 1];
+            int ry = __float2int_rn(__fadd_rn(__fmul_rn(x, b), __fmul_rn(y, a)));
+            int rx = __float2int_rn(__fsub_rn(__fmul_rn(x, a), __fmul_rn(y, b)));
+            int yy = reflect101(cy + ry, L.h), xx = reflect101(cx + rx, L.w);
+            t[e] = img[(size_t)yy * L.pitch + xx];
+        }
+        nib |= (unsigned)(t[0] < t[1]) << q;
+    }
+    unsigned byte = nib | (__shfl_down(nib, 1) << 4);                      // valid on even lanes
+    unsigned w = byte | (__shfl_down(byte, 2) << 8) | (__shfl_down(byte, 4) << 16) | (__shfl_down(byte, 6) << 24);
+    if ((lane & 7) == 0) reinterpret_cast<uint32_t *>(desc + ((size_t)frame * cap + idx) * 32)[lane >> 3] = w;
+    if (lane == 0 && level != 0) {     // keypoint->pt *= scale (ORBextractor.cc:1093-1099)
+        kp->x = __fmul_rn(kx, L.scale);
+        kp->y = __fmul_rn(ky, L.scale);
+    }
+}
+
+// =====================================================================================
+// host side
+// =====================================================================================
+static int round_half_even_f(float v) { return (int)lrintf(v); }
+static int cv_floor_f(float v) { int i = (int)v; return i - (i > v); }
+static short sat_short(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+
+int orb_init_tables(hvo_ctx *ctx)
+{
+    const hvo_params &p = ctx->p;
+    if (p.orb_nlevels < 1 || p.orb_nlevels > HVO_MAX_LEVELS || p.orb_nfeatures < 1 || !(p.orb_scale_factor > 1.0f))
+        return HVO_ERR_INVALID_ARG;
+    // ORBextractor.cc:413-444
+    ctx->scale[0] = 1.0f;
+    for (int i = 1; i < p.orb_nlevels; i++) ctx->scale[i] = ctx->scale[i - 1] * p.orb_scale_factor;
+    for (int i = 0; i < p.orb_nlevels; i++) ctx->inv_scale[i] = 1.0f / ctx->scale[i];
+    float factor = 1.0f / p.orb_scale_factor;
+    float nd = p.orb_nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)p.orb_nlevels));
+    int sum = 0;
+    for (int l = 0; l < p.orb_nlevels - 1; l++) { ctx->nfeat[l] = round_half_even_f(nd); sum += ctx->nfeat[l]; nd *= factor; }
+    ctx->nfeat[p.orb_nlevels - 1] = std::max(p.orb_nfeatures - sum, 0);
+    // ORBextractor.cc:452-467 (umax of the circular patch)
+    int *umax = ctx->umax;
+    int v, v0, vmax = (int)floor(15 * sqrtf(2.f) / 2 + 1), vmin = (int)ceil(15 * sqrtf(2.f) / 2);
+    for (v = 0; v <= vmax; ++v) umax[v] = (int)lrint(sqrt(225.0 - v * v));
+    for (v = 15, v0 = 0; v >= vmin; --v) { while (umax[v0] == umax[v0 + 1]) ++v0; umax[v] = v0; ++v0; }
+    static const int8_t pattern[1024] = {
+#include "orb_pattern.inc"
+    };
+    HVO_HIP(hipMalloc(&ctx->d_pattern, 1024));
+    HVO_HIP(hipMemcpy(ctx->d_pattern, pattern, 1024, hipMemcpyHostToDevice));
+    HVO_HIP(hipMalloc(&ctx->d_umax, 16 * sizeof(int)));
+    HVO_HIP(hipMemcpy(ctx->d_umax, umax, 16 * sizeof(int), hipMemcpyHostToDevice));
+    return HVO_OK;
+}
+
+void orb_free_plan(hvo_ctx *ctx)
+{
+    OrbPlan &P = ctx->orb;
+    void *ptrs[] = { P.d_lev, P.d_cells, P.d_rs_xofs, P.d_rs_xalpha, P.d_rs_yofs, P.d_rs_ybeta, P.d_tiles, P.d_pyr, P.d_blur,
+                     P.d_cell_kp, P.d_cell_cnt, P.d_cand, P.d_keys, P.d_keys_tmp, P.d_nodeA, P.d_nodeB, P.d_vs, P.d_vp,
+                     P.d_order, P.d_lvl_kp, P.d_lvl_cnt, P.d_kp, P.d_desc, P.d_nkp, P.d_flags };
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    P = OrbPlan();
+}
+
+template <class T> static int dev_alloc(hvo_ctx *ctx, T **p, size_t n)
+{
+    HVO_HIP(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return HVO_OK;
+}
+template <class T> static int dev_upload(hvo_ctx *ctx, T **p, const std::vector<T> &v)
+{
+    int rc = dev_alloc(ctx, p, v.size());
+    if (rc) return rc;
+    if (!v.empty()) HVO_HIP(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return HVO_OK;
+}
+
+int orb_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
+{
+    OrbPlan &P = ctx->orb;
+    if (P.w == w && P.h == h && P.batch >= batch) return HVO_OK;
+    if (w < 64 || h < 64 || w > 4095 || h > 4095) return HVO_ERR_UNSUPPORTED;
+    orb_free_plan(ctx);
+    const int nl = ctx->p.orb_nlevels;
+    P.w = w; P.h = h; P.nlevels = nl; P.batch = batch;
+    std::vector<CellDesc> cells;
+    std::vector<int> xofs, xalpha, yofs, ybeta;
+    std::vector<int4> tiles;
+    size_t off = 0;
+    int cand_total = 0, node_total = 0, kp_total = 0;
+    for (int l = 0; l < nl; l++) {
+        LevelGeom &L = P.lev[l];
+        memset(&L, 0, sizeof(L));
+        L.w = round_half_even_f((float)w * ctx->inv_scale[l]);      // ORBextractor.cc:1110
+        L.h = round_half_even_f((float)h * ctx->inv_scale[l]);
+        if (L.w < 38 || L.h < 38) return HVO_ERR_UNSUPPORTED;
+        L.pitch = (L.w + 63) & ~63;
+        L.img_off = off;
+        off += (size_t)L.pitch * L.h;
+        L.scale = ctx->scale[l];
+        L.scaled_patch = (int)(31 * ctx->scale[l]);
+        L.nfeat = ctx->nfeat[l];
+        // ORBextractor.cc:769-785
+        L.minBX = L.minBY = HVO_EDGE_THRESHOLD - 3;
+        L.maxBX = L.w - HVO_EDGE_THRESHOLD + 3; L.maxBY = L.h - HVO_EDGE_THRESHOLD + 3;
+        const float width = (float)(L.maxBX - L.minBX), height = (float)(L.maxBY - L.minBY);
+        L.nCols = (int)(width / 30.f); L.nRows = (int)(height / 30.f);
+        L.cell_off = (int)cells.size();
+        if (L.nCols >= 1 && L.nRows >= 1) {
+            L.wCell = (int)ceilf(width / L.nCols); L.hCell = (int)ceilf(height / L.nRows);
+            for (int i = 0; i < L.nRows; i++) {
+                const float iniY = (float)(L.minBY + i * L.hCell);
+                float maxY = iniY + L.hCell + 6;
+                if (iniY >= L.maxBY - 3) continue;
+                if (maxY > L.maxBY) maxY = (float)L.maxBY;
+                for (int j = 0; j < L.nCols; j++) {
+                    const float iniX = (float)(L.minBX + j * L.wCell);
+                    float maxX = iniX + L.wCell + 6;
+                    if (iniX >= L.maxBX - 6) continue;
+                    if (maxX > L.maxBX) maxX = (float)L.maxBX;
+                    CellDesc c;
+                    c.level = (short)l; c.x0 = (short)iniX; c.y0 = (short)iniY;
+                    c.vw = (short)((int)maxX - (int)iniX); c.vh = (short)((int)maxY - (int)iniY);
+                    c.ox = (short)(j * L.wCell); c.oy = (short)(i * L.hCell); c.pad = 0;
+                    if (c.vw > HVO_CELL_TILE || c.vh > HVO_CELL_TILE) return HVO_ERR_UNSUPPORTED;
+                    if (c.vw < 7 || c.vh < 7) continue;      // cv::FAST finds nothing in such a view
+                    cells.push_back(c);
+                }
+            }
+        }
+        L.ncells = (int)cells.size() - L.cell_off;
+        L.cand_off = cand_total;
+        L.cand_cap = std::min(L.ncells * HVO_CELL_CAP, std::max(4096, 24 * L.nfeat));
+        cand_total += L.cand_cap;
+        L.node_off = node_total;
+        L.node_cap = 6 * L.nfeat + 256;
+        node_total += L.node_cap;
+        L.kp_off = kp_total;
+        L.kp_cap = L.nfeat + 8;
+        kp_total += L.kp_cap;
+        // resize tables for level l (from l-1): cv::resize INTER_LINEAR fixed-point coefficients
+        L.rs_off = (int)xofs.size(); L.ry_off = (int)yofs.size();
+        if (l > 0) {
+            const LevelGeom &S = P.lev[l - 1];
+            const double scale_x = 1. / ((double)L.w / S.w), scale_y = 1. / ((double)L.h / S.h);
+            for (int dx = 0; dx < L.w; dx++) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = cv_floor_f(fx); fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= S.w - 1) { fx = 0; sx = S.w - 1; }
+                short a0 = sat_short(round_half_even_f((1.f - fx) * 2048)), a1 = sat_short(round_half_even_f(fx * 2048));
+                xofs.push_back(sx);
+                xalpha.push_back((int)((uint32_t)(uint16_t)a0 | ((uint32_t)(uint16_t)a1 << 16)));
+            }
+            for (int dy = 0; dy < L.h; dy++) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = cv_floor_f(fy); fy -= sy;
+                short b0 = sat_short(round_half_even_f((1.f - fy) * 2048)), b1 = sat_short(round_half_even_f(fy * 2048));
+                int sy0 = std::min(std::max(sy, 0), S.h - 1), sy1 = std::min(std::max(sy + 1, 0), S.h - 1);
+                yofs.push_back(sy0 | (sy1 << 16));
+                ybeta.push_back((int)((uint32_t)(uint16_t)b0 | ((uint32_t)(uint16_t)b1 << 16)));
+            }
+        }
+        L.tile_off = (int)tiles.size();
+        L.ntx = (L.w + BLUR_TW - 1) / BLUR_TW; L.nty = (L.h + BLUR_TH - 1) / BLUR_TH;
+        for (int ty = 0; ty < L.nty; ty++) for (int tx = 0; tx < L.ntx; tx++) tiles.push_back(make_int4(l, tx, ty, 0));
+    }
+    P.pyr_bytes = (off + 255) & ~(size_t)255;
+    P.ncells = (int)cells.size(); P.cand_total = cand_total; P.node_total = node_total; P.kp_total = kp_total;
+    P.ntiles = (int)tiles.size();
+    P.kp_cap = kp_total;       // >= sum(nfeat)+8*nlevels: never truncates the octree output
+    const size_t B = (size_t)batch;
+    int rc;
+    std::vector<LevelGeom> levv(P.lev, P.lev + nl);
+    if ((rc = dev_upload(ctx, &P.d_lev, levv))) return rc;
+    if ((rc = dev_upload(ctx, &P.d_cells, cells))) return rc;
+    if ((rc = dev_upload(ctx, &P.d_rs_xofs, xofs))) return rc;
+    if ((rc = dev_upload(ctx, &P.d_rs_xalpha, xalpha))) return rc;
+    if ((rc = dev_upload(ctx, &P.d_rs_yofs, yofs))) return rc;
+    if ((rc = dev_upload(ctx, &P.d_rs_ybeta, ybeta))) return rc;
+    if ((rc = dev_upload(ctx, &P.d_tiles, tiles))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_pyr, B * P.pyr_bytes + 256))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_blur, B * P.pyr_bytes + 256))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_cell_kp, B * P.ncells * HVO_CELL_CAP))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_cell_cnt, B * P.ncells))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_cand, B * cand_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_keys, B * cand_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_keys_tmp, B * cand_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_nodeA, B * node_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_nodeB, B * node_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_vs, B * node_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_vp, B * node_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_order, B * node_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_lvl_kp, B * kp_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_lvl_cnt, B * nl))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_kp, B * P.kp_cap))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_desc, B * P.kp_cap * 32))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_nkp, B))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_flags, B))) return rc;
+    HVO_HIP(hipMemset(P.d_pyr, 0, B * P.pyr_bytes + 256));
+    HVO_HIP(hipMemset(P.d_blur, 0, B * P.pyr_bytes + 256));
+    HVO_HIP(hipMemset(P.d_flags, 0, B * sizeof(int)));
+    return HVO_OK;
+}
+
+int orb_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h)
+{
+    int rc = orb_ensure_plan(ctx, w, h, std::max(n, ctx->p.max_batch));
+    if (rc) return rc;
+    OrbPlan &P = ctx->orb;
+    for (int f = 0; f < n; f++) {
+        if (!in[f].gray) return HVO_ERR_INVALID_ARG;
+        HVO_HIP(hipMemcpy2DAsync(P.d_pyr + (size_t)f * P.pyr_bytes, P.lev[0].pitch, in[f].gray, in[f].gray_stride,
+                                 w, h, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    return HVO_OK;
+}
+
+int orb_run(hvo_ctx *ctx, int n)
+{
+    OrbPlan &P = ctx->orb;
+    if (n < 1 || n > P.batch) return HVO_ERR_INVALID_ARG;
+    hipStream_t st = ctx->stream;
+    const int nl = P.nlevels;
+    HVO_HIP(hipMemsetAsync(P.d_flags, 0, n * sizeof(int), st));
+    int id = hvo_prof_begin(ctx, "orb_pyramid");
+    for (int l = 1; l < nl; l++) {
+        const LevelGeom &S = P.lev[l - 1], &D = P.lev[l];
+        dim3 blk(64, 4), grd((D.w + 255) / 256, (D.h + 3) / 4, n);
+        hipLaunchKernelGGL(k_resize, grd, blk, 0, st, P.d_pyr, P.pyr_bytes, S, D, P.d_rs_xofs + D.rs_off, P.d_rs_xalpha + D.rs_off,
+                           P.d_rs_yofs + D.ry_off, P.d_rs_ybeta + D.ry_off);
+    }
+    hvo_prof_end(ctx, id);
+    id = hvo_prof_begin(ctx, "orb_fast_cells");
+    hipLaunchKernelGGL(k_fast_cells, dim3(P.ncells, n), dim3(256), 0, st, P.d_pyr, P.pyr_bytes, P.d_lev, P.d_cells, P.ncells,
+                       P.d_cell_kp, P.d_cell_cnt, ctx->p.orb_ini_th_fast, ctx->p.orb_min_th_fast, P.d_flags);
+    hvo_prof_end(ctx, id);
+    id = hvo_prof_begin(ctx, "orb_octree");
+    OctArgs oa;
+    oa.lev = P.d_lev; oa.cell_kp = P.d_cell_kp; oa.cell_cnt = P.d_cell_cnt; oa.ncells = P.ncells;
+    oa.cand = P.d_cand; oa.keys = P.d_keys; oa.keys_tmp = P.d_keys_tmp; oa.nodeA = P.d_nodeA; oa.nodeB = P.d_nodeB;
+    oa.vs = P.d_vs; oa.vp = P.d_vp; oa.order = P.d_order; oa.lvl_kp = P.d_lvl_kp; oa.lvl_cnt = P.d_lvl_cnt; oa.flags = P.d_flags;
+    oa.cand_total = P.cand_total; oa.node_total = P.node_total; oa.kp_total = P.kp_total; oa.nlevels = nl;
+    hipLaunchKernelGGL(k_octree, dim3(nl, n), dim3(64), 0, st, oa);
+    hvo_prof_end(ctx, id);
+    id = hvo_prof_begin(ctx, "orb_orient");
+    hipLaunchKernelGGL(k_orient, dim3((P.kp_cap + 3) / 4, n), dim3(256), 0, st, P.d_pyr, P.pyr_bytes, P.d_lev, nl, P.d_lvl_kp, P.d_lvl_cnt,
+                       P.kp_total, ctx->d_umax, P.d_kp, P.d_nkp, P.kp_cap);
+    hvo_prof_end(ctx, id);
+    id = hvo_prof_begin(ctx, "orb_blur");
+    // OpenCV fixed-point Gaussian taps for ksize 7, sigma 2: getGaussianKernel(CV_32F) * 256, rounded
+    static int k7[4] = { 0, 0, 0, 0 };
+    if (!k7[3]) {
+        float cf[7]; double sum = 0;
+        for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)exp(-0.5 / 4.0 * x * x); sum += cf[i]; }
+        sum = 1. / sum;
+        for (int i = 0; i < 4; i++) k7[i] = round_half_even_f((float)(cf[i] * sum) * 256.f);
+    }
+    hipLaunchKernelGGL(k_blur7, dim3(P.ntiles, n), dim3(256), 0, st, P.d_pyr, P.d_blur, P.pyr_bytes, P.d_lev, P.d_tiles, k7[0], k7[1], k7[2], k7[3]);
+    hvo_prof_end(ctx, id);
+    id = hvo_prof_begin(ctx, "orb_brief");
+    hipLaunchKernelGGL(k_brief, dim3((P.kp_cap + 3) / 4, n), dim3(256), 0, st, P.d_blur, P.pyr_bytes, P.d_lev, ctx->d_pattern, P.d_kp, P.d_nkp,
+                       P.kp_cap, P.d_desc);
+    hvo_prof_end(ctx, id);
+    HVO_HIP(hipGetLastError());
+    return HVO_OK;
+}
+
+int orb_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
+{
+    OrbPlan &P = ctx->orb;
+    std::vector<int> nk(n), fl(n);
+    HVO_HIP(hipMemcpyAsync(nk.data(), P.d_nkp, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HVO_HIP(hipMemcpyAsync(fl.data(), P.d_flags, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    for (int f = 0; f < n; f++) {
+        int m = nk[f];
+        if (fl[f]) out[f].status = HVO_ERR_CAPACITY;
+        if (out[f].kp) {
+            if (m > out[f].kp_cap) { m = out[f].kp_cap; out[f].status = HVO_ERR_CAPACITY; }
+            if (m > 0) {
+                HVO_HIP(hipMemcpyAsync(out[f].kp, P.d_kp + (size_t)f * P.kp_cap, (size_t)m * sizeof(hvo_keypoint), hipMemcpyDeviceToHost, ctx->stream));
+                if (out[f].desc)
+                    HVO_HIP(hipMemcpyAsync(out[f].desc, P.d_desc + (size_t)f * P.kp_cap * 32, (size_t)m * 32, hipMemcpyDeviceToHost, ctx->stream));
+            }
+        }
+        out[f].n_kp = m;
+    }
+    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    return HVO_OK;
+}

@@ -1,0 +1,175 @@
+/*
+ * hvo.h -- C ABI of libhvo.so: the MI355X (gfx950) per-frame RGB-D front-end
+ * (ORB + LSD/LBD lines + PEAC planes + Hamming matching) that replaces the bodies of
+ *
+ *   Frame::ExtractORB / ExtractORBNDepth   reference src/Frame.cc:886 / :874  (include/Frame.h:92-93)
+ *       -> ORBextractor::operator()        reference src/ORBextractor.cc:1041 (include/ORBextractor.h:59-61)
+ *   Frame::ExtractLSD                      reference src/Frame.cc:895          (include/Frame.h:96)
+ *       -> LINEextractor::operator()       reference src/LineExtractor.cpp:329 (include/LineExtractor.h:193)
+ *   Frame::ComputePlanes                   reference src/Frame.cc:2104         (include/Frame.h:415)
+ *       -> PlaneDetection::readDepthImage / runPlaneDetection
+ *                                          reference src/PlaneExtractor.cpp:26,60 (include/PlaneExtractor.h:50-54)
+ *   ORBmatcher::DescriptorDistance         reference src/ORBmatcher.cc:1676    (include/ORBmatcher.h:44)
+ *   LSDmatcher::match / matchNNR           reference src/LSDmatcher.cpp:828 / :803 (include/LSDmatcher.h:43)
+ *
+ * The reference has no FFI of its own (single C++ process); INTEGRATION.md shows the
+ * adaptor a maintainer adds to Frame.cc to call these entry points.
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every in/out buffer; nothing throws across the ABI
+ *   - return value 0 = HVO_OK, negative = hvo_status; hvo_strerror() names it
+ *   - empty image (NULL or w/h <= 0) -> *n = 0 and HVO_OK, like ORBextractor.cc:1044
+ *   - a ctx is NOT thread-safe (neither is ORBextractor: mvImagePyramid is state); use one ctx
+ *     per thread / per GPU.  Different ctx's may run concurrently (Frame.cc:210-215 pattern).
+ *   - there is NO CPU fallback: every entry point fails with HVO_ERR_NO_DEVICE / HVO_ERR_HIP when
+ *     the GPU or the gfx950 code object is unavailable.
+ */
+#ifndef HVO_H
+#define HVO_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HVO_ABI_VERSION 1
+
+typedef enum {
+    HVO_OK = 0,
+    HVO_ERR_INVALID_ARG = -1,   /* NULL ctx/pointer, bad sizes */
+    HVO_ERR_NO_DEVICE = -2,     /* no HIP device / wrong architecture */
+    HVO_ERR_HIP = -3,           /* a HIP runtime call failed (hvo_last_error has the text) */
+    HVO_ERR_UNSUPPORTED = -4,   /* image geometry outside what the kernels were sized for */
+    HVO_ERR_CAPACITY = -5,      /* an internal fixed-capacity slab overflowed; results truncated */
+    HVO_ERR_BAD_DTYPE = -6      /* mirrors the CV_8UC1 assert (ORBextractor.cc:1048) and the
+                                   CV_16U check (PlaneExtractor.cpp:34-38) */
+} hvo_status;
+
+/* == cv::KeyPoint (28 bytes): what ORBextractor::operator() fills (ORBextractor.cc:1041-1103) */
+typedef struct {
+    float x, y;        /* pt, already multiplied by mvScaleFactor[octave] (ORBextractor.cc:1093-1099) */
+    float size;        /* (int)(31 * scale) */
+    float angle;       /* degrees [0,360), IC_Angle + fastAtan2 */
+    float response;    /* FAST score */
+    int32_t octave;
+    int32_t class_id;  /* -1 */
+} hvo_keypoint;
+
+/* == cv::line_descriptor::KeyLine (68 bytes),
+ * Thirdparty/line_descriptor/include/line_descriptor/descriptor_custom.hpp:105-144 */
+typedef struct {
+    float angle; int32_t class_id, octave;
+    float pt_x, pt_y, response, size;
+    float sx, sy, ex, ey;          /* startPointX/Y, endPointX/Y */
+    float sox, soy, eox, eoy;      /* s/ePointInOctaveX/Y */
+    float length; int32_t num_pixels;
+} hvo_keyline;
+
+/* one ahc::PlaneSeg of PlaneFitter::extractedPlanes (include/peac/AHCPlaneSeg.hpp:129-135) */
+typedef struct {
+    double normal[3], center[3], mse;
+    int32_t n_points;   /* PlaneSeg::N */
+    int32_t rid;        /* root block id */
+} hvo_plane;
+
+typedef struct {
+    /* ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST): Tracking.cc:118-124,
+     * Examples/RGB-D/TUM3.yaml:41-54 */
+    int32_t orb_nfeatures;
+    float   orb_scale_factor;
+    int32_t orb_nlevels;
+    int32_t orb_ini_th_fast;
+    int32_t orb_min_th_fast;
+    /* LINEextractor(numOctaves, scale, nLSDFeature, min_line_length): Tracking.cc:126-132,
+     * TUM3.yaml:60-63.  NOTE the reference passes float scale into an int parameter (-> 1) and only
+     * octave 0 runs for nLevels=1; num_octaves != 1 is HVO_ERR_UNSUPPORTED. */
+    int32_t lsd_num_octaves;
+    float   lsd_scale;
+    int32_t lsd_nfeatures;
+    /* camera / depth: TUM3.yaml:8-11,34; depth_map_factor = 1/DepthMapFactor as a float
+     * (Tracking.cc:156-160) */
+    float fx, fy, cx, cy;
+    float depth_map_factor;
+    /* execution */
+    int32_t device;        /* HIP device ordinal */
+    int32_t max_batch;     /* frames resident per batch call (>=1) */
+} hvo_params;
+
+typedef struct hvo_ctx hvo_ctx;
+
+void        hvo_default_params(hvo_params *p);        /* TUM3.yaml values, device 0, max_batch 1 */
+int         hvo_create(const hvo_params *p, hvo_ctx **out);
+void        hvo_destroy(hvo_ctx *ctx);
+const char *hvo_strerror(int status);
+const char *hvo_last_error(const hvo_ctx *ctx);       /* text of the last HIP failure */
+int         hvo_abi_version(void);
+
+/* ---- single-frame entry points, host buffers (the drop-in boundary) ---- */
+
+/* ORBextractor::operator()(image, mask(ignored), keypoints, descriptors).
+ * gray: CV_8UC1 w x h, `stride` bytes per row.  kp/desc32: capacity `cap` entries (desc is cap x 32). */
+int hvo_extract_orb(hvo_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
+                    hvo_keypoint *kp, uint8_t *desc32, int cap, int *n);
+
+/* LINEextractor::operator()(image, mask(ignored), keylines, descriptors, lineVec2d).
+ * linefn3: cap x 3 doubles (normalised 2-D line functions, LineExtractor.cpp:367-377). */
+int hvo_extract_lsd(hvo_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
+                    hvo_keyline *kl, uint8_t *desc32, double *linefn3, int cap, int *n);
+
+/* PlaneDetection::readDepthImage + runPlaneDetection on the raw 16-bit depth (Frame.cc:2104-2108).
+ * depth: CV_16UC1, `stride` bytes per row.  labels: w*h int32 (PlaneFitter::membershipImg, -1 = none).
+ * planes: extractedPlanes after refineDetails, sorted by N descending. */
+int hvo_compute_planes(hvo_ctx *ctx, const uint16_t *depth, int w, int h, int stride,
+                       int32_t *labels, hvo_plane *planes, int cap, int *n);
+
+/* ---- Hamming matching (32-byte descriptors, row-major n x 32) ---- */
+/* ORBmatcher::DescriptorDistance for every (q,t) pair */
+int hvo_hamming_matrix(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *d);
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, 2) (LSDmatcher.cpp:811-812): two best train indices
+ * per query, ascending distance, ties -> lower train index; -1 / INT32_MAX where nt < 2 */
+int hvo_hamming_knn2(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                     int32_t *idx2, int32_t *dist2);
+/* LSDmatcher::matchNNR(desc1, desc2, nnr, matches_12): returns #matches in *n_matches */
+int hvo_match_nnr(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float nnr,
+                  int32_t *matches12, int *n_matches);
+
+/* ---- batch entry points (config 4: independent frames; inputs stay resident in HBM) ---- */
+#define HVO_STAGE_ORB    1u
+#define HVO_STAGE_LSD    2u
+#define HVO_STAGE_PLANES 4u
+#define HVO_STAGE_ALL    7u
+
+typedef struct {
+    const uint8_t  *gray;  int gray_stride;    /* bytes */
+    const uint16_t *depth; int depth_stride;   /* bytes; may be NULL when planes are not requested */
+} hvo_frame_in;
+
+typedef struct {
+    hvo_keypoint *kp; uint8_t *desc; int kp_cap; int n_kp;
+    hvo_keyline *kl; uint8_t *ldesc; double *linefn; int kl_cap; int n_kl;
+    int32_t *labels; hvo_plane *planes; int pl_cap; int n_planes;
+    int status;                                  /* per-frame hvo_status */
+} hvo_frame_out;
+
+/* host -> HBM copy of n (<= max_batch) frames of one geometry */
+int hvo_batch_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h);
+/* enqueue every kernel of the selected stages for the resident batch and wait for completion */
+int hvo_batch_run(hvo_ctx *ctx, unsigned stages);
+/* HBM -> host copy of results (any pointer in hvo_frame_out may be NULL to skip it) */
+int hvo_batch_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
+/* upload + run + download */
+int hvo_extract_batch(hvo_ctx *ctx, int n, const hvo_frame_in *in, hvo_frame_out *out, int w, int h,
+                      unsigned stages);
+
+/* ---- measurement hooks (bench.py) ---- */
+/* Per-kernel-group device time of the last hvo_batch_run, measured with hipEvents on the ctx
+ * stream.  names[i] points at static strings.  Returns the number of groups written (<= cap). */
+int hvo_profile_last(const hvo_ctx *ctx, const char **names, float *ms, int cap);
+/* enable/disable hipEvent bracketing of each kernel group inside hvo_batch_run (default off) */
+int hvo_profile_enable(hvo_ctx *ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HVO_H */

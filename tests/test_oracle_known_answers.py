@@ -1,0 +1,117 @@
+"""Known-answer tests that pin the oracle to constants derivable from the reference text alone
+(SURVEY.md section 8c).  The reference ships no tests/fixtures for this path, so these are the
+only external pins -- the oracle header says "parity unpinned"."""
+import numpy as np
+
+
+def test_umax_table(orc):
+    # ORBextractor.cc:452-467
+    assert orc.Orb().umax().tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+
+
+def test_features_per_level(orc):
+    # ORBextractor.cc:432-444 with TUM3.yaml:41-54
+    assert orc.Orb(1000, 1.2, 8).features_per_level().tolist() == [217, 181, 151, 126, 105, 87, 73, 60]
+    assert orc.Orb(2000, 1.2, 8).features_per_level().tolist() == [434, 362, 302, 251, 209, 175, 145, 122]
+
+
+def test_pattern_rows(orc):
+    # first / last rows of bit_pattern_31_ (ORBextractor.cc:150,405)
+    p = orc.pattern()
+    assert p[:4].tolist() == [8, -3, 9, 5] and p[-4:].tolist() == [-1, -6, 0, -11]
+    assert np.abs(p).max() <= 13 and len(p) == 1024
+
+
+def test_pyramid_sizes_and_grid(orc, synth):
+    o = orc.Orb()
+    o.extract(synth.make_gray("lowtex", 1, 640, 480))
+    sizes = [o.level(l).shape[::-1] for l in range(8)]
+    assert sizes == [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
+    assert sum(w * h for w, h in sizes) == 950532
+    grids = [o.grid(l)[:2] for l in range(8)]
+    assert grids == [(20, 14), (16, 12), (13, 10), (11, 8), (9, 6), (7, 5), (6, 4), (4, 3)]
+    assert sum(c * r for c, r in grids) == 815
+
+
+def test_gaussian_taps(orc):
+    # cv::GaussianBlur fixed-point taps (pre-3.4 CV_8U path): each sums to 257
+    assert orc.gaussian_kernel_q8(7, 2.0).tolist() == [18, 34, 49, 55, 49, 34, 18]
+    assert orc.gaussian_kernel_q8(5, 1.0).tolist() == [14, 63, 103, 63, 14]
+
+
+def test_hamming_known(orc):
+    z = np.zeros((1, 32), np.uint8); o = np.full((1, 32), 255, np.uint8)
+    assert orc.hamming_matrix(z, o)[0, 0] == 256
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (50, 32), dtype=np.uint8); b = rng.integers(0, 256, (60, 32), dtype=np.uint8)
+    ref = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(axis=2)
+    assert np.array_equal(orc.hamming_matrix(a, b), ref)      # SWAR trick == popcount
+    idx, dist = orc.hamming_knn2(a, b)
+    order = np.lexsort((np.arange(60)[None, :].repeat(50, 0), ref), axis=1)   # (dist, idx) ascending
+    assert np.array_equal(idx, order[:, :2])
+    assert np.array_equal(dist, np.take_along_axis(ref, order[:, :2], 1))
+
+
+def test_fast_atan2(orc):
+    # degrees in [0,360), polynomial error < 0.3 deg
+    L = orc.lib()
+    for y, x in [(0.0, 1.0), (1.0, 0.0), (1.0, 1.0), (-1.0, 1.0), (-1.0, -1.0), (3.0, -7.0), (0.0, 0.0)]:
+        a = L.orc_fast_atan2(y, x)
+        ref = np.degrees(np.arctan2(y, x)) % 360.0
+        assert 0.0 <= a < 360.0 and abs(a - ref) < 0.31
+
+
+def test_cvround_half_even(orc):
+    L = orc.lib()
+    assert [L.orc_cvround_f(v) for v in (0.5, 1.5, 2.5, -0.5, -1.5)] == [0, 2, 2, 0, -2]
+
+
+def test_fast_on_synthetic_corner(orc):
+    # a bright square corner on a dark background is a FAST-9 corner; flat image has none
+    img = np.full((40, 40), 50, np.uint8)
+    assert len(orc.fast9_16(img, 20)) == 0
+    yy, xx = np.mgrid[0:20, 0:20]
+    img[20:, 20:] = (200 - 2 * xx - 2 * yy).astype(np.uint8)   # strict NMS needs a unique maximum
+    k = orc.fast9_16(img, 20)
+    assert len(k) >= 1 and all(3 <= x < 37 and 3 <= y < 37 for x, y, _ in k)
+    # score == largest threshold at which the point is still a corner (cornerScore semantics)
+    x, y, s = k[0]
+    assert len([1 for xx, yy, _ in orc.fast9_16(img, int(s)) if (xx, yy) == (x, y)]) == 1
+    assert len([1 for xx, yy, _ in orc.fast9_16(img, int(s) + 1) if (xx, yy) == (x, y)]) == 0
+
+
+def test_resize_identity_and_constant(orc):
+    img = np.full((48, 64), 77, np.uint8)
+    assert np.all(orc.resize_linear(img, 53, 40) == 77)
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+    assert np.array_equal(orc.resize_linear(img, 64, 48), img)
+
+
+def test_blur_constant_saturation(orc):
+    # taps sum to 257: a constant image c maps to round(c*257*257/65536); 255 saturates
+    for c in (0, 1, 100, 200, 255):
+        img = np.full((20, 24), c, np.uint8)
+        out = orc.gaussian_blur(img, 7, 2.0)
+        exp = min(255, int(np.floor(c * 257 * 257 / 65536 + 0.5)))
+        assert np.all(out == exp), (c, out[0, 0], exp)
+
+
+def test_orb_extract_runs_and_is_deterministic(orc, synth):
+    g = synth.make_gray("std", 0x5EED0002)
+    o = orc.Orb()
+    kp1, d1 = o.extract(g)
+    kp2, d2 = orc.Orb().extract(g)
+    assert len(kp1) > 500 and np.array_equal(kp1, kp2) and np.array_equal(d1, d2)
+    assert np.all(kp1["octave"][:-1] <= kp1["octave"][1:])     # level-major order
+    assert np.all((kp1["angle"] >= 0) & (kp1["angle"] < 360))
+    assert np.all(kp1["class_id"] == -1)
+    # per-level quota: DistributeOctTree returns at most N+3 nodes
+    nf = o.features_per_level()
+    for l in range(8):
+        assert o.level_count(l) <= nf[l] + 3
+
+
+def test_orb_empty_image(orc):
+    kp, d = orc.Orb().extract(np.full((480, 640), 128, np.uint8))
+    assert len(kp) == 0

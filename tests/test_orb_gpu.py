@@ -1,0 +1,103 @@
+"""GPU parity: HIP ORB path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+Bar (BASELINE.json north_star): bit-exact keypoint coordinates / octaves / responses and
+descriptor bytes; float orientations within 1e-4 (they are expected to be bit-equal)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ANGLE_TOL = 1e-4     # degrees, north_star tolerance for float orientations/responses
+
+
+def check_orb(kp_g, d_g, kp_o, d_o):
+    assert len(kp_g) == len(kp_o), (len(kp_g), len(kp_o))
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(kp_g[f], kp_o[f]), f
+    assert np.max(np.abs(kp_g["angle"] - kp_o["angle"]), initial=0) <= ANGLE_TOL
+    assert np.array_equal(d_g, d_o)
+
+
+@pytest.mark.parametrize("kind,seed", [("std", 0x5EED0002), ("lowtex", 0x5EED0001), ("std", 7), ("std", 8)])
+def test_orb_parity_640(gpu_ctx, orc, synth, kind, seed):
+    g = synth.make_gray(kind, seed)
+    kp_o, d_o = orc.Orb().extract(g)
+    kp_g, d_g = gpu_ctx.extract_orb(g)
+    check_orb(kp_g, d_g, kp_o, d_o)
+
+
+def test_orb_parity_random_noise(gpu_ctx, orc):
+    """dense-texture stress: thousands of FAST candidates per level, quadtree fully exercised"""
+    rng = np.random.default_rng(123)
+    g = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    g[100:300, 200:500] = (g[100:300, 200:500] // 8 + 100)      # a calmer region
+    kp_o, d_o = orc.Orb().extract(g)
+    kp_g, d_g = gpu_ctx.extract_orb(g)
+    check_orb(kp_g, d_g, kp_o, d_o)
+
+
+def test_orb_parity_1280(hvo, orc, synth):
+    """BASELINE config 3 geometry: 1280x960, 2000 features"""
+    g = synth.make_gray("std", 0x5EED0003, 1280, 960)
+    kp_o, d_o = orc.Orb(nfeatures=2000).extract(g)
+    ctx = hvo.Context(orb_nfeatures=2000)
+    try:
+        kp_g, d_g = ctx.extract_orb(g)
+    finally:
+        ctx.close()
+    check_orb(kp_g, d_g, kp_o, d_o)
+
+
+def test_orb_odd_geometry_and_stride(gpu_ctx, orc, synth):
+    """non-multiple-of-4 width (exercises the scalar tail of the blur column pass) and a strided view"""
+    big = synth.make_gray("std", 11, 640, 480)
+    g = np.ascontiguousarray(big[:397, :501])
+    kp_o, d_o = orc.Orb().extract(g)
+    kp_g, d_g = gpu_ctx.extract_orb(g)
+    check_orb(kp_g, d_g, kp_o, d_o)
+
+
+def test_orb_flat_image_gives_nothing(gpu_ctx):
+    kp, d = gpu_ctx.extract_orb(np.full((480, 640), 128, np.uint8))
+    assert len(kp) == 0 and d.shape == (0, 32)
+
+
+def test_orb_empty_image_like_reference(gpu_ctx):
+    kp, d = gpu_ctx.extract_orb(np.zeros((0, 0), np.uint8))     # ORBextractor.cc:1044
+    assert len(kp) == 0
+
+
+def test_orb_wrong_dtype_is_an_error(gpu_ctx, hvo):
+    with pytest.raises(hvo.HvoError):
+        gpu_ctx.extract_orb(np.zeros((480, 640), np.float32))   # ORBextractor.cc:1048 assert
+
+
+def test_orb_batch_matches_single(hvo, orc, synth):
+    gray, _ = synth.make_batch("std", 0x5EED1000, 6)
+    ctx = hvo.Context(max_batch=6)
+    try:
+        ctx.batch_upload(gray)
+        ctx.batch_run(hvo.STAGE_ORB)
+        res = ctx.batch_download(hvo.STAGE_ORB)
+    finally:
+        ctx.close()
+    o = orc.Orb()
+    for b in range(6):
+        kp_o, d_o = o.extract(gray[b])
+        assert res[b]["status"] == 0
+        check_orb(res[b]["kp"], res[b]["desc"], kp_o, d_o)
+
+
+def test_orb_properties_full_size(gpu_ctx, synth):
+    """size-independent properties at the benchmark geometry: determinism, level-major order,
+    per-level quota, border margins, angle range"""
+    g = synth.make_gray("std", 0x5EED0002)
+    kp1, d1 = gpu_ctx.extract_orb(g)
+    kp2, d2 = gpu_ctx.extract_orb(g)
+    assert np.array_equal(kp1, kp2) and np.array_equal(d1, d2)
+    assert np.all(np.diff(kp1["octave"]) >= 0)
+    quota = [217, 181, 151, 126, 105, 87, 73, 60]
+    for l in range(8):
+        assert np.sum(kp1["octave"] == l) <= quota[l] + 3
+    s = 1.2 ** kp1["octave"]
+    assert np.all(kp1["x"] / s >= 15.9) and np.all(kp1["y"] / s >= 15.9)
+    assert np.all((kp1["angle"] >= 0) & (kp1["angle"] < 360))
