@@ -694,7 +694,9 @@ int orb_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
         }
         L.ncells = (int)cells.size() - L.cell_off;
         L.cand_off = cand_total;
-        L.cand_cap = std::min(L.ncells * HVO_CELL_CAP, std::max(4096, 24 * L.nfeat));
+        // strict 3x3 NMS leaves at most one survivor per 2x2 block: <= 256 per (<=32x32) cell,
+        // so the per-cell slab capacity is also the exact bound for the level's candidate list
+        L.cand_cap = L.ncells * HVO_CELL_CAP;
         cand_total += L.cand_cap;
         L.node_off = node_total;
         L.node_cap = 6 * L.nfeat + 256;
