@@ -15,6 +15,7 @@
 #define HVO_CELL_TILE 72           // largest FAST cell view (wCell+6) the LDS tile holds
 #define HVO_CELL_CAP 256           // max NMS survivors kept per cell
 #define HVO_MAX_PROFILE 32
+#define HVO_HAVE_PEAC 1           // peac.hip is built (stubs.hip drops its PEAC stubs)
 
 struct LevelGeom {
     int w, h, pitch;

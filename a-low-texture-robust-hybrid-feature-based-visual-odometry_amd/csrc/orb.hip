@@ -613,6 +613,7 @@ int orb_init_tables(hvo_ctx *ctx)
     HVO_HIP(hipMemcpy(ctx->d_pattern, pattern, 1024, hipMemcpyHostToDevice));
     HVO_HIP(hipMalloc(&ctx->d_umax, 16 * sizeof(int)));
     HVO_HIP(hipMemcpy(ctx->d_umax, umax, 16 * sizeof(int), hipMemcpyHostToDevice));
+    HVO_HIP(hipDeviceSynchronize());     // null-stream copies are not ordered against the non-blocking ctx stream
     return HVO_OK;
 }
 
@@ -763,9 +764,11 @@ int orb_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
     if ((rc = dev_alloc(ctx, &P.d_desc, B * P.kp_cap * 32))) return rc;
     if ((rc = dev_alloc(ctx, &P.d_nkp, B))) return rc;
     if ((rc = dev_alloc(ctx, &P.d_flags, B))) return rc;
-    HVO_HIP(hipMemset(P.d_pyr, 0, B * P.pyr_bytes + 256));
-    HVO_HIP(hipMemset(P.d_blur, 0, B * P.pyr_bytes + 256));
-    HVO_HIP(hipMemset(P.d_flags, 0, B * sizeof(int)));
+    // stream-ordered fills: a null-stream hipMemset is not ordered against the non-blocking ctx stream
+    HVO_HIP(hipMemsetAsync(P.d_pyr, 0, B * P.pyr_bytes + 256, ctx->stream));
+    HVO_HIP(hipMemsetAsync(P.d_blur, 0, B * P.pyr_bytes + 256, ctx->stream));
+    HVO_HIP(hipMemsetAsync(P.d_flags, 0, B * sizeof(int), ctx->stream));
+    HVO_HIP(hipDeviceSynchronize());     // also drains the null-stream table uploads above
     return HVO_OK;
 }
 

@@ -1,0 +1,857 @@
+// peac.hip -- batched PEAC / AHC plane extraction for gfx950 (MI355X).
+//
+// Replaces PlaneDetection::readDepthImage + runPlaneDetection (reference src/PlaneExtractor.cpp:26-66)
+// i.e. ahc::PlaneFitter::run (reference include/peac/AHCPlaneFitter.hpp:211-260) for a batch of frames.
+//
+//   k_peac_blocks    readDepthImage fused with the PlaneSeg block constructor + Stats::compute
+//                    (PlaneExtractor.cpp:42-56, AHCPlaneSeg.hpp:210-285, 125-156): the 7.4 MB fp64
+//                    cloud is never materialised, each 10x10 block is unprojected on the fly
+//   k_peac_cluster   initGraph edges (AHCPlaneFitter.hpp:894-954) + ahCluster (983-1189); one wave
+//                    per frame, min-MSE heap in LDS, candidate merges evaluated one per lane
+//   k_peac_blkmap    findBlockMembership (485-587): block erosion, coarse labels
+//   k_peac_refine    seed queue + floodFill (428-476) + last merge round + plidmap (299-340);
+//                    one wave per frame, queue events committed in conflict-free prefixes
+//   k_peac_relabel   membership relabel (353-365), negative "trail" counters reported as -1
+//
+// fp64 throughout, identical operation order to oracle/peac.c (no FMA contraction: -ffp-contract=off).
+// Tie rules where the reference is address dependent (std::set<PlaneSeg*>, priority_queue ties):
+// node creation order, see oracle/peac.c header.
+#include "hvo_internal.hpp"
+#include <math.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+
+#define WIN 10
+#define MIN_SUPPORT 3000
+#define MAX_PLANES 64
+#define SEG_D 16          // doubles per seg: st[9], center[3], normal[3], mse
+#define SEG_I 8           // ints per seg: N, rid, nouse, nb_off, nb_cnt, nb_cap, valid, pad
+#define LCAP 1024         // neighbour-list length staged in LDS
+
+struct PeacPlan {
+    int w = 0, h = 0, pitch = 0, Nw = 0, Nh = 0, nblk = 0, segcap = 0, poolcap = 0, qcap = 0, batch = 0;
+    uint16_t *d_depth = nullptr;
+    double *d_segD = nullptr; int *d_segI = nullptr; int *d_pool = nullptr, *d_pool2 = nullptr;
+    int *d_parent = nullptr, *d_dsize = nullptr, *d_eflag = nullptr;
+    int *d_meta = nullptr;          // per frame 16 ints: [0]=nseg [1]=pooltop [2]=nextracted [3]=flags [4]=nfinal [5]=nq
+    int *d_extracted = nullptr;     // per frame MAX_PLANES seg ids (coarse planes), then MAX_PLANES final
+    int *d_blkmap = nullptr; int32_t *d_labels = nullptr; float *d_dist = nullptr;
+    int *d_qpix = nullptr; int *d_qpl = nullptr; int *d_plidmap = nullptr; int *d_isvalid = nullptr;
+    hvo_plane *d_planes = nullptr;
+    double c15 = 0, c60 = 0, c30 = 0;   // cos thresholds evaluated on the host (glibc), like the oracle
+};
+
+static PeacPlan *plan_of(hvo_ctx *ctx) { return (PeacPlan *)ctx->peac; }
+
+// ------------------------------------------------------------------------------------------------
+// symmetric 3x3 eigen solver: cyclic Jacobi, fixed order -- mirrors oracle/peac.c orc_eig33sym
+// ------------------------------------------------------------------------------------------------
+static __device__ void eig33sym_dev(const double Kin[3][3], double s[3], double V[3][3])
+{
+    double a[3][3], v[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a[i][j] = Kin[i][j];
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+        if (off == 0.0) break;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int p = (r == 2) ? 1 : 0, q = (r == 0) ? 1 : 2;
+            const double apq = a[p][q];
+            if (apq == 0.0) continue;
+            const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+            const double app = a[p][p], aqq = a[q][q];
+            a[p][p] = app - t * apq;
+            a[q][q] = aqq + t * apq;
+            a[p][q] = a[q][p] = 0.0;
+            const int k = 3 - p - q;
+            const double akp = a[k][p], akq = a[k][q];
+            a[k][p] = a[p][k] = c * akp - sn * akq;
+            a[k][q] = a[q][k] = sn * akp + c * akq;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const double vip = v[i][p], viq = v[i][q];
+                v[i][p] = c * vip - sn * viq;
+                v[i][q] = sn * vip + c * viq;
+            }
+        }
+    }
+    int o0 = 0, o1 = 1, o2 = 2;
+    double d[3] = { a[0][0], a[1][1], a[2][2] };
+    // same selection sort as the oracle
+    int o[3] = { o0, o1, o2 };
+    for (int i = 0; i < 3; i++) for (int j = i + 1; j < 3; j++)
+        if (d[o[j]] < d[o[i]]) { int t = o[i]; o[i] = o[j]; o[j] = t; }
+    for (int i = 0; i < 3; i++) { s[i] = d[o[i]]; for (int r = 0; r < 3; r++) V[r][i] = v[r][o[i]]; }
+}
+
+// Stats::compute (AHCPlaneSeg.hpp:125-156); st = {sx,sy,sz,sxx,syy,szz,sxy,syz,sxz}
+static __device__ void stats_compute_dev(const double *st, int N, double center[3], double normal[3], double &mse)
+{
+    const double sc = 1.0 / N;
+    center[0] = st[0] * sc; center[1] = st[1] * sc; center[2] = st[2] * sc;
+    double K[3][3] = {
+        { st[3] - st[0] * st[0] * sc, st[6] - st[0] * st[1] * sc, st[8] - st[0] * st[2] * sc },
+        { 0, st[4] - st[1] * st[1] * sc, st[7] - st[1] * st[2] * sc },
+        { 0, 0, st[5] - st[2] * st[2] * sc } };
+    K[1][0] = K[0][1]; K[2][0] = K[0][2]; K[2][1] = K[1][2];
+    double sv[3], V[3][3];
+    eig33sym_dev(K, sv, V);
+    if (V[0][0] * center[0] + V[1][0] * center[1] + V[2][0] * center[2] <= 0) {
+        normal[0] = V[0][0]; normal[1] = V[1][0]; normal[2] = V[2][0];
+    } else {
+        normal[0] = -V[0][0]; normal[1] = -V[1][0]; normal[2] = -V[2][0];
+    }
+    mse = sv[0] * sc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_peac_blocks: one thread per 10x10 block
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_peac_blocks(const uint16_t *__restrict__ depth, size_t dframe, int pitch,
+                                                    int w, int h, int Nw, int nblk,
+                                                    float fx, float fy, float cx, float cy, float dfac,
+                                                    double *__restrict__ segD, int *__restrict__ segI, int segcap)
+{
+    const int blk = blockIdx.x * 64 + threadIdx.x, frame = blockIdx.y;
+    if (blk >= nblk) return;
+    const uint16_t *D = depth + (size_t)frame * dframe;
+    const int bi = blk / Nw, bj = blk - bi * Nw;
+    double st[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    int N = 0;
+    bool valid = true;
+    const double dfx = (double)fx, dfy = (double)fy, dcx = (double)cx, dcy = (double)cy, df = (double)dfac;
+    for (int ic = 0; ic < WIN && valid; ++ic) {
+        const int i = bi * WIN + ic;
+        const uint16_t *row = D + (size_t)i * pitch;
+        for (int jc = 0; jc < WIN; ++jc) {
+            const int j = bj * WIN + jc;
+            const int d = row[j];
+            if (d == 0) { valid = false; break; }               // ImagePointCloud::get: z == 0
+            const double z = (double)d * df;
+            if (j + 1 < w) { int dn = row[j + 1]; if (dn != 0) { double zn = (double)dn * df; if (fabs(z - zn) > 0.04 * fabs(z) + 0.02) { valid = false; break; } } }
+            if (i + 1 < h) { int dn = row[pitch + j]; if (dn != 0) { double zn = (double)dn * df; if (fabs(z - zn) > 0.04 * fabs(z) + 0.02) { valid = false; break; } } }
+            const double x = ((double)j - dcx) * z / dfx;
+            const double y = ((double)i - dcy) * z / dfy;
+            st[0] += x; st[1] += y; st[2] += z;
+            st[3] += x * x; st[4] += y * y; st[5] += z * z;
+            st[6] += x * y; st[7] += y * z; st[8] += x * z;
+            ++N;
+        }
+    }
+    double *sd = segD + ((size_t)frame * segcap + blk) * SEG_D;
+    int *si = segI + ((size_t)frame * segcap + blk) * SEG_I;
+    double center[3] = { 0, 0, 0 }, normal[3] = { 0, 0, 0 }, mse = 0;
+    int ok = 0;
+    if (valid && N >= 4) {
+        stats_compute_dev(st, N, center, normal, mse);
+        const double t = 1.6e-6 * center[2] * center[2] + 5.0;      // T_mse(P_INIT): AHCParamSet.hpp:88-100
+        ok = mse < t * t;
+    } else { N = 0; for (int k = 0; k < 9; k++) st[k] = 0; }
+    for (int k = 0; k < 9; k++) sd[k] = st[k];
+    sd[9] = center[0]; sd[10] = center[1]; sd[11] = center[2];
+    sd[12] = normal[0]; sd[13] = normal[1]; sd[14] = normal[2]; sd[15] = mse;
+    si[0] = N; si[1] = blk; si[2] = ok ? 0 : 1; si[3] = blk * 4; si[4] = 0; si[5] = 4; si[6] = ok; si[7] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared helpers for the single-wave kernels
+// ------------------------------------------------------------------------------------------------
+struct ClArgs {
+    double *segD; int *segI; int *pool; int *pool2; int *parent; int *dsize; int *eflag; int *meta; int *extracted;
+    int segcap, poolcap, nblk, Nw, Nh;
+    double c15, c60;
+};
+
+static __device__ __forceinline__ double nsim(const double *a, const double *b)
+{
+    return fabs(a[12] * b[12] + a[13] * b[13] + a[14] * b[14]);
+}
+
+static __device__ int ds_find_ro(const int *parent, int x) { while (parent[x] != x) x = parent[x]; return x; }
+
+// min-heap on (mse, id) living in LDS
+struct Heap { double *key; int *id; int n; };
+static __device__ __forceinline__ bool hless(double ka, int ia, double kb, int ib) { return ka < kb || (ka == kb && ia < ib); }
+static __device__ void heap_sift_down(Heap &H, int i)
+{
+    double k = H.key[i]; int id = H.id[i];
+    for (;;) {
+        int l = 2 * i + 1, r = l + 1, m = -1;
+        double km = k; int im = id;
+        if (l < H.n && hless(H.key[l], H.id[l], km, im)) { m = l; km = H.key[l]; im = H.id[l]; }
+        if (r < H.n && hless(H.key[r], H.id[r], km, im)) { m = r; km = H.key[r]; im = H.id[r]; }
+        if (m < 0) break;
+        H.key[i] = km; H.id[i] = im; i = m;
+    }
+    H.key[i] = k; H.id[i] = id;
+}
+static __device__ void heap_push(Heap &H, double k, int id)
+{
+    int i = H.n++;
+    while (i > 0) {
+        int p = (i - 1) / 2;
+        if (hless(k, id, H.key[p], H.id[p])) { H.key[i] = H.key[p]; H.id[i] = H.id[p]; i = p; } else break;
+    }
+    H.key[i] = k; H.id[i] = id;
+}
+
+// remove up to two ids from a sorted neighbour list in place (single lane)
+static __device__ void nb_remove2(int *pool, int *si, int a, int b)
+{
+    const int off = si[3], cnt = si[4];
+    int o = 0;
+    for (int k = 0; k < cnt; k++) { int v = pool[off + k]; if (v != a && v != b) { if (o != k) pool[off + o] = v; o++; } }
+    si[4] = o;
+}
+
+// The core of ahCluster for one wave.  `heap` holds (mse,id); nodes are in segD/segI.
+// Returns through meta/extracted.  Used for the main pass and for the last merge round.
+// Compacts the live neighbour lists into the other pool buffer (ascending node id) and swaps the
+// buffers.  The total live size never exceeds the initial 4*nblk entries (a merged list is at most
+// |A|+|B|-2 long), so a pool of 16*nblk entries with compaction cannot run out.
+static __device__ void pool_gc(int *segI, int nseg, int *&pool, int *&pool2, int &pooltop)
+{
+    const int lane = threadIdx.x;
+    __syncthreads();
+    int top = 0;
+    for (int base = 0; base < nseg; base += 64) {
+        const int id = base + lane;
+        int sz = 0, off = 0;
+        if (id < nseg) { const int *si = segI + (size_t)id * SEG_I; if (!si[2]) { sz = si[4]; off = si[3]; } }
+        int incl = sz;
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const int dst = top + incl - sz;
+        for (int k = 0; k < sz; k++) pool2[dst + k] = pool[off + k];
+        if (id < nseg) { int *si = segI + (size_t)id * SEG_I; if (!si[2]) { si[3] = dst; si[5] = sz; } }
+        top += __shfl(incl, 63);
+    }
+    int *t = pool; pool = pool2; pool2 = t;
+    pooltop = top;
+    __syncthreads();
+}
+
+static __device__ void ah_cluster_wave(const ClArgs &a, int frame, Heap &H, int &nseg, int &pooltop, int *&pool, int *&pool2,
+                                       int *ext, int &next, int *lA, int *lB, double *cm, int *cN, int &flags)
+{
+    const int lane = threadIdx.x;
+    double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
+    int *segI = a.segI + (size_t)frame * a.segcap * SEG_I;
+    int *parent = a.parent + (size_t)frame * a.nblk, *dsize = a.dsize + (size_t)frame * a.nblk;
+    while (H.n > 0) {
+        if (pooltop > a.poolcap - 2 * a.nblk) pool_gc(segI, nseg, pool, pool2, pooltop);
+        // ---- pop ----
+        int p = H.id[0];
+        __syncthreads();
+        if (lane == 0) {
+            H.n--;
+            if (H.n > 0) { H.key[0] = H.key[H.n]; H.id[0] = H.id[H.n]; heap_sift_down(H, 0); }
+        } else H.n--;
+        __syncthreads();
+        int *pi = segI + (size_t)p * SEG_I;
+        if (pi[2]) continue;                                   // nouse
+        const double *pd = segD + (size_t)p * SEG_D;
+        const int pcnt = pi[4], poff = pi[3], pN = pi[0];
+        // ---- evaluate merges with every neighbour, in creation order ----
+        int cand_k = -1; double cand_mse = 0; int cand_N = 0;
+        for (int base = 0; base < pcnt; base += 64) {
+            const int k = base + lane;
+            double m = 0; int mN = 0; bool has = false;
+            if (k < pcnt) {
+                const int nb = pool[poff + k];
+                const double *nd = segD + (size_t)nb * SEG_D;
+                if (!(nsim(pd, nd) < a.c60)) {                 // T_ang(P_MERGING)
+                    double st[9];
+                    for (int q = 0; q < 9; q++) st[q] = pd[q] + nd[q];
+                    mN = pN + segI[(size_t)nb * SEG_I];
+                    double c[3], n[3];
+                    stats_compute_dev(st, mN, c, n, m);
+                    has = true;
+                }
+            }
+            cm[lane] = m; cN[lane] = has ? mN : -1;
+            __syncthreads();
+            // exact sequential selection rule of AHCPlaneFitter.hpp:1043-1049 (evaluated uniformly)
+            const int lim = min(64, pcnt - base);
+            for (int q = 0; q < lim; q++) {
+                if (cN[q] < 0) continue;
+                const double mq = cm[q];
+                if (cand_k < 0 || cand_mse > mq || (cand_mse == mq && (double)cand_N < mq)) { cand_k = base + q; cand_mse = mq; cand_N = cN[q]; }
+            }
+            __syncthreads();
+        }
+        bool merged = false;
+        if (cand_k >= 0) {
+            const int nb = pool[poff + cand_k];
+            const double *nd = segD + (size_t)nb * SEG_D;
+            int *ni = segI + (size_t)nb * SEG_I;
+            double st[9], c[3], n[3], m;
+            for (int q = 0; q < 9; q++) st[q] = pd[q] + nd[q];
+            const int mN = pN + ni[0];
+            stats_compute_dev(st, mN, c, n, m);                // uniform recomputation of the winner
+            const double t = 1.6e-6 * c[2] * c[2] + 8.0;        // T_mse(P_MERGING)
+            if (m < t * t) {
+                const int ncnt = ni[4], noff = ni[3];
+                if (nseg >= a.segcap || pooltop + pcnt + ncnt > a.poolcap) {
+                    flags |= 8;                                 // capacity: stop merging this node
+                } else {
+                    merged = true;
+                    const int id = nseg++;
+                    // new.nbs = (p.nbs U nb.nbs) \ {p, nb}: stage both lists in LDS when they fit (the
+                    // usual case), lane 0 does the sorted merge; over-long lists are merged straight
+                    // from global memory
+                    const bool staged = pcnt <= LCAP && ncnt <= LCAP;
+                    if (staged) {
+                        for (int k = lane; k < pcnt; k += 64) lA[k] = pool[poff + k];
+                        for (int k = lane; k < ncnt; k += 64) lB[k] = pool[noff + k];
+                    }
+                    __syncthreads();
+                    const int *LA = staged ? lA : pool + poff, *LB = staged ? lB : pool + noff;
+                    const int moff = pooltop;
+                    int mcnt = 0;
+                    if (lane == 0) {
+                        int i = 0, j = 0;
+                        while (i < pcnt || j < ncnt) {
+                            int v;
+                            if (j >= ncnt || (i < pcnt && LA[i] <= LB[j])) { v = LA[i]; if (j < ncnt && LB[j] == v) j++; i++; }
+                            else { v = LB[j]; j++; }
+                            if (v != p && v != nb) pool[moff + mcnt++] = v;
+                        }
+                        cN[0] = mcnt;
+                        double *md = segD + (size_t)id * SEG_D;
+                        for (int q = 0; q < 9; q++) md[q] = st[q];
+                        md[9] = c[0]; md[10] = c[1]; md[11] = c[2]; md[12] = n[0]; md[13] = n[1]; md[14] = n[2]; md[15] = m;
+                        int *mi = segI + (size_t)id * SEG_I;
+                        mi[0] = mN; mi[1] = pN >= ni[0] ? pi[1] : ni[1]; mi[2] = 0; mi[3] = moff; mi[4] = mcnt; mi[5] = pcnt + ncnt; mi[6] = 1; mi[7] = 0;
+                        // ds.Union(pa.rid, pb.rid)
+                        int xr = ds_find_ro(parent, pi[1]), yr = ds_find_ro(parent, ni[1]);
+                        if (xr != yr) {
+                            if (dsize[xr] < dsize[yr]) { parent[xr] = yr; dsize[yr] += dsize[xr]; }
+                            else { parent[yr] = xr; dsize[xr] += dsize[yr]; }
+                        }
+                        pi[2] = 1; ni[2] = 1; pi[4] = 0; ni[4] = 0;
+                        heap_push(H, m, id);
+                    } else H.n++;
+                    __syncthreads();
+                    mcnt = cN[0];
+                    pooltop += pcnt + ncnt;
+                    // every neighbour of the new node: drop p / nb, append the new id (largest so far)
+                    for (int k = lane; k < mcnt; k += 64) {
+                        int *qi = segI + (size_t)pool[moff + k] * SEG_I;
+                        nb_remove2(pool, qi, p, nb);
+                        pool[qi[3] + qi[4]] = id; qi[4]++;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        if (!merged) {
+            if (pN >= MIN_SUPPORT) { if (next < MAX_PLANES) { if (lane == 0) ext[next] = p; next++; } else flags |= 16; }
+            // disconnectAllNbs
+            for (int k = lane; k < pcnt; k += 64) nb_remove2(pool, segI + (size_t)pool[poff + k] * SEG_I, p, -1);
+            __syncthreads();
+            if (lane == 0) pi[4] = 0;
+            __syncthreads();
+        }
+    }
+    // std::sort by N descending, ties -> extraction order (stable insertion sort, uniform)
+    __syncthreads();
+    if (lane == 0) {
+        for (int i = 1; i < next; i++) {
+            int v = ext[i], j = i - 1;
+            int vN = segI[(size_t)v * SEG_I];
+            while (j >= 0 && segI[(size_t)ext[j] * SEG_I] < vN) { ext[j + 1] = ext[j]; j--; }
+            ext[j + 1] = v;
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_peac_cluster: initGraph edges + main ahCluster
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a)
+{
+    extern __shared__ double smem[];
+    const int frame = blockIdx.x, lane = threadIdx.x;
+    const int nblk = a.nblk, Nw = a.Nw, Nh = a.Nh;
+    double *hkey = smem;                               // nblk doubles
+    int *hid = (int *)(hkey + nblk);                   // nblk ints
+    int *lA = hid + nblk, *lB = lA + LCAP;             // LCAP ints each
+    double *cm = (double *)(lB + LCAP + (((size_t)(lB + LCAP) & 7) ? 1 : 0));
+    int *cN = (int *)(cm + 64);
+    double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
+    int *segI = a.segI + (size_t)frame * a.segcap * SEG_I;
+    int *pool = a.pool + (size_t)frame * a.poolcap, *pool2 = a.pool2 + (size_t)frame * a.poolcap;
+    int *parent = a.parent + (size_t)frame * nblk, *dsize = a.dsize + (size_t)frame * nblk;
+    int *eflag = a.eflag + (size_t)frame * nblk;
+    for (int b = lane; b < nblk; b += 64) { parent[b] = b; dsize[b] = 1; eflag[b] = 0; }
+    __syncthreads();
+#define GOK(c) (segI[(size_t)(c) * SEG_I + 6] != 0)
+#define SD(c) (segD + (size_t)(c) * SEG_D)
+    // first pass: rows (AHCPlaneFitter.hpp:896-923).  bits: 1=left 2=right 4=up 8=down
+    for (int i = lane; i < Nh; i += 64) {
+        for (int j = 1; j < Nw; j += 2) {
+            const int c = i * Nw + j;
+            if (!GOK(c - 1)) { --j; continue; }
+            if (!GOK(c)) continue;
+            if (j < Nw - 1 && !GOK(c + 1)) { ++j; continue; }
+            const double th = a.c15;                    // T_ang(P_INIT, z): z (metres) < z_near (500) always
+            if ((j < Nw - 1 && nsim(SD(c - 1), SD(c + 1)) >= th) || (j == Nw - 1 && nsim(SD(c), SD(c - 1)) >= th)) {
+                eflag[c] |= 1; eflag[c - 1] |= 2;
+                if (j < Nw - 1) { eflag[c] |= 2; eflag[c + 1] |= 1; }
+            } else --j;
+        }
+    }
+    __syncthreads();
+    for (int j = lane; j < Nw; j += 64) {
+        for (int i = 1; i < Nh; i += 2) {
+            const int c = i * Nw + j;
+            if (!GOK(c - Nw)) { --i; continue; }
+            if (!GOK(c)) continue;
+            if (i < Nh - 1 && !GOK(c + Nw)) { ++i; continue; }
+            const double th = a.c15;
+            if ((i < Nh - 1 && nsim(SD(c - Nw), SD(c + Nw)) >= th) || (i == Nh - 1 && nsim(SD(c), SD(c - Nw)) >= th)) {
+                eflag[c] |= 4; eflag[c - Nw] |= 8;
+                if (i < Nh - 1) { eflag[c] |= 8; eflag[c + Nw] |= 4; }
+            } else --i;
+        }
+    }
+    __syncthreads();
+    // adjacency lists in ascending id order: up, left, right, down
+    Heap H; H.key = hkey; H.id = hid; H.n = 0;
+    for (int base = 0; base < nblk; base += 64) {
+        const int b = base + lane;
+        bool ok = false;
+        if (b < nblk) {
+            int *si = segI + (size_t)b * SEG_I;
+            const int e = eflag[b];
+            int n = 0;
+            if (e & 4) pool[b * 4 + n++] = b - Nw;
+            if (e & 1) pool[b * 4 + n++] = b - 1;
+            if (e & 2) pool[b * 4 + n++] = b + 1;
+            if (e & 8) pool[b * 4 + n++] = b + Nw;
+            si[4] = n;
+            ok = si[6] != 0;
+        }
+        unsigned long long m = __ballot(ok);
+        if (ok) { int pos = H.n + __popcll(m & ((1ull << lane) - 1)); hkey[pos] = segD[(size_t)b * SEG_D + 15]; hid[pos] = b; }
+        H.n += __popcll(m);
+    }
+    __syncthreads();
+    // Floyd heapify, one tree level at a time (sub-trees of a level are disjoint)
+    if (H.n > 1) {
+        int last_parent = (H.n - 2) / 2;
+        int lvl_start = 1; while (lvl_start * 2 - 1 <= last_parent) lvl_start *= 2;   // first index of deepest internal level + 1
+        for (int s = lvl_start - 1; ; s = (s + 1) / 2 - 1) {
+            const int e = min(2 * s, last_parent);
+            for (int i = s + lane; i <= e; i += 64) heap_sift_down(H, i);
+            __syncthreads();
+            if (s == 0) break;
+        }
+    }
+    int nseg = nblk, pooltop = nblk * 4, next = 0, flags = 0;
+    int *ext = a.extracted + (size_t)frame * 2 * MAX_PLANES;
+    ah_cluster_wave(a, frame, H, nseg, pooltop, pool, pool2, ext, next, lA, lB, cm, cN, flags);
+    if (lane == 0) {
+        int *meta = a.meta + (size_t)frame * 16;
+        meta[0] = nseg; meta[1] = pooltop; meta[2] = next; meta[3] = flags;
+        meta[6] = (pool == a.pool + (size_t)frame * a.poolcap) ? 0 : 1;      // which pool buffer is live
+    }
+#undef GOK
+#undef SD
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_peac_blkmap: findBlockMembership (block erosion) + coarse membership image
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_peac_blkmap(const int *__restrict__ parent_, const int *__restrict__ dsize_,
+                                                     const int *__restrict__ segI_, const int *__restrict__ ext_, const int *__restrict__ meta_,
+                                                     int *__restrict__ blkmap_, int *__restrict__ isvalid_, int32_t *__restrict__ labels_,
+                                                     float *__restrict__ dist_, int nblk, int Nw, int Nh, int w, int h, int segcap)
+{
+    const int frame = blockIdx.y;
+    const int *parent = parent_ + (size_t)frame * nblk, *dsize = dsize_ + (size_t)frame * nblk;
+    const int *segI = segI_ + (size_t)frame * segcap * SEG_I;
+    const int *ext = ext_ + (size_t)frame * 2 * MAX_PLANES;
+    const int next = meta_[(size_t)frame * 16 + 2];
+    int *blkmap = blkmap_ + (size_t)frame * nblk, *isvalid = isvalid_ + (size_t)frame * MAX_PLANES;
+    int32_t *labels = labels_ + (size_t)frame * w * h;
+    float *dist = dist_ + (size_t)frame * w * h;
+    // each thread handles whole blocks; pixels of invalid blocks / the remainder strip get -1
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < nblk; b += gridDim.x * 256) {
+        const int i = b / Nw, j = b - i * Nw;
+        const int setid = ds_find_ro(parent, b);
+        int plid = -1;
+        if (dsize[setid] * WIN * WIN >= MIN_SUPPORT) {
+            bool same = true;
+            if (j > 0 && ds_find_ro(parent, b - 1) != setid) same = false;
+            if (same && j < Nw - 1 && ds_find_ro(parent, b + 1) != setid) same = false;
+            if (same && i > 0 && ds_find_ro(parent, b - Nw) != setid) same = false;
+            if (same && i < Nh - 1 && ds_find_ro(parent, b + Nw) != setid) same = false;
+            if (same) {
+                plid = 0;                                           // rid2plid[setid] (std::map default 0)
+                for (int p = 0; p < next; p++) if (segI[(size_t)ext[p] * SEG_I + 1] == setid) plid = p;
+                isvalid[plid] = 1;
+            }
+        }
+        blkmap[b] = plid;
+        for (int y = i * WIN; y < (i + 1) * WIN; y++)
+            for (int x = j * WIN; x < (j + 1) * WIN; x++) { labels[y * w + x] = plid; dist[y * w + x] = 3.402823466e+38f; }
+    }
+    // strips outside the block grid
+    const int gw = Nw * WIN, gh = Nh * WIN;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < w * h; i += gridDim.x * 256) {
+        int y = i / w, x = i - y * w;
+        if (x >= gw || y >= gh) { labels[i] = -1; dist[i] = 3.402823466e+38f; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_peac_refine: seeds, floodFill, last merge round, plidmap.  One wave per frame.
+// ------------------------------------------------------------------------------------------------
+struct RfArgs {
+    ClArgs c;
+    const uint16_t *depth; size_t dframe; int pitch, w, h;
+    float fx, fy, cx, cy, dfac;
+    int *blkmap; int *isvalid; int32_t *labels; float *dist; int *qpix; int *qpl; int qcap; int *plidmap;
+    hvo_plane *planes; double c30;
+};
+
+__global__ __launch_bounds__(64) void k_peac_refine(RfArgs r)
+{
+    __shared__ double pl[MAX_PLANES][8];          // center[3], normal[3], mse, pad
+    __shared__ unsigned long long adj[MAX_PLANES];
+    __shared__ int s_tgt[64];
+    __shared__ double hkey[MAX_PLANES]; __shared__ int hid[MAX_PLANES];
+    __shared__ int lA[LCAP], lB[LCAP]; __shared__ double cm[64]; __shared__ int cN[64];
+    const ClArgs &a = r.c;
+    const int frame = blockIdx.x, lane = threadIdx.x;
+    const int w = r.w, h = r.h, Nw = a.Nw, Nh = a.Nh, nblk = a.nblk;
+    int *meta = a.meta + (size_t)frame * 16;
+    const int nold = meta[2];
+    int *ext = a.extracted + (size_t)frame * 2 * MAX_PLANES;
+    double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
+    int *segI = a.segI + (size_t)frame * a.segcap * SEG_I;
+    int *pool = a.pool + (size_t)frame * a.poolcap, *pool2 = a.pool2 + (size_t)frame * a.poolcap;
+    if (meta[6]) { int *t = pool; pool = pool2; pool2 = t; }
+    const int *blkmap = r.blkmap + (size_t)frame * nblk;
+    const int *isvalid = r.isvalid + (size_t)frame * MAX_PLANES;
+    int32_t *labels = r.labels + (size_t)frame * w * h;
+    float *dist = r.dist + (size_t)frame * w * h;
+    int *qpix = r.qpix + (size_t)frame * r.qcap, *qpl = r.qpl + (size_t)frame * r.qcap;
+    int *plidmap = r.plidmap + (size_t)frame * MAX_PLANES;
+    const uint16_t *D = r.depth + (size_t)frame * r.dframe;
+    int flags = meta[3];
+    if (lane < MAX_PLANES) {
+        adj[lane] = 0;
+        if (lane < nold) { const double *sd = segD + (size_t)ext[lane] * SEG_D; for (int k = 0; k < 7; k++) pl[lane][k] = sd[9 + k]; }
+    }
+    __syncthreads();
+    // ---- seeds in block raster order (AHCPlaneFitter.hpp:543-575): count, scan, write ----
+    int nq = 0;
+    for (int base = 0; base < nblk; base += 64) {
+        const int b = base + lane;
+        int cnt = 0, m = -2, up = -2, lf = -2, i = 0, j = 0;
+        if (b < nblk) {
+            i = b / Nw; j = b - i * Nw; m = blkmap[b];
+            up = i > 0 ? blkmap[b - Nw] : -2; lf = j > 0 ? blkmap[b - 1] : -2;
+            if (m < 0) { if (i > 0 && up >= 0) cnt += WIN - 1; if (j > 0 && lf >= 0) cnt += WIN - 1; }
+            else { if (i > 0 && up != m) cnt += WIN - 1; if (j > 0 && lf != m) cnt += WIN - 1; }
+        }
+        int incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        int pos = nq + incl - cnt;
+        if (cnt && pos + cnt <= r.qcap) {
+            if (m < 0) {
+                if (i > 0 && up >= 0) { const int sp = (i * WIN - 1) * w + j * WIN; for (int k = 1; k < WIN; ++k) { qpix[pos] = sp + k; qpl[pos++] = up; } }
+                if (j > 0 && lf >= 0) { const int sp = (i * WIN) * w + j * WIN - 1; for (int k = 0; k < WIN - 1; ++k) { qpix[pos] = sp + k * w; qpl[pos++] = lf; } }
+            } else {
+                if (i > 0 && up != m) { const int sp = (i * WIN) * w + j * WIN; for (int k = 0; k < WIN - 1; ++k) { qpix[pos] = sp + k; qpl[pos++] = m; } }
+                if (j > 0 && lf != m) { const int sp = (i * WIN) * w + j * WIN; for (int k = 1; k < WIN; ++k) { qpix[pos] = sp + k * w; qpl[pos++] = m; } }
+            }
+        }
+        nq += __shfl(incl, 63);
+    }
+    if (nq > r.qcap) { nq = r.qcap; flags |= 32; }
+    __syncthreads();
+    // ---- floodFill (AHCPlaneFitter.hpp:428-476).  Events = (queue entry, neighbour slot) in queue
+    // order; a round evaluates 64 consecutive events and commits the longest prefix in which no two
+    // events touch the same pixel, so every per-pixel state machine sees its events in queue order.
+    const double dfx = (double)r.fx, dfy = (double)r.fy, dcx = (double)r.cx, dcy = (double)r.cy, df = (double)r.dfac;
+    long long ev = 0;                                   // next event = entry*4 + slot
+    while (ev < (long long)nq * 4) {
+        const long long e = ev + lane;
+        const int k = (int)(e >> 2), slot = (int)(e & 3);
+        int cIdx = -1, plid = 0;
+        if (k < nq) {
+            const int sIdx = qpix[k]; plid = qpl[k];
+            const int sy = sIdx / w, sx = sIdx - sy * w;
+            // getValid4Neighbor order: left, right, up, down (only those inside the image)
+            int c = 0, t = -1;
+            if (sx > 0) { if (c == slot) t = sIdx - 1; c++; }
+            if (sx < w - 1) { if (c == slot) t = sIdx + 1; c++; }
+            if (sy > 0) { if (c == slot) t = sIdx - w; c++; }
+            if (sy < h - 1) { if (c == slot) t = sIdx + w; c++; }
+            cIdx = t;
+        }
+        s_tgt[lane] = cIdx;
+        __syncthreads();
+        bool conflict = false;
+        if (cIdx >= 0) for (int q = 0; q < lane; q++) conflict |= (s_tgt[q] == cIdx);
+        const unsigned long long cm_ = __ballot(conflict);
+        int ncommit = cm_ ? __ffsll((long long)cm_) - 1 : 64;           // >= 1: lane 0 never conflicts
+        // never step past the queue tail as it stood when the round started: entries pushed by
+        // this round's events are evaluated in a later round
+        { const long long avail = (long long)nq * 4 - ev; if (avail < ncommit) ncommit = (int)avail; }
+        bool push = false;
+        if (lane < ncommit && cIdx >= 0) {
+            int trail = labels[cIdx];
+            bool skip = trail <= -6 || (trail >= 0 && trail == plid);
+            if (!skip) {
+                const int cy_ = cIdx / w, cx_ = cIdx - cy_ * w;
+                const int by = cy_ / WIN, bx = cx_ / WIN;
+                const int blkid = (by < Nh && bx < Nw) ? by * Nw + bx : -1;
+                if (!(blkid >= 0 && blkmap[blkid] >= 0)) {
+                    const int d = D[(size_t)cy_ * r.pitch + cx_];
+                    bool ok = d != 0;
+                    float cdist = -1;
+                    if (ok) {
+                        const double z = (double)d * df;
+                        const double x = ((double)cx_ - dcx) * z / dfx, y = ((double)cy_ - dcy) * z / dfy;
+                        const double *P = pl[plid];
+                        const double sd = P[3] * (x - P[0]) + P[4] * (y - P[1]) + P[5] * (z - P[2]);
+                        cdist = (float)fabs(sd);
+                        ok = ((double)cdist * (double)cdist) < 9 * P[6] + 1e-5;
+                    }
+                    if (ok) {
+                        if (trail >= 0) {
+                            const double *Q = pl[trail], *P = pl[plid];
+                            if (fabs(P[3] * Q[3] + P[4] * Q[4] + P[5] * Q[5]) >= r.c30) {
+                                atomicOr(&adj[trail], 1ull << plid); atomicOr(&adj[plid], 1ull << trail);
+                            }
+                        }
+                        if (cdist < dist[cIdx]) { labels[cIdx] = plid; dist[cIdx] = cdist; push = true; }
+                        else if (trail < 0) labels[cIdx] = trail - 1;
+                    } else if (trail < 0) labels[cIdx] = trail - 1;
+                }
+            }
+        }
+        const unsigned long long pm = __ballot(push);
+        if (push) {
+            const int pos = nq + __popcll(pm & ((1ull << lane) - 1));
+            if (pos < r.qcap) { qpix[pos] = cIdx; qpl[pos] = plid; }
+        }
+        nq += __popcll(pm);
+        if (nq > r.qcap) { nq = r.qcap; flags |= 32; }
+        ev += ncommit;
+        __syncthreads();
+    }
+    // ---- one last merge round over the still-valid coarse planes (AHCPlaneFitter.hpp:321-340) ----
+    Heap H; H.key = hkey; H.id = hid; H.n = 0;
+    int nseg = meta[0], pooltop = meta[1];
+    if (pooltop + nold * MAX_PLANES > a.poolcap - 2 * a.nblk) pool_gc(segI, nseg, pool, pool2, pooltop);
+    if (lane == 0) {
+        // fresh adjacency lists from the connect() calls, ascending seg id
+        for (int p = 0; p < nold; p++) {
+            int *si = segI + (size_t)ext[p] * SEG_I;
+            si[3] = pooltop + p * MAX_PLANES; si[4] = 0; si[5] = MAX_PLANES;
+        }
+        for (int p = 0; p < nold; p++) {
+            int ids[MAX_PLANES], n = 0;
+            for (int q = 0; q < nold; q++) if ((adj[p] >> q) & 1ull) ids[n++] = ext[q];
+            for (int x = 1; x < n; x++) { int v = ids[x], y = x - 1; while (y >= 0 && ids[y] > v) { ids[y + 1] = ids[y]; y--; } ids[y + 1] = v; }
+            int *si = segI + (size_t)ext[p] * SEG_I;
+            for (int x = 0; x < n; x++) pool[si[3] + x] = ids[x];
+            si[4] = n;
+        }
+        for (int p = 0; p < nold; p++) if (isvalid[p]) heap_push(H, segD[(size_t)ext[p] * SEG_D + 15], ext[p]);
+        cN[0] = H.n;
+    }
+    __syncthreads();
+    H.n = cN[0];
+    pooltop += nold * MAX_PLANES;
+    __syncthreads();
+    int *fin = ext + MAX_PLANES;
+    int nfin = 0;
+    if (pooltop <= a.poolcap) ah_cluster_wave(a, frame, H, nseg, pooltop, pool, pool2, fin, nfin, lA, lB, cm, cN, flags);
+    else flags |= 8;
+    const int *parent = a.parent + (size_t)frame * nblk;
+    if (lane == 0) {
+        for (int p = 0; p < MAX_PLANES; p++) plidmap[p] = -1;
+        for (int p = 0; p < nold; p++) {
+            if (!isvalid[p]) continue;
+            const int np_rid = ds_find_ro(parent, segI[(size_t)ext[p] * SEG_I + 1]);
+            for (int j = 0; j < nfin; j++) if (segI[(size_t)fin[j] * SEG_I + 1] == np_rid) { plidmap[p] = j; break; }
+        }
+        hvo_plane *out = r.planes + (size_t)frame * MAX_PLANES;
+        for (int j = 0; j < nfin; j++) {
+            const double *sd = segD + (size_t)fin[j] * SEG_D;
+            for (int k = 0; k < 3; k++) { out[j].normal[k] = sd[12 + k]; out[j].center[k] = sd[9 + k]; }
+            out[j].mse = sd[15]; out[j].n_points = segI[(size_t)fin[j] * SEG_I]; out[j].rid = segI[(size_t)fin[j] * SEG_I + 1];
+        }
+        meta[3] = flags; meta[4] = nfin; meta[5] = nq;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_peac_relabel(int32_t *__restrict__ labels, const int *__restrict__ plidmap, int npix)
+{
+    const int frame = blockIdx.y;
+    int32_t *L = labels + (size_t)frame * npix;
+    const int *pm = plidmap + (size_t)frame * MAX_PLANES;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        int v = L[i];
+        L[i] = (v >= 0 && pm[v] >= 0) ? pm[v] : -1;
+    }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+void peac_free(hvo_ctx *ctx)
+{
+    PeacPlan *P = plan_of(ctx);
+    if (!P) return;
+    void *ptrs[] = { P->d_depth, P->d_segD, P->d_segI, P->d_pool, P->d_pool2, P->d_parent, P->d_dsize, P->d_eflag, P->d_meta, P->d_extracted,
+                     P->d_blkmap, P->d_labels, P->d_dist, P->d_qpix, P->d_qpl, P->d_plidmap, P->d_isvalid, P->d_planes };
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    delete P;
+    ctx->peac = nullptr;
+}
+
+static int peac_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
+{
+    PeacPlan *P = plan_of(ctx);
+    if (P && P->w == w && P->h == h && P->batch >= batch) return HVO_OK;
+    if (w < 2 * WIN || h < 2 * WIN || w > 4096 || h > 4096) return HVO_ERR_UNSUPPORTED;
+    peac_free(ctx);
+    P = new PeacPlan();
+    ctx->peac = P;
+    P->w = w; P->h = h; P->pitch = (w + 31) & ~31; P->Nw = w / WIN; P->Nh = h / WIN; P->nblk = P->Nw * P->Nh;
+    P->segcap = 2 * P->nblk + 2 * MAX_PLANES; P->poolcap = 16 * P->nblk + 2 * MAX_PLANES * MAX_PLANES; P->qcap = 2 * w * h + 65536; P->batch = batch;
+    const double deg = 3.14159265358979323846 / 180.0;
+    // ParamSet: T_ang(P_INIT) clipped at z_near, similarityTh_merge, similarityTh_refine (AHCParamSet.hpp:68-76,113-134)
+    const double factor = (90.0 * deg - 15.0 * deg) / (4000.0 - 500.0);
+    P->c15 = cos(factor * 500.0 + 15.0 * deg - factor * 500.0);
+    P->c60 = cos(60.0 * deg); P->c30 = cos(30.0 * deg);
+    const size_t B = batch, npix = (size_t)w * h;
+#define PA(ptr, n) HVO_HIP(hipMalloc((void **)&(ptr), (n)))
+    PA(P->d_depth, B * P->pitch * (h + 1) * sizeof(uint16_t));
+    PA(P->d_segD, B * P->segcap * SEG_D * sizeof(double));
+    PA(P->d_segI, B * P->segcap * SEG_I * sizeof(int));
+    PA(P->d_pool, B * P->poolcap * sizeof(int));
+    PA(P->d_pool2, B * P->poolcap * sizeof(int));
+    PA(P->d_parent, B * P->nblk * sizeof(int)); PA(P->d_dsize, B * P->nblk * sizeof(int)); PA(P->d_eflag, B * P->nblk * sizeof(int));
+    PA(P->d_meta, B * 16 * sizeof(int)); PA(P->d_extracted, B * 2 * MAX_PLANES * sizeof(int));
+    PA(P->d_blkmap, B * P->nblk * sizeof(int)); PA(P->d_labels, B * npix * sizeof(int32_t)); PA(P->d_dist, B * npix * sizeof(float));
+    PA(P->d_qpix, B * P->qcap * sizeof(int)); PA(P->d_qpl, B * P->qcap * sizeof(int));
+    PA(P->d_plidmap, B * MAX_PLANES * sizeof(int)); PA(P->d_isvalid, B * MAX_PLANES * sizeof(int));
+    PA(P->d_planes, B * MAX_PLANES * sizeof(hvo_plane));
+#undef PA
+    // stream-ordered fill: a null-stream hipMemset is not ordered against the non-blocking ctx stream
+    HVO_HIP(hipMemsetAsync(P->d_depth, 0, B * P->pitch * (h + 1) * sizeof(uint16_t), ctx->stream));
+    HVO_HIP(hipDeviceSynchronize());
+    return HVO_OK;
+}
+
+int peac_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h)
+{
+    int rc = peac_ensure_plan(ctx, w, h, std::max(n, ctx->p.max_batch));
+    if (rc) return rc;
+    PeacPlan *P = plan_of(ctx);
+    const size_t dframe = (size_t)P->pitch * (h + 1);
+    for (int f = 0; f < n; f++) {
+        if (!in[f].depth) return HVO_ERR_INVALID_ARG;
+        HVO_HIP(hipMemcpy2DAsync(P->d_depth + f * dframe, P->pitch * sizeof(uint16_t), in[f].depth, in[f].depth_stride,
+                                 (size_t)w * sizeof(uint16_t), h, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    return HVO_OK;
+}
+
+int peac_run(hvo_ctx *ctx, int n)
+{
+    PeacPlan *P = plan_of(ctx);
+    if (!P || n < 1 || n > P->batch) return HVO_ERR_INVALID_ARG;
+    hipStream_t st = ctx->stream;
+    const size_t dframe = (size_t)P->pitch * (P->h + 1);
+    const hvo_params &p = ctx->p;
+    HVO_HIP(hipMemsetAsync(P->d_isvalid, 0, (size_t)n * MAX_PLANES * sizeof(int), st));
+    int id = hvo_prof_begin(ctx, "peac_blocks");
+    hipLaunchKernelGGL(k_peac_blocks, dim3((P->nblk + 63) / 64, n), dim3(64), 0, st, P->d_depth, dframe, P->pitch, P->w, P->h, P->Nw, P->nblk,
+                       p.fx, p.fy, p.cx, p.cy, p.depth_map_factor, P->d_segD, P->d_segI, P->segcap);
+    hvo_prof_end(ctx, id);
+    ClArgs a;
+    a.segD = P->d_segD; a.segI = P->d_segI; a.pool = P->d_pool; a.pool2 = P->d_pool2; a.parent = P->d_parent; a.dsize = P->d_dsize; a.eflag = P->d_eflag;
+    a.meta = P->d_meta; a.extracted = P->d_extracted; a.segcap = P->segcap; a.poolcap = P->poolcap; a.nblk = P->nblk; a.Nw = P->Nw; a.Nh = P->Nh;
+    a.c15 = P->c15; a.c60 = P->c60;
+    const size_t lds = (size_t)P->nblk * 12 + 2 * LCAP * 4 + 8 + 64 * 8 + 64 * 4;
+    if (lds > 160 * 1024) return HVO_ERR_UNSUPPORTED;
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds_set < lds) {
+        HVO_HIP(hipFuncSetAttribute((const void *)k_peac_cluster, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    id = hvo_prof_begin(ctx, "peac_cluster");
+    hipLaunchKernelGGL(k_peac_cluster, dim3(n), dim3(64), lds, st, a);
+    hvo_prof_end(ctx, id);
+    id = hvo_prof_begin(ctx, "peac_refine");
+    hipLaunchKernelGGL(k_peac_blkmap, dim3(16, n), dim3(256), 0, st, P->d_parent, P->d_dsize, P->d_segI, P->d_extracted, P->d_meta, P->d_blkmap,
+                       P->d_isvalid, P->d_labels, P->d_dist, P->nblk, P->Nw, P->Nh, P->w, P->h, P->segcap);
+    RfArgs r;
+    r.c = a; r.depth = P->d_depth; r.dframe = dframe; r.pitch = P->pitch; r.w = P->w; r.h = P->h;
+    r.fx = p.fx; r.fy = p.fy; r.cx = p.cx; r.cy = p.cy; r.dfac = p.depth_map_factor;
+    r.blkmap = P->d_blkmap; r.isvalid = P->d_isvalid; r.labels = P->d_labels; r.dist = P->d_dist; r.qpix = P->d_qpix; r.qpl = P->d_qpl;
+    r.qcap = P->qcap; r.plidmap = P->d_plidmap; r.planes = P->d_planes; r.c30 = P->c30;
+    hipLaunchKernelGGL(k_peac_refine, dim3(n), dim3(64), 0, st, r);
+    hipLaunchKernelGGL(k_peac_relabel, dim3(64, n), dim3(256), 0, st, P->d_labels, P->d_plidmap, P->w * P->h);
+    hvo_prof_end(ctx, id);
+    HVO_HIP(hipGetLastError());
+    return HVO_OK;
+}
+
+int peac_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
+{
+    PeacPlan *P = plan_of(ctx);
+    if (!P) return HVO_ERR_INVALID_ARG;
+    std::vector<int> meta((size_t)n * 16);
+    HVO_HIP(hipMemcpyAsync(meta.data(), P->d_meta, meta.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t npix = (size_t)P->w * P->h;
+    for (int f = 0; f < n; f++) {
+        const int nfin = meta[(size_t)f * 16 + 4], flags = meta[(size_t)f * 16 + 3];
+        if (flags) out[f].status = HVO_ERR_CAPACITY;
+        if (out[f].labels) HVO_HIP(hipMemcpyAsync(out[f].labels, P->d_labels + f * npix, npix * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        int m = nfin;
+        if (out[f].planes) {
+            if (m > out[f].pl_cap) { m = out[f].pl_cap; out[f].status = HVO_ERR_CAPACITY; }
+            if (m > 0) HVO_HIP(hipMemcpyAsync(out[f].planes, P->d_planes + (size_t)f * MAX_PLANES, (size_t)m * sizeof(hvo_plane), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        out[f].n_planes = m;
+    }
+    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    return HVO_OK;
+}
+
+extern "C" int hvo_compute_planes(hvo_ctx *ctx, const uint16_t *depth, int w, int h, int stride,
+                                  int32_t *labels, hvo_plane *planes, int cap, int *n)
+{
+    if (!ctx || !n) return HVO_ERR_INVALID_ARG;
+    *n = 0;
+    if (!depth || w <= 0 || h <= 0) return HVO_ERR_BAD_DTYPE;      // PlaneExtractor.cpp:34-38: empty image -> false
+    if (cap < 0 || stride < w * 2) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    hvo_frame_in in; memset(&in, 0, sizeof(in));
+    in.depth = depth; in.depth_stride = stride;
+    int rc = peac_upload(ctx, 1, &in, w, h);
+    if (rc) return rc;
+    for (int i = 0; i < ctx->nprof; i++) ctx->prof[i].used = false;
+    if ((rc = peac_run(ctx, 1))) return rc;
+    hvo_frame_out out; memset(&out, 0, sizeof(out));
+    out.labels = labels; out.planes = planes; out.pl_cap = cap;
+    if ((rc = peac_download(ctx, 1, &out))) return rc;
+    *n = out.n_planes;
+    return out.status;
+}

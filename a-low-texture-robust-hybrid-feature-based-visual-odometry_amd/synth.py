@@ -110,7 +110,7 @@ def make_depth(seed, w=640, h=480, holes=True):
     dy = (i - K["cy"]) / K["fy"]
     jit = _randint(seed, 10, 8, -50, 51).astype(np.float64) / 1000.0
     planes = [  # (nx, ny, nz, d): n.X = d
-        (0.03 + jit[0] * 0.2, 0.97, -0.24, 1.15 + jit[1]),      # floor
+        (0.03 + jit[0] * 0.2, 0.97, 0.10, 1.20 + jit[1]),       # floor
         (0.05, 0.02 + jit[2] * 0.2, 1.0, 3.5 + jit[3] * 4),     # back wall
         (-0.96, 0.0, 0.28 + jit[4], 1.7 + jit[5]),              # left wall
     ]

@@ -91,6 +91,16 @@ int         orc_orb_grid(const orc_orb *o, int level, int *ncols, int *nrows, in
 int         orc_orb_candidates(const orc_orb *o, int level, const int **xys);
 int         orc_orb_level_count(const orc_orb *o, int level);            /* kps kept at level */
 
+/* ---------------- PEAC planes (peac.c): src/PlaneExtractor.cpp, include/peac ---------------- */
+/* readDepthImage + PlaneFitter::run.  labels: w*h int32 (-1 = none); planes sorted by N desc. */
+int  orc_peac_run(const uint16_t *depth, int w, int h, int stride_bytes,
+                  float fx, float fy, float cx, float cy, float depth_factor,
+                  int32_t *labels, orc_plane *planes, int cap, int *nplanes);
+void orc_eig33sym(const double K[3][3], double s[3], double V[3][3]);
+double orc_peac_T_mse_init(double z);
+double orc_peac_T_ang_init(double z);
+double orc_peac_T_dz(double z);
+
 /* ---------------- Hamming (match.c): src/ORBmatcher.cc:1676, LSDmatcher.cpp:803-863,1137 ---- */
 int  orc_descriptor_distance(const uint8_t *a, const uint8_t *b);
 /* cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, 2): idx2/dist2 are nq*2, -1/INT_MAX padded */

@@ -208,3 +208,22 @@ def fast9_16(view, threshold, cap=4096):
     out = np.zeros((cap, 3), np.int32)
     n = lib().orc_fast9_16(_p(view), view.strides[0], w, h, threshold, _p(out), cap)
     return out[:n].copy()
+
+
+def peac(depth, fx=535.4, fy=539.2, cx=320.1, cy=247.6, depth_factor=None, cap=64):
+    """PlaneDetection::readDepthImage + runPlaneDetection (src/PlaneExtractor.cpp:26-66)"""
+    depth = np.ascontiguousarray(depth, np.uint16); h, w = depth.shape
+    if depth_factor is None:
+        depth_factor = float(np.float32(1.0) / np.float32(5000.0))
+    labels = np.zeros((h, w), np.int32); planes = np.zeros(cap, PLANE_DT); n = C.c_int(0)
+    L = lib()
+    L.orc_peac_run(_p(depth), w, h, depth.strides[0], fx, fy, cx, cy, depth_factor, _p(labels), _p(planes), cap, C.byref(n))
+    return labels, planes[: min(n.value, cap)].copy()
+
+
+def eig33sym(K):
+    K = np.ascontiguousarray(K, np.float64); s = np.zeros(3); V = np.zeros((3, 3))
+    L = lib()
+    L.orc_eig33sym.argtypes = [C.c_void_p] * 3
+    L.orc_eig33sym(_p(K), _p(s), _p(V))
+    return s, V

@@ -115,3 +115,42 @@ def test_orb_extract_runs_and_is_deterministic(orc, synth):
 def test_orb_empty_image(orc):
     kp, d = orc.Orb().extract(np.full((480, 640), 128, np.uint8))
     assert len(kp) == 0
+
+
+# ---------------- PEAC known answers ----------------
+def _peac_fn(orc, name):
+    import ctypes
+    f = getattr(orc.lib(), name); f.restype = ctypes.c_double; f.argtypes = [ctypes.c_double]
+    return f
+
+
+def test_peac_thresholds(orc):
+    # AHCParamSet.hpp:68-76,88-146 with the metres-vs-mm quirk (H4)
+    assert abs(_peac_fn(orc, "orc_peac_T_mse_init")(3.0) - (1.6e-6 * 9 + 5) ** 2) < 1e-12
+    assert abs(_peac_fn(orc, "orc_peac_T_ang_init")(3.0) - np.cos(np.radians(15.0))) < 1e-15
+    assert abs(_peac_fn(orc, "orc_peac_T_ang_init")(499.0) - np.cos(np.radians(15.0))) < 1e-15
+    assert abs(_peac_fn(orc, "orc_peac_T_dz")(2.0) - 0.1) < 1e-15
+
+
+def test_peac_exact_plane_oracle(orc):
+    h, w = 480, 640
+    j = np.arange(w)[None, :]; i = np.arange(h)[:, None]
+    z = 2.0 / (0.1 * (j - 320.1) / 535.4 + 0.2 * (i - 247.6) / 539.2 + 1.0)
+    lab, pl = orc.peac(np.rint(z * 5000).astype(np.uint16))
+    assert len(pl) == 1 and pl["n_points"][0] == w * h and pl["mse"][0] < 1e-6
+    assert np.dot(pl["normal"][0], pl["center"][0]) <= 0 and np.all(lab == 0)
+
+
+def test_eig33sym_against_numpy(orc):
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        a = rng.normal(size=(3, 3)); K = a @ a.T * rng.uniform(1e-3, 1e3)
+        s, V = orc.eig33sym(K)
+        assert np.allclose(s, np.linalg.eigvalsh(K), rtol=1e-10, atol=1e-12)
+        assert np.allclose(K @ V, V * s, atol=1e-9 * np.abs(K).max())
+
+
+def test_peac_synthetic_scene_finds_the_walls(orc, synth):
+    lab, pl = orc.peac(synth.make_depth(0x5EED0002))
+    assert len(pl) == 4 and np.all(np.diff(pl["n_points"]) <= 0)
+    assert set(np.unique(lab)) == {-1, 0, 1, 2, 3}

@@ -1,0 +1,91 @@
+"""GPU parity of the PEAC/AHC plane extraction (hvo_compute_planes) vs the CPU oracle.
+Bar: plane labels bit-exact; plane parameters are fp64 computed in the same operation order --
+expected bit-equal, asserted to 1e-9 relative (well inside the 1e-4 of BASELINE.json)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def check(labels_g, planes_g, labels_o, planes_o):
+    assert len(planes_g) == len(planes_o), (len(planes_g), len(planes_o))
+    assert np.array_equal(planes_g["n_points"], planes_o["n_points"])
+    assert np.array_equal(planes_g["rid"], planes_o["rid"])
+    for f in ("normal", "center", "mse"):
+        assert np.allclose(planes_g[f], planes_o[f], rtol=1e-9, atol=1e-12), f
+    assert np.array_equal(labels_g, labels_o), int((labels_g != labels_o).sum())
+
+
+@pytest.mark.parametrize("seed", [0x5EED0002, 0x5EED1000, 0x5EED1003, 77])
+def test_peac_parity_640(gpu_ctx, orc, synth, seed):
+    d = synth.make_depth(seed)
+    lo, po = orc.peac(d)
+    lg, pg = gpu_ctx.compute_planes(d)
+    assert len(po) >= 3
+    check(lg, pg, lo, po)
+
+
+def test_peac_exact_plane(gpu_ctx, orc):
+    """known answer: an exact plane gives one plane, mse ~ 0, n.c <= 0"""
+    h, w = 480, 640
+    j = np.arange(w)[None, :]; i = np.arange(h)[:, None]
+    z = 2.0 / (0.1 * (j - 320.1) / 535.4 + 0.2 * (i - 247.6) / 539.2 + 1.0)
+    d = np.rint(z * 5000).astype(np.uint16)
+    lg, pg = gpu_ctx.compute_planes(d)
+    lo, po = orc.peac(d)
+    check(lg, pg, lo, po)
+    assert len(pg) == 1 and pg["n_points"][0] == w * h and pg["mse"][0] < 1e-6
+    n = pg["normal"][0]; c = pg["center"][0]
+    assert np.dot(n, c) <= 0
+    assert np.allclose(np.abs(n), np.array([0.1, 0.2, 1.0]) / np.linalg.norm([0.1, 0.2, 1.0]), atol=1e-3)
+    assert np.all(lg == 0)
+
+
+def test_peac_no_depth_gives_no_planes(gpu_ctx):
+    lg, pg = gpu_ctx.compute_planes(np.zeros((480, 640), np.uint16))
+    assert len(pg) == 0 and np.all(lg == -1)
+
+
+def test_peac_holes_and_steps(gpu_ctx, orc):
+    """two fronto-parallel planes at different depth + a band of missing data"""
+    d = np.full((480, 640), 10000, np.uint16)
+    d[:, 330:] = 14000
+    d[200:230, :] = 0
+    rng = np.random.default_rng(5)
+    d = (d.astype(np.int32) + rng.integers(-20, 21, d.shape) * (d > 0)).astype(np.uint16)
+    lo, po = orc.peac(d)
+    lg, pg = gpu_ctx.compute_planes(d)
+    assert len(po) >= 2
+    check(lg, pg, lo, po)
+
+
+def test_peac_1280(hvo, orc, synth):
+    d = synth.make_depth(0x5EED0003, 1280, 960)
+    K = synth.intrinsics(1280, 960)
+    lo, po = orc.peac(d, fx=np.float32(K["fx"]), fy=np.float32(K["fy"]), cx=np.float32(K["cx"]), cy=np.float32(K["cy"]))
+    ctx = hvo.Context(fx=K["fx"], fy=K["fy"], cx=K["cx"], cy=K["cy"])
+    try:
+        lg, pg = ctx.compute_planes(d)
+    finally:
+        ctx.close()
+    check(lg, pg, lo, po)
+
+
+def test_peac_wrong_dtype(gpu_ctx, hvo):
+    with pytest.raises(hvo.HvoError):
+        gpu_ctx.compute_planes(np.zeros((480, 640), np.float32))     # PlaneExtractor.cpp:34-38
+
+
+def test_peac_batch(hvo, orc, synth):
+    gray, depth = synth.make_batch("std", 0x5EED1000, 4)
+    ctx = hvo.Context(max_batch=4)
+    try:
+        ctx.batch_upload(gray, depth)
+        ctx.batch_run(hvo.STAGE_PLANES)
+        res = ctx.batch_download(hvo.STAGE_PLANES)
+    finally:
+        ctx.close()
+    for b in range(4):
+        lo, po = orc.peac(depth[b])
+        assert res[b]["status"] == 0
+        check(res[b]["labels"], res[b]["planes"], lo, po)
