@@ -16,6 +16,7 @@
 #define HVO_CELL_CAP 256           // max NMS survivors kept per cell
 #define HVO_MAX_PROFILE 32
 #define HVO_HAVE_PEAC 1           // peac.hip is built (stubs.hip drops its PEAC stubs)
+#define HVO_HAVE_LSD 1            // lsd.hip is built
 
 struct LevelGeom {
     int w, h, pitch;

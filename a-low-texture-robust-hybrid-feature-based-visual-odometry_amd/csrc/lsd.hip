@@ -1,0 +1,826 @@
+// lsd.hip -- batched LSD line detection + LBD descriptors for gfx950 (MI355X).
+//
+// Replaces LINEextractor::operator() (reference src/LineExtractor.cpp:329-380):
+//   LSDDetector::detect -> cv::LineSegmentDetector (OpenCV 3.2 lsd.cpp, not vendored; semantics as
+//                          documented in oracle/lsd.c), KeyLine construction
+//                          (Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:161-196)
+//   keep the nLSDFeature strongest lines (LineExtractor.cpp:351-360)
+//   BinaryDescriptor::compute -> LBD (Thirdparty/line_descriptor/src/binary_descriptor_custom.cpp:
+//                          350-398 blur+Sobel, 1026-1372 computeLBD, 401-412 binary conversion)
+//   normalised 2-D line functions (LineExtractor.cpp:367-377)
+//
+// Kernels
+//   k_lsd_blur_h / k_lsd_blur_v   GaussianBlur 7x7 sigma 0.75 on the CV_64F image (row / column pass)
+//   k_lsd_resize_grad             0.8x INTER_LINEAR resize (double) fused with ll_angle: gradient norm,
+//                                 level-line angle, per-pixel cos/sin of the angle, "defined" bitmask
+//   k_lsd_grow                    one wave per frame: raster-order seeds, region_grow, region2rect,
+//                                 refine / reduce_region_radius; neighbourhoods of up to 7 pending
+//                                 region points are fetched per memory round trip, decisions are
+//                                 taken in the reference's sequential order; emits segments,
+//                                 key-lines, the top-N selection and the line functions
+//   k_lbd_blur5 / k_lbd_sobel     GaussianBlur 5x5 sigma 1 (u8 fixed point) and Sobel dx, dy (s16)
+//   k_lbd_desc                    one 64-thread workgroup per line: 63 row sums, 9 band sums,
+//                                 normalisation, 32-byte binary descriptor
+//
+// fp64/fp32 steps follow the oracle operation by operation (-ffp-contract=off).
+#include "hvo_internal.hpp"
+#include <math.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+
+#define LSD_PI 3.1415926535897932384626433832795
+#define LSD_NOTDEF (-1024.0)
+#define LSD_MAXSEG 4096           // segments kept per frame before the top-N selection
+#define LSD_RING 1024             // pending region points mirrored in LDS
+
+struct LsdPlan {
+    int w = 0, h = 0, sw = 0, sh = 0, batch = 0, nfeat = 0, nwords = 0;
+    double *d_tmp = nullptr, *d_blur = nullptr;            // w*h doubles each
+    double *d_modgrad = nullptr, *d_ang = nullptr, *d_cs = nullptr, *d_sn = nullptr;   // sw*sh
+    unsigned *d_defined = nullptr;                          // bitmask, nwords per frame
+    int *d_reg = nullptr;                                   // sw*sh ints
+    float *d_segs = nullptr;                                // LSD_MAXSEG x 4
+    hvo_keyline *d_kl_all = nullptr;                        // LSD_MAXSEG
+    hvo_keyline *d_kl = nullptr; uint8_t *d_desc = nullptr; double *d_fn = nullptr; int *d_nkl = nullptr; int *d_flags = nullptr;
+    uint8_t *d_b5 = nullptr; int16_t *d_dx = nullptr, *d_dy = nullptr;
+    int *d_xofs = nullptr, *d_yofs = nullptr; float *d_xa = nullptr, *d_yb = nullptr;   // resize tables
+    double k7[4] = { 0, 0, 0, 0 };                          // gaussian taps (double): k[0..3], symmetric
+    int k5[3] = { 0, 0, 0 };
+    double gL[21], gG[63];
+    float *d_gL = nullptr, *d_gG = nullptr;
+    double rho = 0, prec = 0, p = 0; unsigned min_reg = 0;
+};
+static LsdPlan *plan_of(hvo_ctx *ctx) { return (LsdPlan *)ctx->lsd; }
+
+static __device__ __forceinline__ int refl(int p, int n) { if (p < 0) p = -p; if (p >= n) p = 2 * (n - 1) - p; return p < 0 ? 0 : p; }
+
+// cv::fastAtan2, float, evaluated without contraction (same as orb.hip)
+static __device__ __forceinline__ float fatan2_deg(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float eps = (float)2.2204460492503131e-16;
+    float ax = fabsf(x), ay = fabsf(y), r, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps)); c2 = __fmul_rn(c, c);
+        r = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps)); c2 = __fmul_rn(c, c);
+        r = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) r = __fsub_rn(180.f, r);
+    if (y < 0) r = __fsub_rn(360.f, r);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gaussian blur 7x7 on the double image.  Row pass: s = k0*S[0]; s += k[i]*S[i] (RowFilter order);
+// column pass: s = kc*S[0]; s += k[j]*(S[+j] + S[-j]) (SymmColumnFilter order).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lsd_blur_h(const uint8_t *__restrict__ gray, size_t gframe, int gpitch,
+                                                    double *__restrict__ tmp, int w, int h, double k0, double k1, double k2, double k3)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    if (x >= w) return;
+    const uint8_t *S = gray + (size_t)f * gframe + (size_t)y * gpitch;
+    double s = k0 * (double)S[refl(x - 3, w)];
+    s += k1 * (double)S[refl(x - 2, w)];
+    s += k2 * (double)S[refl(x - 1, w)];
+    s += k3 * (double)S[x];
+    s += k2 * (double)S[refl(x + 1, w)];
+    s += k1 * (double)S[refl(x + 2, w)];
+    s += k0 * (double)S[refl(x + 3, w)];
+    tmp[((size_t)f * h + y) * w + x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_lsd_blur_v(const double *__restrict__ tmp, double *__restrict__ blur, int w, int h,
+                                                    double k0, double k1, double k2, double k3)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    if (x >= w) return;
+    const double *T = tmp + (size_t)f * h * w;
+    double s = k3 * T[(size_t)y * w + x];
+    s += k2 * (T[(size_t)refl(y + 1, h) * w + x] + T[(size_t)refl(y - 1, h) * w + x]);
+    s += k1 * (T[(size_t)refl(y + 2, h) * w + x] + T[(size_t)refl(y - 2, h) * w + x]);
+    s += k0 * (T[(size_t)refl(y + 3, h) * w + x] + T[(size_t)refl(y - 3, h) * w + x]);
+    blur[((size_t)f * h + y) * w + x] = s;
+}
+
+// scaled(y,x) of the 0.8x INTER_LINEAR resize of the blurred double image
+static __device__ __forceinline__ double scaled_at(const double *B, int w, int x, int y,
+                                                   const int *xofs, const float *xa, const int *yofs, const float *yb, int sw_src)
+{
+    const int sx = xofs[x], sx1 = min(sx + 1, sw_src - 1);
+    const double a0 = (double)xa[2 * x], a1 = (double)xa[2 * x + 1];
+    const int yo = yofs[y];
+    const int sy0 = yo & 0xFFFF, sy1 = yo >> 16;
+    const double b0 = (double)yb[2 * y], b1 = (double)yb[2 * y + 1];
+    const double *S0 = B + (size_t)sy0 * w, *S1 = B + (size_t)sy1 * w;
+    const double t0 = S0[sx] * a0 + S0[sx1] * a1;
+    const double t1 = S1[sx] * a0 + S1[sx1] * a1;
+    return t0 * b0 + t1 * b1;
+}
+
+__global__ __launch_bounds__(256) void k_lsd_resize_grad(const double *__restrict__ blur, int w, int h, int sw, int sh,
+                                                         const int *__restrict__ xofs, const float *__restrict__ xa,
+                                                         const int *__restrict__ yofs, const float *__restrict__ yb,
+                                                         double *__restrict__ modgrad, double *__restrict__ ang,
+                                                         double *__restrict__ cs, double *__restrict__ sn,
+                                                         unsigned *__restrict__ defined, int nwords, double rho)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    const double *B = blur + (size_t)f * w * h;
+    bool def = false;
+    if (x < sw) {
+        const size_t o = ((size_t)f * sh + y) * sw + x;
+        double a = LSD_NOTDEF, m = 0, c = 0, s = 0;
+        if (x < sw - 1 && y < sh - 1) {
+            const double v00 = scaled_at(B, w, x, y, xofs, xa, yofs, yb, w), v10 = scaled_at(B, w, x + 1, y, xofs, xa, yofs, yb, w);
+            const double v01 = scaled_at(B, w, x, y + 1, xofs, xa, yofs, yb, w), v11 = scaled_at(B, w, x + 1, y + 1, xofs, xa, yofs, yb, w);
+            const double DA = v11 - v00, BC = v10 - v01;
+            const double gx = DA + BC, gy = DA - BC;
+            m = sqrt((gx * gx + gy * gy) / 4);
+            if (!(m <= rho)) {
+                a = (double)fatan2_deg((float)gx, (float)-gy) * (LSD_PI / 180);
+                // region_grow accumulates cos(float(angle)) / sin(float(angle)) evaluated in double
+                const double af = (double)(float)a;
+                c = cos(af); s = sin(af);
+                def = true;
+            }
+        }
+        modgrad[o] = m; ang[o] = a; cs[o] = c; sn[o] = s;
+    }
+    // 256 threads = 8 words of 32 bits; rows are padded to a multiple of 32 bits in the mask
+    const unsigned long long bal = __ballot(def);
+    const int lane = threadIdx.x & 63;
+    if (x < ((sw + 31) & ~31)) {
+        const int word = (y * ((sw + 31) / 32)) + (x >> 5);
+        if ((lane & 31) == 0) defined[(size_t)f * nwords + word] = (unsigned)(bal >> (lane & 32));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_lsd_grow: the serial heart of LSD, one wave per frame
+// ------------------------------------------------------------------------------------------------
+struct GrowArgs {
+    const double *modgrad, *ang, *cs, *sn; const unsigned *defined; int *reg; float *segs;
+    hvo_keyline *kl_all, *kl; double *fn; int *nkl; int *flags;
+    int sw, sh, nwords, w, h, nfeat, kl_cap;
+    double rho, prec, p; unsigned min_reg;
+};
+
+struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy; };
+
+struct GrowState {
+    const double *modgrad, *ang, *cs, *sn; int *reg; unsigned *used; int *ring;
+    int sw, sh, wpr;          // wpr = mask words per row
+};
+
+static __device__ __forceinline__ bool used_get(const GrowState &S, int x, int y) { return (S.used[y * S.wpr + (x >> 5)] >> (x & 31)) & 1u; }
+static __device__ __forceinline__ void used_set(const GrowState &S, int x, int y) { S.used[y * S.wpr + (x >> 5)] |= 1u << (x & 31); }
+static __device__ __forceinline__ void used_clr(const GrowState &S, int x, int y) { S.used[y * S.wpr + (x >> 5)] &= ~(1u << (x & 31)); }
+
+static __device__ __forceinline__ double angle_diff_signed(double a, double b)
+{
+    double diff = a - b;
+    while (diff <= -LSD_PI) diff += 2 * LSD_PI;
+    while (diff > LSD_PI) diff -= 2 * LSD_PI;
+    return diff;
+}
+
+// region_grow (OpenCV 3.2 lsd.cpp): all lanes enter; lane 0 takes the decisions in the reference's
+// order (point index, then x outer / y inner) on neighbourhood data prefetched for up to 7 points.
+static __device__ void region_grow_wave(GrowState &S, int seed_addr, int &reg_size, double &reg_angle, double prec,
+                                        double *n_ang, double *n_cs, double *n_sn, int *n_addr)
+{
+    const int lane = threadIdx.x, sw = S.sw, sh = S.sh;
+    float sumdx = 0, sumdy = 0;
+    if (lane == 0) {
+        S.reg[0] = seed_addr; S.ring[0] = seed_addr;
+        const double a = S.ang[seed_addr];
+        reg_angle = a;
+        sumdx = (float)cos(a); sumdy = (float)sin(a);
+        used_set(S, seed_addr % sw, seed_addr / sw);
+    }
+    reg_size = 1;
+    reg_angle = __shfl(reg_angle, 0);
+    __syncthreads();
+    int i = 0;
+    while (i < reg_size) {
+        const int cnt = min(7, reg_size - i);
+        // ---- prefetch: lane 9k+j <- neighbour j of point i+k ----
+        const int k = lane / 9, j = lane - 9 * k;
+        int c = -1; double a = LSD_NOTDEF, cc = 0, ss = 0;
+        if (k < cnt) {
+            const int idx = i + k;
+            const int pa = (reg_size - idx <= LSD_RING) ? S.ring[idx & (LSD_RING - 1)] : S.reg[idx];
+            const int px = pa % sw, py = pa / sw;
+            const int xx = px - 1 + j / 3, yy = py - 1 + (j - 3 * (j / 3));
+            if (xx >= 0 && yy >= 0 && xx < sw && yy < sh) {
+                c = xx + yy * sw;
+                a = S.ang[c];
+                if (a != LSD_NOTDEF) { cc = S.cs[c]; ss = S.sn[c]; }
+            }
+        }
+        if (lane < 63) { n_addr[lane] = c; n_ang[lane] = a; n_cs[lane] = cc; n_sn[lane] = ss; }
+        __syncthreads();
+        // all `cnt` points were in the region before this round, so handling them in order with live
+        // `used` bits is exactly the sequential loop; points appended now are handled in later rounds
+        const int done = cnt;
+        if (lane == 0) {
+            int rs = reg_size; double ra = reg_angle;
+            for (int kk = 0; kk < cnt; kk++) {
+                for (int jj = 0; jj < 9; jj++) {
+                    const int ca = n_addr[9 * kk + jj];
+                    if (ca < 0) continue;
+                    const double an = n_ang[9 * kk + jj];
+                    if (an == LSD_NOTDEF) continue;
+                    const int cx = ca % sw, cy = ca / sw;
+                    if (used_get(S, cx, cy)) continue;
+                    // isAligned
+                    double nt = ra - an;
+                    if (nt < 0) nt = -nt;
+                    if (nt > (3 * LSD_PI) / 2) { nt -= 2 * LSD_PI; if (nt < 0) nt = -nt; }
+                    if (!(nt <= prec)) continue;
+                    used_set(S, cx, cy);
+                    S.reg[rs] = ca; S.ring[rs & (LSD_RING - 1)] = ca;
+                    ++rs;
+                    sumdx = (float)((double)sumdx + n_cs[9 * kk + jj]);
+                    sumdy = (float)((double)sumdy + n_sn[9 * kk + jj]);
+                    ra = (double)fatan2_deg(sumdy, sumdx) * (LSD_PI / 180);
+                }
+            }
+            reg_size = rs; reg_angle = ra;
+        }
+        reg_size = __shfl(reg_size, 0); reg_angle = __shfl(reg_angle, 0);
+        i += done;
+        __syncthreads();
+    }
+}
+
+// ordered fp64 accumulation helpers: the sums of region2rect / get_theta / refine must be added in
+// region order; 64 points are fetched per step, lane 0 accumulates them in order.
+static __device__ void region2rect_wave(const GrowState &S, int reg_size, double reg_angle, double prec, Rect &rec,
+                                        double *b0, double *b1, double *b2)
+{
+    const int lane = threadIdx.x, sw = S.sw;
+    double x = 0, y = 0, sum = 0;
+    for (int base = 0; base < reg_size; base += 64) {
+        const int i = base + lane;
+        if (i < reg_size) { const int a = S.reg[i]; b0[lane] = (double)(a % sw); b1[lane] = (double)(a / sw); b2[lane] = S.modgrad[a]; }
+        __syncthreads();
+        if (lane == 0) { const int n = min(64, reg_size - base); for (int q = 0; q < n; q++) { const double wgt = b2[q]; x += b0[q] * wgt; y += b1[q] * wgt; sum += wgt; } }
+        __syncthreads();
+    }
+    if (lane == 0) { x /= sum; y /= sum; }
+    x = __shfl(x, 0); y = __shfl(y, 0);
+    // get_theta
+    double Ixx = 0, Iyy = 0, Ixy = 0;
+    for (int base = 0; base < reg_size; base += 64) {
+        const int i = base + lane;
+        if (i < reg_size) { const int a = S.reg[i]; b0[lane] = (double)(a % sw); b1[lane] = (double)(a / sw); b2[lane] = S.modgrad[a]; }
+        __syncthreads();
+        if (lane == 0) {
+            const int n = min(64, reg_size - base);
+            for (int q = 0; q < n; q++) { const double dx = b0[q] - x, dy = b1[q] - y, wgt = b2[q]; Ixx += dy * dy * wgt; Iyy += dx * dx * wgt; Ixy -= dx * dy * wgt; }
+        }
+        __syncthreads();
+    }
+    double theta = 0, dx = 0, dy = 0;
+    if (lane == 0) {
+        const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+        theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fatan2_deg((float)(lambda - Ixx), (float)Ixy) : (double)fatan2_deg((float)Ixy, (float)(lambda - Iyy));
+        theta *= (LSD_PI / 180);
+        if (fabs(angle_diff_signed(theta, reg_angle)) > prec) theta += LSD_PI;
+        dx = cos(theta); dy = sin(theta);
+    }
+    theta = __shfl(theta, 0); dx = __shfl(dx, 0); dy = __shfl(dy, 0);
+    // extents: the reference's if / else-if chain in region order
+    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+    for (int base = 0; base < reg_size; base += 64) {
+        const int i = base + lane;
+        if (i < reg_size) { const int a = S.reg[i]; b0[lane] = (double)(a % sw); b1[lane] = (double)(a / sw); }
+        __syncthreads();
+        if (lane == 0) {
+            const int n = min(64, reg_size - base);
+            for (int q = 0; q < n; q++) {
+                const double rdx = b0[q] - x, rdy = b1[q] - y;
+                const double l = rdx * dx + rdy * dy, wv = -rdx * dy + rdy * dx;
+                if (l > l_max) l_max = l; else if (l < l_min) l_min = l;
+                if (wv > w_max) w_max = wv; else if (wv < w_min) w_min = wv;
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        rec.x1 = x + l_min * dx; rec.y1 = y + l_min * dy; rec.x2 = x + l_max * dx; rec.y2 = y + l_max * dy;
+        rec.width = w_max - w_min; rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy;
+        if (rec.width < 1.0) rec.width = 1.0;
+    }
+    rec.x1 = __shfl(rec.x1, 0); rec.y1 = __shfl(rec.y1, 0); rec.x2 = __shfl(rec.x2, 0); rec.y2 = __shfl(rec.y2, 0);
+    rec.width = __shfl(rec.width, 0); rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy;
+}
+
+static __device__ __forceinline__ double rect_density(const Rect &r, int reg_size)
+{
+    const double d = sqrt((r.x2 - r.x1) * (r.x2 - r.x1) + (r.y2 - r.y1) * (r.y2 - r.y1));
+    return (double)reg_size / (d * r.width);
+}
+
+// refine + reduce_region_radius (LSD_REFINE_STD).  Returns false when the region is rejected.
+static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle, double prec, Rect &rec, double density_th,
+                                   double *b0, double *b1, double *b2, int *n_addr)
+{
+    const int lane = threadIdx.x, sw = S.sw;
+    double density = rect_density(rec, reg_size);
+    if (density >= density_th) return true;
+    const int a0 = S.reg[0];
+    const double xc = (double)(a0 % sw), yc = (double)(a0 / sw);
+    const double ang_c = S.ang[a0];
+    double sum = 0, s_sum = 0; int n = 0;
+    for (int base = 0; base < reg_size; base += 64) {
+        const int i = base + lane;
+        if (i < reg_size) { const int a = S.reg[i]; b0[lane] = (double)(a % sw); b1[lane] = (double)(a / sw); b2[lane] = S.ang[a]; n_addr[lane] = a; }
+        __syncthreads();
+        if (lane == 0) {
+            const int m = min(64, reg_size - base);
+            for (int q = 0; q < m; q++) {
+                used_clr(S, n_addr[q] % sw, n_addr[q] / sw);
+                const double ddx = b0[q] - xc, ddy = b1[q] - yc;
+                if (sqrt(ddx * ddx + ddy * ddy) < rec.width) {
+                    const double ang_d = angle_diff_signed(b2[q], ang_c);
+                    sum += ang_d; s_sum += ang_d * ang_d; ++n;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    double tau = 0;
+    if (lane == 0) {
+        const double mean_angle = sum / (double)n;
+        tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
+    }
+    tau = __shfl(tau, 0);
+    region_grow_wave(S, a0, reg_size, reg_angle, tau, b0, b1, b2, n_addr);
+    if (reg_size < 2) return false;
+    region2rect_wave(S, reg_size, reg_angle, prec, rec, b0, b1, b2);
+    density = rect_density(rec, reg_size);
+    if (density >= density_th) return true;
+    // reduce_region_radius
+    const double r1 = (rec.x1 - xc) * (rec.x1 - xc) + (rec.y1 - yc) * (rec.y1 - yc);
+    const double r2 = (rec.x2 - xc) * (rec.x2 - xc) + (rec.y2 - yc) * (rec.y2 - yc);
+    double radSq = r1 > r2 ? r1 : r2;
+    while (density < density_th) {
+        radSq *= 0.75 * 0.75;
+        // swap-with-last removal is order dependent: lane 0 walks the region
+        __syncthreads();
+        if (lane == 0) {
+            int rs = reg_size;
+            for (int i = 0; i < rs; ++i) {
+                const int a = S.reg[i];
+                const double ddx = (double)(a % sw) - xc, ddy = (double)(a / sw) - yc;
+                if (ddx * ddx + ddy * ddy > radSq) {
+                    used_clr(S, a % sw, a / sw);
+                    const int last = S.reg[rs - 1];
+                    S.reg[i] = last; S.reg[rs - 1] = a;
+                    --rs; --i;
+                }
+            }
+            reg_size = rs;
+        }
+        reg_size = __shfl(reg_size, 0);
+        __syncthreads();
+        if (reg_size < 2) return false;
+        region2rect_wave(S, reg_size, reg_angle, prec, rec, b0, b1, b2);
+        density = rect_density(rec, reg_size);
+    }
+    return true;
+}
+
+// cv::LineIterator(...).count for clamped float end points: Point2f -> Point rounds half to even
+static __device__ __forceinline__ int line_count(float x1, float y1, float x2, float y2)
+{
+    const int ax = __float2int_rn(x1), ay = __float2int_rn(y1), bx = __float2int_rn(x2), by = __float2int_rn(y2);
+    const int dx = abs(bx - ax), dy = abs(by - ay);
+    return (dx > dy ? dx : dy) + 1;
+}
+
+__global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
+{
+    extern __shared__ unsigned used_lds[];
+    __shared__ double b0[64], b1[64], b2[64];
+    __shared__ int n_addr[64];
+    __shared__ int ring[LSD_RING];
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int sw = g.sw, sh = g.sh, wpr = (sw + 31) / 32, nwords = g.nwords;
+    const size_t np = (size_t)sw * sh;
+    GrowState S;
+    S.modgrad = g.modgrad + f * np; S.ang = g.ang + f * np; S.cs = g.cs + f * np; S.sn = g.sn + f * np;
+    S.reg = g.reg + f * np; S.used = used_lds; S.ring = ring; S.sw = sw; S.sh = sh; S.wpr = wpr;
+    const unsigned *defined = g.defined + (size_t)f * nwords;
+    float *segs = g.segs + (size_t)f * LSD_MAXSEG * 4;
+    for (int i = lane; i < nwords; i += 64) used_lds[i] = 0;
+    __syncthreads();
+    int nseg = 0, flags = 0;
+    // seeds in raster order: words of (defined & ~used), 64 words per step
+    for (int wbase = 0; wbase < nwords; wbase += 64) {
+        for (;;) {
+            const int wi = wbase + lane;
+            unsigned m = 0;
+            if (wi < nwords) m = defined[wi] & ~used_lds[wi];
+            const unsigned long long nz = __ballot(m != 0);
+            if (!nz) break;
+            const int wl = __ffsll((long long)nz) - 1;
+            const unsigned mw = __shfl(m, wl);
+            const int bit = __ffs((int)mw) - 1;
+            const int wsel = wbase + wl;
+            const int sy = wsel / wpr, sx = (wsel - sy * wpr) * 32 + bit;
+            const int seed = sx + sy * sw;
+            int reg_size; double reg_angle = 0;
+            region_grow_wave(S, seed, reg_size, reg_angle, g.prec, b0, b1, b2, n_addr);
+            if ((unsigned)reg_size < g.min_reg) continue;
+            Rect rec;
+            region2rect_wave(S, reg_size, reg_angle, g.prec, rec, b0, b1, b2);
+            if (!refine_wave(S, reg_size, reg_angle, g.prec, rec, 0.7, b0, b1, b2, n_addr)) continue;
+            if (nseg < LSD_MAXSEG) {
+                if (lane == 0) {
+                    double x1 = rec.x1 + 0.5, y1 = rec.y1 + 0.5, x2 = rec.x2 + 0.5, y2 = rec.y2 + 0.5;
+                    x1 /= 0.8; y1 /= 0.8; x2 /= 0.8; y2 /= 0.8;
+                    segs[4 * nseg] = (float)x1; segs[4 * nseg + 1] = (float)y1; segs[4 * nseg + 2] = (float)x2; segs[4 * nseg + 3] = (float)y2;
+                }
+                nseg++;
+            } else flags |= 1;
+        }
+    }
+    __syncthreads();
+    // ---- KeyLines (LSDDetector_custom.cpp:161-196) ----
+    hvo_keyline *all = g.kl_all + (size_t)f * LSD_MAXSEG;
+    const int w = g.w, h = g.h;
+    for (int i = lane; i < nseg; i += 64) {
+        float e0 = segs[4 * i], e1 = segs[4 * i + 1], e2 = segs[4 * i + 2], e3 = segs[4 * i + 3];
+        if (e0 < 0) e0 = 0; if (e0 >= w) e0 = (float)w - 1.0f;
+        if (e2 < 0) e2 = 0; if (e2 >= w) e2 = (float)w - 1.0f;
+        if (e1 < 0) e1 = 0; if (e1 >= h) e1 = (float)h - 1.0f;
+        if (e3 < 0) e3 = 0; if (e3 >= h) e3 = (float)h - 1.0f;
+        hvo_keyline kl;
+        kl.sx = e0; kl.sy = e1; kl.ex = e2; kl.ey = e3; kl.sox = e0; kl.soy = e1; kl.eox = e2; kl.eoy = e3;
+        const double ddx = (double)__fsub_rn(e0, e2), ddy = (double)__fsub_rn(e1, e3);
+        kl.length = (float)sqrt(ddx * ddx + ddy * ddy);
+        kl.num_pixels = line_count(e0, e1, e2, e3);
+        kl.angle = (float)atan2((double)__fsub_rn(kl.ey, kl.sy), (double)__fsub_rn(kl.ex, kl.sx));
+        kl.class_id = i; kl.octave = 0;
+        kl.size = __fmul_rn(__fsub_rn(kl.ex, kl.sx), __fsub_rn(kl.ey, kl.sy));
+        kl.response = __fdiv_rn(kl.length, (float)(w > h ? w : h));
+        kl.pt_x = __fdiv_rn(__fadd_rn(kl.ex, kl.sx), 2.f); kl.pt_y = __fdiv_rn(__fadd_rn(kl.ey, kl.sy), 2.f);
+        all[i] = kl;
+    }
+    __syncthreads();
+    // ---- keep the nfeat strongest (stable by response desc), class_id = rank ----
+    hvo_keyline *out = g.kl + (size_t)f * g.kl_cap;
+    int n = nseg;
+    if (nseg > g.nfeat) {
+        n = g.nfeat;
+        for (int i = lane; i < nseg; i += 64) {
+            const float r = all[i].response;
+            int rank = 0;
+            for (int q = 0; q < nseg; q++) { const float rq = all[q].response; rank += (rq > r) || (rq == r && q < i); }
+            if (rank < n && rank < g.kl_cap) { hvo_keyline kl = all[i]; kl.class_id = rank; out[rank] = kl; }
+        }
+    } else {
+        for (int i = lane; i < nseg; i += 64) if (i < g.kl_cap) out[i] = all[i];
+    }
+    if (n > g.kl_cap) { n = g.kl_cap; flags |= 2; }
+    __syncthreads();
+    // ---- 2-D line functions (LineExtractor.cpp:367-377) ----
+    double *fn = g.fn + (size_t)f * g.kl_cap * 3;
+    for (int i = lane; i < n; i += 64) {
+        const double sx = out[i].sx, sy = out[i].sy, ex = out[i].ex, ey = out[i].ey;
+        const double l0 = sy * 1.0 - 1.0 * ey, l1 = 1.0 * ex - sx * 1.0, l2 = sx * ey - sy * ex;
+        const double nrm = sqrt(l0 * l0 + l1 * l1);
+        fn[3 * i] = l0 / nrm; fn[3 * i + 1] = l1 / nrm; fn[3 * i + 2] = l2 / nrm;
+    }
+    if (lane == 0) { g.nkl[f] = n; g.flags[f] = flags; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LBD: blur 5x5 (u8 fixed point, same rounding rules as the ORB blur), Sobel, descriptor
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lbd_blur5(const uint8_t *__restrict__ gray, size_t gframe, int gpitch,
+                                                   uint8_t *__restrict__ out, int w, int h, int k0, int k1, int k2)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    if (x >= w) return;
+    const uint8_t *G = gray + (size_t)f * gframe;
+    int s = 0;
+    const int kk[5] = { k0, k1, k2, k1, k0 };
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const uint8_t *R = G + (size_t)refl(y + j - 2, h) * gpitch;
+        const int r = k0 * (R[refl(x - 2, w)] + R[refl(x + 2, w)]) + k1 * (R[refl(x - 1, w)] + R[refl(x + 1, w)]) + k2 * R[x];
+        s += kk[j] * r;
+    }
+    int q;
+    if (x < (w & ~3)) { q = s >> 16; const int rem = s & 0xFFFF; if (rem > 32768 || (rem == 32768 && (q & 1))) q++; }
+    else q = (s + 32768) >> 16;
+    out[((size_t)f * h + y) * w + x] = (uint8_t)min(q, 255);
+}
+
+__global__ __launch_bounds__(256) void k_lbd_sobel(const uint8_t *__restrict__ b5, int16_t *__restrict__ dx, int16_t *__restrict__ dy, int w, int h)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    if (x >= w) return;
+    const uint8_t *B = b5 + (size_t)f * w * h;
+    const int xm = refl(x - 1, w), xp = refl(x + 1, w);
+    const uint8_t *R0 = B + (size_t)refl(y - 1, h) * w, *R1 = B + (size_t)y * w, *R2 = B + (size_t)refl(y + 1, h) * w;
+    const int gx = (R0[xp] - R0[xm]) + 2 * (R1[xp] - R1[xm]) + (R2[xp] - R2[xm]);
+    const int gy = (R2[xm] + 2 * R2[x] + R2[xp]) - (R0[xm] + 2 * R0[x] + R0[xp]);
+    const size_t o = ((size_t)f * h + y) * w + x;
+    dx[o] = (int16_t)gx; dy[o] = (int16_t)gy;
+}
+
+__constant__ int c_lbd_comb[32][2] = {
+    { 0, 1 }, { 0, 2 }, { 0, 3 }, { 0, 4 }, { 0, 5 }, { 0, 6 }, { 1, 2 }, { 1, 3 }, { 1, 4 }, { 1, 5 }, { 1, 6 },
+    { 2, 3 }, { 2, 4 }, { 2, 5 }, { 2, 6 }, { 2, 7 }, { 2, 8 }, { 3, 4 }, { 3, 5 }, { 3, 6 }, { 3, 7 }, { 3, 8 },
+    { 4, 5 }, { 4, 6 }, { 4, 7 }, { 4, 8 }, { 5, 6 }, { 5, 7 }, { 5, 8 }, { 6, 7 }, { 6, 8 }, { 7, 8 } };
+
+__global__ __launch_bounds__(64) void k_lbd_desc(const int16_t *__restrict__ dxImg, const int16_t *__restrict__ dyImg, int w, int h,
+                                                 const hvo_keyline *__restrict__ kls, const int *__restrict__ nkl, int kl_cap,
+                                                 const float *__restrict__ gL, const float *__restrict__ gG, uint8_t *__restrict__ desc)
+{
+    __shared__ float rows[63][4];       // pgdL, ngdL, pgdO, ngdO row sums (already scaled by the global weight)
+    __shared__ float band[9][8];
+    __shared__ float dv[72];
+    const int line = blockIdx.x, f = blockIdx.y, t = threadIdx.x;
+    if (line >= nkl[f]) return;
+    const hvo_keyline kl = kls[(size_t)f * kl_cap + line];
+    const int16_t *DX = dxImg + (size_t)f * w * h, *DY = dyImg + (size_t)f * w * h;
+    const short imageWidth = (short)(w - 1), imageHeight = (short)(h - 1);
+    const short halfHeight = 31;
+    const short lengthOfLSP = (short)kl.num_pixels;
+    const short halfWidth = (short)((lengthOfLSP - 1) / 2);
+    const float midX = (float)(0.5 * (double)__fadd_rn(kl.sox, kl.eox));
+    const float midY = (float)(0.5 * (double)__fadd_rn(kl.soy, kl.eoy));
+    const float dL0 = (float)cos((double)kl.angle), dL1 = (float)sin((double)kl.angle);
+    const float dO0 = -dL1, dO1 = dL0;
+    if (t < 63) {
+        // sCorX0/sCorY0 of row hID are reached by hID sequential updates in the reference
+        float sCorX0 = __fadd_rn(__fadd_rn(__fmul_rn(-dL0, (float)halfWidth), __fmul_rn(dL1, (float)halfHeight)), midX);
+        float sCorY0 = __fadd_rn(__fsub_rn(__fmul_rn(-dL1, (float)halfWidth), __fmul_rn(dL0, (float)halfHeight)), midY);
+        for (int q = 0; q < t; q++) { sCorX0 = __fsub_rn(sCorX0, dL1); sCorY0 = __fadd_rn(sCorY0, dL0); }
+        float sCorX = sCorX0, sCorY = sCorY0;
+        float pL = 0, nL = 0, pO = 0, nO = 0;
+        for (short wID = 0; wID < lengthOfLSP; wID++) {
+            short tc = (short)round((double)sCorX);
+            const short xCor = (tc < 0) ? 0 : (tc > imageWidth) ? imageWidth : tc;
+            tc = (short)round((double)sCorY);
+            const short yCor = (tc < 0) ? 0 : (tc > imageHeight) ? imageHeight : tc;
+            const float ddx = (float)DX[(int)yCor * w + xCor], ddy = (float)DY[(int)yCor * w + xCor];
+            const float gDL = __fadd_rn(__fmul_rn(ddx, dL0), __fmul_rn(ddy, dL1));
+            const float gDO = __fadd_rn(__fmul_rn(ddx, dO0), __fmul_rn(ddy, dO1));
+            if (gDL > 0) pL = __fadd_rn(pL, gDL); else nL = __fsub_rn(nL, gDL);
+            if (gDO > 0) pO = __fadd_rn(pO, gDO); else nO = __fsub_rn(nO, gDO);
+            sCorX = __fadd_rn(sCorX, dL0); sCorY = __fadd_rn(sCorY, dL1);
+        }
+        const float coef = gG[t];
+        rows[t][0] = __fmul_rn(coef, pL); rows[t][1] = __fmul_rn(coef, nL); rows[t][2] = __fmul_rn(coef, pO); rows[t][3] = __fmul_rn(coef, nO);
+    }
+    __syncthreads();
+    if (t < 9) {
+        // band b receives rows 7(b-1)..7(b+1)+6 in row order: "below" (gL[h%7]), own (gL[h%7+7]), "above" (gL[h%7+14])
+        float s[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int hID = 7 * (t - 1); hID < 7 * (t + 2); hID++) {
+            if (hID < 0 || hID >= 63) continue;
+            const int rb = hID / 7, m = hID - 7 * rb;
+            const float c = gL[rb == t ? m + 7 : (rb == t + 1 ? m + 14 : m)];
+            const float pL = rows[hID][0], nL = rows[hID][1], pO = rows[hID][2], nO = rows[hID][3];
+            const float cc = __fmul_rn(c, c);
+            s[0] = __fadd_rn(s[0], __fmul_rn(c, pL)); s[1] = __fadd_rn(s[1], __fmul_rn(c, nL));
+            s[2] = __fadd_rn(s[2], __fmul_rn(cc, __fmul_rn(pL, pL))); s[3] = __fadd_rn(s[3], __fmul_rn(cc, __fmul_rn(nL, nL)));
+            s[4] = __fadd_rn(s[4], __fmul_rn(c, pO)); s[5] = __fadd_rn(s[5], __fmul_rn(c, nO));
+            s[6] = __fadd_rn(s[6], __fmul_rn(cc, __fmul_rn(pO, pO))); s[7] = __fadd_rn(s[7], __fmul_rn(cc, __fmul_rn(nO, nO)));
+        }
+        for (int q = 0; q < 8; q++) band[t][q] = s[q];
+    }
+    __syncthreads();
+    if (t == 0) {
+        const float invN2 = (float)(1.0 / 14.0), invN3 = (float)(1.0 / 21.0);
+        for (int b = 0; b < 9; b++) {
+            const float invN = (b == 0 || b == 8) ? invN2 : invN3;
+            float tmp = __fmul_rn(band[b][0], invN);
+            dv[8 * b] = tmp; dv[8 * b + 4] = __fsqrt_rn(__fsub_rn(__fmul_rn(band[b][2], invN), __fmul_rn(tmp, tmp)));
+            tmp = __fmul_rn(band[b][1], invN);
+            dv[8 * b + 1] = tmp; dv[8 * b + 5] = __fsqrt_rn(__fsub_rn(__fmul_rn(band[b][3], invN), __fmul_rn(tmp, tmp)));
+            tmp = __fmul_rn(band[b][4], invN);
+            dv[8 * b + 2] = tmp; dv[8 * b + 6] = __fsqrt_rn(__fsub_rn(__fmul_rn(band[b][6], invN), __fmul_rn(tmp, tmp)));
+            tmp = __fmul_rn(band[b][5], invN);
+            dv[8 * b + 3] = tmp; dv[8 * b + 7] = __fsqrt_rn(__fsub_rn(__fmul_rn(band[b][7], invN), __fmul_rn(tmp, tmp)));
+        }
+        float tempM = 0, tempS = 0;
+        for (int b = 0; b < 9; b++) {
+            for (int q = 0; q < 4; q++) tempM = __fadd_rn(tempM, __fmul_rn(dv[8 * b + q], dv[8 * b + q]));
+            for (int q = 4; q < 8; q++) tempS = __fadd_rn(tempS, __fmul_rn(dv[8 * b + q], dv[8 * b + q]));
+        }
+        tempM = __fdiv_rn(1.f, __fsqrt_rn(tempM)); tempS = __fdiv_rn(1.f, __fsqrt_rn(tempS));
+        for (int b = 0; b < 9; b++) {
+            for (int q = 0; q < 4; q++) dv[8 * b + q] = __fmul_rn(dv[8 * b + q], tempM);
+            for (int q = 4; q < 8; q++) dv[8 * b + q] = __fmul_rn(dv[8 * b + q], tempS);
+        }
+        for (int i = 0; i < 72; i++) if ((double)dv[i] > 0.4) dv[i] = (float)0.4;
+        float tmp = 0;
+        for (int i = 0; i < 72; i++) tmp = __fadd_rn(tmp, __fmul_rn(dv[i], dv[i]));
+        tmp = __fdiv_rn(1.f, __fsqrt_rn(tmp));
+        for (int i = 0; i < 72; i++) dv[i] = __fmul_rn(dv[i], tmp);
+    }
+    __syncthreads();
+    if (t < 32) {
+        const float *f1 = dv + 8 * c_lbd_comb[t][0], *f2 = dv + 8 * c_lbd_comb[t][1];
+        unsigned r = 0;
+        for (int b = 0; b < 8; b++) if (f1[b] > f2[b]) r |= 1u << b;
+        desc[((size_t)f * kl_cap + line) * 32 + t] = (uint8_t)r;
+    }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+void lsd_free(hvo_ctx *ctx)
+{
+    LsdPlan *P = plan_of(ctx);
+    if (!P) return;
+    void *ptrs[] = { P->d_tmp, P->d_blur, P->d_modgrad, P->d_ang, P->d_cs, P->d_sn, P->d_defined, P->d_reg, P->d_segs, P->d_kl_all, P->d_kl,
+                     P->d_desc, P->d_fn, P->d_nkl, P->d_flags, P->d_b5, P->d_dx, P->d_dy, P->d_xofs, P->d_yofs, P->d_xa, P->d_yb, P->d_gL, P->d_gG };
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    delete P;
+    ctx->lsd = nullptr;
+}
+
+static int cvfloor_f(float v) { int i = (int)v; return i - (i > v); }
+
+static int lsd_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
+{
+    LsdPlan *P = plan_of(ctx);
+    if (P && P->w == w && P->h == h && P->batch >= batch) return HVO_OK;
+    lsd_free(ctx);
+    P = new LsdPlan();
+    ctx->lsd = P;
+    P->w = w; P->h = h; P->batch = batch; P->nfeat = std::max(ctx->p.lsd_nfeatures, 1);
+    P->sw = (int)lrint(w * 0.8); P->sh = (int)lrint(h * 0.8);
+    if (P->sw < 8 || P->sh < 8 || w > 32767 || h > 32767) return HVO_ERR_UNSUPPORTED;
+    P->nwords = ((P->sw + 31) / 32) * P->sh;
+    // LSD constants (OpenCV defaults, LSD_REFINE_STD)
+    const double SCALE = 0.8, ANG_TH = 22.5;
+    P->prec = LSD_PI * ANG_TH / 180; P->p = ANG_TH / 180; P->rho = 2.0 / sin(P->prec);
+    const double LOG_NT = 5 * (log10((double)P->sw) + log10((double)P->sh)) / 2 + log10(11.0);
+    P->min_reg = (unsigned)(-LOG_NT / log10(P->p));
+    {   // getGaussianKernel(7, 0.75, CV_64F)
+        const double sigma = 0.6 / SCALE; double k[7], sum = 0;
+        for (int i = 0; i < 7; i++) { double x = i - 3.0; k[i] = exp(-0.5 / (sigma * sigma) * x * x); sum += k[i]; }
+        sum = 1. / sum;
+        for (int i = 0; i < 4; i++) P->k7[i] = k[i] * sum;
+    }
+    {   // getGaussianKernel(5, 1, CV_32F) * 256, rounded (fixed-point CV_8U path)
+        float cf[5]; double sum = 0;
+        for (int i = 0; i < 5; i++) { double x = i - 2.0; cf[i] = (float)exp(-0.5 * x * x); sum += cf[i]; }
+        sum = 1. / sum;
+        for (int i = 0; i < 3; i++) P->k5[i] = (int)lrintf((float)(cf[i] * sum) * 256.f);
+    }
+    {   // BinaryDescriptor weights with the reference's integer divisions (binary_descriptor_custom.cpp:227-258)
+        double u = (7 * 3 - 1) / 2, sigma = (7 * 2 + 1) / 2, inv = -1 / (2 * sigma * sigma);
+        for (int i = 0; i < 21; i++) { double d = i - u; P->gL[i] = exp(d * d * inv); }
+        u = (9 * 7 - 1) / 2; sigma = u; inv = -1 / (2 * sigma * sigma);
+        for (int i = 0; i < 63; i++) { double d = i - u; P->gG[i] = exp(d * d * inv); }
+    }
+    std::vector<int> xofs(P->sw), yofs(P->sh); std::vector<float> xa(2 * P->sw), yb(2 * P->sh);
+    const double scale = 1. / SCALE;
+    for (int dx = 0; dx < P->sw; dx++) {
+        float fx = (float)((dx + 0.5) * scale - 0.5); int sx = cvfloor_f(fx); fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= w - 1) { fx = 0; sx = w - 1; }
+        xofs[dx] = sx; xa[2 * dx] = 1.f - fx; xa[2 * dx + 1] = fx;
+    }
+    for (int dy = 0; dy < P->sh; dy++) {
+        float fy = (float)((dy + 0.5) * scale - 0.5); int sy = cvfloor_f(fy); fy -= sy;
+        int sy0 = std::min(std::max(sy, 0), h - 1), sy1 = std::min(std::max(sy + 1, 0), h - 1);
+        yofs[dy] = sy0 | (sy1 << 16); yb[2 * dy] = 1.f - fy; yb[2 * dy + 1] = fy;
+    }
+    std::vector<float> gLf(21), gGf(63);
+    for (int i = 0; i < 21; i++) gLf[i] = (float)P->gL[i];
+    for (int i = 0; i < 63; i++) gGf[i] = (float)P->gG[i];
+    const size_t B = batch, npix = (size_t)w * h, nsp = (size_t)P->sw * P->sh;
+#define PA(ptr, n) HVO_HIP(hipMalloc((void **)&(ptr), (n)))
+    PA(P->d_tmp, B * npix * 8); PA(P->d_blur, B * npix * 8);
+    PA(P->d_modgrad, B * nsp * 8); PA(P->d_ang, B * nsp * 8); PA(P->d_cs, B * nsp * 8); PA(P->d_sn, B * nsp * 8);
+    PA(P->d_defined, B * P->nwords * 4); PA(P->d_reg, B * nsp * 4);
+    PA(P->d_segs, B * LSD_MAXSEG * 16); PA(P->d_kl_all, B * LSD_MAXSEG * sizeof(hvo_keyline));
+    PA(P->d_kl, B * P->nfeat * sizeof(hvo_keyline)); PA(P->d_desc, B * P->nfeat * 32); PA(P->d_fn, B * P->nfeat * 24);
+    PA(P->d_nkl, B * 4); PA(P->d_flags, B * 4);
+    PA(P->d_b5, B * npix); PA(P->d_dx, B * npix * 2); PA(P->d_dy, B * npix * 2);
+    PA(P->d_xofs, P->sw * 4); PA(P->d_yofs, P->sh * 4); PA(P->d_xa, P->sw * 8); PA(P->d_yb, P->sh * 8);
+    PA(P->d_gL, 21 * 4); PA(P->d_gG, 63 * 4);
+#undef PA
+    HVO_HIP(hipMemcpy(P->d_xofs, xofs.data(), P->sw * 4, hipMemcpyHostToDevice));
+    HVO_HIP(hipMemcpy(P->d_yofs, yofs.data(), P->sh * 4, hipMemcpyHostToDevice));
+    HVO_HIP(hipMemcpy(P->d_xa, xa.data(), P->sw * 8, hipMemcpyHostToDevice));
+    HVO_HIP(hipMemcpy(P->d_yb, yb.data(), P->sh * 8, hipMemcpyHostToDevice));
+    HVO_HIP(hipMemcpy(P->d_gL, gLf.data(), 21 * 4, hipMemcpyHostToDevice));
+    HVO_HIP(hipMemcpy(P->d_gG, gGf.data(), 63 * 4, hipMemcpyHostToDevice));
+    HVO_HIP(hipMemsetAsync(P->d_defined, 0, B * P->nwords * 4, ctx->stream));
+    HVO_HIP(hipDeviceSynchronize());
+    return HVO_OK;
+}
+
+int lsd_run(hvo_ctx *ctx, int n)
+{
+    // input: level 0 of the ORB pyramid slab (the uploaded gray image)
+    OrbPlan &O = ctx->orb;
+    if (O.w <= 0 || n < 1 || n > O.batch) return HVO_ERR_INVALID_ARG;
+    int rc = lsd_ensure_plan(ctx, O.w, O.h, std::max(n, ctx->p.max_batch));
+    if (rc) return rc;
+    LsdPlan *P = plan_of(ctx);
+    hipStream_t st = ctx->stream;
+    const int w = P->w, h = P->h, sw = P->sw, sh = P->sh;
+    const uint8_t *gray = O.d_pyr + O.lev[0].img_off;
+    const int gpitch = O.lev[0].pitch;
+    int id = hvo_prof_begin(ctx, "lsd_blur_scale");
+    hipLaunchKernelGGL(k_lsd_blur_h, dim3((w + 255) / 256, h, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_tmp, w, h, P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
+    hipLaunchKernelGGL(k_lsd_blur_v, dim3((w + 255) / 256, h, n), dim3(256), 0, st, P->d_tmp, P->d_blur, w, h, P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
+    hvo_prof_end(ctx, id);
+    id = hvo_prof_begin(ctx, "lsd_gradient");
+    const int gx = (((sw + 31) & ~31) + 255) / 256;
+    hipLaunchKernelGGL(k_lsd_resize_grad, dim3(gx, sh, n), dim3(256), 0, st, P->d_blur, w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb,
+                       P->d_modgrad, P->d_ang, P->d_cs, P->d_sn, P->d_defined, P->nwords, P->rho);
+    hvo_prof_end(ctx, id);
+    id = hvo_prof_begin(ctx, "lsd_grow");
+    GrowArgs g;
+    g.modgrad = P->d_modgrad; g.ang = P->d_ang; g.cs = P->d_cs; g.sn = P->d_sn; g.defined = P->d_defined; g.reg = P->d_reg; g.segs = P->d_segs;
+    g.kl_all = P->d_kl_all; g.kl = P->d_kl; g.fn = P->d_fn; g.nkl = P->d_nkl; g.flags = P->d_flags;
+    g.sw = sw; g.sh = sh; g.nwords = P->nwords; g.w = w; g.h = h; g.nfeat = P->nfeat; g.kl_cap = P->nfeat;
+    g.rho = P->rho; g.prec = P->prec; g.p = P->p; g.min_reg = P->min_reg;
+    const size_t lds = (size_t)P->nwords * 4;
+    if (lds > 150 * 1024) return HVO_ERR_UNSUPPORTED;
+    static size_t lds_set = 0;
+    if (lds > 32 * 1024 && lds_set < lds) {
+        HVO_HIP(hipFuncSetAttribute((const void *)k_lsd_grow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_lsd_grow, dim3(n), dim3(64), lds, st, g);
+    hvo_prof_end(ctx, id);
+    id = hvo_prof_begin(ctx, "lbd_sobel");
+    hipLaunchKernelGGL(k_lbd_blur5, dim3((w + 255) / 256, h, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_b5, w, h, P->k5[0], P->k5[1], P->k5[2]);
+    hipLaunchKernelGGL(k_lbd_sobel, dim3((w + 255) / 256, h, n), dim3(256), 0, st, P->d_b5, P->d_dx, P->d_dy, w, h);
+    hvo_prof_end(ctx, id);
+    id = hvo_prof_begin(ctx, "lbd_desc");
+    hipLaunchKernelGGL(k_lbd_desc, dim3(P->nfeat, n), dim3(64), 0, st, P->d_dx, P->d_dy, w, h, P->d_kl, P->d_nkl, P->nfeat, P->d_gL, P->d_gG, P->d_desc);
+    hvo_prof_end(ctx, id);
+    HVO_HIP(hipGetLastError());
+    return HVO_OK;
+}
+
+int lsd_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
+{
+    LsdPlan *P = plan_of(ctx);
+    if (!P) return HVO_ERR_INVALID_ARG;
+    std::vector<int> nk(n), fl(n);
+    HVO_HIP(hipMemcpyAsync(nk.data(), P->d_nkl, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HVO_HIP(hipMemcpyAsync(fl.data(), P->d_flags, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    for (int f = 0; f < n; f++) {
+        int m = nk[f];
+        if (fl[f]) out[f].status = HVO_ERR_CAPACITY;
+        if (out[f].kl) {
+            if (m > out[f].kl_cap) { m = out[f].kl_cap; out[f].status = HVO_ERR_CAPACITY; }
+            if (m > 0) {
+                HVO_HIP(hipMemcpyAsync(out[f].kl, P->d_kl + (size_t)f * P->nfeat, (size_t)m * sizeof(hvo_keyline), hipMemcpyDeviceToHost, ctx->stream));
+                if (out[f].ldesc) HVO_HIP(hipMemcpyAsync(out[f].ldesc, P->d_desc + (size_t)f * P->nfeat * 32, (size_t)m * 32, hipMemcpyDeviceToHost, ctx->stream));
+                if (out[f].linefn) HVO_HIP(hipMemcpyAsync(out[f].linefn, P->d_fn + (size_t)f * P->nfeat * 3, (size_t)m * 24, hipMemcpyDeviceToHost, ctx->stream));
+            }
+        }
+        out[f].n_kl = m;
+    }
+    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    return HVO_OK;
+}
+
+extern "C" int hvo_extract_lsd(hvo_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
+                               hvo_keyline *kl, uint8_t *desc32, double *linefn3, int cap, int *n)
+{
+    if (!ctx || !n) return HVO_ERR_INVALID_ARG;
+    *n = 0;
+    if (!gray || w <= 0 || h <= 0) return HVO_OK;           // LineExtractor.cpp:331-332
+    if (!kl || !desc32 || !linefn3 || cap < 0 || stride < w) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    hvo_frame_in in; memset(&in, 0, sizeof(in));
+    in.gray = gray; in.gray_stride = stride;
+    int rc = orb_upload(ctx, 1, &in, w, h);
+    if (rc) return rc;
+    for (int i = 0; i < ctx->nprof; i++) ctx->prof[i].used = false;
+    if ((rc = lsd_run(ctx, 1))) return rc;
+    hvo_frame_out out; memset(&out, 0, sizeof(out));
+    out.kl = kl; out.ldesc = desc32; out.linefn = linefn3; out.kl_cap = cap;
+    if ((rc = lsd_download(ctx, 1, &out))) return rc;
+    *n = out.n_kl;
+    return out.status;
+}

@@ -101,6 +101,18 @@ double orc_peac_T_mse_init(double z);
 double orc_peac_T_ang_init(double z);
 double orc_peac_T_dz(double z);
 
+/* ---------------- lines (lsd.c, lbd.c) ---------------- */
+/* cv::LineSegmentDetector (LSD_REFINE_STD defaults) on a CV_8UC1 image: segs = n x 4 floats */
+int  orc_lsd_detect(const uint8_t *gray, int w, int h, int stride, float *segs, int cap, int *n_out);
+/* LINEextractor::operator() (src/LineExtractor.cpp:329-380) */
+int  orc_line_extract(const uint8_t *gray, int w, int h, int stride, int nfeatures,
+                      orc_keyline *kls, uint8_t *desc32, double *linefn3, int cap, int *n_out);
+/* BinaryDescriptor::compute for octave-0 keylines; desc72 (n x 72 floats) optional */
+void orc_lbd_compute(const uint8_t *gray, int w, int h, int stride, const orc_keyline *kl, int n,
+                     uint8_t *desc32, float *desc72);
+void orc_lbd_weights(double *coefL21, double *coefG63);
+const int *orc_lbd_combinations(void);
+
 /* ---------------- Hamming (match.c): src/ORBmatcher.cc:1676, LSDmatcher.cpp:803-863,1137 ---- */
 int  orc_descriptor_distance(const uint8_t *a, const uint8_t *b);
 /* cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, 2): idx2/dist2 are nq*2, -1/INT_MAX padded */

@@ -88,8 +88,12 @@ def _bind_optional(L):
         L.orc_line_extract.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     if hasattr(L, "orc_lbd_compute"):
+        L.orc_lbd_compute.restype = None
         L.orc_lbd_compute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p]
+        L.orc_lbd_weights.restype = None
+        L.orc_lbd_weights.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_lbd_combinations.restype = C.POINTER(C.c_int)
 
 
 def _p(a):
@@ -227,3 +231,38 @@ def eig33sym(K):
     L.orc_eig33sym.argtypes = [C.c_void_p] * 3
     L.orc_eig33sym(_p(K), _p(s), _p(V))
     return s, V
+
+
+def lsd_detect(gray, cap=16384):
+    """cv::LineSegmentDetector::detect, default parameters -> (n,4) float32 segments"""
+    gray = np.ascontiguousarray(gray, np.uint8); h, w = gray.shape
+    segs = np.zeros((cap, 4), np.float32); n = C.c_int(0)
+    lib().orc_lsd_detect(_p(gray), w, h, gray.strides[0], _p(segs), cap, C.byref(n))
+    return segs[: min(n.value, cap)].copy()
+
+
+def line_extract(gray, nfeatures=200):
+    """LINEextractor::operator() -> (keylines, descriptors, line functions)"""
+    gray = np.ascontiguousarray(gray, np.uint8); h, w = gray.shape
+    cap = max(nfeatures, 1)
+    kl = np.zeros(cap, KEYLINE_DT); desc = np.zeros((cap, 32), np.uint8); fn = np.zeros((cap, 3)); n = C.c_int(0)
+    lib().orc_line_extract(_p(gray), w, h, gray.strides[0], nfeatures, _p(kl), _p(desc), _p(fn), cap, C.byref(n))
+    return kl[: n.value].copy(), desc[: n.value].copy(), fn[: n.value].copy()
+
+
+def lbd_compute(gray, keylines, want_float=False):
+    gray = np.ascontiguousarray(gray, np.uint8); h, w = gray.shape
+    kl = np.ascontiguousarray(keylines); n = len(kl)
+    desc = np.zeros((n, 32), np.uint8); f = np.zeros((n, 72), np.float32)
+    lib().orc_lbd_compute(_p(gray), w, h, gray.strides[0], _p(kl), n, _p(desc), _p(f))
+    return (desc, f) if want_float else desc
+
+
+def lbd_weights():
+    a = np.zeros(21); b = np.zeros(63)
+    lib().orc_lbd_weights(_p(a), _p(b))
+    return a, b
+
+
+def lbd_combinations():
+    return np.ctypeslib.as_array(lib().orc_lbd_combinations(), shape=(32, 2)).copy()

@@ -1,0 +1,95 @@
+"""GPU parity of LINEextractor::operator() (LSD detect + top-N + LBD + line functions) vs the oracle.
+Bar: key-line structure (count, order, class ids, pixel counts) and descriptor bytes bit-exact;
+float geometry within 1e-4 (north_star tolerance) -- expected to be bit-equal."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def check(kl_g, d_g, fn_g, kl_o, d_o, fn_o):
+    assert len(kl_g) == len(kl_o), (len(kl_g), len(kl_o))
+    for f in ("class_id", "octave", "num_pixels"):
+        assert np.array_equal(kl_g[f], kl_o[f]), f
+    for f in ("angle", "pt_x", "pt_y", "response", "sx", "sy", "ex", "ey", "sox", "soy", "eox", "eoy", "length"):
+        assert np.allclose(kl_g[f], kl_o[f], rtol=0, atol=TOL), f
+    assert np.allclose(kl_g["size"], kl_o["size"], rtol=1e-6, atol=1e-2)
+    assert np.array_equal(d_g, d_o), int((d_g != d_o).sum())
+    assert np.allclose(fn_g, fn_o, rtol=1e-9, atol=1e-7)
+
+
+@pytest.mark.parametrize("kind,seed", [("std", 0x5EED0002), ("lowtex", 0x5EED0001), ("std", 0x5EED1001), ("std", 9)])
+def test_lines_parity_640(gpu_ctx, orc, synth, kind, seed):
+    g = synth.make_gray(kind, seed)
+    kl_o, d_o, fn_o = orc.line_extract(g)
+    kl_g, d_g, fn_g = gpu_ctx.extract_lsd(g)
+    assert len(kl_o) > 10
+    check(kl_g, d_g, fn_g, kl_o, d_o, fn_o)
+
+
+def test_lines_exactness_report(gpu_ctx, orc, synth):
+    """how exact is 'within 1e-4'?  key-line floats are expected bit-equal on these frames"""
+    g = synth.make_gray("std", 0x5EED0002)
+    kl_o, d_o, fn_o = orc.line_extract(g)
+    kl_g, d_g, fn_g = gpu_ctx.extract_lsd(g)
+    same = all(np.array_equal(kl_g[f], kl_o[f]) for f in kl_o.dtype.names)
+    assert same or np.allclose(kl_g["sx"], kl_o["sx"], atol=TOL)
+
+
+def test_lines_flat_image(gpu_ctx):
+    kl, d, fn = gpu_ctx.extract_lsd(np.full((480, 640), 90, np.uint8))
+    assert len(kl) == 0
+
+
+def test_lines_empty_image(gpu_ctx):
+    kl, d, fn = gpu_ctx.extract_lsd(np.zeros((0, 0), np.uint8))     # LineExtractor.cpp:331-332
+    assert len(kl) == 0
+
+
+def test_lines_wrong_dtype(gpu_ctx, hvo):
+    with pytest.raises(hvo.HvoError):
+        gpu_ctx.extract_lsd(np.zeros((480, 640), np.float32))
+
+
+def test_lines_few_lines_keep_detection_order(gpu_ctx, orc):
+    """fewer than nLSDFeature lines: no sort, class_id = detection index (LineExtractor.cpp:351)"""
+    g = np.full((480, 640), 60, np.uint8)
+    g[100:300, 200:420] = 180
+    g[350:420, 50:600] = 20
+    kl_o, d_o, fn_o = orc.line_extract(g)
+    kl_g, d_g, fn_g = gpu_ctx.extract_lsd(g)
+    assert 4 <= len(kl_o) < 200
+    assert np.array_equal(kl_o["class_id"], np.arange(len(kl_o)))
+    check(kl_g, d_g, fn_g, kl_o, d_o, fn_o)
+
+
+def test_lines_1280(hvo, orc, synth):
+    g = synth.make_gray("std", 0x5EED0003, 1280, 960)
+    kl_o, d_o, fn_o = orc.line_extract(g)
+    ctx = hvo.Context()
+    try:
+        kl_g, d_g, fn_g = ctx.extract_lsd(g)
+    finally:
+        ctx.close()
+    check(kl_g, d_g, fn_g, kl_o, d_o, fn_o)
+
+
+def test_lines_batch_and_all_stages(hvo, orc, synth):
+    gray, depth = synth.make_batch("std", 0x5EED1000, 3)
+    ctx = hvo.Context(max_batch=3)
+    try:
+        ctx.batch_upload(gray, depth)
+        ctx.batch_run(hvo.STAGE_ALL)
+        res = ctx.batch_download(hvo.STAGE_ALL)
+    finally:
+        ctx.close()
+    o = orc.Orb()
+    for b in range(3):
+        assert res[b]["status"] == 0
+        kl_o, d_o, fn_o = orc.line_extract(gray[b])
+        check(res[b]["kl"], res[b]["ldesc"], res[b]["linefn"], kl_o, d_o, fn_o)
+        kp_o, dd_o = o.extract(gray[b])
+        assert np.array_equal(res[b]["desc"], dd_o) and len(res[b]["kp"]) == len(kp_o)
+        lo, po = orc.peac(depth[b])
+        assert np.array_equal(res[b]["labels"], lo) and len(res[b]["planes"]) == len(po)

@@ -154,3 +154,47 @@ def test_peac_synthetic_scene_finds_the_walls(orc, synth):
     lab, pl = orc.peac(synth.make_depth(0x5EED0002))
     assert len(pl) == 4 and np.all(np.diff(pl["n_points"]) <= 0)
     assert set(np.unique(lab)) == {-1, 0, 1, 2, 3}
+
+
+# ---------------- LSD / LBD known answers ----------------
+def test_lbd_combinations_and_weights(orc):
+    comb = orc.lbd_combinations()
+    # binary_descriptor_custom.cpp:74-107: the 32 band pairs, lexicographic except the far pairs 0-7,0-8,1-7,1-8
+    assert comb[0].tolist() == [0, 1] and comb[5].tolist() == [0, 6] and comb[6].tolist() == [1, 2]
+    assert comb[31].tolist() == [7, 8] and len({tuple(c) for c in comb}) == 32
+    assert not any(tuple(c) in {(0, 7), (0, 8), (1, 7), (1, 8)} for c in comb.tolist())
+    gL, gG = orc.lbd_weights()
+    assert np.allclose(gL, np.exp(-(np.arange(21) - 10) ** 2 / 98.0), rtol=1e-15)       # sigma_l = 7 (int div)
+    assert np.allclose(gG, np.exp(-(np.arange(63) - 31) ** 2 / 1922.0), rtol=1e-15)     # sigma_g = 31
+
+
+def test_lsd_finds_a_synthetic_edge(orc):
+    g = np.full((480, 640), 60, np.uint8)
+    g[:, 300:] = 180                                   # one vertical step edge
+    segs = orc.lsd_detect(g)
+    assert len(segs) >= 1
+    long = segs[np.argmax(np.hypot(segs[:, 2] - segs[:, 0], segs[:, 3] - segs[:, 1]))]
+    assert abs(long[0] - 300) < 1.5 and abs(long[2] - 300) < 1.5 and abs(long[3] - long[1]) > 400
+
+
+def test_line_extract_top_n_and_functions(orc, synth):
+    g = synth.make_gray("std", 0x5EED0002)
+    kl, desc, fn = orc.line_extract(g, nfeatures=200)
+    assert len(kl) == 200 and np.array_equal(kl["class_id"], np.arange(200))
+    assert np.all(np.diff(kl["response"]) <= 0)                    # sorted by response, descending
+    assert np.allclose(kl["response"], kl["length"] / 640.0, rtol=1e-6)
+    assert np.allclose(np.hypot(fn[:, 0], fn[:, 1]), 1.0, atol=1e-12)
+    # both end points lie on the line function
+    assert np.allclose(fn[:, 0] * kl["sx"] + fn[:, 1] * kl["sy"] + fn[:, 2], 0, atol=1e-6)
+    assert np.allclose(fn[:, 0] * kl["ex"] + fn[:, 1] * kl["ey"] + fn[:, 2], 0, atol=1e-6)
+    d2 = orc.lbd_compute(g, kl)
+    assert np.array_equal(d2, desc)
+
+
+def test_lbd_float_descriptor_is_unit_and_clipped(orc, synth):
+    g = synth.make_gray("std", 0x5EED0002)
+    kl, _, _ = orc.line_extract(g)
+    _, f = orc.lbd_compute(g, kl, want_float=True)
+    ok = ~np.isnan(f).any(axis=1)
+    assert ok.mean() > 0.9
+    assert np.allclose(np.linalg.norm(f[ok], axis=1), 1.0, atol=1e-5)
