@@ -191,74 +191,79 @@ static __device__ __forceinline__ double angle_diff_signed(double a, double b)
     return diff;
 }
 
-// region_grow (OpenCV 3.2 lsd.cpp): all lanes enter; lane 0 takes the decisions in the reference's
-// order (point index, then x outer / y inner) on neighbourhood data prefetched for up to 7 points.
-static __device__ void region_grow_wave(GrowState &S, int seed_addr, int &reg_size, double &reg_angle, double prec,
-                                        double *n_ang, double *n_cs, double *n_sn, int *n_addr)
+// region_grow (OpenCV 3.2 lsd.cpp).  Region points are stored packed (y << 16 | x).
+// Per round the wave fetches the 3x3 neighbourhoods of up to 28 pending region points (4 slots of 64
+// lanes, slot-major = the reference's visiting order: point index, then x outer / y inner).  The
+// sequential decisions are then taken without a scalar scan: every lane holds "valid & aligned with
+// the current region angle" for its neighbour, a ballot yields the first such neighbour at or after the
+// cursor -- exactly the next pixel the reference would add -- the region angle is updated uniformly,
+// and the remaining lanes re-evaluate against the new angle.  Neighbours tested before the cursor are
+// never revisited, like the reference's single pass.
+#define GROW_SLOTS 4
+static __device__ __forceinline__ bool lsd_aligned(double a, double theta, double prec)
+{
+    double n_theta = theta - a;
+    if (n_theta < 0) n_theta = -n_theta;
+    if (n_theta > (3 * LSD_PI) / 2) { n_theta -= 2 * LSD_PI; if (n_theta < 0) n_theta = -n_theta; }
+    return n_theta <= prec;
+}
+
+static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size, double &reg_angle, double prec)
 {
     const int lane = threadIdx.x, sw = S.sw, sh = S.sh;
-    float sumdx = 0, sumdy = 0;
-    if (lane == 0) {
-        S.reg[0] = seed_addr; S.ring[0] = seed_addr;
-        const double a = S.ang[seed_addr];
-        reg_angle = a;
-        sumdx = (float)cos(a); sumdy = (float)sin(a);
-        used_set(S, seed_addr % sw, seed_addr / sw);
-    }
-    reg_size = 1;
-    reg_angle = __shfl(reg_angle, 0);
+    const int sx0 = seed_xy & 0xFFFF, sy0 = seed_xy >> 16;
+    const double a0 = S.ang[sx0 + sy0 * sw];
+    double ra = a0;
+    float sumdx = (float)cos(a0), sumdy = (float)sin(a0);
+    if (lane == 0) { S.reg[0] = seed_xy; S.ring[0] = seed_xy; used_set(S, sx0, sy0); }
+    int rs = 1;
     __syncthreads();
     int i = 0;
-    while (i < reg_size) {
-        const int cnt = min(7, reg_size - i);
-        // ---- prefetch: lane 9k+j <- neighbour j of point i+k ----
-        const int k = lane / 9, j = lane - 9 * k;
-        int c = -1; double a = LSD_NOTDEF, cc = 0, ss = 0;
-        if (k < cnt) {
-            const int idx = i + k;
-            const int pa = (reg_size - idx <= LSD_RING) ? S.ring[idx & (LSD_RING - 1)] : S.reg[idx];
-            const int px = pa % sw, py = pa / sw;
-            const int xx = px - 1 + j / 3, yy = py - 1 + (j - 3 * (j / 3));
-            if (xx >= 0 && yy >= 0 && xx < sw && yy < sh) {
-                c = xx + yy * sw;
-                a = S.ang[c];
-                if (a != LSD_NOTDEF) { cc = S.cs[c]; ss = S.sn[c]; }
-            }
-        }
-        if (lane < 63) { n_addr[lane] = c; n_ang[lane] = a; n_cs[lane] = cc; n_sn[lane] = ss; }
-        __syncthreads();
-        // all `cnt` points were in the region before this round, so handling them in order with live
-        // `used` bits is exactly the sequential loop; points appended now are handled in later rounds
-        const int done = cnt;
-        if (lane == 0) {
-            int rs = reg_size; double ra = reg_angle;
-            for (int kk = 0; kk < cnt; kk++) {
-                for (int jj = 0; jj < 9; jj++) {
-                    const int ca = n_addr[9 * kk + jj];
-                    if (ca < 0) continue;
-                    const double an = n_ang[9 * kk + jj];
-                    if (an == LSD_NOTDEF) continue;
-                    const int cx = ca % sw, cy = ca / sw;
-                    if (used_get(S, cx, cy)) continue;
-                    // isAligned
-                    double nt = ra - an;
-                    if (nt < 0) nt = -nt;
-                    if (nt > (3 * LSD_PI) / 2) { nt -= 2 * LSD_PI; if (nt < 0) nt = -nt; }
-                    if (!(nt <= prec)) continue;
-                    used_set(S, cx, cy);
-                    S.reg[rs] = ca; S.ring[rs & (LSD_RING - 1)] = ca;
-                    ++rs;
-                    sumdx = (float)((double)sumdx + n_cs[9 * kk + jj]);
-                    sumdy = (float)((double)sumdy + n_sn[9 * kk + jj]);
-                    ra = (double)fatan2_deg(sumdy, sumdx) * (LSD_PI / 180);
+    while (i < rs) {
+        const int cnt = min(7 * GROW_SLOTS, rs - i);
+        int c[GROW_SLOTS]; double an[GROW_SLOTS], cs[GROW_SLOTS], sn[GROW_SLOTS]; bool valid[GROW_SLOTS];
+#pragma unroll
+        for (int s = 0; s < GROW_SLOTS; s++) {
+            const int n = s * 63 + lane;             // 63 neighbours (7 points) per slot, lane 63 idles
+            const int k = n / 9, j = n - 9 * k;
+            c[s] = -1; an[s] = LSD_NOTDEF; cs[s] = 0; sn[s] = 0; valid[s] = false;
+            if (lane < 63 && k < cnt) {
+                const int idx = i + k;
+                const int pxy = (rs - idx <= LSD_RING) ? S.ring[idx & (LSD_RING - 1)] : S.reg[idx];
+                const int xx = (pxy & 0xFFFF) - 1 + j / 3, yy = (pxy >> 16) - 1 + (j - 3 * (j / 3));
+                if (xx >= 0 && yy >= 0 && xx < sw && yy < sh) {
+                    const int ad = xx + yy * sw;
+                    const double a = S.ang[ad];
+                    if (a != LSD_NOTDEF && !used_get(S, xx, yy)) { c[s] = (yy << 16) | xx; an[s] = a; cs[s] = S.cs[ad]; sn[s] = S.sn[ad]; valid[s] = true; }
                 }
             }
-            reg_size = rs; reg_angle = ra;
         }
-        reg_size = __shfl(reg_size, 0); reg_angle = __shfl(reg_angle, 0);
-        i += done;
+        const int rs0 = rs;
+#pragma unroll
+        for (int s = 0; s < GROW_SLOTS; s++) {
+            unsigned long long done_mask = 0;        // lanes already passed in this slot
+            for (;;) {
+                const bool al = valid[s] && lsd_aligned(an[s], ra, prec);
+                const unsigned long long m = __ballot(al) & ~done_mask;
+                if (!m) break;
+                const int L = __ffsll((long long)m) - 1;
+                const int cA = __shfl(c[s], L);
+                const double csA = __shfl(cs[s], L), snA = __shfl(sn[s], L);
+                if (lane == 0) { used_set(S, cA & 0xFFFF, cA >> 16); S.reg[rs] = cA; S.ring[rs & (LSD_RING - 1)] = cA; }
+                ++rs;
+                sumdx = (float)((double)sumdx + csA);
+                sumdy = (float)((double)sumdy + snA);
+                ra = (double)fatan2_deg(sumdy, sumdx) * (LSD_PI / 180);
+#pragma unroll
+                for (int t = 0; t < GROW_SLOTS; t++) if (c[t] == cA) valid[t] = false;
+                done_mask = (L == 63) ? ~0ull : ((1ull << (L + 1)) - 1);
+            }
+        }
+        (void)rs0;
+        i += cnt;
         __syncthreads();
     }
+    reg_size = rs; reg_angle = ra;
 }
 
 // ordered fp64 accumulation helpers: the sums of region2rect / get_theta / refine must be added in
@@ -270,7 +275,7 @@ static __device__ void region2rect_wave(const GrowState &S, int reg_size, double
     double x = 0, y = 0, sum = 0;
     for (int base = 0; base < reg_size; base += 64) {
         const int i = base + lane;
-        if (i < reg_size) { const int a = S.reg[i]; b0[lane] = (double)(a % sw); b1[lane] = (double)(a / sw); b2[lane] = S.modgrad[a]; }
+        if (i < reg_size) { const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; b0[lane] = (double)px; b1[lane] = (double)py; b2[lane] = S.modgrad[px + py * sw]; }
         __syncthreads();
         if (lane == 0) { const int n = min(64, reg_size - base); for (int q = 0; q < n; q++) { const double wgt = b2[q]; x += b0[q] * wgt; y += b1[q] * wgt; sum += wgt; } }
         __syncthreads();
@@ -281,7 +286,7 @@ static __device__ void region2rect_wave(const GrowState &S, int reg_size, double
     double Ixx = 0, Iyy = 0, Ixy = 0;
     for (int base = 0; base < reg_size; base += 64) {
         const int i = base + lane;
-        if (i < reg_size) { const int a = S.reg[i]; b0[lane] = (double)(a % sw); b1[lane] = (double)(a / sw); b2[lane] = S.modgrad[a]; }
+        if (i < reg_size) { const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; b0[lane] = (double)px; b1[lane] = (double)py; b2[lane] = S.modgrad[px + py * sw]; }
         __syncthreads();
         if (lane == 0) {
             const int n = min(64, reg_size - base);
@@ -302,7 +307,7 @@ static __device__ void region2rect_wave(const GrowState &S, int reg_size, double
     double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
     for (int base = 0; base < reg_size; base += 64) {
         const int i = base + lane;
-        if (i < reg_size) { const int a = S.reg[i]; b0[lane] = (double)(a % sw); b1[lane] = (double)(a / sw); }
+        if (i < reg_size) { const int a = S.reg[i]; b0[lane] = (double)(a & 0xFFFF); b1[lane] = (double)(a >> 16); }
         __syncthreads();
         if (lane == 0) {
             const int n = min(64, reg_size - base);
@@ -338,17 +343,17 @@ static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle
     double density = rect_density(rec, reg_size);
     if (density >= density_th) return true;
     const int a0 = S.reg[0];
-    const double xc = (double)(a0 % sw), yc = (double)(a0 / sw);
-    const double ang_c = S.ang[a0];
+    const double xc = (double)(a0 & 0xFFFF), yc = (double)(a0 >> 16);
+    const double ang_c = S.ang[(a0 & 0xFFFF) + (a0 >> 16) * sw];
     double sum = 0, s_sum = 0; int n = 0;
     for (int base = 0; base < reg_size; base += 64) {
         const int i = base + lane;
-        if (i < reg_size) { const int a = S.reg[i]; b0[lane] = (double)(a % sw); b1[lane] = (double)(a / sw); b2[lane] = S.ang[a]; n_addr[lane] = a; }
+        if (i < reg_size) { const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; b0[lane] = (double)px; b1[lane] = (double)py; b2[lane] = S.ang[px + py * sw]; n_addr[lane] = a; }
         __syncthreads();
         if (lane == 0) {
             const int m = min(64, reg_size - base);
             for (int q = 0; q < m; q++) {
-                used_clr(S, n_addr[q] % sw, n_addr[q] / sw);
+                used_clr(S, n_addr[q] & 0xFFFF, n_addr[q] >> 16);
                 const double ddx = b0[q] - xc, ddy = b1[q] - yc;
                 if (sqrt(ddx * ddx + ddy * ddy) < rec.width) {
                     const double ang_d = angle_diff_signed(b2[q], ang_c);
@@ -364,7 +369,7 @@ static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle
         tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
     }
     tau = __shfl(tau, 0);
-    region_grow_wave(S, a0, reg_size, reg_angle, tau, b0, b1, b2, n_addr);
+    region_grow_wave(S, a0, reg_size, reg_angle, tau);
     if (reg_size < 2) return false;
     region2rect_wave(S, reg_size, reg_angle, prec, rec, b0, b1, b2);
     density = rect_density(rec, reg_size);
@@ -381,9 +386,9 @@ static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle
             int rs = reg_size;
             for (int i = 0; i < rs; ++i) {
                 const int a = S.reg[i];
-                const double ddx = (double)(a % sw) - xc, ddy = (double)(a / sw) - yc;
+                const double ddx = (double)(a & 0xFFFF) - xc, ddy = (double)(a >> 16) - yc;
                 if (ddx * ddx + ddy * ddy > radSq) {
-                    used_clr(S, a % sw, a / sw);
+                    used_clr(S, a & 0xFFFF, a >> 16);
                     const int last = S.reg[rs - 1];
                     S.reg[i] = last; S.reg[rs - 1] = a;
                     --rs; --i;
@@ -438,9 +443,9 @@ __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
             const int bit = __ffs((int)mw) - 1;
             const int wsel = wbase + wl;
             const int sy = wsel / wpr, sx = (wsel - sy * wpr) * 32 + bit;
-            const int seed = sx + sy * sw;
+            const int seed = (sy << 16) | sx;
             int reg_size; double reg_angle = 0;
-            region_grow_wave(S, seed, reg_size, reg_angle, g.prec, b0, b1, b2, n_addr);
+            region_grow_wave(S, seed, reg_size, reg_angle, g.prec);
             if ((unsigned)reg_size < g.min_reg) continue;
             Rect rec;
             region2rect_wave(S, reg_size, reg_angle, g.prec, rec, b0, b1, b2);

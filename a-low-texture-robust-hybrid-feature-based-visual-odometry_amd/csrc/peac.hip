@@ -9,8 +9,9 @@
 //   k_peac_cluster   initGraph edges (AHCPlaneFitter.hpp:894-954) + ahCluster (983-1189); one wave
 //                    per frame, min-MSE heap in LDS, candidate merges evaluated one per lane
 //   k_peac_blkmap    findBlockMembership (485-587): block erosion, coarse labels
-//   k_peac_refine    seed queue + floodFill (428-476) + last merge round + plidmap (299-340);
-//                    one wave per frame, queue events committed in conflict-free prefixes
+//   k_peac_flood     seed queue + floodFill (428-476): 1024 threads per frame, 1024 queue events per
+//                    round, same-pixel events serialised through an LDS hash
+//   k_peac_final     last merge round + plidmap (299-340), one wave per frame
 //   k_peac_relabel   membership relabel (353-365), negative "trail" counters reported as -1
 //
 // fp64 throughout, identical operation order to oracle/peac.c (no FMA contraction: -ffp-contract=off).
@@ -39,6 +40,7 @@ struct PeacPlan {
     int *d_blkmap = nullptr; int32_t *d_labels = nullptr; float *d_dist = nullptr;
     int *d_qpix = nullptr; int *d_qpl = nullptr; int *d_plidmap = nullptr; int *d_isvalid = nullptr;
     hvo_plane *d_planes = nullptr;
+    unsigned long long *d_adj = nullptr;
     double c15 = 0, c60 = 0, c30 = 0;   // cos thresholds evaluated on the host (glibc), like the oracle
 };
 
@@ -520,105 +522,97 @@ struct RfArgs {
     hvo_plane *planes; double c30;
 };
 
-__global__ __launch_bounds__(64) void k_peac_refine(RfArgs r)
+// k_peac_flood: seeds + floodFill (AHCPlaneFitter.hpp:543-575, 428-476), 1024 threads per frame.
+// Events = (queue entry, neighbour slot) in queue order.  A round takes the next 1024 events that
+// existed when it started.  The part of an event that does not depend on the pixel's state (block
+// test, unprojection, point-plane distance) is evaluated for all events at once; the per-pixel
+// state machine (membership "trail", distMap) must see its events in queue order, so events that
+// hit the same pixel are serialised: in each sub-round an LDS hash elects, per pixel, the pending
+// event with the smallest index, which is then applied.  Pushes are appended in event order with a
+// block scan, which reproduces the reference's queue order exactly.
+#define FLOOD_T 1024
+#define FLOOD_HS 4096
+__global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long long *__restrict__ adj_out)
 {
     __shared__ double pl[MAX_PLANES][8];          // center[3], normal[3], mse, pad
     __shared__ unsigned long long adj[MAX_PLANES];
-    __shared__ int s_tgt[64];
-    __shared__ double hkey[MAX_PLANES]; __shared__ int hid[MAX_PLANES];
-    __shared__ int lA[LCAP], lB[LCAP]; __shared__ double cm[64]; __shared__ int cN[64];
+    __shared__ int hkeys[FLOOD_HS], hvals[FLOOD_HS];
+    __shared__ int wsum[FLOOD_T / 64];
+    __shared__ int s_nq;
     const ClArgs &a = r.c;
-    const int frame = blockIdx.x, lane = threadIdx.x;
+    const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int w = r.w, h = r.h, Nw = a.Nw, Nh = a.Nh, nblk = a.nblk;
     int *meta = a.meta + (size_t)frame * 16;
     const int nold = meta[2];
-    int *ext = a.extracted + (size_t)frame * 2 * MAX_PLANES;
-    double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
-    int *segI = a.segI + (size_t)frame * a.segcap * SEG_I;
-    int *pool = a.pool + (size_t)frame * a.poolcap, *pool2 = a.pool2 + (size_t)frame * a.poolcap;
-    if (meta[6]) { int *t = pool; pool = pool2; pool2 = t; }
+    const int *ext = a.extracted + (size_t)frame * 2 * MAX_PLANES;
+    const double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
     const int *blkmap = r.blkmap + (size_t)frame * nblk;
-    const int *isvalid = r.isvalid + (size_t)frame * MAX_PLANES;
     int32_t *labels = r.labels + (size_t)frame * w * h;
     float *dist = r.dist + (size_t)frame * w * h;
     int *qpix = r.qpix + (size_t)frame * r.qcap, *qpl = r.qpl + (size_t)frame * r.qcap;
-    int *plidmap = r.plidmap + (size_t)frame * MAX_PLANES;
     const uint16_t *D = r.depth + (size_t)frame * r.dframe;
-    int flags = meta[3];
-    if (lane < MAX_PLANES) {
-        adj[lane] = 0;
-        if (lane < nold) { const double *sd = segD + (size_t)ext[lane] * SEG_D; for (int k = 0; k < 7; k++) pl[lane][k] = sd[9 + k]; }
+    int flags = 0;
+    if (tid < MAX_PLANES) {
+        adj[tid] = 0;
+        if (tid < nold) { const double *sd = segD + (size_t)ext[tid] * SEG_D; for (int k = 0; k < 7; k++) pl[tid][k] = sd[9 + k]; }
     }
-    __syncthreads();
-    // ---- seeds in block raster order (AHCPlaneFitter.hpp:543-575): count, scan, write ----
-    int nq = 0;
-    for (int base = 0; base < nblk; base += 64) {
-        const int b = base + lane;
-        int cnt = 0, m = -2, up = -2, lf = -2, i = 0, j = 0;
-        if (b < nblk) {
-            i = b / Nw; j = b - i * Nw; m = blkmap[b];
-            up = i > 0 ? blkmap[b - Nw] : -2; lf = j > 0 ? blkmap[b - 1] : -2;
-            if (m < 0) { if (i > 0 && up >= 0) cnt += WIN - 1; if (j > 0 && lf >= 0) cnt += WIN - 1; }
-            else { if (i > 0 && up != m) cnt += WIN - 1; if (j > 0 && lf != m) cnt += WIN - 1; }
-        }
-        int incl = cnt;
-        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-        int pos = nq + incl - cnt;
-        if (cnt && pos + cnt <= r.qcap) {
-            if (m < 0) {
-                if (i > 0 && up >= 0) { const int sp = (i * WIN - 1) * w + j * WIN; for (int k = 1; k < WIN; ++k) { qpix[pos] = sp + k; qpl[pos++] = up; } }
-                if (j > 0 && lf >= 0) { const int sp = (i * WIN) * w + j * WIN - 1; for (int k = 0; k < WIN - 1; ++k) { qpix[pos] = sp + k * w; qpl[pos++] = lf; } }
-            } else {
-                if (i > 0 && up != m) { const int sp = (i * WIN) * w + j * WIN; for (int k = 0; k < WIN - 1; ++k) { qpix[pos] = sp + k; qpl[pos++] = m; } }
-                if (j > 0 && lf != m) { const int sp = (i * WIN) * w + j * WIN; for (int k = 1; k < WIN; ++k) { qpix[pos] = sp + k * w; qpl[pos++] = m; } }
+    // ---- seeds in block raster order: count, scan, write (wave 0) ----
+    if (wv == 0) {
+        int nq = 0;
+        for (int base = 0; base < nblk; base += 64) {
+            const int b = base + lane;
+            int cnt = 0, m = -2, up = -2, lf = -2, i = 0, j = 0;
+            if (b < nblk) {
+                i = b / Nw; j = b - i * Nw; m = blkmap[b];
+                up = i > 0 ? blkmap[b - Nw] : -2; lf = j > 0 ? blkmap[b - 1] : -2;
+                if (m < 0) { if (i > 0 && up >= 0) cnt += WIN - 1; if (j > 0 && lf >= 0) cnt += WIN - 1; }
+                else { if (i > 0 && up != m) cnt += WIN - 1; if (j > 0 && lf != m) cnt += WIN - 1; }
             }
+            int incl = cnt;
+            for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            int pos = nq + incl - cnt;
+            if (cnt && pos + cnt <= r.qcap) {
+                if (m < 0) {
+                    if (i > 0 && up >= 0) { const int sp = (i * WIN - 1) * w + j * WIN; for (int k = 1; k < WIN; ++k) { qpix[pos] = sp + k; qpl[pos++] = up; } }
+                    if (j > 0 && lf >= 0) { const int sp = (i * WIN) * w + j * WIN - 1; for (int k = 0; k < WIN - 1; ++k) { qpix[pos] = sp + k * w; qpl[pos++] = lf; } }
+                } else {
+                    if (i > 0 && up != m) { const int sp = (i * WIN) * w + j * WIN; for (int k = 0; k < WIN - 1; ++k) { qpix[pos] = sp + k; qpl[pos++] = m; } }
+                    if (j > 0 && lf != m) { const int sp = (i * WIN) * w + j * WIN; for (int k = 1; k < WIN; ++k) { qpix[pos] = sp + k * w; qpl[pos++] = m; } }
+                }
+            }
+            nq += __shfl(incl, 63);
         }
-        nq += __shfl(incl, 63);
+        if (lane == 0) s_nq = nq;
     }
-    if (nq > r.qcap) { nq = r.qcap; flags |= 32; }
     __syncthreads();
-    // ---- floodFill (AHCPlaneFitter.hpp:428-476).  Events = (queue entry, neighbour slot) in queue
-    // order; a round evaluates 64 consecutive events and commits the longest prefix in which no two
-    // events touch the same pixel, so every per-pixel state machine sees its events in queue order.
+    int nq = s_nq;
+    if (nq > r.qcap) { nq = r.qcap; flags |= 32; }
     const double dfx = (double)r.fx, dfy = (double)r.fy, dcx = (double)r.cx, dcy = (double)r.cy, df = (double)r.dfac;
-    long long ev = 0;                                   // next event = entry*4 + slot
+    long long ev = 0;
     while (ev < (long long)nq * 4) {
-        const long long e = ev + lane;
-        const int k = (int)(e >> 2), slot = (int)(e & 3);
+        const long long avail = (long long)nq * 4 - ev;
+        const int nev = avail < FLOOD_T ? (int)avail : FLOOD_T;
         int cIdx = -1, plid = 0;
-        if (k < nq) {
+        bool ok = false; float cdist = -1;
+        if (tid < nev) {
+            const long long e = ev + tid;
+            const int k = (int)(e >> 2), slot = (int)(e & 3);
             const int sIdx = qpix[k]; plid = qpl[k];
             const int sy = sIdx / w, sx = sIdx - sy * w;
-            // getValid4Neighbor order: left, right, up, down (only those inside the image)
-            int c = 0, t = -1;
+            int c = 0, t = -1;       // getValid4Neighbor order: left, right, up, down
             if (sx > 0) { if (c == slot) t = sIdx - 1; c++; }
             if (sx < w - 1) { if (c == slot) t = sIdx + 1; c++; }
             if (sy > 0) { if (c == slot) t = sIdx - w; c++; }
             if (sy < h - 1) { if (c == slot) t = sIdx + w; c++; }
             cIdx = t;
-        }
-        s_tgt[lane] = cIdx;
-        __syncthreads();
-        bool conflict = false;
-        if (cIdx >= 0) for (int q = 0; q < lane; q++) conflict |= (s_tgt[q] == cIdx);
-        const unsigned long long cm_ = __ballot(conflict);
-        int ncommit = cm_ ? __ffsll((long long)cm_) - 1 : 64;           // >= 1: lane 0 never conflicts
-        // never step past the queue tail as it stood when the round started: entries pushed by
-        // this round's events are evaluated in a later round
-        { const long long avail = (long long)nq * 4 - ev; if (avail < ncommit) ncommit = (int)avail; }
-        bool push = false;
-        if (lane < ncommit && cIdx >= 0) {
-            int trail = labels[cIdx];
-            bool skip = trail <= -6 || (trail >= 0 && trail == plid);
-            if (!skip) {
+            if (cIdx >= 0) {
                 const int cy_ = cIdx / w, cx_ = cIdx - cy_ * w;
                 const int by = cy_ / WIN, bx = cx_ / WIN;
                 const int blkid = (by < Nh && bx < Nw) ? by * Nw + bx : -1;
-                if (!(blkid >= 0 && blkmap[blkid] >= 0)) {
+                if (blkid >= 0 && blkmap[blkid] >= 0) cIdx = -1;         // pixel of a still-valid block: never touched
+                else {
                     const int d = D[(size_t)cy_ * r.pitch + cx_];
-                    bool ok = d != 0;
-                    float cdist = -1;
-                    if (ok) {
+                    if (d != 0) {
                         const double z = (double)d * df;
                         const double x = ((double)cx_ - dcx) * z / dfx, y = ((double)cy_ - dcy) * z / dfy;
                         const double *P = pl[plid];
@@ -626,6 +620,29 @@ __global__ __launch_bounds__(64) void k_peac_refine(RfArgs r)
                         cdist = (float)fabs(sd);
                         ok = ((double)cdist * (double)cdist) < 9 * P[6] + 1e-5;
                     }
+                }
+            }
+        }
+        bool pending = cIdx >= 0, push = false;
+        int hslot = -1;
+        while (__syncthreads_or(pending)) {
+            for (int i = tid; i < FLOOD_HS; i += FLOOD_T) { hkeys[i] = -1; hvals[i] = 0x7FFFFFFF; }
+            __syncthreads();
+            if (pending) {
+                int hs = (int)(((unsigned)cIdx * 2654435761u) >> 20) & (FLOOD_HS - 1);
+                for (;;) {
+                    const int old = atomicCAS(&hkeys[hs], -1, cIdx);
+                    if (old == -1 || old == cIdx) break;
+                    hs = (hs + 1) & (FLOOD_HS - 1);
+                }
+                atomicMin(&hvals[hs], tid);
+                hslot = hs;
+            }
+            __syncthreads();
+            if (pending && hvals[hslot] == tid) {
+                pending = false;
+                const int trail = labels[cIdx];
+                if (!(trail <= -6 || (trail >= 0 && trail == plid))) {
                     if (ok) {
                         if (trail >= 0) {
                             const double *Q = pl[trail], *P = pl[plid];
@@ -638,18 +655,48 @@ __global__ __launch_bounds__(64) void k_peac_refine(RfArgs r)
                     } else if (trail < 0) labels[cIdx] = trail - 1;
                 }
             }
+            // the loop condition's barrier orders these global writes before the next sub-round
         }
-        const unsigned long long pm = __ballot(push);
+        // ---- ordered append: exclusive scan of `push` over the block ----
+        const unsigned long long bm = __ballot(push);
+        const int wcnt = __popcll(bm);
+        if (lane == 0) wsum[wv] = wcnt;
+        __syncthreads();
+        int base = 0, total = 0;
+        for (int i = 0; i < FLOOD_T / 64; i++) { const int v = wsum[i]; if (i < wv) base += v; total += v; }
         if (push) {
-            const int pos = nq + __popcll(pm & ((1ull << lane) - 1));
+            const int pos = nq + base + __popcll(bm & ((1ull << lane) - 1));
             if (pos < r.qcap) { qpix[pos] = cIdx; qpl[pos] = plid; }
         }
-        nq += __popcll(pm);
+        nq += total;
         if (nq > r.qcap) { nq = r.qcap; flags |= 32; }
-        ev += ncommit;
+        ev += nev;
         __syncthreads();
     }
-    // ---- one last merge round over the still-valid coarse planes (AHCPlaneFitter.hpp:321-340) ----
+    if (tid < MAX_PLANES) adj_out[(size_t)frame * MAX_PLANES + tid] = adj[tid];
+    if (tid == 0) { meta[5] = nq; meta[7] = flags; }
+}
+
+// k_peac_final: one last merge round over the still-valid coarse planes, plidmap, plane records
+// (AHCPlaneFitter.hpp:321-340).  One wave per frame.
+__global__ __launch_bounds__(64) void k_peac_final(RfArgs r, const unsigned long long *__restrict__ adj_in)
+{
+    __shared__ double hkey[MAX_PLANES]; __shared__ int hid[MAX_PLANES];
+    __shared__ int lA[LCAP], lB[LCAP]; __shared__ double cm[64]; __shared__ int cN[64];
+    const ClArgs &a = r.c;
+    const int frame = blockIdx.x, lane = threadIdx.x;
+    const int nblk = a.nblk;
+    int *meta = a.meta + (size_t)frame * 16;
+    const int nold = meta[2];
+    int *ext = a.extracted + (size_t)frame * 2 * MAX_PLANES;
+    double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
+    int *segI = a.segI + (size_t)frame * a.segcap * SEG_I;
+    int *pool = a.pool + (size_t)frame * a.poolcap, *pool2 = a.pool2 + (size_t)frame * a.poolcap;
+    if (meta[6]) { int *t = pool; pool = pool2; pool2 = t; }
+    const int *isvalid = r.isvalid + (size_t)frame * MAX_PLANES;
+    int *plidmap = r.plidmap + (size_t)frame * MAX_PLANES;
+    const unsigned long long *adj = adj_in + (size_t)frame * MAX_PLANES;
+    int flags = meta[3] | meta[7];
     Heap H; H.key = hkey; H.id = hid; H.n = 0;
     int nseg = meta[0], pooltop = meta[1];
     if (pooltop + nold * MAX_PLANES > a.poolcap - 2 * a.nblk) pool_gc(segI, nseg, pool, pool2, pooltop);
@@ -692,7 +739,7 @@ __global__ __launch_bounds__(64) void k_peac_refine(RfArgs r)
             for (int k = 0; k < 3; k++) { out[j].normal[k] = sd[12 + k]; out[j].center[k] = sd[9 + k]; }
             out[j].mse = sd[15]; out[j].n_points = segI[(size_t)fin[j] * SEG_I]; out[j].rid = segI[(size_t)fin[j] * SEG_I + 1];
         }
-        meta[3] = flags; meta[4] = nfin; meta[5] = nq;
+        meta[3] = flags; meta[4] = nfin;
     }
 }
 
@@ -715,7 +762,7 @@ void peac_free(hvo_ctx *ctx)
     PeacPlan *P = plan_of(ctx);
     if (!P) return;
     void *ptrs[] = { P->d_depth, P->d_segD, P->d_segI, P->d_pool, P->d_pool2, P->d_parent, P->d_dsize, P->d_eflag, P->d_meta, P->d_extracted,
-                     P->d_blkmap, P->d_labels, P->d_dist, P->d_qpix, P->d_qpl, P->d_plidmap, P->d_isvalid, P->d_planes };
+                     P->d_blkmap, P->d_labels, P->d_dist, P->d_qpix, P->d_qpl, P->d_plidmap, P->d_isvalid, P->d_planes, P->d_adj };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
     ctx->peac = nullptr;
@@ -749,6 +796,7 @@ static int peac_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_qpix, B * P->qcap * sizeof(int)); PA(P->d_qpl, B * P->qcap * sizeof(int));
     PA(P->d_plidmap, B * MAX_PLANES * sizeof(int)); PA(P->d_isvalid, B * MAX_PLANES * sizeof(int));
     PA(P->d_planes, B * MAX_PLANES * sizeof(hvo_plane));
+    PA(P->d_adj, B * MAX_PLANES * sizeof(unsigned long long));
 #undef PA
     // stream-ordered fill: a null-stream hipMemset is not ordered against the non-blocking ctx stream
     HVO_HIP(hipMemsetAsync(P->d_depth, 0, B * P->pitch * (h + 1) * sizeof(uint16_t), ctx->stream));
@@ -805,7 +853,8 @@ int peac_run(hvo_ctx *ctx, int n)
     r.fx = p.fx; r.fy = p.fy; r.cx = p.cx; r.cy = p.cy; r.dfac = p.depth_map_factor;
     r.blkmap = P->d_blkmap; r.isvalid = P->d_isvalid; r.labels = P->d_labels; r.dist = P->d_dist; r.qpix = P->d_qpix; r.qpl = P->d_qpl;
     r.qcap = P->qcap; r.plidmap = P->d_plidmap; r.planes = P->d_planes; r.c30 = P->c30;
-    hipLaunchKernelGGL(k_peac_refine, dim3(n), dim3(64), 0, st, r);
+    hipLaunchKernelGGL(k_peac_flood, dim3(n), dim3(FLOOD_T), 0, st, r, P->d_adj);
+    hipLaunchKernelGGL(k_peac_final, dim3(n), dim3(64), 0, st, r, P->d_adj);
     hipLaunchKernelGGL(k_peac_relabel, dim3(64, n), dim3(256), 0, st, P->d_labels, P->d_plidmap, P->w * P->h);
     hvo_prof_end(ctx, id);
     HVO_HIP(hipGetLastError());
