@@ -50,12 +50,14 @@ int hvo_create(const hvo_params *p, hvo_ctx **out)
     hvo_ctx *ctx = new (std::nothrow) hvo_ctx();
     if (!ctx) return HVO_ERR_INVALID_ARG;
     ctx->p = *p; ctx->device = p->device;
-    for (auto &r : ctx->prof) { r.name = nullptr; r.e0 = r.e1 = nullptr; r.ms = 0; r.used = false; }
+    for (auto &r : ctx->prof) { r.name = nullptr; r.e0 = r.e1 = nullptr; r.ms = 0; r.used = false; r.st = nullptr; }
     if (hipSetDevice(ctx->device) != hipSuccess) { delete ctx; return HVO_ERR_NO_DEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) { delete ctx; return HVO_ERR_NO_DEVICE; }
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete ctx; return HVO_ERR_NO_DEVICE; }   // code object is gfx950 only
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HVO_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->s_lsd, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->s_peac, hipStreamNonBlocking) != hipSuccess) { hvo_destroy(ctx); return HVO_ERR_HIP; }
     int rc = orb_init_tables(ctx);
     if (rc) { hvo_destroy(ctx); return rc; }
     *out = ctx;
@@ -66,7 +68,7 @@ void hvo_destroy(hvo_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipDeviceSynchronize();
     orb_free_plan(ctx);
     match_free(ctx);
     peac_free(ctx);
@@ -76,6 +78,8 @@ void hvo_destroy(hvo_ctx *ctx)
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     for (auto &r : ctx->prof) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->s_lsd) (void)hipStreamDestroy(ctx->s_lsd);
+    if (ctx->s_peac) (void)hipStreamDestroy(ctx->s_peac);
     delete ctx;
 }
 
@@ -118,12 +122,15 @@ int hvo_batch_run(hvo_ctx *ctx, unsigned stages)
     if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
     for (int i = 0; i < ctx->nprof; i++) ctx->prof[i].used = false;
     int rc;
-    if (stages & HVO_STAGE_ORB) { rc = orb_run(ctx, ctx->batch_n); if (rc) return rc; }
+    // The serial stages go first so that their long single-wave kernels overlap the streaming ones.
     if (stages & HVO_STAGE_PLANES) {
         if (!ctx->have_depth) return HVO_ERR_INVALID_ARG;
         rc = peac_run(ctx, ctx->batch_n); if (rc) return rc;
     }
     if (stages & HVO_STAGE_LSD) { rc = lsd_run(ctx, ctx->batch_n); if (rc) return rc; }
+    if (stages & HVO_STAGE_ORB) { rc = orb_run(ctx, ctx->batch_n); if (rc) return rc; }
+    HVO_HIP(hipStreamSynchronize(ctx->s_peac));
+    HVO_HIP(hipStreamSynchronize(ctx->s_lsd));
     HVO_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->profile)
         for (int i = 0; i < ctx->nprof; i++)
@@ -221,7 +228,7 @@ int hvo_match_nnr(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, in
 }  // extern "C"
 
 // ---- helpers shared by the subsystem files ----
-int hvo_prof_begin(hvo_ctx *ctx, const char *name)
+int hvo_prof_begin(hvo_ctx *ctx, const char *name, hipStream_t st)
 {
     if (!ctx->profile) return -1;
     int id = -1;
@@ -233,14 +240,14 @@ int hvo_prof_begin(hvo_ctx *ctx, const char *name)
         (void)hipEventCreate(&ctx->prof[id].e0);
         (void)hipEventCreate(&ctx->prof[id].e1);
     }
-    ctx->prof[id].used = true;
-    (void)hipEventRecord(ctx->prof[id].e0, ctx->stream);
+    ctx->prof[id].used = true; ctx->prof[id].st = st;
+    (void)hipEventRecord(ctx->prof[id].e0, st);
     return id;
 }
 
 void hvo_prof_end(hvo_ctx *ctx, int id)
 {
-    if (id >= 0) (void)hipEventRecord(ctx->prof[id].e1, ctx->stream);
+    if (id >= 0) (void)hipEventRecord(ctx->prof[id].e1, ctx->prof[id].st);
 }
 
 void *hvo_stage_host(hvo_ctx *ctx, size_t bytes)

@@ -60,12 +60,14 @@ struct OrbPlan {
     int *d_flags = nullptr;             // per frame error flags
 };
 
-struct ProfileRec { const char *name; hipEvent_t e0, e1; float ms; bool used; };
+struct ProfileRec { const char *name; hipEvent_t e0, e1; float ms; bool used; hipStream_t st; };
 
 struct hvo_ctx {
     hvo_params p;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // ORB + matching + uploads
+    hipStream_t s_lsd = nullptr;           // LSD/LBD kernels   } the three subsystems are independent and run
+    hipStream_t s_peac = nullptr;          // PEAC kernels      } concurrently, like Frame.cc:210-215's threads
     std::string last_error;
     OrbPlan orb;
     // ORB tables
@@ -99,7 +101,7 @@ struct hvo_ctx {
     } while (0)
 
 // profiling scope helpers (api.hip)
-int  hvo_prof_begin(hvo_ctx *ctx, const char *name);
+int  hvo_prof_begin(hvo_ctx *ctx, const char *name, hipStream_t st);
 void hvo_prof_end(hvo_ctx *ctx, int id);
 void *hvo_stage_host(hvo_ctx *ctx, size_t bytes);
 

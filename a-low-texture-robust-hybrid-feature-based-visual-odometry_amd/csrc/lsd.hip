@@ -50,6 +50,7 @@ struct LsdPlan {
     double gL[21], gG[63];
     float *d_gL = nullptr, *d_gG = nullptr;
     double rho = 0, prec = 0, p = 0; unsigned min_reg = 0;
+    long long *d_stats = nullptr;      // per frame 8 counters (diagnostics: hvo_debug_lsd_stats)
 };
 static LsdPlan *plan_of(hvo_ctx *ctx) { return (LsdPlan *)ctx->lsd; }
 
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void k_lsd_resize_grad(const double *__restric
 // ------------------------------------------------------------------------------------------------
 struct GrowArgs {
     const double *modgrad, *ang, *cs, *sn; const unsigned *defined; int *reg; float *segs;
-    hvo_keyline *kl_all, *kl; double *fn; int *nkl; int *flags;
+    hvo_keyline *kl_all, *kl; double *fn; int *nkl; int *flags; long long *stats;
     int sw, sh, nwords, w, h, nfeat, kl_cap;
     double rho, prec, p; unsigned min_reg;
 };
@@ -219,18 +220,18 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
     int rs = 1;
     __syncthreads();
     int i = 0;
+    const int k0 = lane / 9, j0 = lane - 9 * k0, jx = j0 / 3 - 1, jy = j0 - 3 * (j0 / 3) - 1;   // lane -> (point, neighbour)
     while (i < rs) {
         const int cnt = min(7 * GROW_SLOTS, rs - i);
         int c[GROW_SLOTS]; double an[GROW_SLOTS], cs[GROW_SLOTS], sn[GROW_SLOTS]; bool valid[GROW_SLOTS];
 #pragma unroll
         for (int s = 0; s < GROW_SLOTS; s++) {
-            const int n = s * 63 + lane;             // 63 neighbours (7 points) per slot, lane 63 idles
-            const int k = n / 9, j = n - 9 * k;
+            const int k = s * 7 + k0;                // 63 neighbours (7 points) per slot, lane 63 idles
             c[s] = -1; an[s] = LSD_NOTDEF; cs[s] = 0; sn[s] = 0; valid[s] = false;
             if (lane < 63 && k < cnt) {
                 const int idx = i + k;
                 const int pxy = (rs - idx <= LSD_RING) ? S.ring[idx & (LSD_RING - 1)] : S.reg[idx];
-                const int xx = (pxy & 0xFFFF) - 1 + j / 3, yy = (pxy >> 16) - 1 + (j - 3 * (j / 3));
+                const int xx = (pxy & 0xFFFF) + jx, yy = (pxy >> 16) + jy;
                 if (xx >= 0 && yy >= 0 && xx < sw && yy < sh) {
                     const int ad = xx + yy * sw;
                     const double a = S.ang[ad];
@@ -238,9 +239,9 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
                 }
             }
         }
-        const int rs0 = rs;
 #pragma unroll
         for (int s = 0; s < GROW_SLOTS; s++) {
+            if (s * 7 >= cnt) break;                 // no pending points in this slot (uniform)
             unsigned long long done_mask = 0;        // lanes already passed in this slot
             for (;;) {
                 const bool al = valid[s] && lsd_aligned(an[s], ra, prec);
@@ -259,7 +260,6 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
                 done_mask = (L == 63) ? ~0ull : ((1ull << (L + 1)) - 1);
             }
         }
-        (void)rs0;
         i += cnt;
         __syncthreads();
     }
@@ -268,30 +268,44 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
 
 // ordered fp64 accumulation helpers: the sums of region2rect / get_theta / refine must be added in
 // region order; 64 points are fetched per step, lane 0 accumulates them in order.
+// Sequentially adds the 64 staged terms of three LDS arrays onto three accumulators (lane 0 only).
+// Unused tail terms are staged as +0.0, which leaves a (never negative-zero) running sum unchanged.
+static __device__ __forceinline__ void seq_add3(const double *t0, const double *t1, const double *t2, double &a0, double &a1, double &a2)
+{
+#pragma unroll
+    for (int q = 0; q < 64; q++) { a0 += t0[q]; a1 += t1[q]; a2 += t2[q]; }
+}
+
 static __device__ void region2rect_wave(const GrowState &S, int reg_size, double reg_angle, double prec, Rect &rec,
                                         double *b0, double *b1, double *b2)
 {
     const int lane = threadIdx.x, sw = S.sw;
+    // weighted centroid: x += px*w; y += py*w; sum += w   (region order)
     double x = 0, y = 0, sum = 0;
     for (int base = 0; base < reg_size; base += 64) {
         const int i = base + lane;
-        if (i < reg_size) { const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; b0[lane] = (double)px; b1[lane] = (double)py; b2[lane] = S.modgrad[px + py * sw]; }
+        double t0 = 0, t1 = 0, t2 = 0;
+        if (i < reg_size) { const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; const double wgt = S.modgrad[px + py * sw]; t0 = (double)px * wgt; t1 = (double)py * wgt; t2 = wgt; }
+        b0[lane] = t0; b1[lane] = t1; b2[lane] = t2;
         __syncthreads();
-        if (lane == 0) { const int n = min(64, reg_size - base); for (int q = 0; q < n; q++) { const double wgt = b2[q]; x += b0[q] * wgt; y += b1[q] * wgt; sum += wgt; } }
+        if (lane == 0) seq_add3(b0, b1, b2, x, y, sum);
         __syncthreads();
     }
     if (lane == 0) { x /= sum; y /= sum; }
     x = __shfl(x, 0); y = __shfl(y, 0);
-    // get_theta
+    // get_theta: Ixx += dy*dy*w; Iyy += dx*dx*w; Ixy -= dx*dy*w
     double Ixx = 0, Iyy = 0, Ixy = 0;
     for (int base = 0; base < reg_size; base += 64) {
         const int i = base + lane;
-        if (i < reg_size) { const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; b0[lane] = (double)px; b1[lane] = (double)py; b2[lane] = S.modgrad[px + py * sw]; }
-        __syncthreads();
-        if (lane == 0) {
-            const int n = min(64, reg_size - base);
-            for (int q = 0; q < n; q++) { const double dx = b0[q] - x, dy = b1[q] - y, wgt = b2[q]; Ixx += dy * dy * wgt; Iyy += dx * dx * wgt; Ixy -= dx * dy * wgt; }
+        double t0 = 0, t1 = 0, t2 = 0;
+        if (i < reg_size) {
+            const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; const double wgt = S.modgrad[px + py * sw];
+            const double dx = (double)px - x, dy = (double)py - y;
+            t0 = dy * dy * wgt; t1 = dx * dx * wgt; t2 = -(dx * dy * wgt);      // a -= b  ==  a += (-b), exactly
         }
+        b0[lane] = t0; b1[lane] = t1; b2[lane] = t2;
+        __syncthreads();
+        if (lane == 0) seq_add3(b0, b1, b2, Ixx, Iyy, Ixy);
         __syncthreads();
     }
     double theta = 0, dx = 0, dy = 0;
@@ -303,30 +317,24 @@ static __device__ void region2rect_wave(const GrowState &S, int reg_size, double
         dx = cos(theta); dy = sin(theta);
     }
     theta = __shfl(theta, 0); dx = __shfl(dx, 0); dy = __shfl(dy, 0);
-    // extents: the reference's if / else-if chain in region order
+    // extents.  The reference's "if (l > l_max) .. else if (l < l_min)" chain with l_max, l_min starting
+    // at 0 yields l_max = max(0, max l) and l_min = min(0, min l): a value cannot be both above the
+    // running max (>= 0) and below the running min (<= 0), so the else never hides an update.
     double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
-    for (int base = 0; base < reg_size; base += 64) {
-        const int i = base + lane;
-        if (i < reg_size) { const int a = S.reg[i]; b0[lane] = (double)(a & 0xFFFF); b1[lane] = (double)(a >> 16); }
-        __syncthreads();
-        if (lane == 0) {
-            const int n = min(64, reg_size - base);
-            for (int q = 0; q < n; q++) {
-                const double rdx = b0[q] - x, rdy = b1[q] - y;
-                const double l = rdx * dx + rdy * dy, wv = -rdx * dy + rdy * dx;
-                if (l > l_max) l_max = l; else if (l < l_min) l_min = l;
-                if (wv > w_max) w_max = wv; else if (wv < w_min) w_min = wv;
-            }
-        }
-        __syncthreads();
+    for (int i = lane; i < reg_size; i += 64) {
+        const int a = S.reg[i];
+        const double rdx = (double)(a & 0xFFFF) - x, rdy = (double)(a >> 16) - y;
+        const double l = rdx * dx + rdy * dy, wv = -rdx * dy + rdy * dx;
+        l_max = fmax(l_max, l); l_min = fmin(l_min, l); w_max = fmax(w_max, wv); w_min = fmin(w_min, wv);
     }
-    if (lane == 0) {
-        rec.x1 = x + l_min * dx; rec.y1 = y + l_min * dy; rec.x2 = x + l_max * dx; rec.y2 = y + l_max * dy;
-        rec.width = w_max - w_min; rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy;
-        if (rec.width < 1.0) rec.width = 1.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        l_max = fmax(l_max, __shfl_xor(l_max, o)); l_min = fmin(l_min, __shfl_xor(l_min, o));
+        w_max = fmax(w_max, __shfl_xor(w_max, o)); w_min = fmin(w_min, __shfl_xor(w_min, o));
     }
-    rec.x1 = __shfl(rec.x1, 0); rec.y1 = __shfl(rec.y1, 0); rec.x2 = __shfl(rec.x2, 0); rec.y2 = __shfl(rec.y2, 0);
-    rec.width = __shfl(rec.width, 0); rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy;
+    rec.x1 = x + l_min * dx; rec.y1 = y + l_min * dy; rec.x2 = x + l_max * dx; rec.y2 = y + l_max * dy;
+    rec.width = w_max - w_min; rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy;
+    if (rec.width < 1.0) rec.width = 1.0;
 }
 
 static __device__ __forceinline__ double rect_density(const Rect &r, int reg_size)
@@ -345,21 +353,26 @@ static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle
     const int a0 = S.reg[0];
     const double xc = (double)(a0 & 0xFFFF), yc = (double)(a0 >> 16);
     const double ang_c = S.ang[(a0 & 0xFFFF) + (a0 >> 16) * sw];
-    double sum = 0, s_sum = 0; int n = 0;
+    double sum = 0, s_sum = 0, dummy = 0; int n = 0;
     for (int base = 0; base < reg_size; base += 64) {
         const int i = base + lane;
-        if (i < reg_size) { const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; b0[lane] = (double)px; b1[lane] = (double)py; b2[lane] = S.ang[px + py * sw]; n_addr[lane] = a; }
+        double t0 = 0, t1 = 0; bool in = false;
+        if (i < reg_size) {
+            const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16;
+            n_addr[lane] = a;
+            const double ddx = (double)px - xc, ddy = (double)py - yc;
+            if (sqrt(ddx * ddx + ddy * ddy) < rec.width) {
+                const double ang_d = angle_diff_signed(S.ang[px + py * sw], ang_c);
+                t0 = ang_d; t1 = ang_d * ang_d; in = true;
+            }
+        }
+        b0[lane] = t0; b1[lane] = t1; b2[lane] = 0;
+        n += __popcll(__ballot(in));
         __syncthreads();
         if (lane == 0) {
             const int m = min(64, reg_size - base);
-            for (int q = 0; q < m; q++) {
-                used_clr(S, n_addr[q] & 0xFFFF, n_addr[q] >> 16);
-                const double ddx = b0[q] - xc, ddy = b1[q] - yc;
-                if (sqrt(ddx * ddx + ddy * ddy) < rec.width) {
-                    const double ang_d = angle_diff_signed(b2[q], ang_c);
-                    sum += ang_d; s_sum += ang_d * ang_d; ++n;
-                }
-            }
+            for (int q = 0; q < m; q++) used_clr(S, n_addr[q] & 0xFFFF, n_addr[q] >> 16);
+            seq_add3(b0, b1, b2, sum, s_sum, dummy);
         }
         __syncthreads();
     }
@@ -430,6 +443,8 @@ __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
     for (int i = lane; i < nwords; i += 64) used_lds[i] = 0;
     __syncthreads();
     int nseg = 0, flags = 0;
+    long long st_seeds = 0, st_pts = 0, st_tg = 0, st_tr = 0, st_tf = 0, st_big = 0;
+    const long long t_begin = wall_clock64();
     // seeds in raster order: words of (defined & ~used), 64 words per step
     for (int wbase = 0; wbase < nwords; wbase += 64) {
         for (;;) {
@@ -445,11 +460,17 @@ __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
             const int sy = wsel / wpr, sx = (wsel - sy * wpr) * 32 + bit;
             const int seed = (sy << 16) | sx;
             int reg_size; double reg_angle = 0;
+            long long t0 = wall_clock64();
             region_grow_wave(S, seed, reg_size, reg_angle, g.prec);
+            long long t1 = wall_clock64(); st_tg += t1 - t0; st_seeds++; st_pts += reg_size;
             if ((unsigned)reg_size < g.min_reg) continue;
+            st_big++;
             Rect rec;
             region2rect_wave(S, reg_size, reg_angle, g.prec, rec, b0, b1, b2);
-            if (!refine_wave(S, reg_size, reg_angle, g.prec, rec, 0.7, b0, b1, b2, n_addr)) continue;
+            long long t2 = wall_clock64(); st_tr += t2 - t1;
+            const bool okr = refine_wave(S, reg_size, reg_angle, g.prec, rec, 0.7, b0, b1, b2, n_addr);
+            st_tf += wall_clock64() - t2;
+            if (!okr) continue;
             if (nseg < LSD_MAXSEG) {
                 if (lane == 0) {
                     double x1 = rec.x1 + 0.5, y1 = rec.y1 + 0.5, x2 = rec.x2 + 0.5, y2 = rec.y2 + 0.5;
@@ -507,7 +528,11 @@ __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
         const double nrm = sqrt(l0 * l0 + l1 * l1);
         fn[3 * i] = l0 / nrm; fn[3 * i + 1] = l1 / nrm; fn[3 * i + 2] = l2 / nrm;
     }
-    if (lane == 0) { g.nkl[f] = n; g.flags[f] = flags; }
+    if (lane == 0) {
+        g.nkl[f] = n; g.flags[f] = flags;
+        long long *st = g.stats + (size_t)f * 8;
+        st[0] = st_seeds; st[1] = st_pts; st[2] = st_big; st[3] = st_tg; st[4] = st_tr; st[5] = st_tf; st[6] = wall_clock64() - t_begin; st[7] = nseg;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -656,7 +681,7 @@ void lsd_free(hvo_ctx *ctx)
     LsdPlan *P = plan_of(ctx);
     if (!P) return;
     void *ptrs[] = { P->d_tmp, P->d_blur, P->d_modgrad, P->d_ang, P->d_cs, P->d_sn, P->d_defined, P->d_reg, P->d_segs, P->d_kl_all, P->d_kl,
-                     P->d_desc, P->d_fn, P->d_nkl, P->d_flags, P->d_b5, P->d_dx, P->d_dy, P->d_xofs, P->d_yofs, P->d_xa, P->d_yb, P->d_gL, P->d_gG };
+                     P->d_desc, P->d_fn, P->d_nkl, P->d_flags, P->d_b5, P->d_dx, P->d_dy, P->d_xofs, P->d_yofs, P->d_xa, P->d_yb, P->d_gL, P->d_gG, P->d_stats };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
     ctx->lsd = nullptr;
@@ -724,7 +749,7 @@ static int lsd_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_nkl, B * 4); PA(P->d_flags, B * 4);
     PA(P->d_b5, B * npix); PA(P->d_dx, B * npix * 2); PA(P->d_dy, B * npix * 2);
     PA(P->d_xofs, P->sw * 4); PA(P->d_yofs, P->sh * 4); PA(P->d_xa, P->sw * 8); PA(P->d_yb, P->sh * 8);
-    PA(P->d_gL, 21 * 4); PA(P->d_gG, 63 * 4);
+    PA(P->d_gL, 21 * 4); PA(P->d_gG, 63 * 4); PA(P->d_stats, B * 64);
 #undef PA
     HVO_HIP(hipMemcpy(P->d_xofs, xofs.data(), P->sw * 4, hipMemcpyHostToDevice));
     HVO_HIP(hipMemcpy(P->d_yofs, yofs.data(), P->sh * 4, hipMemcpyHostToDevice));
@@ -732,7 +757,7 @@ static int lsd_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
     HVO_HIP(hipMemcpy(P->d_yb, yb.data(), P->sh * 8, hipMemcpyHostToDevice));
     HVO_HIP(hipMemcpy(P->d_gL, gLf.data(), 21 * 4, hipMemcpyHostToDevice));
     HVO_HIP(hipMemcpy(P->d_gG, gGf.data(), 63 * 4, hipMemcpyHostToDevice));
-    HVO_HIP(hipMemsetAsync(P->d_defined, 0, B * P->nwords * 4, ctx->stream));
+    HVO_HIP(hipMemsetAsync(P->d_defined, 0, B * P->nwords * 4, ctx->s_lsd));
     HVO_HIP(hipDeviceSynchronize());
     return HVO_OK;
 }
@@ -745,23 +770,23 @@ int lsd_run(hvo_ctx *ctx, int n)
     int rc = lsd_ensure_plan(ctx, O.w, O.h, std::max(n, ctx->p.max_batch));
     if (rc) return rc;
     LsdPlan *P = plan_of(ctx);
-    hipStream_t st = ctx->stream;
+    hipStream_t st = ctx->s_lsd;
     const int w = P->w, h = P->h, sw = P->sw, sh = P->sh;
     const uint8_t *gray = O.d_pyr + O.lev[0].img_off;
     const int gpitch = O.lev[0].pitch;
-    int id = hvo_prof_begin(ctx, "lsd_blur_scale");
+    int id = hvo_prof_begin(ctx, "lsd_blur_scale", st);
     hipLaunchKernelGGL(k_lsd_blur_h, dim3((w + 255) / 256, h, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_tmp, w, h, P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
     hipLaunchKernelGGL(k_lsd_blur_v, dim3((w + 255) / 256, h, n), dim3(256), 0, st, P->d_tmp, P->d_blur, w, h, P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
     hvo_prof_end(ctx, id);
-    id = hvo_prof_begin(ctx, "lsd_gradient");
+    id = hvo_prof_begin(ctx, "lsd_gradient", st);
     const int gx = (((sw + 31) & ~31) + 255) / 256;
     hipLaunchKernelGGL(k_lsd_resize_grad, dim3(gx, sh, n), dim3(256), 0, st, P->d_blur, w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb,
                        P->d_modgrad, P->d_ang, P->d_cs, P->d_sn, P->d_defined, P->nwords, P->rho);
     hvo_prof_end(ctx, id);
-    id = hvo_prof_begin(ctx, "lsd_grow");
+    id = hvo_prof_begin(ctx, "lsd_grow", st);
     GrowArgs g;
     g.modgrad = P->d_modgrad; g.ang = P->d_ang; g.cs = P->d_cs; g.sn = P->d_sn; g.defined = P->d_defined; g.reg = P->d_reg; g.segs = P->d_segs;
-    g.kl_all = P->d_kl_all; g.kl = P->d_kl; g.fn = P->d_fn; g.nkl = P->d_nkl; g.flags = P->d_flags;
+    g.stats = P->d_stats; g.kl_all = P->d_kl_all; g.kl = P->d_kl; g.fn = P->d_fn; g.nkl = P->d_nkl; g.flags = P->d_flags;
     g.sw = sw; g.sh = sh; g.nwords = P->nwords; g.w = w; g.h = h; g.nfeat = P->nfeat; g.kl_cap = P->nfeat;
     g.rho = P->rho; g.prec = P->prec; g.p = P->p; g.min_reg = P->min_reg;
     const size_t lds = (size_t)P->nwords * 4;
@@ -773,11 +798,11 @@ int lsd_run(hvo_ctx *ctx, int n)
     }
     hipLaunchKernelGGL(k_lsd_grow, dim3(n), dim3(64), lds, st, g);
     hvo_prof_end(ctx, id);
-    id = hvo_prof_begin(ctx, "lbd_sobel");
+    id = hvo_prof_begin(ctx, "lbd_sobel", st);
     hipLaunchKernelGGL(k_lbd_blur5, dim3((w + 255) / 256, h, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_b5, w, h, P->k5[0], P->k5[1], P->k5[2]);
     hipLaunchKernelGGL(k_lbd_sobel, dim3((w + 255) / 256, h, n), dim3(256), 0, st, P->d_b5, P->d_dx, P->d_dy, w, h);
     hvo_prof_end(ctx, id);
-    id = hvo_prof_begin(ctx, "lbd_desc");
+    id = hvo_prof_begin(ctx, "lbd_desc", st);
     hipLaunchKernelGGL(k_lbd_desc, dim3(P->nfeat, n), dim3(64), 0, st, P->d_dx, P->d_dy, w, h, P->d_kl, P->d_nkl, P->nfeat, P->d_gL, P->d_gG, P->d_desc);
     hvo_prof_end(ctx, id);
     HVO_HIP(hipGetLastError());
@@ -789,23 +814,23 @@ int lsd_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
     LsdPlan *P = plan_of(ctx);
     if (!P) return HVO_ERR_INVALID_ARG;
     std::vector<int> nk(n), fl(n);
-    HVO_HIP(hipMemcpyAsync(nk.data(), P->d_nkl, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HVO_HIP(hipMemcpyAsync(fl.data(), P->d_flags, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    HVO_HIP(hipMemcpyAsync(nk.data(), P->d_nkl, n * sizeof(int), hipMemcpyDeviceToHost, ctx->s_lsd));
+    HVO_HIP(hipMemcpyAsync(fl.data(), P->d_flags, n * sizeof(int), hipMemcpyDeviceToHost, ctx->s_lsd));
+    HVO_HIP(hipStreamSynchronize(ctx->s_lsd));
     for (int f = 0; f < n; f++) {
         int m = nk[f];
         if (fl[f]) out[f].status = HVO_ERR_CAPACITY;
         if (out[f].kl) {
             if (m > out[f].kl_cap) { m = out[f].kl_cap; out[f].status = HVO_ERR_CAPACITY; }
             if (m > 0) {
-                HVO_HIP(hipMemcpyAsync(out[f].kl, P->d_kl + (size_t)f * P->nfeat, (size_t)m * sizeof(hvo_keyline), hipMemcpyDeviceToHost, ctx->stream));
-                if (out[f].ldesc) HVO_HIP(hipMemcpyAsync(out[f].ldesc, P->d_desc + (size_t)f * P->nfeat * 32, (size_t)m * 32, hipMemcpyDeviceToHost, ctx->stream));
-                if (out[f].linefn) HVO_HIP(hipMemcpyAsync(out[f].linefn, P->d_fn + (size_t)f * P->nfeat * 3, (size_t)m * 24, hipMemcpyDeviceToHost, ctx->stream));
+                HVO_HIP(hipMemcpyAsync(out[f].kl, P->d_kl + (size_t)f * P->nfeat, (size_t)m * sizeof(hvo_keyline), hipMemcpyDeviceToHost, ctx->s_lsd));
+                if (out[f].ldesc) HVO_HIP(hipMemcpyAsync(out[f].ldesc, P->d_desc + (size_t)f * P->nfeat * 32, (size_t)m * 32, hipMemcpyDeviceToHost, ctx->s_lsd));
+                if (out[f].linefn) HVO_HIP(hipMemcpyAsync(out[f].linefn, P->d_fn + (size_t)f * P->nfeat * 3, (size_t)m * 24, hipMemcpyDeviceToHost, ctx->s_lsd));
             }
         }
         out[f].n_kl = m;
     }
-    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    HVO_HIP(hipStreamSynchronize(ctx->s_lsd));
     return HVO_OK;
 }
 
@@ -828,4 +853,15 @@ extern "C" int hvo_extract_lsd(hvo_ctx *ctx, const uint8_t *gray, int w, int h, 
     if ((rc = lsd_download(ctx, 1, &out))) return rc;
     *n = out.n_kl;
     return out.status;
+}
+
+// diagnostics (not part of include/hvo.h): per-frame counters of the last k_lsd_grow launch:
+// [0] seeds [1] region points grown [2] regions >= min size [3] ticks in region_grow [4] region2rect
+// [5] refine [6] whole kernel [7] segments; ticks are 100 MHz wall-clock ticks.
+extern "C" int hvo_debug_lsd_stats(hvo_ctx *ctx, int frame, long long *out8)
+{
+    LsdPlan *P = ctx ? plan_of(ctx) : nullptr;
+    if (!P || frame < 0 || frame >= P->batch) return HVO_ERR_INVALID_ARG;
+    HVO_HIP(hipMemcpy(out8, P->d_stats + (size_t)frame * 8, 64, hipMemcpyDeviceToHost));
+    return HVO_OK;
 }

@@ -793,7 +793,7 @@ int orb_run(hvo_ctx *ctx, int n)
     hipStream_t st = ctx->stream;
     const int nl = P.nlevels;
     HVO_HIP(hipMemsetAsync(P.d_flags, 0, n * sizeof(int), st));
-    int id = hvo_prof_begin(ctx, "orb_pyramid");
+    int id = hvo_prof_begin(ctx, "orb_pyramid", st);
     for (int l = 1; l < nl; l++) {
         const LevelGeom &S = P.lev[l - 1], &D = P.lev[l];
         dim3 blk(64, 4), grd((D.w + 255) / 256, (D.h + 3) / 4, n);
@@ -801,11 +801,11 @@ int orb_run(hvo_ctx *ctx, int n)
                            P.d_rs_yofs + D.ry_off, P.d_rs_ybeta + D.ry_off);
     }
     hvo_prof_end(ctx, id);
-    id = hvo_prof_begin(ctx, "orb_fast_cells");
+    id = hvo_prof_begin(ctx, "orb_fast_cells", st);
     hipLaunchKernelGGL(k_fast_cells, dim3(P.ncells, n), dim3(256), 0, st, P.d_pyr, P.pyr_bytes, P.d_lev, P.d_cells, P.ncells,
                        P.d_cell_kp, P.d_cell_cnt, ctx->p.orb_ini_th_fast, ctx->p.orb_min_th_fast, P.d_flags);
     hvo_prof_end(ctx, id);
-    id = hvo_prof_begin(ctx, "orb_octree");
+    id = hvo_prof_begin(ctx, "orb_octree", st);
     OctArgs oa;
     oa.lev = P.d_lev; oa.cell_kp = P.d_cell_kp; oa.cell_cnt = P.d_cell_cnt; oa.ncells = P.ncells;
     oa.cand = P.d_cand; oa.keys = P.d_keys; oa.keys_tmp = P.d_keys_tmp; oa.nodeA = P.d_nodeA; oa.nodeB = P.d_nodeB;
@@ -813,11 +813,11 @@ int orb_run(hvo_ctx *ctx, int n)
     oa.cand_total = P.cand_total; oa.node_total = P.node_total; oa.kp_total = P.kp_total; oa.nlevels = nl;
     hipLaunchKernelGGL(k_octree, dim3(nl, n), dim3(64), 0, st, oa);
     hvo_prof_end(ctx, id);
-    id = hvo_prof_begin(ctx, "orb_orient");
+    id = hvo_prof_begin(ctx, "orb_orient", st);
     hipLaunchKernelGGL(k_orient, dim3((P.kp_cap + 3) / 4, n), dim3(256), 0, st, P.d_pyr, P.pyr_bytes, P.d_lev, nl, P.d_lvl_kp, P.d_lvl_cnt,
                        P.kp_total, ctx->d_umax, P.d_kp, P.d_nkp, P.kp_cap);
     hvo_prof_end(ctx, id);
-    id = hvo_prof_begin(ctx, "orb_blur");
+    id = hvo_prof_begin(ctx, "orb_blur", st);
     // OpenCV fixed-point Gaussian taps for ksize 7, sigma 2: getGaussianKernel(CV_32F) * 256, rounded
     static int k7[4] = { 0, 0, 0, 0 };
     if (!k7[3]) {
@@ -828,7 +828,7 @@ int orb_run(hvo_ctx *ctx, int n)
     }
     hipLaunchKernelGGL(k_blur7, dim3(P.ntiles, n), dim3(256), 0, st, P.d_pyr, P.d_blur, P.pyr_bytes, P.d_lev, P.d_tiles, k7[0], k7[1], k7[2], k7[3]);
     hvo_prof_end(ctx, id);
-    id = hvo_prof_begin(ctx, "orb_brief");
+    id = hvo_prof_begin(ctx, "orb_brief", st);
     hipLaunchKernelGGL(k_brief, dim3((P.kp_cap + 3) / 4, n), dim3(256), 0, st, P.d_blur, P.pyr_bytes, P.d_lev, ctx->d_pattern, P.d_kp, P.d_nkp,
                        P.kp_cap, P.d_desc);
     hvo_prof_end(ctx, id);

@@ -41,6 +41,7 @@ struct PeacPlan {
     int *d_qpix = nullptr; int *d_qpl = nullptr; int *d_plidmap = nullptr; int *d_isvalid = nullptr;
     hvo_plane *d_planes = nullptr;
     unsigned long long *d_adj = nullptr;
+    double *d_hkey = nullptr; int *d_hid = nullptr;
     double c15 = 0, c60 = 0, c30 = 0;   // cos thresholds evaluated on the host (glibc), like the oracle
 };
 
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(64) void k_peac_blocks(const uint16_t *__restrict__
 // ------------------------------------------------------------------------------------------------
 struct ClArgs {
     double *segD; int *segI; int *pool; int *pool2; int *parent; int *dsize; int *eflag; int *meta; int *extracted;
+    double *hkey; int *hid;
     int segcap, poolcap, nblk, Nw, Nh;
     double c15, c60;
 };
@@ -174,30 +176,54 @@ static __device__ __forceinline__ double nsim(const double *a, const double *b)
 
 static __device__ int ds_find_ro(const int *parent, int x) { while (parent[x] != x) x = parent[x]; return x; }
 
-// min-heap on (mse, id) living in LDS
+// min-heap on (mse, id).  8-ary and wave-cooperative so that it can live in global memory (L2):
+// the 8 children of a node are fetched by 8 lanes in one round trip, a 3-step shuffle reduction picks
+// the smallest, i.e. a pop costs ~4 dependent accesses for 3072 entries.  Keeping the heap out of LDS
+// is what lets ~16 frames per CU be resident (the kernel is latency bound, not LDS bound).
+// Every call is made by all 64 lanes with uniform arguments; H.n is tracked uniformly.
 struct Heap { double *key; int *id; int n; };
 static __device__ __forceinline__ bool hless(double ka, int ia, double kb, int ib) { return ka < kb || (ka == kb && ia < ib); }
-static __device__ void heap_sift_down(Heap &H, int i)
+static __device__ void heap_sift_down(Heap &H, int i, double k, int id)
 {
-    double k = H.key[i]; int id = H.id[i];
+    const int lane = threadIdx.x & 63;
     for (;;) {
-        int l = 2 * i + 1, r = l + 1, m = -1;
-        double km = k; int im = id;
-        if (l < H.n && hless(H.key[l], H.id[l], km, im)) { m = l; km = H.key[l]; im = H.id[l]; }
-        if (r < H.n && hless(H.key[r], H.id[r], km, im)) { m = r; km = H.key[r]; im = H.id[r]; }
-        if (m < 0) break;
-        H.key[i] = km; H.id[i] = im; i = m;
+        const int c0 = 8 * i + 1;
+        if (c0 >= H.n) break;
+        double ck = 1.0e308; int cid = 0x7FFFFFFF, ci = -1;
+        if (lane < 8 && c0 + lane < H.n) { ci = c0 + lane; ck = H.key[ci]; cid = H.id[ci]; }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            const double ok = __shfl_xor(ck, o); const int oid = __shfl_xor(cid, o), oi = __shfl_xor(ci, o);
+            if (oi >= 0 && (ci < 0 || hless(ok, oid, ck, cid))) { ck = ok; cid = oid; ci = oi; }
+        }
+        ck = __shfl(ck, 0); cid = __shfl(cid, 0); ci = __shfl(ci, 0);
+        if (!hless(ck, cid, k, id)) break;
+        if (lane == 0) { H.key[i] = ck; H.id[i] = cid; }
+        i = ci;
     }
-    H.key[i] = k; H.id[i] = id;
+    if (lane == 0) { H.key[i] = k; H.id[i] = id; }
 }
 static __device__ void heap_push(Heap &H, double k, int id)
 {
+    const int lane = threadIdx.x & 63;
     int i = H.n++;
     while (i > 0) {
-        int p = (i - 1) / 2;
-        if (hless(k, id, H.key[p], H.id[p])) { H.key[i] = H.key[p]; H.id[i] = H.id[p]; i = p; } else break;
+        const int p = (i - 1) / 8;
+        const double pk = H.key[p]; const int pid = H.id[p];       // uniform load
+        if (!hless(k, id, pk, pid)) break;
+        if (lane == 0) { H.key[i] = pk; H.id[i] = pid; }
+        i = p;
     }
-    H.key[i] = k; H.id[i] = id;
+    if (lane == 0) { H.key[i] = k; H.id[i] = id; }
+}
+// removes and returns the top id (uniform)
+static __device__ int heap_pop(Heap &H)
+{
+    const int top = H.id[0];
+    H.n--;
+    if (H.n > 0) { const double k = H.key[H.n]; const int id = H.id[H.n]; __syncthreads(); heap_sift_down(H, 0, k, id); }
+    __syncthreads();
+    return top;
 }
 
 // remove up to two ids from a sorted neighbour list in place (single lane)
@@ -245,13 +271,7 @@ static __device__ void ah_cluster_wave(const ClArgs &a, int frame, Heap &H, int 
     while (H.n > 0) {
         if (pooltop > a.poolcap - 2 * a.nblk) pool_gc(segI, nseg, pool, pool2, pooltop);
         // ---- pop ----
-        int p = H.id[0];
-        __syncthreads();
-        if (lane == 0) {
-            H.n--;
-            if (H.n > 0) { H.key[0] = H.key[H.n]; H.id[0] = H.id[H.n]; heap_sift_down(H, 0); }
-        } else H.n--;
-        __syncthreads();
+        const int p = heap_pop(H);
         int *pi = segI + (size_t)p * SEG_I;
         if (pi[2]) continue;                                   // nouse
         const double *pd = segD + (size_t)p * SEG_D;
@@ -334,8 +354,9 @@ static __device__ void ah_cluster_wave(const ClArgs &a, int frame, Heap &H, int 
                             else { parent[yr] = xr; dsize[xr] += dsize[yr]; }
                         }
                         pi[2] = 1; ni[2] = 1; pi[4] = 0; ni[4] = 0;
-                        heap_push(H, m, id);
-                    } else H.n++;
+                    }
+                    __syncthreads();
+                    heap_push(H, m, id);
                     __syncthreads();
                     mcnt = cN[0];
                     pooltop += pcnt + ncnt;
@@ -379,11 +400,11 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a)
     extern __shared__ double smem[];
     const int frame = blockIdx.x, lane = threadIdx.x;
     const int nblk = a.nblk, Nw = a.Nw, Nh = a.Nh;
-    double *hkey = smem;                               // nblk doubles
-    int *hid = (int *)(hkey + nblk);                   // nblk ints
-    int *lA = hid + nblk, *lB = lA + LCAP;             // LCAP ints each
-    double *cm = (double *)(lB + LCAP + (((size_t)(lB + LCAP) & 7) ? 1 : 0));
-    int *cN = (int *)(cm + 64);
+    double *hkey = a.hkey + (size_t)frame * nblk;     // heap arrays in global memory (L2)
+    int *hid = a.hid + (size_t)frame * nblk;
+    double *cm = smem;                                 // 64 doubles
+    int *cN = (int *)(cm + 64);                        // 64 ints
+    int *lA = cN + 64, *lB = lA + LCAP;                // LCAP ints each
     double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
     int *segI = a.segI + (size_t)frame * a.segcap * SEG_I;
     int *pool = a.pool + (size_t)frame * a.poolcap, *pool2 = a.pool2 + (size_t)frame * a.poolcap;
@@ -443,15 +464,13 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a)
         H.n += __popcll(m);
     }
     __syncthreads();
-    // Floyd heapify, one tree level at a time (sub-trees of a level are disjoint)
+    // Floyd heapify from the last parent down (each sift is wave-cooperative)
     if (H.n > 1) {
-        int last_parent = (H.n - 2) / 2;
-        int lvl_start = 1; while (lvl_start * 2 - 1 <= last_parent) lvl_start *= 2;   // first index of deepest internal level + 1
-        for (int s = lvl_start - 1; ; s = (s + 1) / 2 - 1) {
-            const int e = min(2 * s, last_parent);
-            for (int i = s + lane; i <= e; i += 64) heap_sift_down(H, i);
+        for (int i = (H.n - 2) / 8; i >= 0; i--) {
+            const double k = hkey[i]; const int id = hid[i];
             __syncthreads();
-            if (s == 0) break;
+            heap_sift_down(H, i, k, id);
+            __syncthreads();
         }
     }
     int nseg = nblk, pooltop = nblk * 4, next = 0, flags = 0;
@@ -714,11 +733,9 @@ __global__ __launch_bounds__(64) void k_peac_final(RfArgs r, const unsigned long
             for (int x = 0; x < n; x++) pool[si[3] + x] = ids[x];
             si[4] = n;
         }
-        for (int p = 0; p < nold; p++) if (isvalid[p]) heap_push(H, segD[(size_t)ext[p] * SEG_D + 15], ext[p]);
-        cN[0] = H.n;
     }
     __syncthreads();
-    H.n = cN[0];
+    for (int p = 0; p < nold; p++) if (isvalid[p]) { heap_push(H, segD[(size_t)ext[p] * SEG_D + 15], ext[p]); __syncthreads(); }
     pooltop += nold * MAX_PLANES;
     __syncthreads();
     int *fin = ext + MAX_PLANES;
@@ -762,7 +779,7 @@ void peac_free(hvo_ctx *ctx)
     PeacPlan *P = plan_of(ctx);
     if (!P) return;
     void *ptrs[] = { P->d_depth, P->d_segD, P->d_segI, P->d_pool, P->d_pool2, P->d_parent, P->d_dsize, P->d_eflag, P->d_meta, P->d_extracted,
-                     P->d_blkmap, P->d_labels, P->d_dist, P->d_qpix, P->d_qpl, P->d_plidmap, P->d_isvalid, P->d_planes, P->d_adj };
+                     P->d_blkmap, P->d_labels, P->d_dist, P->d_qpix, P->d_qpl, P->d_plidmap, P->d_isvalid, P->d_planes, P->d_adj, P->d_hkey, P->d_hid };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
     ctx->peac = nullptr;
@@ -797,9 +814,10 @@ static int peac_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_plidmap, B * MAX_PLANES * sizeof(int)); PA(P->d_isvalid, B * MAX_PLANES * sizeof(int));
     PA(P->d_planes, B * MAX_PLANES * sizeof(hvo_plane));
     PA(P->d_adj, B * MAX_PLANES * sizeof(unsigned long long));
+    PA(P->d_hkey, B * P->nblk * sizeof(double)); PA(P->d_hid, B * P->nblk * sizeof(int));
 #undef PA
     // stream-ordered fill: a null-stream hipMemset is not ordered against the non-blocking ctx stream
-    HVO_HIP(hipMemsetAsync(P->d_depth, 0, B * P->pitch * (h + 1) * sizeof(uint16_t), ctx->stream));
+    HVO_HIP(hipMemsetAsync(P->d_depth, 0, B * P->pitch * (h + 1) * sizeof(uint16_t), ctx->s_peac));
     HVO_HIP(hipDeviceSynchronize());
     return HVO_OK;
 }
@@ -813,9 +831,9 @@ int peac_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h)
     for (int f = 0; f < n; f++) {
         if (!in[f].depth) return HVO_ERR_INVALID_ARG;
         HVO_HIP(hipMemcpy2DAsync(P->d_depth + f * dframe, P->pitch * sizeof(uint16_t), in[f].depth, in[f].depth_stride,
-                                 (size_t)w * sizeof(uint16_t), h, hipMemcpyHostToDevice, ctx->stream));
+                                 (size_t)w * sizeof(uint16_t), h, hipMemcpyHostToDevice, ctx->s_peac));
     }
-    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    HVO_HIP(hipStreamSynchronize(ctx->s_peac));
     return HVO_OK;
 }
 
@@ -823,29 +841,23 @@ int peac_run(hvo_ctx *ctx, int n)
 {
     PeacPlan *P = plan_of(ctx);
     if (!P || n < 1 || n > P->batch) return HVO_ERR_INVALID_ARG;
-    hipStream_t st = ctx->stream;
+    hipStream_t st = ctx->s_peac;
     const size_t dframe = (size_t)P->pitch * (P->h + 1);
     const hvo_params &p = ctx->p;
     HVO_HIP(hipMemsetAsync(P->d_isvalid, 0, (size_t)n * MAX_PLANES * sizeof(int), st));
-    int id = hvo_prof_begin(ctx, "peac_blocks");
+    int id = hvo_prof_begin(ctx, "peac_blocks", st);
     hipLaunchKernelGGL(k_peac_blocks, dim3((P->nblk + 63) / 64, n), dim3(64), 0, st, P->d_depth, dframe, P->pitch, P->w, P->h, P->Nw, P->nblk,
                        p.fx, p.fy, p.cx, p.cy, p.depth_map_factor, P->d_segD, P->d_segI, P->segcap);
     hvo_prof_end(ctx, id);
     ClArgs a;
     a.segD = P->d_segD; a.segI = P->d_segI; a.pool = P->d_pool; a.pool2 = P->d_pool2; a.parent = P->d_parent; a.dsize = P->d_dsize; a.eflag = P->d_eflag;
     a.meta = P->d_meta; a.extracted = P->d_extracted; a.segcap = P->segcap; a.poolcap = P->poolcap; a.nblk = P->nblk; a.Nw = P->Nw; a.Nh = P->Nh;
-    a.c15 = P->c15; a.c60 = P->c60;
-    const size_t lds = (size_t)P->nblk * 12 + 2 * LCAP * 4 + 8 + 64 * 8 + 64 * 4;
-    if (lds > 160 * 1024) return HVO_ERR_UNSUPPORTED;
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024 && lds_set < lds) {
-        HVO_HIP(hipFuncSetAttribute((const void *)k_peac_cluster, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
-    id = hvo_prof_begin(ctx, "peac_cluster");
+    a.c15 = P->c15; a.c60 = P->c60; a.hkey = P->d_hkey; a.hid = P->d_hid;
+    const size_t lds = 64 * 8 + 64 * 4 + 2 * LCAP * 4;
+    id = hvo_prof_begin(ctx, "peac_cluster", st);
     hipLaunchKernelGGL(k_peac_cluster, dim3(n), dim3(64), lds, st, a);
     hvo_prof_end(ctx, id);
-    id = hvo_prof_begin(ctx, "peac_refine");
+    id = hvo_prof_begin(ctx, "peac_refine", st);
     hipLaunchKernelGGL(k_peac_blkmap, dim3(16, n), dim3(256), 0, st, P->d_parent, P->d_dsize, P->d_segI, P->d_extracted, P->d_meta, P->d_blkmap,
                        P->d_isvalid, P->d_labels, P->d_dist, P->nblk, P->Nw, P->Nh, P->w, P->h, P->segcap);
     RfArgs r;
@@ -866,21 +878,21 @@ int peac_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
     PeacPlan *P = plan_of(ctx);
     if (!P) return HVO_ERR_INVALID_ARG;
     std::vector<int> meta((size_t)n * 16);
-    HVO_HIP(hipMemcpyAsync(meta.data(), P->d_meta, meta.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    HVO_HIP(hipMemcpyAsync(meta.data(), P->d_meta, meta.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->s_peac));
+    HVO_HIP(hipStreamSynchronize(ctx->s_peac));
     const size_t npix = (size_t)P->w * P->h;
     for (int f = 0; f < n; f++) {
         const int nfin = meta[(size_t)f * 16 + 4], flags = meta[(size_t)f * 16 + 3];
         if (flags) out[f].status = HVO_ERR_CAPACITY;
-        if (out[f].labels) HVO_HIP(hipMemcpyAsync(out[f].labels, P->d_labels + f * npix, npix * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (out[f].labels) HVO_HIP(hipMemcpyAsync(out[f].labels, P->d_labels + f * npix, npix * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->s_peac));
         int m = nfin;
         if (out[f].planes) {
             if (m > out[f].pl_cap) { m = out[f].pl_cap; out[f].status = HVO_ERR_CAPACITY; }
-            if (m > 0) HVO_HIP(hipMemcpyAsync(out[f].planes, P->d_planes + (size_t)f * MAX_PLANES, (size_t)m * sizeof(hvo_plane), hipMemcpyDeviceToHost, ctx->stream));
+            if (m > 0) HVO_HIP(hipMemcpyAsync(out[f].planes, P->d_planes + (size_t)f * MAX_PLANES, (size_t)m * sizeof(hvo_plane), hipMemcpyDeviceToHost, ctx->s_peac));
         }
         out[f].n_planes = m;
     }
-    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    HVO_HIP(hipStreamSynchronize(ctx->s_peac));
     return HVO_OK;
 }
 
