@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames resident per GPU per step")
+    ap.add_argument("--batch", type=int, default=2048, help="frames resident per GPU per step")
     ap.add_argument("--stages", default="orb,lsd,planes")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)

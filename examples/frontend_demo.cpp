@@ -1,0 +1,39 @@
+// frontend_demo.cpp -- uses the C++ mirror (include/hvo.hpp) the way Frame::Frame() uses the
+// reference extractors (src/Frame.cc:205-233): ORB, lines and planes of one RGB-D frame, then a
+// Hamming match of the ORB descriptors against themselves.  Reads a raw 640x480 gray (u8) + depth
+// (u16) pair written by tests/test_cpp_adaptor.py and prints one line of counts/checksums.
+//
+// build:  g++ -std=c++14 -Iinclude examples/frontend_demo.cpp -L<csrc> -lhvo -Wl,-rpath,<csrc> -o demo
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "hvo.hpp"
+
+static uint64_t fnv(const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; uint64_t h = 1469598103934665603ull; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } return h; }
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) { fprintf(stderr, "usage: %s gray.u8 depth.u16\n", argv[0]); return 2; }
+    const int W = 640, H = 480;
+    std::vector<uint8_t> gray(W * H); std::vector<uint16_t> depth(W * H);
+    FILE *f = fopen(argv[1], "rb"); if (!f || fread(gray.data(), 1, gray.size(), f) != gray.size()) return 3; fclose(f);
+    f = fopen(argv[2], "rb"); if (!f || fread(depth.data(), 2, depth.size(), f) != depth.size()) return 3; fclose(f);
+    try {
+        hvo::ORBextractor orb(1000, 1.2f, 8, 20, 7);                  // Tracking.cc:124 / TUM3.yaml:41-54
+        hvo::LINEextractor lsd(1, 1.2f, 200, 0);                      // Tracking.cc:132 / TUM3.yaml:60-63
+        hvo::PlaneDetection planes;
+        std::vector<hvo::KeyPoint> kps; std::vector<uint8_t> desc;
+        orb(hvo::Image8{ gray.data(), W, H, W }, kps, desc);
+        std::vector<hvo::KeyLine> kls; std::vector<uint8_t> ldesc; std::vector<double> fn;
+        lsd(hvo::Image8{ gray.data(), W, H, W }, kls, ldesc, fn);
+        planes.readDepthImage(hvo::Image16{ depth.data(), W, H, W * 2 }, 535.4f, 539.2f, 320.1f, 247.6f, 1.0f / 5000.0f);
+        planes.runPlaneDetection();
+        hvo::LSDmatcher lm(orb.ctx());
+        std::vector<int> m12;
+        int nm = lm.match(desc.data(), (int)kps.size(), desc.data(), (int)kps.size(), 0.9f, m12);
+        printf("kp %zu desc %016llx lines %zu ldesc %016llx planes %d labels %016llx matches %d\n", kps.size(),
+               (unsigned long long)fnv(desc.data(), desc.size()), kls.size(), (unsigned long long)fnv(ldesc.data(), ldesc.size()),
+               planes.plane_num_, (unsigned long long)fnv(planes.membership.data(), planes.membership.size() * 4), nm);
+    } catch (const hvo::Error &e) { fprintf(stderr, "hvo error: %s\n", e.what()); return 1; }
+    return 0;
+}

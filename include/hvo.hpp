@@ -1,0 +1,191 @@
+// hvo.hpp -- header-only C++ mirror of the reference's front-end interfaces on top of the C ABI
+// (include/hvo.h).  Same class names, constructor arguments, call operators and error behaviour as
+//
+//   ORB_SLAM2::ORBextractor      reference include/ORBextractor.h:47-116, src/ORBextractor.cc:408,1041
+//   ORB_SLAM2::LINEextractor     reference include/LineExtractor.h:186-283, src/LineExtractor.cpp:329
+//   PlaneDetection               reference include/PlaneExtractor.h:36-56,  src/PlaneExtractor.cpp:26-66
+//   ORB_SLAM2::ORBmatcher        reference include/ORBmatcher.h:44,         src/ORBmatcher.cc:1676
+//   ORB_SLAM2::LSDmatcher        reference include/LSDmatcher.h:43,         src/LSDmatcher.cpp:803-863
+//
+// but without OpenCV/Eigen types: images are (pointer, width, height, stride) and results are
+// std::vectors of PODs whose layout equals cv::KeyPoint / cv::line_descriptor::KeyLine, so a
+// Frame.cc adaptor is a reinterpret of vector storage.  No CPU fallback: every call
+// throws hvo::Error when libhvo.so / a gfx950 device is unavailable.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "hvo.h"
+
+namespace hvo {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const std::string &what) : std::runtime_error(what + ": " + hvo_strerror(s)), status(s) {}
+};
+inline void check(int rc, const char *what) { if (rc != HVO_OK) throw Error(rc, what); }
+
+using KeyPoint = hvo_keypoint;   // == cv::KeyPoint (28 B)
+using KeyLine = hvo_keyline;     // == cv::line_descriptor::KeyLine (68 B)
+using Plane = hvo_plane;
+static_assert(sizeof(KeyPoint) == 28 && sizeof(KeyLine) == 68, "layouts must match OpenCV's");
+
+struct Image8 { const uint8_t *data; int width, height, stride; bool empty() const { return !data || width <= 0 || height <= 0; } };
+struct Image16 { const uint16_t *data; int width, height, stride; bool empty() const { return !data || width <= 0 || height <= 0; } };
+
+// shared ownership of one hvo_ctx (one HIP stream set; NOT thread-safe, like ORBextractor)
+class Context {
+public:
+    explicit Context(const hvo_params &p) { check(hvo_create(&p, &ctx_), "hvo_create"); }
+    ~Context() { hvo_destroy(ctx_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    hvo_ctx *get() const { return ctx_; }
+private:
+    hvo_ctx *ctx_ = nullptr;
+};
+
+class ORBextractor {
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = 0)
+        : nfeatures_(nfeatures), nlevels_(nlevels), scaleFactor_(scaleFactor)
+    {
+        hvo_params p; hvo_default_params(&p);
+        p.orb_nfeatures = nfeatures; p.orb_scale_factor = scaleFactor; p.orb_nlevels = nlevels;
+        p.orb_ini_th_fast = iniThFAST; p.orb_min_th_fast = minThFAST; p.device = device;
+        ctx_.reset(new Context(p));
+        // scale tables exactly as ORBextractor.cc:413-428
+        mvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels); mvInvScaleFactor.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
+        mvScaleFactor[0] = 1.0f; mvLevelSigma2[0] = 1.0f;
+        for (int i = 1; i < nlevels; i++) { mvScaleFactor[i] = mvScaleFactor[i - 1] * scaleFactor; mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i]; }
+        for (int i = 0; i < nlevels; i++) { mvInvScaleFactor[i] = 1.0f / mvScaleFactor[i]; mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i]; }
+    }
+    // operator()(image, mask, keypoints, descriptors): the mask is ignored (ORBextractor.h:58)
+    void operator()(const Image8 &image, std::vector<KeyPoint> &keypoints, std::vector<uint8_t> &descriptors)
+    {
+        keypoints.clear(); descriptors.clear();
+        if (image.empty()) return;                                   // ORBextractor.cc:1044
+        const int cap = nfeatures_ + 8 * nlevels_ + 64;
+        keypoints.resize(cap); descriptors.resize((size_t)cap * 32);
+        int n = 0;
+        check(hvo_extract_orb(ctx_->get(), image.data, image.width, image.height, image.stride, keypoints.data(), descriptors.data(), cap, &n), "hvo_extract_orb");
+        keypoints.resize(n); descriptors.resize((size_t)n * 32);
+    }
+    int GetLevels() const { return nlevels_; }
+    float GetScaleFactor() const { return scaleFactor_; }
+    const std::vector<float> &GetScaleFactors() const { return mvScaleFactor; }
+    const std::vector<float> &GetInverseScaleFactors() const { return mvInvScaleFactor; }
+    const std::vector<float> &GetScaleSigmaSquares() const { return mvLevelSigma2; }
+    const std::vector<float> &GetInverseScaleSigmaSquares() const { return mvInvLevelSigma2; }
+    hvo_ctx *ctx() const { return ctx_->get(); }
+private:
+    int nfeatures_, nlevels_; float scaleFactor_;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    std::unique_ptr<Context> ctx_;
+};
+
+class LINEextractor {
+public:
+    // LINEextractor(numOctaves, scale, nLSDFeature, min_line_length) (LineExtractor.h:190)
+    LINEextractor(int numOctaves, float scale, unsigned nLSDFeature, double /*min_line_length*/ = 0, int device = 0)
+        : nfeat_((int)nLSDFeature), numOctaves_(numOctaves), scale_(scale)
+    {
+        hvo_params p; hvo_default_params(&p);
+        p.lsd_num_octaves = numOctaves; p.lsd_scale = scale; p.lsd_nfeatures = (int)nLSDFeature; p.device = device;
+        ctx_.reset(new Context(p));
+    }
+    // operator()(image, mask, keylines, descriptors, lineVec2d); lineVec2d is n x 3 doubles
+    void operator()(const Image8 &image, std::vector<KeyLine> &keylines, std::vector<uint8_t> &descriptors, std::vector<double> &lineVec2d)
+    {
+        keylines.clear(); descriptors.clear(); lineVec2d.clear();
+        if (image.empty()) return;                                   // LineExtractor.cpp:331-332
+        const int cap = nfeat_ > 0 ? nfeat_ : 1;
+        keylines.resize(cap); descriptors.resize((size_t)cap * 32); lineVec2d.resize((size_t)cap * 3);
+        int n = 0;
+        check(hvo_extract_lsd(ctx_->get(), image.data, image.width, image.height, image.stride, keylines.data(), descriptors.data(), lineVec2d.data(), cap, &n), "hvo_extract_lsd");
+        keylines.resize(n); descriptors.resize((size_t)n * 32); lineVec2d.resize((size_t)n * 3);
+    }
+    int GetLevels() const { return numOctaves_; }
+    float GetScaleFactor() const { return scale_; }
+private:
+    int nfeat_, numOctaves_; float scale_;
+    std::unique_ptr<Context> ctx_;
+};
+
+class PlaneDetection {
+public:
+    std::vector<std::vector<int>> plane_vertices_;   // vertex indices each plane contains (PlaneExtractor.h:43)
+    std::vector<Plane> planes;                        // plane_filter.extractedPlanes (normal, center, mse, N)
+    std::vector<int32_t> membership;                  // plane_filter.membershipImg, -1 = none
+    int plane_num_ = 0;
+
+    explicit PlaneDetection(int device = 0) : device_(device) {}
+    // readDepthImage(depthImg, K, kScaleFactor): CV_16U only (PlaneExtractor.cpp:34-38) -> false otherwise
+    bool readDepthImage(const Image16 &depth, float fx, float fy, float cx, float cy, float kScaleFactor)
+    {
+        if (depth.empty()) return false;
+        depth_ = depth;
+        if (!ctx_ || fx != fx_ || fy != fy_ || cx != cx_ || cy != cy_ || kScaleFactor != sf_) {
+            hvo_params p; hvo_default_params(&p);
+            p.fx = fx; p.fy = fy; p.cx = cx; p.cy = cy; p.depth_map_factor = kScaleFactor; p.device = device_;
+            ctx_.reset(new Context(p));
+            fx_ = fx; fy_ = fy; cx_ = cx; cy_ = cy; sf_ = kScaleFactor;
+        }
+        return true;
+    }
+    void runPlaneDetection()
+    {
+        const int w = depth_.width, h = depth_.height;
+        membership.assign((size_t)w * h, -1);
+        planes.resize(64);
+        int n = 0;
+        check(hvo_compute_planes(ctx_->get(), depth_.data, w, h, depth_.stride, membership.data(), planes.data(), 64, &n), "hvo_compute_planes");
+        planes.resize(n); plane_num_ = n;
+        plane_vertices_.assign(n, std::vector<int>());
+        for (int i = 0; i < w * h; i++) if (membership[i] >= 0) plane_vertices_[membership[i]].push_back(i);   // raster order, like refineDetails
+    }
+private:
+    int device_; Image16 depth_{ nullptr, 0, 0, 0 };
+    float fx_ = 0, fy_ = 0, cx_ = 0, cy_ = 0, sf_ = 0;
+    std::unique_ptr<Context> ctx_;
+};
+
+class ORBmatcher {
+public:
+    static const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;       // ORBmatcher.cc:37-39
+    explicit ORBmatcher(hvo_ctx *ctx) : ctx_(ctx) {}
+    // DescriptorDistance(a, b): 32-byte descriptors
+    int DescriptorDistance(const uint8_t *a, const uint8_t *b) const
+    {
+        uint16_t d = 0; check(hvo_hamming_matrix(ctx_, a, 1, b, 1, &d), "hvo_hamming_matrix"); return d;
+    }
+    // all-pairs distances for the guided searches (nq x nt, row-major)
+    void DistanceMatrix(const uint8_t *q, int nq, const uint8_t *t, int nt, std::vector<uint16_t> &d) const
+    {
+        d.resize((size_t)nq * nt); check(hvo_hamming_matrix(ctx_, q, nq, t, nt, d.data()), "hvo_hamming_matrix");
+    }
+private:
+    hvo_ctx *ctx_;
+};
+
+class LSDmatcher {
+public:
+    static const int TH_HIGH = 80, TH_LOW = 50;                            // LSDmatcher.cpp:12-14
+    explicit LSDmatcher(hvo_ctx *ctx) : ctx_(ctx) {}
+    // int match(desc1, desc2, nnr, matches_12) -> matchNNR (LSDmatcher.cpp:828-863, 803-826)
+    int match(const uint8_t *desc1, int n1, const uint8_t *desc2, int n2, float nnr, std::vector<int> &matches_12) const
+    {
+        matches_12.assign(n1, -1);
+        int m = 0;
+        check(hvo_match_nnr(ctx_, desc1, n1, desc2, n2, nnr, matches_12.data(), &m), "hvo_match_nnr");
+        return m;
+    }
+private:
+    hvo_ctx *ctx_;
+};
+
+}  // namespace hvo

@@ -1,0 +1,43 @@
+"""The C++ host-side mirror of the reference interfaces (include/hvo.hpp) compiles with g++ and, on
+the GPU box, produces the same results as the Python path / the oracle."""
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, PKG_DIR
+
+
+def _fnv(b):
+    h = 1469598103934665603
+    for x in bytes(b):
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_cpp_mirror_compiles():
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           "-fsyntax-only", os.path.join(ROOT, "examples", "frontend_demo.cpp")])
+    # and the C ABI header is plain C
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "hvo.h")])
+
+
+@pytest.mark.gpu
+def test_cpp_demo_matches_oracle(tmp_path, orc, synth):
+    csrc = os.path.join(PKG_DIR, "csrc")
+    exe = str(tmp_path / "demo")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "frontend_demo.cpp"),
+                           "-L" + csrc, "-lhvo", "-Wl,-rpath," + csrc, "-o", exe])
+    g, d = synth.make_frame("std", 0x5EED0002)
+    g.tofile(tmp_path / "g.u8"); d.tofile(tmp_path / "d.u16")
+    out = subprocess.check_output([exe, str(tmp_path / "g.u8"), str(tmp_path / "d.u16")]).decode().split()
+    kp_o, d_o = orc.Orb().extract(g)
+    kl_o, ld_o, _ = orc.line_extract(g)
+    lab_o, pl_o = orc.peac(d)
+    nm, _ = orc.match_nnr(d_o, d_o, 0.9)
+    assert int(out[1]) == len(kp_o) and int(out[3], 16) == _fnv(d_o.tobytes())
+    assert int(out[5]) == len(kl_o) and int(out[7], 16) == _fnv(ld_o.tobytes())
+    assert int(out[9]) == len(pl_o) and int(out[11], 16) == _fnv(lab_o.tobytes())
+    assert int(out[13]) == nm
