@@ -227,8 +227,10 @@ class Context:
     def batch_run(self, stages=STAGE_ALL):
         self._chk(lib().hvo_batch_run(self.h, stages), "batch_run")
 
-    def batch_download(self, stages=STAGE_ALL, pl_cap=64):
+    def batch_download(self, stages=STAGE_ALL, pl_cap=64, n=None):
+        """results of the first n (default all) frames of the resident batch"""
         B, w, h = self._B, self._w, self._h
+        B = B if n is None else min(B, n)
         kcap = self.params.orb_nfeatures + 8 * self.params.orb_nlevels + 64
         lcap = max(self.params.lsd_nfeatures, 1)
         fo = (FrameOut * B)()

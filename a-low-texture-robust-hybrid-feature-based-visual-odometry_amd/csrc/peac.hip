@@ -19,6 +19,7 @@
 // node creation order, see oracle/peac.c header.
 #include "hvo_internal.hpp"
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include <algorithm>
@@ -56,7 +57,7 @@ static __device__ void eig33sym_dev(const double Kin[3][3], double s[3], double 
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a[i][j] = Kin[i][j];
     for (int sweep = 0; sweep < 30; sweep++) {
         double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
-        if (off == 0.0) break;
+        if (off <= 1e-20 * (fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]))) break;
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const int p = (r == 2) ? 1 : 0, q = (r == 0) ? 1 : 2;
@@ -276,43 +277,47 @@ static __device__ void ah_cluster_wave(const ClArgs &a, int frame, Heap &H, int 
         if (pi[2]) continue;                                   // nouse
         const double *pd = segD + (size_t)p * SEG_D;
         const int pcnt = pi[4], poff = pi[3], pN = pi[0];
-        // ---- evaluate merges with every neighbour, in creation order ----
+        // ---- evaluate merges with every neighbour, in creation order; one candidate per lane ----
         int cand_k = -1; double cand_mse = 0; int cand_N = 0;
+        double st[9], c[3], n[3], m = 0; int mN = 0;           // the selected candidate (uniform after the loop)
         for (int base = 0; base < pcnt; base += 64) {
             const int k = base + lane;
-            double m = 0; int mN = 0; bool has = false;
+            double lst[9], lc[3] = { 0, 0, 0 }, ln[3] = { 0, 0, 0 }, lm = 0; int lN = 0; bool has = false;
+#pragma unroll
+            for (int q = 0; q < 9; q++) lst[q] = 0;
             if (k < pcnt) {
                 const int nb = pool[poff + k];
                 const double *nd = segD + (size_t)nb * SEG_D;
                 if (!(nsim(pd, nd) < a.c60)) {                 // T_ang(P_MERGING)
-                    double st[9];
-                    for (int q = 0; q < 9; q++) st[q] = pd[q] + nd[q];
-                    mN = pN + segI[(size_t)nb * SEG_I];
-                    double c[3], n[3];
-                    stats_compute_dev(st, mN, c, n, m);
+                    for (int q = 0; q < 9; q++) lst[q] = pd[q] + nd[q];
+                    lN = pN + segI[(size_t)nb * SEG_I];
+                    stats_compute_dev(lst, lN, lc, ln, lm);
                     has = true;
                 }
             }
-            cm[lane] = m; cN[lane] = has ? mN : -1;
+            cm[lane] = lm; cN[lane] = has ? lN : -1;
             __syncthreads();
             // exact sequential selection rule of AHCPlaneFitter.hpp:1043-1049 (evaluated uniformly)
             const int lim = min(64, pcnt - base);
+            int sel = -1;
             for (int q = 0; q < lim; q++) {
                 if (cN[q] < 0) continue;
                 const double mq = cm[q];
-                if (cand_k < 0 || cand_mse > mq || (cand_mse == mq && (double)cand_N < mq)) { cand_k = base + q; cand_mse = mq; cand_N = cN[q]; }
+                if (cand_k < 0 || cand_mse > mq || (cand_mse == mq && (double)cand_N < mq)) { cand_k = base + q; cand_mse = mq; cand_N = cN[q]; sel = q; }
+            }
+            if (sel >= 0) {                                     // take the winner's fit from its lane
+#pragma unroll
+                for (int q = 0; q < 9; q++) st[q] = __shfl(lst[q], sel);
+#pragma unroll
+                for (int q = 0; q < 3; q++) { c[q] = __shfl(lc[q], sel); n[q] = __shfl(ln[q], sel); }
+                m = __shfl(lm, sel); mN = __shfl(lN, sel);
             }
             __syncthreads();
         }
         bool merged = false;
         if (cand_k >= 0) {
             const int nb = pool[poff + cand_k];
-            const double *nd = segD + (size_t)nb * SEG_D;
             int *ni = segI + (size_t)nb * SEG_I;
-            double st[9], c[3], n[3], m;
-            for (int q = 0; q < 9; q++) st[q] = pd[q] + nd[q];
-            const int mN = pN + ni[0];
-            stats_compute_dev(st, mN, c, n, m);                // uniform recomputation of the winner
             const double t = 1.6e-6 * c[2] * c[2] + 8.0;        // T_mse(P_MERGING)
             if (m < t * t) {
                 const int ncnt = ni[4], noff = ni[3];
@@ -549,10 +554,10 @@ struct RfArgs {
 // hit the same pixel are serialised: in each sub-round an LDS hash elects, per pixel, the pending
 // event with the smallest index, which is then applied.  Pushes are appended in event order with a
 // block scan, which reproduces the reference's queue order exactly.
-#define FLOOD_T 1024
-#define FLOOD_HS 4096
+template <int FLOOD_T>
 __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long long *__restrict__ adj_out)
 {
+    constexpr int FLOOD_HS = FLOOD_T * 4;
     __shared__ double pl[MAX_PLANES][8];          // center[3], normal[3], mse, pad
     __shared__ unsigned long long adj[MAX_PLANES];
     __shared__ int hkeys[FLOOD_HS], hvals[FLOOD_HS];
@@ -865,7 +870,13 @@ int peac_run(hvo_ctx *ctx, int n)
     r.fx = p.fx; r.fy = p.fy; r.cx = p.cx; r.cy = p.cy; r.dfac = p.depth_map_factor;
     r.blkmap = P->d_blkmap; r.isvalid = P->d_isvalid; r.labels = P->d_labels; r.dist = P->d_dist; r.qpix = P->d_qpix; r.qpl = P->d_qpl;
     r.qcap = P->qcap; r.plidmap = P->d_plidmap; r.planes = P->d_planes; r.c30 = P->c30;
-    hipLaunchKernelGGL(k_peac_flood, dim3(n), dim3(FLOOD_T), 0, st, r, P->d_adj);
+    {
+        static int flood_t = 0;
+        if (!flood_t) { const char *e = getenv("HVO_FLOOD_T"); flood_t = e ? atoi(e) : 512; }
+        if (flood_t == 1024) hipLaunchKernelGGL(k_peac_flood<1024>, dim3(n), dim3(1024), 0, st, r, P->d_adj);
+        else if (flood_t == 512) hipLaunchKernelGGL(k_peac_flood<512>, dim3(n), dim3(512), 0, st, r, P->d_adj);
+        else hipLaunchKernelGGL(k_peac_flood<256>, dim3(n), dim3(256), 0, st, r, P->d_adj);
+    }
     hipLaunchKernelGGL(k_peac_final, dim3(n), dim3(64), 0, st, r, P->d_adj);
     hipLaunchKernelGGL(k_peac_relabel, dim3(64, n), dim3(256), 0, st, P->d_labels, P->d_plidmap, P->w * P->h);
     hvo_prof_end(ctx, id);

@@ -62,15 +62,17 @@ static double T_ang_init(double z)
 }
 
 /* symmetric 3x3 eigen-decomposition, eigenvalues ascending, V[:,i] <-> s[i].
- * Cyclic Jacobi, fixed order (0,1),(0,2),(1,2), at most 30 sweeps. */
+ * Cyclic Jacobi, fixed order (0,1),(0,2),(1,2), relative convergence test, at most 30 sweeps. */
 void orc_eig33sym(const double Kin[3][3], double s[3], double V[3][3])
 {
     double a[3][3], v[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a[i][j] = Kin[i][j];
     static const int PQ[3][2] = { { 0, 1 }, { 0, 2 }, { 1, 2 } };
     for (int sweep = 0; sweep < 30; sweep++) {
+        /* converged once the off-diagonal mass is below 1e-20 of the diagonal mass: a further rotation
+         * would change neither eigenvalues nor eigenvectors at double precision */
         double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
-        if (off == 0.0) break;
+        if (off <= 1e-20 * (fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]))) break;
         for (int r = 0; r < 3; r++) {
             const int p = PQ[r][0], q = PQ[r][1];
             const double apq = a[p][q];
