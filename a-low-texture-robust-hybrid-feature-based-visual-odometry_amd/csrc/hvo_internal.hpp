@@ -42,7 +42,7 @@ struct CellDesc {   // one FAST cell view (ORBextractor.cc:787-806)
 struct OrbPlan {
     int w = 0, h = 0, nlevels = 0, batch = 0;
     LevelGeom lev[HVO_MAX_LEVELS];
-    int ncells = 0, cand_total = 0, node_total = 0, kp_total = 0, ntiles = 0;
+    int ncells = 0, cand_total = 0, node_total = 0, kp_total = 0, ntiles = 0, max_cell = 0;
     size_t pyr_bytes = 0;               // per frame
     int kp_cap = 0;                     // output capacity per frame
     // device
@@ -99,6 +99,14 @@ struct hvo_ctx {
             return HVO_ERR_HIP;                                                              \
         }                                                                                    \
     } while (0)
+
+// Workgroup dispatch costs ~6 ns on MI355X: an EMPTY kernel over 834k tiny workgroups takes 5 ms.
+// Streaming kernels therefore launch a bounded number of persistent workgroups that grid-stride over
+// flattened work items (cdna_hip_programming.md Guideline 11).
+static inline int hvo_grid(long long items, int wg_per_cu) {
+    const long long cap = 256LL * wg_per_cu;
+    return (int)(items < cap ? (items < 1 ? 1 : items) : cap);
+}
 
 // profiling scope helpers (api.hip)
 int  hvo_prof_begin(hvo_ctx *ctx, const char *name, hipStream_t st);

@@ -84,30 +84,42 @@ static __device__ __forceinline__ float fatan2_deg(float y, float x)
 __global__ __launch_bounds__(256) void k_lsd_blur_h(const uint8_t *__restrict__ gray, size_t gframe, int gpitch,
                                                     double *__restrict__ tmp, int w, int h, double k0, double k1, double k2, double k3)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    const int x = blockIdx.x * 256 + threadIdx.x, f = blockIdx.z;
     if (x >= w) return;
-    const uint8_t *S = gray + (size_t)f * gframe + (size_t)y * gpitch;
-    double s = k0 * (double)S[refl(x - 3, w)];
-    s += k1 * (double)S[refl(x - 2, w)];
-    s += k2 * (double)S[refl(x - 1, w)];
-    s += k3 * (double)S[x];
-    s += k2 * (double)S[refl(x + 1, w)];
-    s += k1 * (double)S[refl(x + 2, w)];
-    s += k0 * (double)S[refl(x + 3, w)];
-    tmp[((size_t)f * h + y) * w + x] = s;
+    const int xm3 = refl(x - 3, w), xm2 = refl(x - 2, w), xm1 = refl(x - 1, w), xp1 = refl(x + 1, w), xp2 = refl(x + 2, w), xp3 = refl(x + 3, w);
+    for (int y = blockIdx.y * 8; y < min(h, blockIdx.y * 8 + 8); y++) {     // 8 rows per thread: fewer, fatter workgroups
+        const uint8_t *S = gray + (size_t)f * gframe + (size_t)y * gpitch;
+        double s = k0 * (double)S[xm3];
+        s += k1 * (double)S[xm2];
+        s += k2 * (double)S[xm1];
+        s += k3 * (double)S[x];
+        s += k2 * (double)S[xp1];
+        s += k1 * (double)S[xp2];
+        s += k0 * (double)S[xp3];
+        tmp[((size_t)f * h + y) * w + x] = s;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_lsd_blur_v(const double *__restrict__ tmp, double *__restrict__ blur, int w, int h,
                                                     double k0, double k1, double k2, double k3)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    const int x = blockIdx.x * 256 + threadIdx.x, f = blockIdx.z;
     if (x >= w) return;
     const double *T = tmp + (size_t)f * h * w;
-    double s = k3 * T[(size_t)y * w + x];
-    s += k2 * (T[(size_t)refl(y + 1, h) * w + x] + T[(size_t)refl(y - 1, h) * w + x]);
-    s += k1 * (T[(size_t)refl(y + 2, h) * w + x] + T[(size_t)refl(y - 2, h) * w + x]);
-    s += k0 * (T[(size_t)refl(y + 3, h) * w + x] + T[(size_t)refl(y - 3, h) * w + x]);
-    blur[((size_t)f * h + y) * w + x] = s;
+    const int yb = blockIdx.y * 8;
+    double v[14];                                      // rows yb-3 .. yb+10 of this column, loaded once
+#pragma unroll
+    for (int j = 0; j < 14; j++) v[j] = T[(size_t)refl(min(yb + j - 3, h + 2), h) * w + x];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int y = yb + j;
+        if (y >= h) break;
+        double s = k3 * v[j + 3];
+        s += k2 * (v[j + 4] + v[j + 2]);
+        s += k1 * (v[j + 5] + v[j + 1]);
+        s += k0 * (v[j + 6] + v[j]);
+        blur[((size_t)f * h + y) * w + x] = s;
+    }
 }
 
 // scaled(y,x) of the 0.8x INTER_LINEAR resize of the blurred double image
@@ -228,6 +240,7 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
         for (int s = 0; s < GROW_SLOTS; s++) {
             const int k = s * 7 + k0;                // 63 neighbours (7 points) per slot, lane 63 idles
             c[s] = -1; an[s] = LSD_NOTDEF; cs[s] = 0; sn[s] = 0; valid[s] = false;
+            if (s * 7 >= cnt) continue;              // slot has no pending point (uniform)
             if (lane < 63 && k < cnt) {
                 const int idx = i + k;
                 const int pxy = (rs - idx <= LSD_RING) ? S.ring[idx & (LSD_RING - 1)] : S.reg[idx];
@@ -541,11 +554,12 @@ __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
 __global__ __launch_bounds__(256) void k_lbd_blur5(const uint8_t *__restrict__ gray, size_t gframe, int gpitch,
                                                    uint8_t *__restrict__ out, int w, int h, int k0, int k1, int k2)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    const int x = blockIdx.x * 256 + threadIdx.x, f = blockIdx.z;
     if (x >= w) return;
     const uint8_t *G = gray + (size_t)f * gframe;
-    int s = 0;
     const int kk[5] = { k0, k1, k2, k1, k0 };
+    for (int y = blockIdx.y * 8; y < min(h, blockIdx.y * 8 + 8); y++) {
+    int s = 0;
 #pragma unroll
     for (int j = 0; j < 5; j++) {
         const uint8_t *R = G + (size_t)refl(y + j - 2, h) * gpitch;
@@ -556,19 +570,22 @@ __global__ __launch_bounds__(256) void k_lbd_blur5(const uint8_t *__restrict__ g
     if (x < (w & ~3)) { q = s >> 16; const int rem = s & 0xFFFF; if (rem > 32768 || (rem == 32768 && (q & 1))) q++; }
     else q = (s + 32768) >> 16;
     out[((size_t)f * h + y) * w + x] = (uint8_t)min(q, 255);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_lbd_sobel(const uint8_t *__restrict__ b5, int16_t *__restrict__ dx, int16_t *__restrict__ dy, int w, int h)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    const int x = blockIdx.x * 256 + threadIdx.x, f = blockIdx.z;
     if (x >= w) return;
     const uint8_t *B = b5 + (size_t)f * w * h;
     const int xm = refl(x - 1, w), xp = refl(x + 1, w);
+    for (int y = blockIdx.y * 8; y < min(h, blockIdx.y * 8 + 8); y++) {
     const uint8_t *R0 = B + (size_t)refl(y - 1, h) * w, *R1 = B + (size_t)y * w, *R2 = B + (size_t)refl(y + 1, h) * w;
     const int gx = (R0[xp] - R0[xm]) + 2 * (R1[xp] - R1[xm]) + (R2[xp] - R2[xm]);
     const int gy = (R2[xm] + 2 * R2[x] + R2[xp]) - (R0[xm] + 2 * R0[x] + R0[xp]);
     const size_t o = ((size_t)f * h + y) * w + x;
     dx[o] = (int16_t)gx; dy[o] = (int16_t)gy;
+    }
 }
 
 __constant__ int c_lbd_comb[32][2] = {
@@ -775,8 +792,8 @@ int lsd_run(hvo_ctx *ctx, int n)
     const uint8_t *gray = O.d_pyr + O.lev[0].img_off;
     const int gpitch = O.lev[0].pitch;
     int id = hvo_prof_begin(ctx, "lsd_blur_scale", st);
-    hipLaunchKernelGGL(k_lsd_blur_h, dim3((w + 255) / 256, h, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_tmp, w, h, P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
-    hipLaunchKernelGGL(k_lsd_blur_v, dim3((w + 255) / 256, h, n), dim3(256), 0, st, P->d_tmp, P->d_blur, w, h, P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
+    hipLaunchKernelGGL(k_lsd_blur_h, dim3((w + 255) / 256, (h + 7) / 8, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_tmp, w, h, P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
+    hipLaunchKernelGGL(k_lsd_blur_v, dim3((w + 255) / 256, (h + 7) / 8, n), dim3(256), 0, st, P->d_tmp, P->d_blur, w, h, P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lsd_gradient", st);
     const int gx = (((sw + 31) & ~31) + 255) / 256;
@@ -799,8 +816,8 @@ int lsd_run(hvo_ctx *ctx, int n)
     hipLaunchKernelGGL(k_lsd_grow, dim3(n), dim3(64), lds, st, g);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lbd_sobel", st);
-    hipLaunchKernelGGL(k_lbd_blur5, dim3((w + 255) / 256, h, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_b5, w, h, P->k5[0], P->k5[1], P->k5[2]);
-    hipLaunchKernelGGL(k_lbd_sobel, dim3((w + 255) / 256, h, n), dim3(256), 0, st, P->d_b5, P->d_dx, P->d_dy, w, h);
+    hipLaunchKernelGGL(k_lbd_blur5, dim3((w + 255) / 256, (h + 7) / 8, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_b5, w, h, P->k5[0], P->k5[1], P->k5[2]);
+    hipLaunchKernelGGL(k_lbd_sobel, dim3((w + 255) / 256, (h + 7) / 8, n), dim3(256), 0, st, P->d_b5, P->d_dx, P->d_dy, w, h);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lbd_desc", st);
     hipLaunchKernelGGL(k_lbd_desc, dim3(P->nfeat, n), dim3(64), 0, st, P->d_dx, P->d_dy, w, h, P->d_kl, P->d_nkl, P->nfeat, P->d_gL, P->d_gG, P->d_desc);

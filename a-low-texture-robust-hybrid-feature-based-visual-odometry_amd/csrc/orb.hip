@@ -45,34 +45,43 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, size_
                                                 const int *__restrict__ xofs, const int *__restrict__ xalpha,
                                                 const int *__restrict__ yofs, const int *__restrict__ ybeta)
 {
-    const int dy = blockIdx.y * blockDim.y + threadIdx.y;
     const int dx0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (dy >= D.h || dx0 >= D.w) return;
+    if (dx0 >= D.w) return;
     uint8_t *base = pyr + (size_t)blockIdx.z * frame_stride;
     const uint8_t *src = base + S.img_off;
     uint8_t *dst = base + D.img_off;
-    const int yo = yofs[dy];
-    const int sy0 = yo & 0xFFFF, sy1 = yo >> 16;
-    const int yb = ybeta[dy];
-    const int b0 = (short)(yb & 0xFFFF), b1 = (short)(yb >> 16);
-    const uint8_t *r0 = src + (size_t)sy0 * S.pitch, *r1 = src + (size_t)sy1 * S.pitch;
-    uint32_t out = 0;
+    // horizontal taps of this thread's 4 pixels are row independent: fetch them once
+    int sx[4], sx1[4], a0[4], a1[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        int dx = dx0 + i;
-        if (dx < D.w) {
-            int sx = xofs[dx];
-            int xa = xalpha[dx];
-            int a0 = (short)(xa & 0xFFFF), a1 = (short)(xa >> 16);
-            int sx1 = min(sx + 1, S.w - 1);       // a1 == 0 whenever sx+1 is outside
-            int t0 = r0[sx] * a0 + r0[sx1] * a1;
-            int t1 = r1[sx] * a0 + r1[sx1] * a1;
-            int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
-            out |= (uint32_t)(v & 0xFF) << (8 * i);
-        }
+        const int dx = min(dx0 + i, D.w - 1);
+        sx[i] = xofs[dx];
+        const int xa = xalpha[dx];
+        a0[i] = (short)(xa & 0xFFFF); a1[i] = (short)(xa >> 16);
+        sx1[i] = min(sx[i] + 1, S.w - 1);                       // a1 == 0 whenever sx+1 is outside
     }
-    // pitch is a multiple of 64 so a full dword store stays inside the row
-    *reinterpret_cast<uint32_t *>(dst + (size_t)dy * D.pitch + dx0) = out;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int dy = (blockIdx.y * blockDim.y + threadIdx.y) * 4 + r;
+        if (dy >= D.h) break;
+        const int yo = yofs[dy];
+        const int sy0 = yo & 0xFFFF, sy1 = yo >> 16;
+        const int yb = ybeta[dy];
+        const int b0 = (short)(yb & 0xFFFF), b1 = (short)(yb >> 16);
+        const uint8_t *r0 = src + (size_t)sy0 * S.pitch, *r1 = src + (size_t)sy1 * S.pitch;
+        uint32_t out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (dx0 + i < D.w) {
+                const int t0 = r0[sx[i]] * a0[i] + r0[sx1[i]] * a1[i];
+                const int t1 = r1[sx[i]] * a0[i] + r1[sx1[i]] * a1[i];
+                const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+                out |= (uint32_t)(v & 0xFF) << (8 * i);
+            }
+        }
+        // pitch is a multiple of 64 so a full dword store stays inside the row
+        *reinterpret_cast<uint32_t *>(dst + (size_t)dy * D.pitch + dx0) = out;
+    }
 }
 
 // =====================================================================================
@@ -108,90 +117,149 @@ static __device__ __forceinline__ int fast_score(const uint8_t *tile, int tp, in
     return best - 1;
 }
 
+// Four independent cells per 256-thread workgroup, one wave each (the tiles are ~1400 pixels: a whole
+// workgroup per cell spends its life in barriers and the launch becomes dispatch bound: an EMPTY
+// kernel over the 834k cell-workgroups of a 1024-frame batch already takes 5 ms).  Inside a wave the
+// interior pixels are flattened in raster order, 64 per step, so all lanes work (interiors are ~31
+// wide) and a ballot over a step is already in emission order -- no atomics or scans.  The tile keeps
+// the 4-byte phase it has in global memory so loads and LDS stores are whole dwords.
+template <int TILE>
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, size_t frame_stride,
                                                     const LevelGeom *__restrict__ lev,
                                                     const CellDesc *__restrict__ cells, int ncells,
                                                     uint32_t *__restrict__ cell_kp, int *__restrict__ cell_cnt,
                                                     int iniTh, int minTh, int *__restrict__ flags)
 {
-    constexpr int TP = HVO_CELL_TILE + 8;
-    __shared__ uint8_t tile[HVO_CELL_TILE * TP];
-    __shared__ uint8_t sc[HVO_CELL_TILE * TP];
-    __shared__ int wsum[4];
-    __shared__ int s_cnt_ini;
-    const int cell = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    constexpr int TP = TILE + 8;                               // LDS pitch (multiple of 4; +3 phase bytes fit)
+    constexpr int ND = TP / 4;
+    constexpr int CAND_CAP = TILE * TILE / 4;
+    constexpr int NSTEP = (TILE * TILE + 63) / 64;
+    __shared__ __attribute__((aligned(16))) uint8_t tile_[4][TILE * TP];
+    __shared__ __attribute__((aligned(16))) uint8_t sc_[4][TILE * TP];
+    __shared__ unsigned long long sm_min[4][NSTEP], sm_ini[4][NSTEP];
+    __shared__ unsigned short cand_[4][CAND_CAP];              // packed y << 8 | x
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int frame = blockIdx.y;
+    int cell = blockIdx.x * 4 + wv;
+    const bool live = cell < ncells;
+    if (!live) cell = ncells - 1;                              // idle wave: run along harmlessly, write nothing
+    uint8_t *tile = tile_[wv], *sc = sc_[wv];
     const CellDesc c = cells[cell];
     const LevelGeom L = lev[c.level];
     const uint8_t *img = pyr + (size_t)frame * frame_stride + L.img_off;
     const int vw = c.vw, vh = c.vh;
-    for (int i = tid; i < vw * vh; i += 256) {
-        int y = i / vw, x = i - y * vw;
-        tile[y * TP + x] = img[(size_t)(c.y0 + y) * L.pitch + c.x0 + x];
-        sc[y * TP + x] = 0;
-    }
-    if (tid == 0) s_cnt_ini = 0;
-    __syncthreads();
-    const int iw = vw - 6, ih = vh - 6;
-    const int P = iw * ih;
-    for (int p = tid; p < P; p += 256) {
-        int y = 3 + p / iw, x = 3 + p % iw;
-        const uint8_t *q = tile + y * TP + x;
-        int v = q[0];
-        // necessary condition for a 9-arc at threshold minTh: one of ring pixels 0 / 8 differs by
-        // more than minTh (every arc of 9 contains pixel 0 or pixel 8), likewise 4 / 12.
-        int lo = v - minTh, hi = v + minTh;
-        int a = q[3 * TP], b = q[-3 * TP], e = q[3], f = q[-3];
-        bool c0 = (a < lo) | (a > hi) | (b < lo) | (b > hi);
-        bool c1 = (e < lo) | (e > hi) | (f < lo) | (f > hi);
-        if (c0 & c1) {
-            int s = fast_score(tile, TP, x, y, v);
-            sc[y * TP + x] = (uint8_t)(s >= minTh ? s : 0);
+    const int ax0 = c.x0 & ~3, sh = c.x0 - ax0;                // aligned start, byte phase
+    {
+        const int nd = (sh + vw + 3) >> 2;
+        for (int i = lane; i < vh * ND; i += 64) {
+            const int y = i / ND, dx = i - y * ND;
+            uint32_t v = 0;
+            if (dx < nd) v = *reinterpret_cast<const uint32_t *>(img + (size_t)(c.y0 + y) * L.pitch + ax0 + 4 * dx);
+            reinterpret_cast<uint32_t *>(tile)[y * ND + dx] = v;
+            reinterpret_cast<uint32_t *>(sc)[y * ND + dx] = 0;
         }
     }
     __syncthreads();
-    // NMS + ordered emission.  Thread t owns the raster-contiguous pixels [t*chunk, (t+1)*chunk).
-    const int chunk = (P + 255) / 256;
-    const int p0 = tid * chunk, p1 = min(P, p0 + chunk);
-    unsigned long long keep = 0;   // chunk <= 64 given HVO_CELL_TILE (66*66/256 = 18)
-    int n_ini = 0, n_min = 0;
-    for (int p = p0; p < p1; p++) {
-        int y = 3 + p / iw, x = 3 + p % iw;
-        const uint8_t *s = sc + y * TP + x;
-        int v = s[0];
-        if (v == 0) continue;
-        // neighbours outside the interior region are never written -> 0, like the zeroed score
-        // rows/columns of the reference's per-view FAST call
-        bool ok = v > s[-1] && v > s[1] && v > s[-TP - 1] && v > s[-TP] && v > s[-TP + 1] &&
-                  v > s[TP - 1] && v > s[TP] && v > s[TP + 1];
-        if (ok) { keep |= 1ull << (p - p0); n_min++; n_ini += (v >= iniTh); }
+    const int iw = vw - 6, ih = vh - 6, P = iw * ih;
+    const uint8_t *T0 = tile + sh;                             // T0[y*TP + x] = view pixel (x, y)
+    uint8_t *S0 = sc + sh;
+    // lane's first pixel and the per-step advance (64 = a*iw + b)
+    const int adv_y = 64 / iw, adv_x = 64 - adv_y * iw;
+    // ---- phase A: necessary conditions for every interior pixel, survivors compacted into an LDS list.
+    // A 9-arc of the 16-ring contains ring pixel k or k+8 for every k, and all its pixels are on the
+    // same side of the centre, so with cls = 1 (darker than v - t) | 2 (brighter than v + t):
+    //   AND over the 8 opposite pairs of (cls[k] | cls[k+8]) != 0     (the test cv::FAST itself uses)
+    int ncand = 0;
+    {
+        int yy = lane / iw, xx = lane - yy * iw;
+        for (int p0 = 0; p0 < P; p0 += 64) {
+            bool pass = false;
+            const int x = xx + 3, y = yy + 3;
+            if (p0 + lane < P) {
+                const uint8_t *q = T0 + y * TP + x;
+                const int v = q[0], lo = v - minTh, hi = v + minTh;
+#define CLS(o) ((q[o] < lo ? 1 : 0) | (q[o] > hi ? 2 : 0))
+                int d = CLS(3 * TP) | CLS(-3 * TP);                       // ring 0 | 8
+                if (d) {
+                    d &= CLS(3) | CLS(-3);                                // ring 4 | 12
+                    if (d) {
+                        d &= CLS(2 * TP + 2) | CLS(-2 * TP - 2);          // 2 | 10
+                        d &= CLS(-2 * TP + 2) | CLS(2 * TP - 2);          // 6 | 14
+                        if (d) {
+                            d &= CLS(3 * TP + 1) | CLS(-3 * TP - 1);      // 1 | 9
+                            d &= CLS(TP + 3) | CLS(-TP - 3);              // 3 | 11
+                            d &= CLS(-TP + 3) | CLS(TP - 3);              // 5 | 13
+                            d &= CLS(-3 * TP + 1) | CLS(3 * TP - 1);      // 7 | 15
+                            pass = d != 0;
+                        }
+                    }
+                }
+#undef CLS
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass) { const int p = ncand + __popcll(m & ((1ull << lane) - 1)); if (p < CAND_CAP) cand_[wv][p] = (unsigned short)((y << 8) | x); }
+            ncand += __popcll(m);
+            xx += adv_x; yy += adv_y; if (xx >= iw) { xx -= iw; yy++; }
+        }
     }
-    if (n_ini) atomicAdd(&s_cnt_ini, n_ini);
     __syncthreads();
-    const bool use_ini = s_cnt_ini > 0;
-    const int th = use_ini ? iniTh : minTh;
-    int mine = use_ini ? n_ini : n_min;
-    // block exclusive scan of `mine`
-    const int lane = tid & 63, wv = tid >> 6;
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    if (lane == 63) wsum[wv] = incl;
+    // ---- phase B: exact score of the candidates, one per lane (~250 instructions each) ----
+    if (ncand <= CAND_CAP) {
+        for (int i = lane; i < ncand; i += 64) {
+            const int xy = cand_[wv][i], x = xy & 0xFF, y = xy >> 8;
+            const int s = fast_score(T0, TP, x, y, T0[y * TP + x]);
+            S0[y * TP + x] = (uint8_t)(s >= minTh ? s : 0);
+        }
+    } else {                                                   // pathological tile: score everything
+        for (int p = lane; p < P; p += 64) {
+            const int y = p / iw + 3, x = p - (y - 3) * iw + 3;
+            const int s = fast_score(T0, TP, x, y, T0[y * TP + x]);
+            S0[y * TP + x] = (uint8_t)(s >= minTh ? s : 0);
+        }
+    }
     __syncthreads();
-    int base = 0, total = 0;
-    for (int i = 0; i < 4; i++) { if (i < wv) base += wsum[i]; total += wsum[i]; }
-    int pos = base + incl - mine;
+    // ---- strict 3x3 NMS, 64 raster-consecutive pixels per step; survivors = ballot ----
+    int n_ini = 0;
+    {
+        int yy = lane / iw, xx = lane - yy * iw, st = 0;
+        for (int p0 = 0; p0 < P; p0 += 64, st++) {
+            bool ok = false; int v = 0;
+            if (p0 + lane < P) {
+                const uint8_t *s = S0 + (yy + 3) * TP + xx + 3;
+                v = s[0];
+                // neighbours outside the interior region are never written -> 0, like the zeroed score
+                // rows/columns of the reference's per-view FAST call
+                ok = v != 0 && v > s[-1] && v > s[1] && v > s[-TP - 1] && v > s[-TP] && v > s[-TP + 1] &&
+                     v > s[TP - 1] && v > s[TP] && v > s[TP + 1];
+            }
+            const unsigned long long mm = __ballot(ok), mi = __ballot(ok && v >= iniTh);
+            n_ini += __popcll(mi);
+            if (lane == 0) { sm_min[wv][st] = mm; sm_ini[wv][st] = mi; }
+            xx += adv_x; yy += adv_y; if (xx >= iw) { xx -= iw; yy++; }
+        }
+    }
+    __syncthreads();
+    const bool use_ini = n_ini > 0;                            // iniThFAST survivors, else the minThFAST fallback
     uint32_t *out = cell_kp + ((size_t)frame * ncells + cell) * HVO_CELL_CAP;
-    for (int p = p0; p < p1; p++) {
-        if (!((keep >> (p - p0)) & 1)) continue;
-        int y = 3 + p / iw, x = 3 + p % iw;
-        int v = sc[y * TP + x];
-        if (v < th) continue;
-        if (pos < HVO_CELL_CAP) out[pos] = (uint32_t)(x + c.ox) | ((uint32_t)(y + c.oy) << 12) | ((uint32_t)v << 24);
-        pos++;
+    int pos = 0;
+    {
+        int yy = lane / iw, xx = lane - yy * iw, st = 0;
+        for (int p0 = 0; p0 < P; p0 += 64, st++) {
+            const unsigned long long m = use_ini ? sm_ini[wv][st] : sm_min[wv][st];
+            if (m) {
+                if (live && ((m >> lane) & 1ull)) {
+                    const int x = xx + 3, y = yy + 3;
+                    const int p = pos + __popcll(m & ((1ull << lane) - 1));
+                    if (p < HVO_CELL_CAP) out[p] = (uint32_t)(x + c.ox) | ((uint32_t)(y + c.oy) << 12) | ((uint32_t)S0[y * TP + x] << 24);
+                }
+                pos += __popcll(m);
+            }
+            xx += adv_x; yy += adv_y; if (xx >= iw) { xx -= iw; yy++; }
+        }
     }
-    if (tid == 0) {
-        if (total > HVO_CELL_CAP) { atomicOr(&flags[frame], 1); total = HVO_CELL_CAP; }
-        cell_cnt[(size_t)frame * ncells + cell] = total;
+    if (live && lane == 0) {
+        if (pos > HVO_CELL_CAP) { atomicOr(&flags[frame], 1); pos = HVO_CELL_CAP; }
+        cell_cnt[(size_t)frame * ncells + cell] = pos;
     }
 }
 
@@ -449,7 +517,8 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
                                                 hvo_keypoint *__restrict__ kp_out, int *__restrict__ nkp, int cap)
 {
     const int frame = blockIdx.y, lane = threadIdx.x & 63;
-    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int rep = 0; rep < 4; rep++) {
+    const int idx = blockIdx.x * 16 + rep * 4 + (threadIdx.x >> 6);
     int level, k, total;
     bool ok = locate_kp(lvl_cnt + (size_t)frame * nlevels, nlevels, cap, idx, level, k, total);
     if (blockIdx.x == 0 && threadIdx.x == 0) nkp[frame] = total;
@@ -480,6 +549,7 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
         kp.octave = level; kp.class_id = -1;
         kp_out[(size_t)frame * cap + idx] = kp;
     }
+    }   // rep
 }
 
 // =====================================================================================
@@ -515,13 +585,15 @@ __global__ __launch_bounds__(256) void k_blur7(const uint8_t *__restrict__ pyr, 
         hb[i] = (uint16_t)s;
     }
     __syncthreads();
-    const int c = tid & 63, rg = tid >> 6;     // 4 row groups of 8 rows
+    // thread = one column x 16 rows (2 row groups), sliding down the column
+    const int c = tid & (BLUR_TW - 1), rg = tid / BLUR_TW;
     const int x = x0 + c;
     if (x >= L.w) return;
     const bool vec = x < (L.w & ~3);
+    constexpr int RPT = BLUR_TH / (256 / BLUR_TW);
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        int r = rg * 8 + j, y = y0 + r;
+    for (int j = 0; j < RPT; j++) {
+        int r = rg * RPT + j, y = y0 + r;
         if (y >= L.h) break;
         const uint16_t *p = hb + r * BLUR_TW + c;
         int s = k0 * (p[0] + p[6 * BLUR_TW]) + k1 * (p[BLUR_TW] + p[5 * BLUR_TW]) +
@@ -543,7 +615,8 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t *__restrict__ blur,
                                                uint8_t *__restrict__ desc)
 {
     const int frame = blockIdx.y, lane = threadIdx.x & 63;
-    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int rep = 0; rep < 4; rep++) {
+    const int idx = blockIdx.x * 16 + rep * 4 + (threadIdx.x >> 6);
     if (idx >= nkp[frame]) return;
     hvo_keypoint *kp = kps + (size_t)frame * cap + idx;
     const float kx = kp->x, ky = kp->y, ang = kp->angle;
@@ -578,6 +651,7 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t *__restrict__ blur,
         kp->x = __fmul_rn(kx, L.scale);
         kp->y = __fmul_rn(ky, L.scale);
     }
+    }   // rep
 }
 
 // =====================================================================================
@@ -687,7 +761,8 @@ int orb_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
                     c.level = (short)l; c.x0 = (short)iniX; c.y0 = (short)iniY;
                     c.vw = (short)((int)maxX - (int)iniX); c.vh = (short)((int)maxY - (int)iniY);
                     c.ox = (short)(j * L.wCell); c.oy = (short)(i * L.hCell); c.pad = 0;
-                    if (c.vw > HVO_CELL_TILE || c.vh > HVO_CELL_TILE) return HVO_ERR_UNSUPPORTED;
+                    if (c.vw > HVO_CELL_TILE - 3 || c.vh > HVO_CELL_TILE) return HVO_ERR_UNSUPPORTED;
+                    P.max_cell = std::max(P.max_cell, (int)std::max(c.vw, c.vh));
                     if (c.vw < 7 || c.vh < 7) continue;      // cv::FAST finds nothing in such a view
                     cells.push_back(c);
                 }
@@ -796,14 +871,18 @@ int orb_run(hvo_ctx *ctx, int n)
     int id = hvo_prof_begin(ctx, "orb_pyramid", st);
     for (int l = 1; l < nl; l++) {
         const LevelGeom &S = P.lev[l - 1], &D = P.lev[l];
-        dim3 blk(64, 4), grd((D.w + 255) / 256, (D.h + 3) / 4, n);
+        dim3 blk(64, 4), grd((D.w + 255) / 256, (D.h + 15) / 16, n);
         hipLaunchKernelGGL(k_resize, grd, blk, 0, st, P.d_pyr, P.pyr_bytes, S, D, P.d_rs_xofs + D.rs_off, P.d_rs_xalpha + D.rs_off,
                            P.d_rs_yofs + D.ry_off, P.d_rs_ybeta + D.ry_off);
     }
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "orb_fast_cells", st);
-    hipLaunchKernelGGL(k_fast_cells, dim3(P.ncells, n), dim3(256), 0, st, P.d_pyr, P.pyr_bytes, P.d_lev, P.d_cells, P.ncells,
-                       P.d_cell_kp, P.d_cell_cnt, ctx->p.orb_ini_th_fast, ctx->p.orb_min_th_fast, P.d_flags);
+    if (P.max_cell <= 45)
+        hipLaunchKernelGGL(k_fast_cells<48>, dim3((P.ncells + 3) / 4, n), dim3(256), 0, st, P.d_pyr, P.pyr_bytes, P.d_lev, P.d_cells, P.ncells,
+                           P.d_cell_kp, P.d_cell_cnt, ctx->p.orb_ini_th_fast, ctx->p.orb_min_th_fast, P.d_flags);
+    else
+        hipLaunchKernelGGL(k_fast_cells<HVO_CELL_TILE>, dim3((P.ncells + 3) / 4, n), dim3(256), 0, st, P.d_pyr, P.pyr_bytes, P.d_lev, P.d_cells, P.ncells,
+                           P.d_cell_kp, P.d_cell_cnt, ctx->p.orb_ini_th_fast, ctx->p.orb_min_th_fast, P.d_flags);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "orb_octree", st);
     OctArgs oa;
@@ -814,7 +893,7 @@ int orb_run(hvo_ctx *ctx, int n)
     hipLaunchKernelGGL(k_octree, dim3(nl, n), dim3(64), 0, st, oa);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "orb_orient", st);
-    hipLaunchKernelGGL(k_orient, dim3((P.kp_cap + 3) / 4, n), dim3(256), 0, st, P.d_pyr, P.pyr_bytes, P.d_lev, nl, P.d_lvl_kp, P.d_lvl_cnt,
+    hipLaunchKernelGGL(k_orient, dim3((P.kp_cap + 15) / 16, n), dim3(256), 0, st, P.d_pyr, P.pyr_bytes, P.d_lev, nl, P.d_lvl_kp, P.d_lvl_cnt,
                        P.kp_total, ctx->d_umax, P.d_kp, P.d_nkp, P.kp_cap);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "orb_blur", st);
@@ -829,7 +908,7 @@ int orb_run(hvo_ctx *ctx, int n)
     hipLaunchKernelGGL(k_blur7, dim3(P.ntiles, n), dim3(256), 0, st, P.d_pyr, P.d_blur, P.pyr_bytes, P.d_lev, P.d_tiles, k7[0], k7[1], k7[2], k7[3]);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "orb_brief", st);
-    hipLaunchKernelGGL(k_brief, dim3((P.kp_cap + 3) / 4, n), dim3(256), 0, st, P.d_blur, P.pyr_bytes, P.d_lev, ctx->d_pattern, P.d_kp, P.d_nkp,
+    hipLaunchKernelGGL(k_brief, dim3((P.kp_cap + 15) / 16, n), dim3(256), 0, st, P.d_blur, P.pyr_bytes, P.d_lev, ctx->d_pattern, P.d_kp, P.d_nkp,
                        P.kp_cap, P.d_desc);
     hvo_prof_end(ctx, id);
     HVO_HIP(hipGetLastError());
