@@ -259,8 +259,9 @@ class Context:
                 r["planes"] = r["planes"][: fo[b].n_planes]
         return res
 
-    def profile_enable(self, on=True):
-        self._chk(lib().hvo_profile_enable(self.h, 1 if on else 0), "profile_enable")
+    def profile_enable(self, mode=1):
+        """0 off, 1 hipEvents around each kernel group, 2 events + stages serialised on one stream"""
+        self._chk(lib().hvo_profile_enable(self.h, int(mode)), "profile_enable")
 
     def profile_last(self):
         names = (C.c_char_p * 32)(); ms = (C.c_float * 32)()

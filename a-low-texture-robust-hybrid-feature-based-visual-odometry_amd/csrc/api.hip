@@ -87,6 +87,7 @@ int hvo_profile_enable(hvo_ctx *ctx, int on)
 {
     if (!ctx) return HVO_ERR_INVALID_ARG;
     ctx->profile = on != 0;
+    ctx->serialize = on == 2;              // 2: also run ORB, LSD, PEAC back to back on one stream
     return HVO_OK;
 }
 

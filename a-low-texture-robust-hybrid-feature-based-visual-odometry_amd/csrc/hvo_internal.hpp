@@ -85,6 +85,7 @@ struct hvo_ctx {
     void *h_stage = nullptr; size_t h_stage_cap = 0;
     // profiling
     bool profile = false;
+    bool serialize = false;                // profiling mode 2: all stages on one stream (clean per-kernel times)
     ProfileRec prof[HVO_MAX_PROFILE]; int nprof = 0;
     // opaque per-subsystem state (peac.hip / lsd.hip own these)
     void *peac = nullptr;
@@ -108,6 +109,8 @@ static inline int hvo_grid(long long items, int wg_per_cu) {
     return (int)(items < cap ? (items < 1 ? 1 : items) : cap);
 }
 
+static inline hipStream_t hvo_stream_lsd(hvo_ctx *c);
+static inline hipStream_t hvo_stream_peac(hvo_ctx *c);
 // profiling scope helpers (api.hip)
 int  hvo_prof_begin(hvo_ctx *ctx, const char *name, hipStream_t st);
 void hvo_prof_end(hvo_ctx *ctx, int id);
@@ -136,3 +139,6 @@ void peac_free(hvo_ctx *ctx);
 int lsd_run(hvo_ctx *ctx, int n);
 int lsd_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
 void lsd_free(hvo_ctx *ctx);
+
+static inline hipStream_t hvo_stream_lsd(hvo_ctx *c) { return c->serialize ? c->stream : c->s_lsd; }
+static inline hipStream_t hvo_stream_peac(hvo_ctx *c) { return c->serialize ? c->stream : c->s_peac; }

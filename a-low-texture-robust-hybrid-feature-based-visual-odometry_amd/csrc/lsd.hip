@@ -787,7 +787,7 @@ int lsd_run(hvo_ctx *ctx, int n)
     int rc = lsd_ensure_plan(ctx, O.w, O.h, std::max(n, ctx->p.max_batch));
     if (rc) return rc;
     LsdPlan *P = plan_of(ctx);
-    hipStream_t st = ctx->s_lsd;
+    hipStream_t st = hvo_stream_lsd(ctx);
     const int w = P->w, h = P->h, sw = P->sw, sh = P->sh;
     const uint8_t *gray = O.d_pyr + O.lev[0].img_off;
     const int gpitch = O.lev[0].pitch;

@@ -558,51 +558,94 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
 // Row pass with integer taps {18,34,49,55,49,34,18} (sum 257) fits u16; column pass in int32,
 // then: columns x < (w & ~3) round-half-to-even of s/65536 (the SSE2 float path of
 // SymmColumnVec_32s8u -- exact in float here), the last w%4 columns (s + 32768) >> 16.
-#define BLUR_TW 64
-#define BLUR_TH 32
+// Register sliding-window formulation (no LDS, no barriers): a thread owns a 4-pixel-wide column strip
+// of BLUR_TH rows.  Per input row it loads the 12 bytes [x0-4, x0+8) as three aligned dwords, forms the
+// byte windows with v_alignbyte and evaluates the 7-tap row sum of each of its 4 pixels with two
+// v_dot4_u32_u8; the last 7 row sums per pixel stay in registers for the column pass.  Output is one
+// dword store per row.  Strips that touch the left/right image border assemble their window byte by
+// byte with REFLECT_101 indices (two threads per row).
+#define BLUR_TW 256            // pixels per workgroup row (64 threads x 4 px)
+#define BLUR_TH 32             // rows per wave; a workgroup (4 waves) covers 128 rows
+struct BlurWin { unsigned W0, W1, W2; };
+static __device__ __forceinline__ BlurWin blur_load(const uint8_t *__restrict__ row, int x0, int w, bool interior)
+{
+    BlurWin o;
+    if (interior) {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(row + x0 - 4);
+        o.W0 = p[0]; o.W1 = p[1]; o.W2 = p[2];
+    } else {
+        unsigned b[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) b[i] = row[reflect101(x0 - 4 + i, w)];
+        o.W0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        o.W1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        o.W2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+    }
+    return o;
+}
+static __device__ __forceinline__ void blur_row_sums(const BlurWin &W, unsigned klo, unsigned khi, int hs[4])
+{
+    // pixel j reads window bytes j+1 .. j+7
+    const unsigned A0 = __builtin_amdgcn_alignbyte(W.W1, W.W0, 1), B0 = __builtin_amdgcn_alignbyte(W.W2, W.W1, 1);
+    const unsigned A1 = __builtin_amdgcn_alignbyte(W.W1, W.W0, 2), B1 = __builtin_amdgcn_alignbyte(W.W2, W.W1, 2);
+    const unsigned A2 = __builtin_amdgcn_alignbyte(W.W1, W.W0, 3), B2 = __builtin_amdgcn_alignbyte(W.W2, W.W1, 3);
+    hs[0] = (int)__builtin_amdgcn_udot4(A0, klo, __builtin_amdgcn_udot4(B0, khi, 0u, false), false);
+    hs[1] = (int)__builtin_amdgcn_udot4(A1, klo, __builtin_amdgcn_udot4(B1, khi, 0u, false), false);
+    hs[2] = (int)__builtin_amdgcn_udot4(A2, klo, __builtin_amdgcn_udot4(B2, khi, 0u, false), false);
+    hs[3] = (int)__builtin_amdgcn_udot4(W.W1, klo, __builtin_amdgcn_udot4(W.W2, khi, 0u, false), false);
+}
+
 __global__ __launch_bounds__(256) void k_blur7(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, size_t frame_stride,
                                                const LevelGeom *__restrict__ lev, const int4 *__restrict__ tiles,
                                                int k0, int k1, int k2, int k3)
 {
-    __shared__ uint8_t in[(BLUR_TH + 6) * (BLUR_TW + 8)];
-    __shared__ uint16_t hb[(BLUR_TH + 6) * BLUR_TW];
     const int4 t = tiles[blockIdx.x];
     const LevelGeom L = lev[t.x];
     const uint8_t *src = pyr + (size_t)blockIdx.y * frame_stride + L.img_off;
     uint8_t *dst = blur + (size_t)blockIdx.y * frame_stride + L.img_off;
-    const int x0 = t.y * BLUR_TW, y0 = t.z * BLUR_TH, tid = threadIdx.x;
-    constexpr int IP = BLUR_TW + 8;
-    for (int i = tid; i < (BLUR_TH + 6) * (BLUR_TW + 6); i += 256) {
-        int r = i / (BLUR_TW + 6), c = i - r * (BLUR_TW + 6);
-        int yy = reflect101(y0 + r - 3, L.h), xx = reflect101(x0 + c - 3, L.w);
-        in[r * IP + c] = src[(size_t)yy * L.pitch + xx];
-    }
-    __syncthreads();
-    for (int i = tid; i < (BLUR_TH + 6) * BLUR_TW; i += 256) {
-        int r = i / BLUR_TW, c = i - r * BLUR_TW;
-        const uint8_t *p = in + r * IP + c;
-        int s = k0 * (p[0] + p[6]) + k1 * (p[1] + p[5]) + k2 * (p[2] + p[4]) + k3 * p[3];
-        hb[i] = (uint16_t)s;
-    }
-    __syncthreads();
-    // thread = one column x 16 rows (2 row groups), sliding down the column
-    const int c = tid & (BLUR_TW - 1), rg = tid / BLUR_TW;
-    const int x = x0 + c;
-    if (x >= L.w) return;
-    const bool vec = x < (L.w & ~3);
-    constexpr int RPT = BLUR_TH / (256 / BLUR_TW);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x0 = t.y * BLUR_TW + lane * 4;
+    const int y0 = (t.z * 4 + wv) * BLUR_TH;
+    if (x0 >= L.w || y0 >= L.h) return;
+    const bool interior = x0 >= 4 && x0 + 7 < L.w;           // window [x0-4, x0+8) needs columns x0-3 .. x0+6
+    const unsigned klo = (unsigned)k0 | ((unsigned)k1 << 8) | ((unsigned)k2 << 16) | ((unsigned)k3 << 24);
+    const unsigned khi = (unsigned)k2 | ((unsigned)k1 << 8) | ((unsigned)k0 << 16);
+    const int wv4 = L.w & ~3;
+    const int rows = min(BLUR_TH, L.h - y0);
+#define BLUR_ROW(i) (src + (size_t)reflect101(y0 + (i) - 3, L.h) * L.pitch)
+    // all six priming rows are fetched before any is consumed; inside the loop the window of row r+2 is
+    // requested while row r is being processed (two loads in flight per thread)
+    BlurWin pw[6];
 #pragma unroll
-    for (int j = 0; j < RPT; j++) {
-        int r = rg * RPT + j, y = y0 + r;
-        if (y >= L.h) break;
-        const uint16_t *p = hb + r * BLUR_TW + c;
-        int s = k0 * (p[0] + p[6 * BLUR_TW]) + k1 * (p[BLUR_TW] + p[5 * BLUR_TW]) +
-                k2 * (p[2 * BLUR_TW] + p[4 * BLUR_TW]) + k3 * p[3 * BLUR_TW];
-        int q;
-        if (vec) { q = s >> 16; int rem = s & 0xFFFF; if (rem > 32768 || (rem == 32768 && (q & 1))) q++; }
-        else q = (s + 32768) >> 16;
-        dst[(size_t)y * L.pitch + x] = (uint8_t)min(q, 255);
+    for (int r = 0; r < 6; r++) pw[r] = blur_load(BLUR_ROW(r), x0, L.w, interior);
+    BlurWin n0 = blur_load(BLUR_ROW(6), x0, L.w, interior);
+    BlurWin n1 = blur_load(BLUR_ROW(7), x0, L.w, interior);
+    int h[7][4];
+#pragma unroll
+    for (int r = 0; r < 6; r++) blur_row_sums(pw[r], klo, khi, h[r]);
+    for (int r = 0; r < rows; r++) {
+        const BlurWin cur = n0;
+        n0 = n1;
+        n1 = blur_load(BLUR_ROW(r + 8), x0, L.w, interior);       // rows past the band are loaded (reflected) but unused
+        blur_row_sums(cur, klo, khi, h[6]);
+        unsigned out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int sv = k0 * (h[0][j] + h[6][j]) + k1 * (h[1][j] + h[5][j]) + k2 * (h[2][j] + h[4][j]) + k3 * h[3][j];
+            int q;
+            if (x0 + j < wv4) { q = sv >> 16; const int rem = sv & 0xFFFF; if (rem > 32768 || (rem == 32768 && (q & 1))) q++; }
+            else q = (sv + 32768) >> 16;
+            q = min(q, 255);
+            if (x0 + j < L.w) out |= (unsigned)q << (8 * j);
+        }
+        *reinterpret_cast<uint32_t *>(dst + (size_t)(y0 + r) * L.pitch + x0) = out;   // pitch % 64 == 0: stays in the row
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) h[q][j] = h[q + 1][j];
+        }
     }
+#undef BLUR_ROW
 }
 
 // =====================================================================================
@@ -804,7 +847,7 @@ int orb_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
             }
         }
         L.tile_off = (int)tiles.size();
-        L.ntx = (L.w + BLUR_TW - 1) / BLUR_TW; L.nty = (L.h + BLUR_TH - 1) / BLUR_TH;
+        L.ntx = (L.w + BLUR_TW - 1) / BLUR_TW; L.nty = (L.h + 4 * BLUR_TH - 1) / (4 * BLUR_TH);
         for (int ty = 0; ty < L.nty; ty++) for (int tx = 0; tx < L.ntx; tx++) tiles.push_back(make_int4(l, tx, ty, 0));
     }
     P.pyr_bytes = (off + 255) & ~(size_t)255;

@@ -846,7 +846,7 @@ int peac_run(hvo_ctx *ctx, int n)
 {
     PeacPlan *P = plan_of(ctx);
     if (!P || n < 1 || n > P->batch) return HVO_ERR_INVALID_ARG;
-    hipStream_t st = ctx->s_peac;
+    hipStream_t st = hvo_stream_peac(ctx);
     const size_t dframe = (size_t)P->pitch * (P->h + 1);
     const hvo_params &p = ctx->p;
     HVO_HIP(hipMemsetAsync(P->d_isvalid, 0, (size_t)n * MAX_PLANES * sizeof(int), st));
@@ -873,9 +873,11 @@ int peac_run(hvo_ctx *ctx, int n)
     {
         static int flood_t = 0;
         if (!flood_t) { const char *e = getenv("HVO_FLOOD_T"); flood_t = e ? atoi(e) : 512; }
-        if (flood_t == 1024) hipLaunchKernelGGL(k_peac_flood<1024>, dim3(n), dim3(1024), 0, st, r, P->d_adj);
-        else if (flood_t == 512) hipLaunchKernelGGL(k_peac_flood<512>, dim3(n), dim3(512), 0, st, r, P->d_adj);
-        else hipLaunchKernelGGL(k_peac_flood<256>, dim3(n), dim3(256), 0, st, r, P->d_adj);
+        if (flood_t == 64) hipLaunchKernelGGL(k_peac_flood<64>, dim3(n), dim3(64), 0, st, r, P->d_adj);
+        else if (flood_t == 128) hipLaunchKernelGGL(k_peac_flood<128>, dim3(n), dim3(128), 0, st, r, P->d_adj);
+        else if (flood_t == 256) hipLaunchKernelGGL(k_peac_flood<256>, dim3(n), dim3(256), 0, st, r, P->d_adj);
+        else if (flood_t == 1024) hipLaunchKernelGGL(k_peac_flood<1024>, dim3(n), dim3(1024), 0, st, r, P->d_adj);
+        else hipLaunchKernelGGL(k_peac_flood<512>, dim3(n), dim3(512), 0, st, r, P->d_adj);
     }
     hipLaunchKernelGGL(k_peac_final, dim3(n), dim3(64), 0, st, r, P->d_adj);
     hipLaunchKernelGGL(k_peac_relabel, dim3(64, n), dim3(256), 0, st, P->d_labels, P->d_plidmap, P->w * P->h);

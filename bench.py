@@ -127,7 +127,6 @@ def main():
     ctx = hvo.Context(max_batch=B, device=local_rank, orb_nfeatures=1000 if args.width <= 640 else 2000,
                       fx=535.4 * s, fy=539.2 * s, cx=320.1 * s, cy=247.6 * s)
     ctx.batch_upload(gray, depth)           # inputs resident in HBM before the timed region
-    ctx.profile_enable(True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -137,19 +136,28 @@ def main():
 
     for _ in range(args.warmup):
         ctx.batch_run(mask)
-    prof = {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ctx.batch_run(mask)                 # enqueues all kernels and waits for the stream
-        for k, v in ctx.profile_last().items():
-            prof[k] = prof.get(k, 0.0) + v
+        ctx.batch_run(mask)                 # enqueues every kernel (ORB || LSD || PEAC streams) and waits
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # Per-kernel durations for the roofline: the same steps again with hipEvents on the kernels' stream
+    # and the three subsystems serialised, so that a group's time is its own (with the streams
+    # overlapped a group's event interval mostly measures waiting for CU slots held by the others).
+    prof = {}
+    psteps = max(1, min(args.steps, 3))
+    ctx.profile_enable(2)
+    for _ in range(psteps):
+        ctx.batch_run(mask)
+        for k, v in ctx.profile_last().items():
+            prof[k] = prof.get(k, 0.0) + v
+    ctx.profile_enable(0)
 
     res = ctx.batch_download(mask, n=64)     # a sample is enough for the workload statistics
     nkp = float(np.mean([len(r["kp"]) for r in res])) if "orb" in stages else 0.0
@@ -160,7 +168,7 @@ def main():
     if rank == 0:
         frames = world * B * args.steps
         value = frames / dt
-        groups = {k: v / args.steps for k, v in prof.items()}       # ms per launch group per step
+        groups = {k: v / psteps for k, v in prof.items()}           # ms per launch group per step (serialised pass)
         dom = max(groups, key=groups.get) if groups else None
         roof = None
         if dom:
@@ -182,7 +190,7 @@ def main():
                        "stages": stages, "frames_per_gpu": B, "parallelism": "frames sharded, %d rank(s), no data-path collective" % world,
                        "mean_keypoints": round(nkp, 1), "mean_lines": round(nlines, 1), "mean_planes": round(nplanes, 2),
                        "frames_with_capacity_flags": bad},
-            "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1])},
+            "kernel_ms_per_step_serialised": {k: round(v, 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1])},
             "roofline": roof,
         }
         if not args.no_cpu_baseline:

@@ -166,7 +166,8 @@ int hvo_extract_batch(hvo_ctx *ctx, int n, const hvo_frame_in *in, hvo_frame_out
 /* Per-kernel-group device time of the last hvo_batch_run, measured with hipEvents on the ctx
  * stream.  names[i] points at static strings.  Returns the number of groups written (<= cap). */
 int hvo_profile_last(const hvo_ctx *ctx, const char **names, float *ms, int cap);
-/* enable/disable hipEvent bracketing of each kernel group inside hvo_batch_run (default off) */
+/* 0: off (default); 1: hipEvent bracketing of each kernel group inside hvo_batch_run; 2: as 1 and the
+ * three subsystems run back to back on one stream, so that group times are free of cross-stream contention */
 int hvo_profile_enable(hvo_ctx *ctx, int on);
 
 #ifdef __cplusplus
