@@ -42,7 +42,7 @@ assert KEYPOINT_DT.itemsize == 28 and KEYLINE_DT.itemsize == 68 and PLANE_DT.ite
 EXPORTS = [
     "hvo_abi_version", "hvo_default_params", "hvo_create", "hvo_destroy", "hvo_strerror", "hvo_last_error",
     "hvo_extract_orb", "hvo_extract_lsd", "hvo_compute_planes",
-    "hvo_hamming_matrix", "hvo_hamming_knn2", "hvo_match_nnr",
+    "hvo_hamming_matrix", "hvo_hamming_knn2", "hvo_match_nnr", "hvo_search_by_projection", "hvo_stereo_from_rgbd",
     "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch",
     "hvo_profile_last", "hvo_profile_enable",
 ]
@@ -107,6 +107,8 @@ def lib():
         L.hvo_hamming_knn2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.hvo_match_nnr.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
                                     C.POINTER(C.c_int)]
+        L.hvo_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_void_p] * 4 + [C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.hvo_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         L.hvo_batch_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameIn), C.c_int, C.c_int]
         L.hvo_batch_run.argtypes = [C.c_void_p, C.c_uint]
         L.hvo_batch_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameOut)]
@@ -208,6 +210,31 @@ class Context:
         m = np.full(len(d1), -1, np.int32); n = C.c_int(0)
         self._chk(lib().hvo_match_nnr(self.h, _p(d1), len(d1), _p(d2), len(d2), nnr, _p(m), C.byref(n)), "match_nnr")
         return n.value, m
+
+    def search_by_projection(self, q_desc, q_u, q_v, q_radius, q_min_level, q_max_level, q_ur, q_angle, q_blocks,
+                             t_kp, t_uright, t_occupied, t_desc, bounds, th_high=100, check_orientation=True):
+        """ORBmatcher::SearchByProjection(Cur, Last) core (src/ORBmatcher.cc:1353-1497) -> (nmatches, idx, dist)"""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        q_desc = np.ascontiguousarray(q_desc, np.uint8); t_desc = np.ascontiguousarray(t_desc, np.uint8)
+        nq, nt = len(q_desc), len(t_desc)
+        q_u, q_v, q_radius, q_ur, q_angle, t_uright = map(f32, (q_u, q_v, q_radius, q_ur, q_angle, t_uright))
+        q_min_level = np.ascontiguousarray(q_min_level, np.int32); q_max_level = np.ascontiguousarray(q_max_level, np.int32)
+        q_blocks = np.ascontiguousarray(q_blocks, np.uint8); t_occupied = np.ascontiguousarray(t_occupied, np.uint8)
+        t_kp = np.ascontiguousarray(t_kp)
+        mi = np.zeros(nq, np.int32); md = np.zeros(nq, np.int32); n = C.c_int(0)
+        self._chk(lib().hvo_search_by_projection(self.h, _p(q_desc), nq, _p(q_u), _p(q_v), _p(q_radius), _p(q_min_level), _p(q_max_level),
+                                                 _p(q_ur), _p(q_angle), _p(q_blocks), _p(t_kp), _p(t_uright), _p(t_occupied), _p(t_desc), nt,
+                                                 bounds[0], bounds[1], bounds[2], bounds[3], th_high, 1 if check_orientation else 0,
+                                                 _p(mi), _p(md), C.byref(n)), "search_by_projection")
+        return n.value, mi, md
+
+    def stereo_from_rgbd(self, kp, kp_un, depth, bf):
+        """Frame::ComputeStereoFromRGBD (src/Frame.cc:1940-1961) -> (mvuRight, mvDepth)"""
+        kp = np.ascontiguousarray(kp); kp_un = np.ascontiguousarray(kp_un); depth = np.ascontiguousarray(depth, np.uint16)
+        h, w = depth.shape
+        ur = np.zeros(len(kp), np.float32); z = np.zeros(len(kp), np.float32)
+        self._chk(lib().hvo_stereo_from_rgbd(self.h, _p(kp), _p(kp_un), len(kp), _p(depth), w, h, depth.strides[0], bf, _p(ur), _p(z)), "stereo_from_rgbd")
+        return ur, z
 
     # ---- batch ----
     def batch_upload(self, gray, depth=None):

@@ -2,8 +2,10 @@
 // checks, device selection, staging, and dispatch to the per-subsystem batch runners.
 // There is deliberately no CPU path: without a usable gfx950 device every call fails.
 #include "hvo_internal.hpp"
+#include <math.h>
 #include <string.h>
 #include <new>
+#include <vector>
 
 extern "C" {
 
@@ -224,6 +226,90 @@ int hvo_match_nnr(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, in
     }
     *n_matches = m;
     return HVO_OK;
+}
+
+int hvo_search_by_projection(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
+                             const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur, const float *q_angle,
+                             const uint8_t *q_blocks, const hvo_keypoint *t_kp, const float *t_uright, const uint8_t *t_occupied,
+                             const uint8_t *t_desc, int nt, float mnMinX, float mnMinY, float mnMaxX, float mnMaxY,
+                             int th_high, int check_orientation, int32_t *match_idx, int32_t *match_dist, int *n_matches)
+{
+    if (!ctx || !n_matches || nq < 0 || nt < 0) return HVO_ERR_INVALID_ARG;
+    *n_matches = 0;
+    if (nq == 0) return HVO_OK;
+    if (!q_desc || !q_u || !q_v || !q_radius || !q_min_level || !q_max_level || !q_angle || !q_blocks || !match_idx || !match_dist) return HVO_ERR_INVALID_ARG;
+    for (int i = 0; i < nq; i++) { match_idx[i] = -1; match_dist[i] = 256; }
+    if (nt == 0) return HVO_OK;
+    if (!t_kp || !t_desc || nt > 65535 || !(mnMaxX > mnMinX) || !(mnMaxY > mnMinY)) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    std::vector<unsigned long long> keys((size_t)nq * HVO_SBP_K);
+    std::vector<int> cnt(nq);
+    // host epilogue: the reference's sequential pass (ORBmatcher.cc:1376-1470) over the ranked candidates.
+    // occ = features that already hold an observed map point + features claimed so far.  If a query finds
+    // all of its HVO_SBP_K ranked candidates claimed although more exist, the pass stops there and the
+    // remaining queries are ranked again against the occupancy reached so far (exact; rarely needed).
+    std::vector<uint8_t> occ(nt, 0);
+    if (t_occupied) for (int j = 0; j < nt; j++) occ[j] = t_occupied[j] ? 1 : 0;
+    std::vector<int> rot_bin(nq, -1);
+    int nm = 0;
+    const float factor = 1.0f / 30;
+    int start = 0;
+    while (start < nq) {
+        const int m = nq - start;
+        int rc = match_search_by_projection(ctx, q_desc + (size_t)start * 32, m, q_u + start, q_v + start, q_radius + start, q_min_level + start,
+                                            q_max_level + start, q_ur ? q_ur + start : nullptr, t_kp, t_uright, occ.data(), t_desc, nt,
+                                            mnMinX, mnMinY, mnMaxX, mnMaxY, keys.data(), cnt.data());
+        if (rc) return rc;
+        int i = start;
+        for (; i < nq; i++) {
+            const unsigned long long *kq = &keys[(size_t)(i - start) * HVO_SBP_K];
+            const int total = cnt[i - start], navail = total < HVO_SBP_K ? total : HVO_SBP_K;
+            int k = 0;
+            for (; k < navail; k++) if (!occ[(int)(kq[k] & 0xFFFF)]) break;
+            if (k == navail) { if (total > HVO_SBP_K) break; continue; }     // exhausted: re-rank from query i
+            const int j = (int)(kq[k] & 0xFFFF), d = (int)(kq[k] >> 32);
+            if (d <= th_high) {
+                match_idx[i] = j; match_dist[i] = d; nm++;
+                if (q_blocks[i]) occ[j] = 1;
+                if (check_orientation) {
+                    float rot = q_angle[i] - t_kp[j].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)round(rot * factor);
+                    if (bin == 30) bin = 0;
+                    rot_bin[i] = bin;
+                }
+            }
+        }
+        start = i;
+    }
+    int status = HVO_OK;
+    if (check_orientation) {                                  // ComputeThreeMaxima (ORBmatcher.cc:1630-1673)
+        int hist[30] = { 0 };
+        for (int i = 0; i < nq; i++) if (rot_bin[i] >= 0) hist[rot_bin[i]]++;
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int b = 0; b < 30; b++) {
+            const int s = hist[b];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = b; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = b; }
+            else if (s > max3) { max3 = s; ind3 = b; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) ind3 = -1;
+        for (int i = 0; i < nq; i++)
+            if (rot_bin[i] >= 0 && rot_bin[i] != ind1 && rot_bin[i] != ind2 && rot_bin[i] != ind3) { match_idx[i] = -1; nm--; }
+    }
+    *n_matches = nm;
+    return status;
+}
+
+int hvo_stereo_from_rgbd(hvo_ctx *ctx, const hvo_keypoint *kp, const hvo_keypoint *kp_un, int n, const uint16_t *depth, int w, int h, int stride,
+                         float bf, float *uright, float *zdepth)
+{
+    if (!ctx || n < 0) return HVO_ERR_INVALID_ARG;
+    if (n == 0) return HVO_OK;
+    if (!kp || !kp_un || !depth || !uright || !zdepth || w <= 0 || h <= 0 || stride < 2 * w) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    return match_stereo_from_rgbd(ctx, kp, kp_un, n, depth, w, h, stride, bf, uright, zdepth);
 }
 
 }  // extern "C"

@@ -128,6 +128,13 @@ int orb_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
 int match_matrix(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *d);
 int match_knn2(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx2, int32_t *dist2);
 void match_free(hvo_ctx *ctx);
+#define HVO_SBP_K 16
+int match_search_by_projection(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
+                               const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur,
+                               const hvo_keypoint *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
+                               float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, unsigned long long *keys, int *cnt);
+int match_stereo_from_rgbd(hvo_ctx *ctx, const hvo_keypoint *kp, const hvo_keypoint *kpun, int n, const uint16_t *depth, int w, int h, int stride,
+                           float bf, float *uright, float *zdepth);
 
 // peac.hip
 int peac_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h);

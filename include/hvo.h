@@ -134,6 +134,25 @@ int hvo_hamming_knn2(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, i
 int hvo_match_nnr(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float nnr,
                   int32_t *matches12, int *n_matches);
 
+/* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, mono) core (reference src/ORBmatcher.cc:1353-1497,
+ * Frame::GetFeaturesInArea src/Frame.cc:1502-1555).  One query per last-frame map point that passed the
+ * projection tests (:1381-1404): projected (u,v), radius = th * scale[octave], octave band [min,max] with
+ * GetFeaturesInArea's conventions (min <= 0 and max < 0: no level check), ur = u - bf*invz (q_ur may be NULL),
+ * key-point angle (rotation histogram) and q_blocks[i] != 0 when the map point has observations (the feature
+ * it claims is then skipped by later queries, :1425-1427).  t_* describe the current frame: undistorted key
+ * points, mvuRight (may be NULL), features already holding an observed map point (may be NULL), descriptors;
+ * mnMin/Max are the frame's image bounds (64 x 48 grid).  match_idx[i] = current-frame index or -1. */
+int hvo_search_by_projection(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
+                             const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur, const float *q_angle,
+                             const uint8_t *q_blocks, const hvo_keypoint *t_kp, const float *t_uright, const uint8_t *t_occupied,
+                             const uint8_t *t_desc, int nt, float mnMinX, float mnMinY, float mnMaxX, float mnMaxY,
+                             int th_high, int check_orientation, int32_t *match_idx, int32_t *match_dist, int *n_matches);
+
+/* Frame::ComputeStereoFromRGBD (reference src/Frame.cc:1940-1961): uright[i] = kp_un[i].x - bf/d and zdepth[i] = d
+ * where d = depth(v,u) * depth_map_factor at the truncated key-point position, if 0 < d < 7; else -1. */
+int hvo_stereo_from_rgbd(hvo_ctx *ctx, const hvo_keypoint *kp, const hvo_keypoint *kp_un, int n,
+                         const uint16_t *depth, int w, int h, int stride, float bf, float *uright, float *zdepth);
+
 /* ---- batch entry points (config 4: independent frames; inputs stay resident in HBM) ---- */
 #define HVO_STAGE_ORB    1u
 #define HVO_STAGE_LSD    2u

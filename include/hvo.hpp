@@ -168,6 +168,22 @@ public:
     {
         d.resize((size_t)nq * nt); check(hvo_hamming_matrix(ctx_, q, nq, t, nt, d.data()), "hvo_hamming_matrix");
     }
+    // SearchByProjection(CurrentFrame, LastFrame, th, mono) core (ORBmatcher.cc:1353-1497): see hvo.h.
+    // Returns the number of matches; match_idx[i] is the current-frame feature of query i or -1.
+    int SearchByProjection(const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
+                           const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur, const float *q_angle,
+                           const uint8_t *q_blocks, const KeyPoint *t_kp, const float *t_uright, const uint8_t *t_occupied,
+                           const uint8_t *t_desc, int nt, float mnMinX, float mnMinY, float mnMaxX, float mnMaxY,
+                           bool checkOrientation, std::vector<int> &match_idx) const
+    {
+        match_idx.assign(nq, -1);
+        std::vector<int> dist(nq);
+        int n = 0;
+        check(hvo_search_by_projection(ctx_, q_desc, nq, q_u, q_v, q_radius, q_min_level, q_max_level, q_ur, q_angle, q_blocks, t_kp, t_uright,
+                                       t_occupied, t_desc, nt, mnMinX, mnMinY, mnMaxX, mnMaxY, TH_HIGH, checkOrientation ? 1 : 0,
+                                       match_idx.data(), dist.data(), &n), "hvo_search_by_projection");
+        return n;
+    }
 private:
     hvo_ctx *ctx_;
 };

@@ -58,3 +58,117 @@ int orc_match_nnr(const uint8_t *d1, int n1, const uint8_t *d2, int n2, float nn
     }
     return matches;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) core (src/ORBmatcher.cc:1353-1497)
+ * with Frame::GetFeaturesInArea (src/Frame.cc:1502-1555), Frame::PosInGrid / AssignFeaturesToGrid
+ * (src/Frame.cc:1679-1690, 832-847) and ComputeThreeMaxima (src/ORBmatcher.cc:1630-1673).
+ * The caller supplies, per last-frame map point that survived the projection tests (ORBmatcher.cc:
+ * 1381-1404): the projected (u,v), the search radius th*scale[octave], the octave band, ur = u - bf*invz
+ * (< 0: no stereo check), its descriptor, its key-point angle and whether the map point has
+ * observations (then the current-frame feature it claims is skipped by later queries, :1425-1427).
+ * ---------------------------------------------------------------------------------------------- */
+#include <math.h>
+#include <stdlib.h>
+#define GRID_COLS 64
+#define GRID_ROWS 48
+
+typedef struct { float x, y, size, angle, response; int32_t octave, class_id; } kp_t;
+
+int orc_search_by_projection(const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
+                             const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur, const float *q_angle,
+                             const uint8_t *q_blocks,
+                             const void *t_kp_, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
+                             float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, int th_high, int check_orientation,
+                             int32_t *match_idx, int32_t *match_dist)
+{
+    const kp_t *t_kp = (const kp_t *)t_kp_;
+    const float invW = (float)GRID_COLS / (mnMaxX - mnMinX), invH = (float)GRID_ROWS / (mnMaxY - mnMinY);
+    /* AssignFeaturesToGrid */
+    int *cell_of = (int *)malloc(sizeof(int) * (nt + 1));
+    for (int i = 0; i < nt; i++) {
+        int px = (int)round((t_kp[i].x - mnMinX) * invW), py = (int)round((t_kp[i].y - mnMinY) * invH);
+        cell_of[i] = (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) ? -1 : px * GRID_ROWS + py;
+    }
+    uint8_t *occ = (uint8_t *)calloc(nt + 1, 1);
+    for (int i = 0; i < nt; i++) occ[i] = t_occupied ? t_occupied[i] : 0;
+    int nmatches = 0;
+    int *rot_bin = (int *)malloc(sizeof(int) * (nq + 1));
+    const float factor = 1.0f / 30;
+    for (int i = 0; i < nq; i++) {
+        match_idx[i] = -1; match_dist[i] = 256; rot_bin[i] = -1;
+        const float x = q_u[i], y = q_v[i], r = q_radius[i];
+        const int minLevel = q_min_level[i], maxLevel = q_max_level[i];
+        int nMinCellX = (int)floorf((x - mnMinX - r) * invW); if (nMinCellX < 0) nMinCellX = 0;
+        if (nMinCellX >= GRID_COLS) continue;
+        int nMaxCellX = (int)ceilf((x - mnMinX + r) * invW); if (nMaxCellX > GRID_COLS - 1) nMaxCellX = GRID_COLS - 1;
+        if (nMaxCellX < 0) continue;
+        int nMinCellY = (int)floorf((y - mnMinY - r) * invH); if (nMinCellY < 0) nMinCellY = 0;
+        if (nMinCellY >= GRID_ROWS) continue;
+        int nMaxCellY = (int)ceilf((y - mnMinY + r) * invH); if (nMaxCellY > GRID_ROWS - 1) nMaxCellY = GRID_ROWS - 1;
+        if (nMaxCellY < 0) continue;
+        const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        int bestDist = 256, bestIdx = -1;
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+                for (int j = 0; j < nt; j++) {           /* cell content in insertion (= index) order */
+                    if (cell_of[j] != ix * GRID_ROWS + iy) continue;
+                    if (bCheckLevels) {
+                        if (t_kp[j].octave < minLevel) continue;
+                        if (maxLevel >= 0 && t_kp[j].octave > maxLevel) continue;
+                    }
+                    const float distx = t_kp[j].x - x, disty = t_kp[j].y - y;
+                    if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
+                    if (occ[j]) continue;
+                    if (t_uright && t_uright[j] > 0 && q_ur) {
+                        const float er = fabsf(q_ur[i] - t_uright[j]);
+                        if (er > r) continue;
+                    }
+                    const int dist = orc_descriptor_distance(q_desc + 32 * (size_t)i, t_desc + 32 * (size_t)j);
+                    if (dist < bestDist) { bestDist = dist; bestIdx = j; }
+                }
+        if (bestIdx >= 0 && bestDist <= th_high) {
+            match_idx[i] = bestIdx; match_dist[i] = bestDist; nmatches++;
+            if (q_blocks[i]) occ[bestIdx] = 1;
+            if (check_orientation) {
+                float rot = q_angle[i] - t_kp[bestIdx].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)round(rot * factor);
+                if (bin == 30) bin = 0;
+                rot_bin[i] = bin;
+            }
+        }
+    }
+    if (check_orientation) {
+        int hist[30]; for (int b = 0; b < 30; b++) hist[b] = 0;
+        for (int i = 0; i < nq; i++) if (rot_bin[i] >= 0) hist[rot_bin[i]]++;
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int b = 0; b < 30; b++) {
+            const int s = hist[b];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = b; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = b; }
+            else if (s > max3) { max3 = s; ind3 = b; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) ind3 = -1;
+        for (int i = 0; i < nq; i++)
+            if (rot_bin[i] >= 0 && rot_bin[i] != ind1 && rot_bin[i] != ind2 && rot_bin[i] != ind3) { match_idx[i] = -1; nmatches--; }
+    }
+    free(cell_of); free(occ); free(rot_bin);
+    return nmatches;
+}
+
+/* Frame::ComputeStereoFromRGBD (src/Frame.cc:1940-1961): depth image = raw u16 * depthMapFactor in
+ * float (Frame.cc:200-203), indexed with the float key-point coordinates truncated to int. */
+void orc_stereo_from_rgbd(const void *kp_, const void *kpun_, int n, const uint16_t *depth, int w, int h, int stride_bytes,
+                          float depth_factor, float bf, float *uright, float *zdepth)
+{
+    const kp_t *kp = (const kp_t *)kp_, *kpu = (const kp_t *)kpun_;
+    for (int i = 0; i < n; i++) {
+        uright[i] = -1; zdepth[i] = -1;
+        const int v = (int)kp[i].y, u = (int)kp[i].x;
+        if (u < 0 || v < 0 || u >= w || v >= h) continue;
+        const float d = (float)((const uint16_t *)((const uint8_t *)depth + (size_t)v * stride_bytes))[u] * depth_factor;
+        if (d > 0 && d < 7.0) { zdepth[i] = d; uright[i] = kpu[i].x - bf / d; }
+    }
+}

@@ -121,6 +121,17 @@ void orc_hamming_matrix(const uint8_t *q, int nq, const uint8_t *t, int nt, uint
 /* LSDmatcher::matchNNR */
 int  orc_match_nnr(const uint8_t *d1, int n1, const uint8_t *d2, int n2, float nnr, int32_t *m12);
 
+/* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, mono) core (src/ORBmatcher.cc:1353-1497) */
+int  orc_search_by_projection(const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
+                              const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur, const float *q_angle,
+                              const uint8_t *q_blocks,
+                              const void *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
+                              float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, int th_high, int check_orientation,
+                              int32_t *match_idx, int32_t *match_dist);
+/* Frame::ComputeStereoFromRGBD (src/Frame.cc:1940-1961) */
+void orc_stereo_from_rgbd(const void *kp, const void *kp_un, int n, const uint16_t *depth, int w, int h, int stride_bytes,
+                          float depth_factor, float bf, float *uright, float *zdepth);
+
 #ifdef __cplusplus
 }
 #endif

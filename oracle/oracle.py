@@ -266,3 +266,33 @@ def lbd_weights():
 
 def lbd_combinations():
     return np.ctypeslib.as_array(lib().orc_lbd_combinations(), shape=(32, 2)).copy()
+
+
+def search_by_projection(q_desc, q_u, q_v, q_radius, q_min_level, q_max_level, q_ur, q_angle, q_blocks,
+                         t_kp, t_uright, t_occupied, t_desc, bounds, th_high=100, check_orientation=True):
+    """ORBmatcher::SearchByProjection(Cur, Last) core -> (nmatches, match_idx, match_dist)"""
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    q_desc = np.ascontiguousarray(q_desc, np.uint8); t_desc = np.ascontiguousarray(t_desc, np.uint8)
+    nq, nt = len(q_desc), len(t_desc)
+    q_u, q_v, q_radius, q_ur, q_angle = map(f32, (q_u, q_v, q_radius, q_ur, q_angle))
+    q_min_level = np.ascontiguousarray(q_min_level, np.int32); q_max_level = np.ascontiguousarray(q_max_level, np.int32)
+    q_blocks = np.ascontiguousarray(q_blocks, np.uint8); t_occupied = np.ascontiguousarray(t_occupied, np.uint8)
+    t_kp = np.ascontiguousarray(t_kp); t_uright = f32(t_uright)
+    mi = np.zeros(nq, np.int32); md = np.zeros(nq, np.int32)
+    L = lib()
+    L.orc_search_by_projection.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_void_p] * 4 + [C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    n = L.orc_search_by_projection(_p(q_desc), nq, _p(q_u), _p(q_v), _p(q_radius), _p(q_min_level), _p(q_max_level), _p(q_ur), _p(q_angle),
+                                   _p(q_blocks), _p(t_kp), _p(t_uright), _p(t_occupied), _p(t_desc), nt,
+                                   bounds[0], bounds[1], bounds[2], bounds[3], th_high, 1 if check_orientation else 0, _p(mi), _p(md))
+    return n, mi, md
+
+
+def stereo_from_rgbd(kp, kp_un, depth, depth_factor, bf):
+    kp = np.ascontiguousarray(kp); kp_un = np.ascontiguousarray(kp_un); depth = np.ascontiguousarray(depth, np.uint16)
+    h, w = depth.shape
+    ur = np.zeros(len(kp), np.float32); z = np.zeros(len(kp), np.float32)
+    L = lib()
+    L.orc_stereo_from_rgbd.restype = None
+    L.orc_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_stereo_from_rgbd(_p(kp), _p(kp_un), len(kp), _p(depth), w, h, depth.strides[0], depth_factor, bf, _p(ur), _p(z))
+    return ur, z
