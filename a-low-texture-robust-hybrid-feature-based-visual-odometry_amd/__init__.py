@@ -237,17 +237,20 @@ class Context:
         return ur, z
 
     # ---- batch ----
-    def batch_upload(self, gray, depth=None):
-        """gray: (B,H,W) u8; depth: (B,H,W) u16 or None"""
+    def batch_upload(self, gray, depth=None, repeat=1):
+        """gray: (B,H,W) u8; depth: (B,H,W) u16 or None.  repeat > 1 uploads the B frames cyclically
+        B*repeat times (frames are passed by pointer, host memory is not replicated)."""
         gray = np.ascontiguousarray(gray, np.uint8)
-        B, h, w = gray.shape
+        B0, h, w = gray.shape
         if depth is not None:
             depth = np.ascontiguousarray(depth, np.uint16)
+        B = B0 * repeat
         fi = (FrameIn * B)()
         for b in range(B):
-            fi[b].gray = gray[b].ctypes.data; fi[b].gray_stride = gray.strides[1]
+            s = b % B0
+            fi[b].gray = gray[s].ctypes.data; fi[b].gray_stride = gray.strides[1]
             if depth is not None:
-                fi[b].depth = depth[b].ctypes.data; fi[b].depth_stride = depth.strides[1]
+                fi[b].depth = depth[s].ctypes.data; fi[b].depth_stride = depth.strides[1]
         self._chk(lib().hvo_batch_upload(self.h, B, fi, w, h), "batch_upload")
         self._B, self._w, self._h = B, w, h
 

@@ -397,30 +397,274 @@ static __device__ void ah_cluster_wave(const ClArgs &a, int frame, Heap &H, int 
     __syncthreads();
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_peac_cluster: initGraph edges + main ahCluster
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a)
+// ================================================================================================
+// Grouped AHC: GL lanes per frame, 64/GL frames per wave, executed in lockstep.
+// One frame keeps only a handful of lanes busy (a node has ~5 neighbours, and the 3x3 eigen-solve of
+// the candidate merges dominates the instruction count), so four frames share a wave: every
+// group-dependent loop becomes `while (any group still needs it)` with the body predicated per group,
+// shuffles and ballots are confined to the group.  Semantics per frame are exactly those of
+// ah_cluster_wave above (which remains in use, at one frame per wave, for the last merge round).
+// ================================================================================================
+template <int GL> struct Grp {
+    static_assert(GL == 16 || GL == 32 || GL == 64, "group width");
+    static __device__ __forceinline__ int gl() { return threadIdx.x & (GL - 1); }
+    static __device__ __forceinline__ int gb() { return threadIdx.x & 63 & ~(GL - 1); }
+    static __device__ __forceinline__ unsigned long long ballot(bool p)
+    { const unsigned long long m = __ballot(p) >> gb(); return GL == 64 ? m : (m & ((1ull << GL) - 1)); }
+    template <class T> static __device__ __forceinline__ T shfl(T v, int l) { return __shfl(v, gb() + l); }
+};
+
+template <int GL>
+static __device__ void gheap_sift_down(double *key, int *id, int n, int i, double k, int idv, bool act)
 {
-    extern __shared__ double smem[];
-    const int frame = blockIdx.x, lane = threadIdx.x;
+    const int gl = Grp<GL>::gl();
+    bool go = act;
+    while (__any(go)) {
+        const int c0 = 8 * i + 1;
+        const bool cont = go && c0 < n;
+        double ck = 1.0e308; int cid = 0x7FFFFFFF, ci = -1;
+        if (cont && gl < 8 && c0 + gl < n) { ci = c0 + gl; ck = key[ci]; cid = id[ci]; }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            const double ok = __shfl_xor(ck, o); const int oid = __shfl_xor(cid, o), oi = __shfl_xor(ci, o);
+            if (oi >= 0 && (ci < 0 || hless(ok, oid, ck, cid))) { ck = ok; cid = oid; ci = oi; }
+        }
+        ck = Grp<GL>::shfl(ck, 0); cid = Grp<GL>::shfl(cid, 0); ci = Grp<GL>::shfl(ci, 0);
+        const bool mv = cont && ci >= 0 && hless(ck, cid, k, idv);
+        if (mv) { if (gl == 0) { key[i] = ck; id[i] = cid; } i = ci; }
+        go = mv;
+    }
+    if (act && gl == 0) { key[i] = k; id[i] = idv; }
+}
+
+template <int GL>
+static __device__ void gheap_push(double *key, int *id, int &n, double k, int idv, bool act)
+{
+    const int gl = Grp<GL>::gl();
+    int i = n;
+    if (act) n++;
+    bool go = act && i > 0;
+    while (__any(go)) {
+        const int p = go ? (i - 1) / 8 : 0;
+        double pk = 0; int pid = 0;
+        if (go) { pk = key[p]; pid = id[p]; }
+        const bool mv = go && hless(k, idv, pk, pid);
+        if (mv) { if (gl == 0) { key[i] = pk; id[i] = pid; } i = p; }
+        go = mv && i > 0;
+    }
+    if (act && gl == 0) { key[i] = k; id[i] = idv; }
+}
+
+template <int GL>
+static __device__ int gheap_pop(double *key, int *id, int &n, bool act)
+{
+    int top = -1;
+    double k = 0; int idv = 0;
+    if (act) { top = id[0]; n--; }
+    const bool need = act && n > 0;
+    if (need) { k = key[n]; idv = id[n]; }
+    __syncthreads();
+    gheap_sift_down<GL>(key, id, n, 0, k, idv, need);
+    __syncthreads();
+    return top;
+}
+
+template <int GL>
+static __device__ void gpool_gc(int *segI, int nseg, int *&pool, int *&pool2, int &pooltop, bool need)
+{
+    const int gl = Grp<GL>::gl();
+    __syncthreads();
+    int top = 0;
+    for (int base = 0; __any(need && base < nseg); base += GL) {
+        const int id = base + gl;
+        int sz = 0, off = 0;
+        const bool in = need && id < nseg;
+        if (in) { const int *si = segI + (size_t)id * SEG_I; if (!si[2]) { sz = si[4]; off = si[3]; } }
+        int incl = sz;
+#pragma unroll
+        for (int o = 1; o < GL; o <<= 1) { const int t = __shfl_up(incl, o, GL); if (gl >= o) incl += t; }
+        const int dst = top + incl - sz;
+        for (int k = 0; k < sz; k++) pool2[dst + k] = pool[off + k];
+        if (in) { int *si = segI + (size_t)id * SEG_I; if (!si[2]) { si[3] = dst; si[5] = sz; } }
+        top += Grp<GL>::shfl(incl, GL - 1);
+    }
+    if (need) { int *t = pool; pool = pool2; pool2 = t; pooltop = top; }
+    __syncthreads();
+}
+
+template <int GL, int LCG>
+static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hkey, int *hid, int &hn, int &nseg, int &pooltop,
+                                          int *&pool, int *&pool2, int *ext, int &next, int *lA, int *lB, double *cm, int *cN, int &flags)
+{
+    const int lane = threadIdx.x & 63, gl = Grp<GL>::gl(), gb = Grp<GL>::gb();
+    double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
+    int *segI = a.segI + (size_t)frame * a.segcap * SEG_I;
+    int *parent = a.parent + (size_t)frame * a.nblk, *dsize = a.dsize + (size_t)frame * a.nblk;
+    while (__any(hn > 0)) {
+        const bool act = hn > 0;
+        const bool need_gc = act && pooltop > a.poolcap - 2 * a.nblk;
+        if (__any(need_gc)) gpool_gc<GL>(segI, nseg, pool, pool2, pooltop, need_gc);
+        // ---- pop ----
+        const int p = gheap_pop<GL>(hkey, hid, hn, act);
+        int *pi = segI + (size_t)(p < 0 ? 0 : p) * SEG_I;
+        const double *pd = segD + (size_t)(p < 0 ? 0 : p) * SEG_D;
+        const bool live = act && pi[2] == 0;                   // skip nouse nodes (lazy deletion)
+        const int pcnt = live ? pi[4] : 0, poff = pi[3], pN = pi[0];
+        // ---- evaluate merges with every neighbour, in creation order; one candidate per lane ----
+        int cand_k = -1; double cand_mse = 0; int cand_N = 0;
+        double st[9], c[3] = { 0, 0, 0 }, n[3] = { 0, 0, 0 }, m = 0; int mN = 0;
+#pragma unroll
+        for (int q = 0; q < 9; q++) st[q] = 0;
+        for (int base = 0; __any(base < pcnt); base += GL) {
+            const int k = base + gl;
+            double lst[9], lc[3] = { 0, 0, 0 }, ln[3] = { 0, 0, 0 }, lm = 0; int lN = 0; bool has = false;
+#pragma unroll
+            for (int q = 0; q < 9; q++) lst[q] = 0;
+            if (k < pcnt) {
+                const int nb = pool[poff + k];
+                const double *nd = segD + (size_t)nb * SEG_D;
+                if (!(nsim(pd, nd) < a.c60)) {                 // T_ang(P_MERGING)
+                    for (int q = 0; q < 9; q++) lst[q] = pd[q] + nd[q];
+                    lN = pN + segI[(size_t)nb * SEG_I];
+                    has = true;
+                }
+            }
+            // one 3x3 eigen-solve pass serves every group (uniform call: no divergence inside)
+            if (__any(has)) { double tc[3], tn[3], tm; stats_compute_dev(lst, has ? lN : 4, tc, tn, tm); if (has) { lm = tm; for (int q = 0; q < 3; q++) { lc[q] = tc[q]; ln[q] = tn[q]; } } }
+            cm[lane] = lm; cN[lane] = has ? lN : -1;
+            __syncthreads();
+            // exact sequential selection rule of AHCPlaneFitter.hpp:1043-1049 (uniform per group)
+            const int lim = min(GL, pcnt - base);
+            int sel = -1;
+            for (int q = 0; q < lim; q++) {
+                if (cN[gb + q] < 0) continue;
+                const double mq = cm[gb + q];
+                if (cand_k < 0 || cand_mse > mq || (cand_mse == mq && (double)cand_N < mq)) { cand_k = base + q; cand_mse = mq; cand_N = cN[gb + q]; sel = q; }
+            }
+            // winner's fit from its lane; groups without a new winner read a dummy lane and ignore it
+            {
+                const int src = gb + (sel >= 0 ? sel : 0);
+#pragma unroll
+                for (int q = 0; q < 9; q++) { const double v = __shfl(lst[q], src); if (sel >= 0) st[q] = v; }
+#pragma unroll
+                for (int q = 0; q < 3; q++) { const double v = __shfl(lc[q], src), w = __shfl(ln[q], src); if (sel >= 0) { c[q] = v; n[q] = w; } }
+                const double vm = __shfl(lm, src); const int vN = __shfl(lN, src);
+                if (sel >= 0) { m = vm; mN = vN; }
+            }
+            __syncthreads();
+        }
+        // ---- merge decision ----
+        int nb = 0, ncnt = 0, noff = 0; int *ni = segI;
+        bool do_merge = false;
+        if (live && cand_k >= 0) {
+            nb = pool[poff + cand_k];
+            ni = segI + (size_t)nb * SEG_I;
+            const double t = 1.6e-6 * c[2] * c[2] + 8.0;        // T_mse(P_MERGING)
+            if (m < t * t) {
+                ncnt = ni[4]; noff = ni[3];
+                if (nseg >= a.segcap || pooltop + pcnt + ncnt > a.poolcap) flags |= 8;     // capacity: keep the node unmerged
+                else do_merge = true;
+            }
+        }
+        if (__any(do_merge)) {
+            const bool staged = do_merge && pcnt <= LCG && ncnt <= LCG;
+            if (staged) {
+                for (int k = gl; k < pcnt; k += GL) lA[k] = pool[poff + k];
+                for (int k = gl; k < ncnt; k += GL) lB[k] = pool[noff + k];
+            }
+            __syncthreads();
+            const int id = nseg;
+            if (do_merge) nseg++;
+            const int moff = pooltop;
+            if (do_merge && gl == 0) {
+                const int *LA = staged ? lA : pool + poff, *LB = staged ? lB : pool + noff;
+                int mcnt = 0, i = 0, j = 0;
+                while (i < pcnt || j < ncnt) {
+                    int v;
+                    if (j >= ncnt || (i < pcnt && LA[i] <= LB[j])) { v = LA[i]; if (j < ncnt && LB[j] == v) j++; i++; }
+                    else { v = LB[j]; j++; }
+                    if (v != p && v != nb) pool[moff + mcnt++] = v;
+                }
+                cN[gb] = mcnt;
+                double *md = segD + (size_t)id * SEG_D;
+                for (int q = 0; q < 9; q++) md[q] = st[q];
+                md[9] = c[0]; md[10] = c[1]; md[11] = c[2]; md[12] = n[0]; md[13] = n[1]; md[14] = n[2]; md[15] = m;
+                int *mi = segI + (size_t)id * SEG_I;
+                mi[0] = mN; mi[1] = pN >= ni[0] ? pi[1] : ni[1]; mi[2] = 0; mi[3] = moff; mi[4] = mcnt; mi[5] = pcnt + ncnt; mi[6] = 1; mi[7] = 0;
+                int xr = ds_find_ro(parent, pi[1]), yr = ds_find_ro(parent, ni[1]);       // ds.Union(pa.rid, pb.rid)
+                if (xr != yr) {
+                    if (dsize[xr] < dsize[yr]) { parent[xr] = yr; dsize[yr] += dsize[xr]; }
+                    else { parent[yr] = xr; dsize[xr] += dsize[yr]; }
+                }
+                pi[2] = 1; ni[2] = 1; pi[4] = 0; ni[4] = 0;
+            }
+            __syncthreads();
+            gheap_push<GL>(hkey, hid, hn, m, id, do_merge);
+            __syncthreads();
+            if (do_merge) {
+                const int mcnt = cN[gb];
+                pooltop += pcnt + ncnt;
+                // every neighbour of the new node: drop p / nb, append the new id (largest so far)
+                for (int k = gl; k < mcnt; k += GL) {
+                    int *qi = segI + (size_t)pool[moff + k] * SEG_I;
+                    nb_remove2(pool, qi, p, nb);
+                    pool[qi[3] + qi[4]] = id; qi[4]++;
+                }
+            }
+            __syncthreads();
+        }
+        const bool no_merge = live && !do_merge;
+        if (__any(no_merge)) {
+            if (no_merge) {
+                if (pN >= MIN_SUPPORT) { if (next < MAX_PLANES) { if (gl == 0) ext[next] = p; next++; } else flags |= 16; }
+                for (int k = gl; k < pcnt; k += GL) nb_remove2(pool, segI + (size_t)pool[poff + k] * SEG_I, p, -1);   // disconnectAllNbs
+            }
+            __syncthreads();
+            if (no_merge && gl == 0) pi[4] = 0;
+            __syncthreads();
+        }
+    }
+    // std::sort by N descending, ties -> extraction order (stable insertion sort)
+    __syncthreads();
+    if (gl == 0) {
+        for (int i = 1; i < next; i++) {
+            int v = ext[i], j = i - 1;
+            int vN = segI[(size_t)v * SEG_I];
+            while (j >= 0 && segI[(size_t)ext[j] * SEG_I] < vN) { ext[j + 1] = ext[j]; j--; }
+            ext[j + 1] = v;
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_peac_cluster: initGraph edges + main ahCluster, 64/GL frames per wave
+// ------------------------------------------------------------------------------------------------
+template <int GL>
+__global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
+{
+    constexpr int NG = 64 / GL, LCG = LCAP / NG;
+    __shared__ double cm[64];
+    __shared__ int cN[64];
+    __shared__ int lAs[NG][LCG], lBs[NG][LCG];
+    const int lane = threadIdx.x, gl = Grp<GL>::gl(), gid = lane / GL;
+    int frame = blockIdx.x * NG + gid;
+    const bool galive = frame < nframes;
+    if (!galive) frame = nframes - 1;                          // idle group: aliases a frame read-only, writes nothing
     const int nblk = a.nblk, Nw = a.Nw, Nh = a.Nh;
-    double *hkey = a.hkey + (size_t)frame * nblk;     // heap arrays in global memory (L2)
+    double *hkey = a.hkey + (size_t)frame * nblk;              // heap arrays in global memory (L2)
     int *hid = a.hid + (size_t)frame * nblk;
-    double *cm = smem;                                 // 64 doubles
-    int *cN = (int *)(cm + 64);                        // 64 ints
-    int *lA = cN + 64, *lB = lA + LCAP;                // LCAP ints each
     double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
     int *segI = a.segI + (size_t)frame * a.segcap * SEG_I;
     int *pool = a.pool + (size_t)frame * a.poolcap, *pool2 = a.pool2 + (size_t)frame * a.poolcap;
     int *parent = a.parent + (size_t)frame * nblk, *dsize = a.dsize + (size_t)frame * nblk;
     int *eflag = a.eflag + (size_t)frame * nblk;
-    for (int b = lane; b < nblk; b += 64) { parent[b] = b; dsize[b] = 1; eflag[b] = 0; }
+    if (galive) for (int b = gl; b < nblk; b += GL) { parent[b] = b; dsize[b] = 1; eflag[b] = 0; }
     __syncthreads();
 #define GOK(c) (segI[(size_t)(c) * SEG_I + 6] != 0)
 #define SD(c) (segD + (size_t)(c) * SEG_D)
     // first pass: rows (AHCPlaneFitter.hpp:896-923).  bits: 1=left 2=right 4=up 8=down
-    for (int i = lane; i < Nh; i += 64) {
+    if (galive) for (int i = gl; i < Nh; i += GL) {
         for (int j = 1; j < Nw; j += 2) {
             const int c = i * Nw + j;
             if (!GOK(c - 1)) { --j; continue; }
@@ -434,7 +678,7 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a)
         }
     }
     __syncthreads();
-    for (int j = lane; j < Nw; j += 64) {
+    if (galive) for (int j = gl; j < Nw; j += GL) {
         for (int i = 1; i < Nh; i += 2) {
             const int c = i * Nw + j;
             if (!GOK(c - Nw)) { --i; continue; }
@@ -448,12 +692,12 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a)
         }
     }
     __syncthreads();
-    // adjacency lists in ascending id order: up, left, right, down
-    Heap H; H.key = hkey; H.id = hid; H.n = 0;
-    for (int base = 0; base < nblk; base += 64) {
-        const int b = base + lane;
+    // adjacency lists in ascending id order (up, left, right, down) and the heap's initial content
+    int hn = 0;
+    for (int base = 0; base < nblk; base += GL) {
+        const int b = base + gl;
         bool ok = false;
-        if (b < nblk) {
+        if (galive && b < nblk) {
             int *si = segI + (size_t)b * SEG_I;
             const int e = eflag[b];
             int n = 0;
@@ -464,24 +708,25 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a)
             si[4] = n;
             ok = si[6] != 0;
         }
-        unsigned long long m = __ballot(ok);
-        if (ok) { int pos = H.n + __popcll(m & ((1ull << lane) - 1)); hkey[pos] = segD[(size_t)b * SEG_D + 15]; hid[pos] = b; }
-        H.n += __popcll(m);
+        const unsigned long long m = Grp<GL>::ballot(ok);
+        if (ok) { const int pos = hn + __popcll(m & ((1ull << gl) - 1)); hkey[pos] = segD[(size_t)b * SEG_D + 15]; hid[pos] = b; }
+        hn += __popcll(m);
     }
     __syncthreads();
-    // Floyd heapify from the last parent down (each sift is wave-cooperative)
-    if (H.n > 1) {
-        for (int i = (H.n - 2) / 8; i >= 0; i--) {
-            const double k = hkey[i]; const int id = hid[i];
-            __syncthreads();
-            heap_sift_down(H, i, k, id);
-            __syncthreads();
-        }
+    // Floyd heapify from the last parent down (each sift is group-cooperative)
+    for (int i = (nblk - 2) / 8; i >= 0; i--) {
+        const bool act = hn > 1 && i <= (hn - 2) / 8;
+        if (!__any(act)) continue;
+        double k = 0; int id = 0;
+        if (act) { k = hkey[i]; id = hid[i]; }
+        __syncthreads();
+        gheap_sift_down<GL>(hkey, hid, hn, i, k, id, act);
+        __syncthreads();
     }
     int nseg = nblk, pooltop = nblk * 4, next = 0, flags = 0;
     int *ext = a.extracted + (size_t)frame * 2 * MAX_PLANES;
-    ah_cluster_wave(a, frame, H, nseg, pooltop, pool, pool2, ext, next, lA, lB, cm, cN, flags);
-    if (lane == 0) {
+    ah_cluster_grouped<GL, LCG>(a, frame, hkey, hid, hn, nseg, pooltop, pool, pool2, ext, next, lAs[gid], lBs[gid], cm, cN, flags);
+    if (galive && gl == 0) {
         int *meta = a.meta + (size_t)frame * 16;
         meta[0] = nseg; meta[1] = pooltop; meta[2] = next; meta[3] = flags;
         meta[6] = (pool == a.pool + (size_t)frame * a.poolcap) ? 0 : 1;      // which pool buffer is live
@@ -858,9 +1103,16 @@ int peac_run(hvo_ctx *ctx, int n)
     a.segD = P->d_segD; a.segI = P->d_segI; a.pool = P->d_pool; a.pool2 = P->d_pool2; a.parent = P->d_parent; a.dsize = P->d_dsize; a.eflag = P->d_eflag;
     a.meta = P->d_meta; a.extracted = P->d_extracted; a.segcap = P->segcap; a.poolcap = P->poolcap; a.nblk = P->nblk; a.Nw = P->Nw; a.Nh = P->Nh;
     a.c15 = P->c15; a.c60 = P->c60; a.hkey = P->d_hkey; a.hid = P->d_hid;
-    const size_t lds = 64 * 8 + 64 * 4 + 2 * LCAP * 4;
     id = hvo_prof_begin(ctx, "peac_cluster", st);
-    hipLaunchKernelGGL(k_peac_cluster, dim3(n), dim3(64), lds, st, a);
+    {
+        static int gl = 0;
+        // 4 frames per wave pay off once the wave slots are saturated (measured: >= ~3000 resident frames)
+        if (!gl) { const char *e = getenv("HVO_PEAC_GL"); gl = e ? atoi(e) : -1; }
+        const int use = gl > 0 ? gl : (n >= 3072 ? 16 : 64);
+        if (use == 64) hipLaunchKernelGGL(k_peac_cluster<64>, dim3(n), dim3(64), 0, st, a, n);
+        else if (use == 32) hipLaunchKernelGGL(k_peac_cluster<32>, dim3((n + 1) / 2), dim3(64), 0, st, a, n);
+        else hipLaunchKernelGGL(k_peac_cluster<16>, dim3((n + 3) / 4), dim3(64), 0, st, a, n);
+    }
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "peac_refine", st);
     hipLaunchKernelGGL(k_peac_blkmap, dim3(16, n), dim3(256), 0, st, P->d_parent, P->d_dsize, P->d_segI, P->d_extracted, P->d_meta, P->d_blkmap,
@@ -872,11 +1124,12 @@ int peac_run(hvo_ctx *ctx, int n)
     r.qcap = P->qcap; r.plidmap = P->d_plidmap; r.planes = P->d_planes; r.c30 = P->c30;
     {
         static int flood_t = 0;
-        if (!flood_t) { const char *e = getenv("HVO_FLOOD_T"); flood_t = e ? atoi(e) : 512; }
-        if (flood_t == 64) hipLaunchKernelGGL(k_peac_flood<64>, dim3(n), dim3(64), 0, st, r, P->d_adj);
-        else if (flood_t == 128) hipLaunchKernelGGL(k_peac_flood<128>, dim3(n), dim3(128), 0, st, r, P->d_adj);
-        else if (flood_t == 256) hipLaunchKernelGGL(k_peac_flood<256>, dim3(n), dim3(256), 0, st, r, P->d_adj);
-        else if (flood_t == 1024) hipLaunchKernelGGL(k_peac_flood<1024>, dim3(n), dim3(1024), 0, st, r, P->d_adj);
+        if (!flood_t) { const char *e = getenv("HVO_FLOOD_T"); flood_t = e ? atoi(e) : -1; }
+        const int ft = flood_t > 0 ? flood_t : (n >= 3072 ? 256 : 512);
+        if (ft == 64) hipLaunchKernelGGL(k_peac_flood<64>, dim3(n), dim3(64), 0, st, r, P->d_adj);
+        else if (ft == 128) hipLaunchKernelGGL(k_peac_flood<128>, dim3(n), dim3(128), 0, st, r, P->d_adj);
+        else if (ft == 256) hipLaunchKernelGGL(k_peac_flood<256>, dim3(n), dim3(256), 0, st, r, P->d_adj);
+        else if (ft == 1024) hipLaunchKernelGGL(k_peac_flood<1024>, dim3(n), dim3(1024), 0, st, r, P->d_adj);
         else hipLaunchKernelGGL(k_peac_flood<512>, dim3(n), dim3(512), 0, st, r, P->d_adj);
     }
     hipLaunchKernelGGL(k_peac_final, dim3(n), dim3(64), 0, st, r, P->d_adj);
