@@ -38,8 +38,8 @@ struct PeacPlan {
     int *d_parent = nullptr, *d_dsize = nullptr, *d_eflag = nullptr;
     int *d_meta = nullptr;          // per frame 16 ints: [0]=nseg [1]=pooltop [2]=nextracted [3]=flags [4]=nfinal [5]=nq
     int *d_extracted = nullptr;     // per frame MAX_PLANES seg ids (coarse planes), then MAX_PLANES final
-    int *d_blkmap = nullptr; int32_t *d_labels = nullptr; float *d_dist = nullptr;
-    int *d_qpix = nullptr; int *d_qpl = nullptr; int *d_plidmap = nullptr; int *d_isvalid = nullptr;
+    int *d_blkmap = nullptr; int32_t *d_labels = nullptr; uint2 *d_state = nullptr;
+    int *d_queue = nullptr; int *d_plidmap = nullptr; int *d_isvalid = nullptr;
     hvo_plane *d_planes = nullptr;
     unsigned long long *d_adj = nullptr;
     double *d_hkey = nullptr; int *d_hid = nullptr;
@@ -405,6 +405,18 @@ static __device__ void ah_cluster_wave(const ClArgs &a, int frame, Heap &H, int 
 // shuffles and ballots are confined to the group.  Semantics per frame are exactly those of
 // ah_cluster_wave above (which remains in use, at one frame per wave, for the last merge round).
 // ================================================================================================
+#ifdef HVO_PEAC_TIMING
+__device__ unsigned long long g_peac_t[32];
+#define PT_DECL unsigned long long pt_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long pt_last = clock64();
+#define PT(i) { const unsigned long long t_ = clock64(); pt_[i] += t_ - pt_last; pt_last = t_; }
+#define PT_CNT(i, v) { pt_[i] += (v); }
+#define PT_FLUSH if ((threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 12; q_++) atomicAdd(&g_peac_t[q_], pt_[q_]); }
+#else
+#define PT_DECL
+#define PT(i)
+#define PT_CNT(i, v)
+#define PT_FLUSH
+#endif
 template <int GL> struct Grp {
     static_assert(GL == 16 || GL == 32 || GL == 64, "group width");
     static __device__ __forceinline__ int gl() { return threadIdx.x & (GL - 1); }
@@ -500,12 +512,16 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
     double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
     int *segI = a.segI + (size_t)frame * a.segcap * SEG_I;
     int *parent = a.parent + (size_t)frame * a.nblk, *dsize = a.dsize + (size_t)frame * a.nblk;
+    PT_DECL
     while (__any(hn > 0)) {
         const bool act = hn > 0;
+        PT_CNT(8, 1)
         const bool need_gc = act && pooltop > a.poolcap - 2 * a.nblk;
         if (__any(need_gc)) gpool_gc<GL>(segI, nseg, pool, pool2, pooltop, need_gc);
         // ---- pop ----
+        PT(0)
         const int p = gheap_pop<GL>(hkey, hid, hn, act);
+        PT(1)
         int *pi = segI + (size_t)(p < 0 ? 0 : p) * SEG_I;
         const double *pd = segD + (size_t)(p < 0 ? 0 : p) * SEG_D;
         const bool live = act && pi[2] == 0;                   // skip nouse nodes (lazy deletion)
@@ -515,7 +531,9 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
         double st[9], c[3] = { 0, 0, 0 }, n[3] = { 0, 0, 0 }, m = 0; int mN = 0;
 #pragma unroll
         for (int q = 0; q < 9; q++) st[q] = 0;
+        PT(2)
         for (int base = 0; __any(base < pcnt); base += GL) {
+            PT_CNT(9, 1)
             const int k = base + gl;
             double lst[9], lc[3] = { 0, 0, 0 }, ln[3] = { 0, 0, 0 }, lm = 0; int lN = 0; bool has = false;
 #pragma unroll
@@ -553,6 +571,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
             }
             __syncthreads();
         }
+        PT(3)
         // ---- merge decision ----
         int nb = 0, ncnt = 0, noff = 0; int *ni = segI;
         bool do_merge = false;
@@ -566,7 +585,9 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
                 else do_merge = true;
             }
         }
+        PT(4)
         if (__any(do_merge)) {
+            PT_CNT(10, 1)
             const bool staged = do_merge && pcnt <= LCG && ncnt <= LCG;
             if (staged) {
                 for (int k = gl; k < pcnt; k += GL) lA[k] = pool[poff + k];
@@ -599,8 +620,10 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
                 pi[2] = 1; ni[2] = 1; pi[4] = 0; ni[4] = 0;
             }
             __syncthreads();
+            PT(5)
             gheap_push<GL>(hkey, hid, hn, m, id, do_merge);
             __syncthreads();
+            PT(6)
             if (do_merge) {
                 const int mcnt = cN[gb];
                 pooltop += pcnt + ncnt;
@@ -613,8 +636,10 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
             }
             __syncthreads();
         }
+        PT(7)
         const bool no_merge = live && !do_merge;
         if (__any(no_merge)) {
+            PT_CNT(11, 1)
             if (no_merge) {
                 if (pN >= MIN_SUPPORT) { if (next < MAX_PLANES) { if (gl == 0) ext[next] = p; next++; } else flags |= 16; }
                 for (int k = gl; k < pcnt; k += GL) nb_remove2(pool, segI + (size_t)pool[poff + k] * SEG_I, p, -1);   // disconnectAllNbs
@@ -635,6 +660,8 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
         }
     }
     __syncthreads();
+    PT(0)
+    PT_FLUSH
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -659,6 +686,9 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
     int *pool = a.pool + (size_t)frame * a.poolcap, *pool2 = a.pool2 + (size_t)frame * a.poolcap;
     int *parent = a.parent + (size_t)frame * nblk, *dsize = a.dsize + (size_t)frame * nblk;
     int *eflag = a.eflag + (size_t)frame * nblk;
+#ifdef HVO_PEAC_TIMING
+    const unsigned long long t_in0 = clock64();
+#endif
     if (galive) for (int b = gl; b < nblk; b += GL) { parent[b] = b; dsize[b] = 1; eflag[b] = 0; }
     __syncthreads();
 #define GOK(c) (segI[(size_t)(c) * SEG_I + 6] != 0)
@@ -713,6 +743,9 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
         hn += __popcll(m);
     }
     __syncthreads();
+#ifdef HVO_PEAC_TIMING
+    const unsigned long long t_in1 = clock64();
+#endif
     // Floyd heapify from the last parent down (each sift is group-cooperative)
     for (int i = (nblk - 2) / 8; i >= 0; i--) {
         const bool act = hn > 1 && i <= (hn - 2) / 8;
@@ -723,6 +756,9 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
         gheap_sift_down<GL>(hkey, hid, hn, i, k, id, act);
         __syncthreads();
     }
+#ifdef HVO_PEAC_TIMING
+    if (lane == 0) { const unsigned long long t_in2 = clock64(); atomicAdd(&g_peac_t[12], t_in1 - t_in0); atomicAdd(&g_peac_t[13], t_in2 - t_in1); atomicAdd(&g_peac_t[14], 1ull); }
+#endif
     int nseg = nblk, pooltop = nblk * 4, next = 0, flags = 0;
     int *ext = a.extracted + (size_t)frame * 2 * MAX_PLANES;
     ah_cluster_grouped<GL, LCG>(a, frame, hkey, hid, hn, nseg, pooltop, pool, pool2, ext, next, lAs[gid], lBs[gid], cm, cN, flags);
@@ -738,21 +774,28 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
 // ------------------------------------------------------------------------------------------------
 // k_peac_blkmap: findBlockMembership (block erosion) + coarse membership image
 // ------------------------------------------------------------------------------------------------
+// Per-pixel flood state, 8 bytes, so that one scattered access per event fetches everything the
+// floodFill state machine needs:  x = (int8 membership "trail") | FS_VALID (pixel of a block that
+// survived the erosion: never touched) | depth << 16,  y = distMap entry (float bits).
+#define FS_VALID 0x100u
+#define FS_LABEL(x) ((int)(signed char)((x) & 0xFFu))
+#define FS_MAKE(lab, valid, d) (((unsigned)(lab) & 0xFFu) | ((valid) ? FS_VALID : 0u) | ((unsigned)(d) << 16))
 __global__ __launch_bounds__(256) void k_peac_blkmap(const int *__restrict__ parent_, const int *__restrict__ dsize_,
                                                      const int *__restrict__ segI_, const int *__restrict__ ext_, const int *__restrict__ meta_,
-                                                     int *__restrict__ blkmap_, int *__restrict__ isvalid_, int32_t *__restrict__ labels_,
-                                                     float *__restrict__ dist_, int nblk, int Nw, int Nh, int w, int h, int segcap)
+                                                     int *__restrict__ blkmap_, int *__restrict__ isvalid_, uint2 *__restrict__ state_,
+                                                     const uint16_t *__restrict__ depth_, size_t dframe, int pitch,
+                                                     int nblk, int Nw, int Nh, int w, int h, int segcap)
 {
-    const int frame = blockIdx.y;
+    const int frame = blockIdx.x, tid = threadIdx.x;
     const int *parent = parent_ + (size_t)frame * nblk, *dsize = dsize_ + (size_t)frame * nblk;
     const int *segI = segI_ + (size_t)frame * segcap * SEG_I;
     const int *ext = ext_ + (size_t)frame * 2 * MAX_PLANES;
     const int next = meta_[(size_t)frame * 16 + 2];
     int *blkmap = blkmap_ + (size_t)frame * nblk, *isvalid = isvalid_ + (size_t)frame * MAX_PLANES;
-    int32_t *labels = labels_ + (size_t)frame * w * h;
-    float *dist = dist_ + (size_t)frame * w * h;
-    // each thread handles whole blocks; pixels of invalid blocks / the remainder strip get -1
-    for (int b = blockIdx.x * 256 + threadIdx.x; b < nblk; b += gridDim.x * 256) {
+    uint2 *state = state_ + (size_t)frame * w * h;
+    const uint16_t *D = depth_ + (size_t)frame * dframe;
+    // phase 1: one thread per block
+    for (int b = tid; b < nblk; b += 256) {
         const int i = b / Nw, j = b - i * Nw;
         const int setid = ds_find_ro(parent, b);
         int plid = -1;
@@ -769,14 +812,16 @@ __global__ __launch_bounds__(256) void k_peac_blkmap(const int *__restrict__ par
             }
         }
         blkmap[b] = plid;
-        for (int y = i * WIN; y < (i + 1) * WIN; y++)
-            for (int x = j * WIN; x < (j + 1) * WIN; x++) { labels[y * w + x] = plid; dist[y * w + x] = 3.402823466e+38f; }
     }
-    // strips outside the block grid
-    const int gw = Nw * WIN, gh = Nh * WIN;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < w * h; i += gridDim.x * 256) {
-        int y = i / w, x = i - y * w;
-        if (x >= gw || y >= gh) { labels[i] = -1; dist[i] = 3.402823466e+38f; }
+    __syncthreads();
+    // phase 2: the frame's pixels, row by row (coalesced); pixels outside the block grid get -1
+    for (int y = 0; y < h; y++) {
+        const int by = y / WIN;
+        for (int x = tid; x < w; x += 256) {
+            const int bx = x / WIN;
+            const int lab = (by < Nh && bx < Nw) ? blkmap[by * Nw + bx] : -1;
+            state[(size_t)y * w + x] = make_uint2(FS_MAKE(lab, lab >= 0, D[(size_t)y * pitch + x]), 0x7F7FFFFFu);   // FLT_MAX
+        }
     }
 }
 
@@ -787,44 +832,55 @@ struct RfArgs {
     ClArgs c;
     const uint16_t *depth; size_t dframe; int pitch, w, h;
     float fx, fy, cx, cy, dfac;
-    int *blkmap; int *isvalid; int32_t *labels; float *dist; int *qpix; int *qpl; int qcap; int *plidmap;
+    int *blkmap; int *isvalid; uint2 *state; int *queue; int qcap; int *plidmap;
     hvo_plane *planes; double c30;
 };
 
-// k_peac_flood: seeds + floodFill (AHCPlaneFitter.hpp:543-575, 428-476), 1024 threads per frame.
-// Events = (queue entry, neighbour slot) in queue order.  A round takes the next 1024 events that
+// k_peac_flood: seeds + floodFill (AHCPlaneFitter.hpp:543-575, 428-476), FLOOD_T threads per frame.
+// Events = (queue entry, neighbour slot) in queue order.  A round takes the next FLOOD_T events that
 // existed when it started.  The part of an event that does not depend on the pixel's state (block
 // test, unprojection, point-plane distance) is evaluated for all events at once; the per-pixel
 // state machine (membership "trail", distMap) must see its events in queue order, so events that
-// hit the same pixel are serialised: in each sub-round an LDS hash elects, per pixel, the pending
-// event with the smallest index, which is then applied.  Pushes are appended in event order with a
-// block scan, which reproduces the reference's queue order exactly.
+// hit the same pixel are serialised: an LDS hash groups the round's events by pixel, every event
+// learns its rank among the events of its pixel (ordered by event index), and sub-round r applies
+// the events of rank r.  Pushes are appended in event order with a block scan, which reproduces the
+// reference's queue order exactly.  Queue entries are packed plid<<26 | y<<13 | x.
+#define FQ_PACK(x, y, pl) (((pl) << 26) | ((y) << 13) | (x))
+// workgroup barrier that orders LDS traffic only: outstanding global stores are not waited for
+static __device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 template <int FLOOD_T>
 __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long long *__restrict__ adj_out)
 {
-    constexpr int FLOOD_HS = FLOOD_T * 4;
+    constexpr int FLOOD_HS = FLOOD_T * 2, FLOOD_HL = 4;
     __shared__ double pl[MAX_PLANES][8];          // center[3], normal[3], mse, pad
     __shared__ unsigned long long adj[MAX_PLANES];
-    __shared__ int hkeys[FLOOD_HS], hvals[FLOOD_HS];
+    __shared__ int hkeys[FLOOD_HS], hcnt[FLOOD_HS], hlist[FLOOD_HS * FLOOD_HL];
+    __shared__ int evpix[FLOOD_T];                // the round's target pixels (rank fallback for crowded pixels)
+    __shared__ int hlab[FLOOD_HS]; __shared__ float hdist[FLOOD_HS];   // per-pixel state handed from rank to rank
     __shared__ int wsum[FLOOD_T / 64];
-    __shared__ int s_nq;
+    __shared__ int s_nq, s_max[2];
     const ClArgs &a = r.c;
     const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int w = r.w, h = r.h, Nw = a.Nw, Nh = a.Nh, nblk = a.nblk;
+    const int w = r.w, h = r.h, Nw = a.Nw, nblk = a.nblk;
     int *meta = a.meta + (size_t)frame * 16;
     const int nold = meta[2];
     const int *ext = a.extracted + (size_t)frame * 2 * MAX_PLANES;
     const double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
     const int *blkmap = r.blkmap + (size_t)frame * nblk;
-    int32_t *labels = r.labels + (size_t)frame * w * h;
-    float *dist = r.dist + (size_t)frame * w * h;
-    int *qpix = r.qpix + (size_t)frame * r.qcap, *qpl = r.qpl + (size_t)frame * r.qcap;
-    const uint16_t *D = r.depth + (size_t)frame * r.dframe;
+    uint2 *state = r.state + (size_t)frame * w * h;
+    int *queue = r.queue + (size_t)frame * r.qcap;
     int flags = 0;
     if (tid < MAX_PLANES) {
         adj[tid] = 0;
         if (tid < nold) { const double *sd = segD + (size_t)ext[tid] * SEG_D; for (int k = 0; k < 7; k++) pl[tid][k] = sd[9 + k]; }
     }
+    for (int i = tid; i < FLOOD_HS; i += FLOOD_T) { hkeys[i] = -1; hcnt[i] = 0; }
+    if (tid < 2) s_max[tid] = 1;
     // ---- seeds in block raster order: count, scan, write (wave 0) ----
     if (wv == 0) {
         int nq = 0;
@@ -841,12 +897,13 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
             for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
             int pos = nq + incl - cnt;
             if (cnt && pos + cnt <= r.qcap) {
+                const int x0 = j * WIN, y0 = i * WIN;
                 if (m < 0) {
-                    if (i > 0 && up >= 0) { const int sp = (i * WIN - 1) * w + j * WIN; for (int k = 1; k < WIN; ++k) { qpix[pos] = sp + k; qpl[pos++] = up; } }
-                    if (j > 0 && lf >= 0) { const int sp = (i * WIN) * w + j * WIN - 1; for (int k = 0; k < WIN - 1; ++k) { qpix[pos] = sp + k * w; qpl[pos++] = lf; } }
+                    if (i > 0 && up >= 0) for (int k = 1; k < WIN; ++k) queue[pos++] = FQ_PACK(x0 + k, y0 - 1, up);
+                    if (j > 0 && lf >= 0) for (int k = 0; k < WIN - 1; ++k) queue[pos++] = FQ_PACK(x0 - 1, y0 + k, lf);
                 } else {
-                    if (i > 0 && up != m) { const int sp = (i * WIN) * w + j * WIN; for (int k = 0; k < WIN - 1; ++k) { qpix[pos] = sp + k; qpl[pos++] = m; } }
-                    if (j > 0 && lf != m) { const int sp = (i * WIN) * w + j * WIN; for (int k = 1; k < WIN; ++k) { qpix[pos] = sp + k * w; qpl[pos++] = m; } }
+                    if (i > 0 && up != m) for (int k = 0; k < WIN - 1; ++k) queue[pos++] = FQ_PACK(x0 + k, y0, m);
+                    if (j > 0 && lf != m) for (int k = 1; k < WIN; ++k) queue[pos++] = FQ_PACK(x0, y0 + k, m);
                 }
             }
             nq += __shfl(incl, 63);
@@ -857,91 +914,146 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
     int nq = s_nq;
     if (nq > r.qcap) { nq = r.qcap; flags |= 32; }
     const double dfx = (double)r.fx, dfy = (double)r.fy, dcx = (double)r.cx, dcy = (double)r.cy, df = (double)r.dfac;
+#ifdef HVO_PEAC_TIMING
+    unsigned long long ft[6] = {0,0,0,0,0,0}, ftl = clock64();
+#define FT(i) { const unsigned long long t_ = clock64(); ft[i] += t_ - ftl; ftl = t_; }
+#else
+#define FT(i)
+#endif
+    FT(0)
+    // state machine of one event on its pixel (AHCPlaneFitter.hpp:445-470): (trail, dcur) -> (nl, nd), push
+    auto apply = [&](int trail, float dcur, int plid, bool ok, float cdist, int &nl, float &nd, bool &push) {
+        nl = trail; nd = dcur;
+        if (trail <= -6 || (trail >= 0 && trail == plid)) return;
+        if (ok) {
+            if (trail >= 0) {
+                const double *Q = pl[trail], *P = pl[plid];
+                if (fabs(P[3] * Q[3] + P[4] * Q[4] + P[5] * Q[5]) >= r.c30) {
+                    atomicOr(&adj[trail], 1ull << plid); atomicOr(&adj[plid], 1ull << trail);
+                }
+            }
+            if (cdist < dcur) { nl = plid; nd = cdist; push = true; }
+            else if (trail < 0) nl = trail - 1;
+        } else if (trail < 0) nl = trail - 1;
+    };
     long long ev = 0;
+    int par = 0, qpf = 0, pf_nq = 0;                     // queue entry prefetched for the next round, valid for k < pf_nq
     while (ev < (long long)nq * 4) {
+#ifdef HVO_PEAC_TIMING
+        ft[4]++;
+#endif
         const long long avail = (long long)nq * 4 - ev;
         const int nev = avail < FLOOD_T ? (int)avail : FLOOD_T;
-        int cIdx = -1, plid = 0;
-        bool ok = false; float cdist = -1;
-        if (tid < nev) {
+        if (tid == 0) s_max[par ^ 1] = 1;
+        int cIdx = -1, plid = 0, cx_ = 0, cy_ = 0, trail0 = 0; unsigned sx0 = 0;
+        bool ok = false; float cdist = -1, dist0 = 0;
+        {
             const long long e = ev + tid;
             const int k = (int)(e >> 2), slot = (int)(e & 3);
-            const int sIdx = qpix[k]; plid = qpl[k];
-            const int sy = sIdx / w, sx = sIdx - sy * w;
-            int c = 0, t = -1;       // getValid4Neighbor order: left, right, up, down
-            if (sx > 0) { if (c == slot) t = sIdx - 1; c++; }
-            if (sx < w - 1) { if (c == slot) t = sIdx + 1; c++; }
-            if (sy > 0) { if (c == slot) t = sIdx - w; c++; }
-            if (sy < h - 1) { if (c == slot) t = sIdx + w; c++; }
-            cIdx = t;
-            if (cIdx >= 0) {
-                const int cy_ = cIdx / w, cx_ = cIdx - cy_ * w;
-                const int by = cy_ / WIN, bx = cx_ / WIN;
-                const int blkid = (by < Nh && bx < Nw) ? by * Nw + bx : -1;
-                if (blkid >= 0 && blkmap[blkid] >= 0) cIdx = -1;         // pixel of a still-valid block: never touched
-                else {
-                    const int d = D[(size_t)cy_ * r.pitch + cx_];
-                    if (d != 0) {
-                        const double z = (double)d * df;
-                        const double x = ((double)cx_ - dcx) * z / dfx, y = ((double)cy_ - dcy) * z / dfy;
-                        const double *P = pl[plid];
-                        const double sd = P[3] * (x - P[0]) + P[4] * (y - P[1]) + P[5] * (z - P[2]);
-                        cdist = (float)fabs(sd);
-                        ok = ((double)cdist * (double)cdist) < 9 * P[6] + 1e-5;
+            int q = qpf;
+            if (tid < nev && k >= pf_nq) q = queue[k];
+            // next round's entries, if they exist already (they do while the frontier is long)
+            const int kn = (int)((e + FLOOD_T) >> 2);
+            if (nev == FLOOD_T) { if (kn < nq) qpf = queue[kn]; pf_nq = nq; } else pf_nq = 0;
+            if (tid < nev) {
+                plid = (int)((unsigned)q >> 26);
+                const int sx = q & 8191, sy = (q >> 13) & 8191;
+                // getValid4Neighbor order: left, right, up, down -- slot = index among the EXISTING neighbours
+                const int hasl = sx > 0, hasr = sx < w - 1, hasu = sy > 0, hasd = sy < h - 1;
+                int c = 0; bool hit = false;
+                cx_ = sx; cy_ = sy;
+                if (hasl) { if (c == slot) { cx_ = sx - 1; hit = true; } c++; }
+                if (hasr) { if (c == slot) { cx_ = sx + 1; hit = true; } c++; }
+                if (hasu) { if (c == slot) { cy_ = sy - 1; hit = true; } c++; }
+                if (hasd) { if (c == slot) { cy_ = sy + 1; hit = true; } c++; }
+                if (hit) {
+                    const int pix = cy_ * w + cx_;
+                    const uint2 st = state[pix];                           // the only scattered access of the event
+                    sx0 = st.x; trail0 = FS_LABEL(st.x); dist0 = __uint_as_float(st.y);
+                    if (!(st.x & FS_VALID)) {                              // pixel of a still-valid block: never touched
+                        cIdx = pix;
+                        const int d = (int)(st.x >> 16);
+                        if (d != 0) {
+                            const double z = (double)d * df;
+                            const double x = ((double)cx_ - dcx) * z / dfx, y = ((double)cy_ - dcy) * z / dfy;
+                            const double *P = pl[plid];
+                            const double sd = P[3] * (x - P[0]) + P[4] * (y - P[1]) + P[5] * (z - P[2]);
+                            cdist = (float)fabs(sd);
+                            ok = ((double)cdist * (double)cdist) < 9 * P[6] + 1e-5;
+                        }
                     }
                 }
             }
         }
         bool pending = cIdx >= 0, push = false;
-        int hslot = -1;
-        while (__syncthreads_or(pending)) {
-            for (int i = tid; i < FLOOD_HS; i += FLOOD_T) { hkeys[i] = -1; hvals[i] = 0x7FFFFFFF; }
-            __syncthreads();
-            if (pending) {
-                int hs = (int)(((unsigned)cIdx * 2654435761u) >> 20) & (FLOOD_HS - 1);
-                for (;;) {
-                    const int old = atomicCAS(&hkeys[hs], -1, cIdx);
-                    if (old == -1 || old == cIdx) break;
-                    hs = (hs + 1) & (FLOOD_HS - 1);
-                }
-                atomicMin(&hvals[hs], tid);
-                hslot = hs;
+        int hs = 0;
+        FT(1)
+        // ---- group the round's events by pixel ----
+        evpix[tid] = cIdx;
+        if (pending) {
+            hs = (int)(((unsigned)cIdx * 2654435761u) >> 20) & (FLOOD_HS - 1);
+            for (;;) {
+                const int old = atomicCAS(&hkeys[hs], -1, cIdx);
+                if (old == -1 || old == cIdx) break;
+                hs = (hs + 1) & (FLOOD_HS - 1);
             }
-            __syncthreads();
-            if (pending && hvals[hslot] == tid) {
-                pending = false;
-                const int trail = labels[cIdx];
-                if (!(trail <= -6 || (trail >= 0 && trail == plid))) {
-                    if (ok) {
-                        if (trail >= 0) {
-                            const double *Q = pl[trail], *P = pl[plid];
-                            if (fabs(P[3] * Q[3] + P[4] * Q[4] + P[5] * Q[5]) >= r.c30) {
-                                atomicOr(&adj[trail], 1ull << plid); atomicOr(&adj[plid], 1ull << trail);
-                            }
-                        }
-                        if (cdist < dist[cIdx]) { labels[cIdx] = plid; dist[cIdx] = cdist; push = true; }
-                        else if (trail < 0) labels[cIdx] = trail - 1;
-                    } else if (trail < 0) labels[cIdx] = trail - 1;
-                }
-            }
-            // the loop condition's barrier orders these global writes before the next sub-round
+            const int pos = atomicAdd(&hcnt[hs], 1);
+            if (pos < FLOOD_HL) hlist[hs * FLOOD_HL + pos] = tid;
         }
+        lds_barrier();
+        int rank = 0, cnt = 0;
+        if (pending) {
+            cnt = hcnt[hs];
+            if (cnt <= FLOOD_HL) { for (int i = 0; i < cnt; i++) rank += hlist[hs * FLOOD_HL + i] < tid; }
+            else { for (int t = 0; t < tid; t++) rank += evpix[t] == cIdx; }       // crowded pixel (rare)
+        }
+        // ---- rank 0 works on the state fetched from memory; later ranks hand the state on through LDS,
+        //      the last one writes it back ----
+        if (pending && rank == 0) {
+            pending = false;
+            int nl; float nd;
+            apply(trail0, dist0, plid, ok, cdist, nl, nd, push);
+            if (cnt > 1) { hlab[hs] = nl; hdist[hs] = nd; atomicMax(&s_max[par], cnt); }
+            else if (nl != trail0 || nd != dist0) state[cIdx] = make_uint2((sx0 & ~0xFFu) | ((unsigned)nl & 0xFFu), __float_as_uint(nd));
+        }
+        lds_barrier();
+        const int nsub = s_max[par];
+        for (int rr = 1; rr < nsub; rr++) {
+#ifdef HVO_PEAC_TIMING
+            ft[5]++;
+#endif
+            if (pending && rank == rr) {
+                pending = false;
+                int nl; float nd;
+                apply(hlab[hs], hdist[hs], plid, ok, cdist, nl, nd, push);
+                if (rr == cnt - 1) state[cIdx] = make_uint2((sx0 & ~0xFFu) | ((unsigned)nl & 0xFFu), __float_as_uint(nd));
+                else { hlab[hs] = nl; hdist[hs] = nd; }
+            }
+            lds_barrier();
+        }
+        if (cIdx >= 0) { hkeys[hs] = -1; hcnt[hs] = 0; }                          // leave the hash empty for the next round
+        FT(2)
         // ---- ordered append: exclusive scan of `push` over the block ----
         const unsigned long long bm = __ballot(push);
         const int wcnt = __popcll(bm);
         if (lane == 0) wsum[wv] = wcnt;
-        __syncthreads();
+        lds_barrier();
         int base = 0, total = 0;
         for (int i = 0; i < FLOOD_T / 64; i++) { const int v = wsum[i]; if (i < wv) base += v; total += v; }
         if (push) {
             const int pos = nq + base + __popcll(bm & ((1ull << lane) - 1));
-            if (pos < r.qcap) { qpix[pos] = cIdx; qpl[pos] = plid; }
+            if (pos < r.qcap) queue[pos] = FQ_PACK(cx_, cy_, plid);
         }
         nq += total;
         if (nq > r.qcap) { nq = r.qcap; flags |= 32; }
         ev += nev;
-        __syncthreads();
+        par ^= 1;
+        __syncthreads();                                 // drains this round's label / dist / queue stores
+        FT(3)
     }
+#ifdef HVO_PEAC_TIMING
+    if (tid == 0) { for (int q = 0; q < 6; q++) atomicAdd(&g_peac_t[16 + q], ft[q]); atomicAdd(&g_peac_t[22], (unsigned long long)nq); atomicAdd(&g_peac_t[23], 1ull); }
+#endif
     if (tid < MAX_PLANES) adj_out[(size_t)frame * MAX_PLANES + tid] = adj[tid];
     if (tid == 0) { meta[5] = nq; meta[7] = flags; }
 }
@@ -1010,13 +1122,14 @@ __global__ __launch_bounds__(64) void k_peac_final(RfArgs r, const unsigned long
     }
 }
 
-__global__ __launch_bounds__(256) void k_peac_relabel(int32_t *__restrict__ labels, const int *__restrict__ plidmap, int npix)
+__global__ __launch_bounds__(256) void k_peac_relabel(const uint2 *__restrict__ state, int32_t *__restrict__ labels, const int *__restrict__ plidmap, int npix)
 {
     const int frame = blockIdx.y;
+    const uint2 *S = state + (size_t)frame * npix;
     int32_t *L = labels + (size_t)frame * npix;
     const int *pm = plidmap + (size_t)frame * MAX_PLANES;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
-        int v = L[i];
+        const int v = FS_LABEL(S[i].x);
         L[i] = (v >= 0 && pm[v] >= 0) ? pm[v] : -1;
     }
 }
@@ -1029,7 +1142,7 @@ void peac_free(hvo_ctx *ctx)
     PeacPlan *P = plan_of(ctx);
     if (!P) return;
     void *ptrs[] = { P->d_depth, P->d_segD, P->d_segI, P->d_pool, P->d_pool2, P->d_parent, P->d_dsize, P->d_eflag, P->d_meta, P->d_extracted,
-                     P->d_blkmap, P->d_labels, P->d_dist, P->d_qpix, P->d_qpl, P->d_plidmap, P->d_isvalid, P->d_planes, P->d_adj, P->d_hkey, P->d_hid };
+                     P->d_blkmap, P->d_labels, P->d_state, P->d_queue, P->d_plidmap, P->d_isvalid, P->d_planes, P->d_adj, P->d_hkey, P->d_hid };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
     ctx->peac = nullptr;
@@ -1059,8 +1172,8 @@ static int peac_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_pool2, B * P->poolcap * sizeof(int));
     PA(P->d_parent, B * P->nblk * sizeof(int)); PA(P->d_dsize, B * P->nblk * sizeof(int)); PA(P->d_eflag, B * P->nblk * sizeof(int));
     PA(P->d_meta, B * 16 * sizeof(int)); PA(P->d_extracted, B * 2 * MAX_PLANES * sizeof(int));
-    PA(P->d_blkmap, B * P->nblk * sizeof(int)); PA(P->d_labels, B * npix * sizeof(int32_t)); PA(P->d_dist, B * npix * sizeof(float));
-    PA(P->d_qpix, B * P->qcap * sizeof(int)); PA(P->d_qpl, B * P->qcap * sizeof(int));
+    PA(P->d_blkmap, B * P->nblk * sizeof(int)); PA(P->d_labels, B * npix * sizeof(int32_t)); PA(P->d_state, B * npix * sizeof(uint2));
+    PA(P->d_queue, B * P->qcap * sizeof(int));
     PA(P->d_plidmap, B * MAX_PLANES * sizeof(int)); PA(P->d_isvalid, B * MAX_PLANES * sizeof(int));
     PA(P->d_planes, B * MAX_PLANES * sizeof(hvo_plane));
     PA(P->d_adj, B * MAX_PLANES * sizeof(unsigned long long));
@@ -1115,12 +1228,12 @@ int peac_run(hvo_ctx *ctx, int n)
     }
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "peac_refine", st);
-    hipLaunchKernelGGL(k_peac_blkmap, dim3(16, n), dim3(256), 0, st, P->d_parent, P->d_dsize, P->d_segI, P->d_extracted, P->d_meta, P->d_blkmap,
-                       P->d_isvalid, P->d_labels, P->d_dist, P->nblk, P->Nw, P->Nh, P->w, P->h, P->segcap);
+    hipLaunchKernelGGL(k_peac_blkmap, dim3(n), dim3(256), 0, st, P->d_parent, P->d_dsize, P->d_segI, P->d_extracted, P->d_meta, P->d_blkmap,
+                       P->d_isvalid, P->d_state, P->d_depth, dframe, P->pitch, P->nblk, P->Nw, P->Nh, P->w, P->h, P->segcap);
     RfArgs r;
     r.c = a; r.depth = P->d_depth; r.dframe = dframe; r.pitch = P->pitch; r.w = P->w; r.h = P->h;
     r.fx = p.fx; r.fy = p.fy; r.cx = p.cx; r.cy = p.cy; r.dfac = p.depth_map_factor;
-    r.blkmap = P->d_blkmap; r.isvalid = P->d_isvalid; r.labels = P->d_labels; r.dist = P->d_dist; r.qpix = P->d_qpix; r.qpl = P->d_qpl;
+    r.blkmap = P->d_blkmap; r.isvalid = P->d_isvalid; r.state = P->d_state; r.queue = P->d_queue;
     r.qcap = P->qcap; r.plidmap = P->d_plidmap; r.planes = P->d_planes; r.c30 = P->c30;
     {
         static int flood_t = 0;
@@ -1133,7 +1246,7 @@ int peac_run(hvo_ctx *ctx, int n)
         else hipLaunchKernelGGL(k_peac_flood<512>, dim3(n), dim3(512), 0, st, r, P->d_adj);
     }
     hipLaunchKernelGGL(k_peac_final, dim3(n), dim3(64), 0, st, r, P->d_adj);
-    hipLaunchKernelGGL(k_peac_relabel, dim3(64, n), dim3(256), 0, st, P->d_labels, P->d_plidmap, P->w * P->h);
+    hipLaunchKernelGGL(k_peac_relabel, dim3(64, n), dim3(256), 0, st, P->d_state, P->d_labels, P->d_plidmap, P->w * P->h);
     hvo_prof_end(ctx, id);
     HVO_HIP(hipGetLastError());
     return HVO_OK;
@@ -1182,3 +1295,13 @@ extern "C" int hvo_compute_planes(hvo_ctx *ctx, const uint16_t *depth, int w, in
     *n = out.n_planes;
     return out.status;
 }
+
+#ifdef HVO_PEAC_TIMING
+// diagnostics build only (make DEFS=-DHVO_PEAC_TIMING): accumulated clock64() ticks per AHC phase
+extern "C" int hvo_debug_peac_timing(unsigned long long *out32, int reset)
+{
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_peac_t), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = { 0 }; if (hipMemcpyToSymbol(HIP_SYMBOL(g_peac_t), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
