@@ -504,14 +504,24 @@ static __device__ void gpool_gc(int *segI, int nseg, int *&pool, int *&pool2, in
     __syncthreads();
 }
 
-template <int GL, int LCG>
+// Neighbour sets are kept UNORDERED here (the reference iterates a std::set<PlaneSeg*>, i.e. by
+// address; the oracle fixes that as ascending creation id).  The only place where the iteration
+// order can change the result is the candidate selection rule of AHCPlaneFitter.hpp:1043-1049
+//     if (cand_mse > mse || (cand_mse == mse && cand->N < mse)) take
+// walked in ascending id.  Restated without order: the winner has the minimum mse; among candidates
+// that tie on it, walking in ascending id the cursor moves on while N(cursor) < mse, i.e. the winner
+// is the smallest-id tied candidate with N >= mse, or the largest-id tied candidate if there is none.
+// That is three reductions (min mse; min id with N >= mse; max id), so lists need no order, merging
+// two lists is mark / test / compact in parallel, and removing an id is replace-or-swap-with-last.
+template <int GL>
 static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hkey, int *hid, int &hn, int &nseg, int &pooltop,
-                                          int *&pool, int *&pool2, int *ext, int &next, int *lA, int *lB, double *cm, int *cN, int &flags)
+                                          int *&pool, int *&pool2, int *ext, int &next, int &flags)
 {
-    const int lane = threadIdx.x & 63, gl = Grp<GL>::gl(), gb = Grp<GL>::gb();
+    const int gl = Grp<GL>::gl(), gb = Grp<GL>::gb();
     double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
     int *segI = a.segI + (size_t)frame * a.segcap * SEG_I;
     int *parent = a.parent + (size_t)frame * a.nblk, *dsize = a.dsize + (size_t)frame * a.nblk;
+    const unsigned long long lt_mask = (1ull << gl) - 1;       // lanes of my group below me
     PT_DECL
     while (__any(hn > 0)) {
         const bool act = hn > 0;
@@ -526,57 +536,104 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
         const double *pd = segD + (size_t)(p < 0 ? 0 : p) * SEG_D;
         const bool live = act && pi[2] == 0;                   // skip nouse nodes (lazy deletion)
         const int pcnt = live ? pi[4] : 0, poff = pi[3], pN = pi[0];
-        // ---- evaluate merges with every neighbour, in creation order; one candidate per lane ----
-        int cand_k = -1; double cand_mse = 0; int cand_N = 0;
-        double st[9], c[3] = { 0, 0, 0 }, n[3] = { 0, 0, 0 }, m = 0; int mN = 0;
+        double ps[9], pn[3];                                   // popped node: sums and normal (uniform per group)
 #pragma unroll
-        for (int q = 0; q < 9; q++) st[q] = 0;
+        for (int q = 0; q < 9; q++) ps[q] = pd[q];
+        pn[0] = pd[12]; pn[1] = pd[13]; pn[2] = pd[14];
+        // ---- evaluate the merge with every neighbour, one candidate per lane; each lane keeps its best ----
+        bool bhas = false; double bm = 0; int bid = 0x7FFFFFFF, bN = 0, gid = 0x7FFFFFFF, xid = -1;
+        double bst[9], bc[3] = { 0, 0, 0 }, bn[3] = { 0, 0, 0 };
+#pragma unroll
+        for (int q = 0; q < 9; q++) bst[q] = 0;
         PT(2)
         for (int base = 0; __any(base < pcnt); base += GL) {
             PT_CNT(9, 1)
             const int k = base + gl;
-            double lst[9], lc[3] = { 0, 0, 0 }, ln[3] = { 0, 0, 0 }, lm = 0; int lN = 0; bool has = false;
+            double lst[9]; int lN = 4, nb = 0; bool has = false;
 #pragma unroll
             for (int q = 0; q < 9; q++) lst[q] = 0;
             if (k < pcnt) {
-                const int nb = pool[poff + k];
+                nb = pool[poff + k];
                 const double *nd = segD + (size_t)nb * SEG_D;
-                if (!(nsim(pd, nd) < a.c60)) {                 // T_ang(P_MERGING)
-                    for (int q = 0; q < 9; q++) lst[q] = pd[q] + nd[q];
+                if (!(fabs(pn[0] * nd[12] + pn[1] * nd[13] + pn[2] * nd[14]) < a.c60)) {      // T_ang(P_MERGING)
+#pragma unroll
+                    for (int q = 0; q < 9; q++) lst[q] = ps[q] + nd[q];
                     lN = pN + segI[(size_t)nb * SEG_I];
                     has = true;
                 }
             }
             // one 3x3 eigen-solve pass serves every group (uniform call: no divergence inside)
-            if (__any(has)) { double tc[3], tn[3], tm; stats_compute_dev(lst, has ? lN : 4, tc, tn, tm); if (has) { lm = tm; for (int q = 0; q < 3; q++) { lc[q] = tc[q]; ln[q] = tn[q]; } } }
-            cm[lane] = lm; cN[lane] = has ? lN : -1;
-            __syncthreads();
-            // exact sequential selection rule of AHCPlaneFitter.hpp:1043-1049 (uniform per group)
-            const int lim = min(GL, pcnt - base);
-            int sel = -1;
-            for (int q = 0; q < lim; q++) {
-                if (cN[gb + q] < 0) continue;
-                const double mq = cm[gb + q];
-                if (cand_k < 0 || cand_mse > mq || (cand_mse == mq && (double)cand_N < mq)) { cand_k = base + q; cand_mse = mq; cand_N = cN[gb + q]; sel = q; }
-            }
-            // winner's fit from its lane; groups without a new winner read a dummy lane and ignore it
-            {
-                const int src = gb + (sel >= 0 ? sel : 0);
+            if (__any(has)) {
+                double tc[3], tn[3], tm;
+                stats_compute_dev(lst, lN, tc, tn, tm);
+                if (has) {
+                    const bool good = (double)lN >= tm, better = !bhas || tm < bm, equal = bhas && tm == bm;
+                    if (better) { gid = good ? nb : 0x7FFFFFFF; xid = nb; }
+                    else if (equal) { if (good && nb < gid) gid = nb; if (nb > xid) xid = nb; }
+                    if (better || (equal && nb < bid)) {                   // payload follows (mse, id)
+                        bid = nb; bN = lN;
 #pragma unroll
-                for (int q = 0; q < 9; q++) { const double v = __shfl(lst[q], src); if (sel >= 0) st[q] = v; }
+                        for (int q = 0; q < 9; q++) bst[q] = lst[q];
 #pragma unroll
-                for (int q = 0; q < 3; q++) { const double v = __shfl(lc[q], src), w = __shfl(ln[q], src); if (sel >= 0) { c[q] = v; n[q] = w; } }
-                const double vm = __shfl(lm, src); const int vN = __shfl(lN, src);
-                if (sel >= 0) { m = vm; mN = vN; }
+                        for (int q = 0; q < 3; q++) { bc[q] = tc[q]; bn[q] = tn[q]; }
+                    }
+                    if (better) bm = tm;
+                    bhas = true;
+                }
             }
-            __syncthreads();
+        }
+        // ---- group reductions: min mse, then the tie rule ----
+        double gmin = bhas ? bm : 1.7976931348623157e308;
+#pragma unroll
+        for (int o = 1; o < GL; o <<= 1) { const double t = __shfl_xor(gmin, o); gmin = t < gmin ? t : gmin; }
+        const bool tied = bhas && bm == gmin;
+        int rg = tied ? gid : 0x7FFFFFFF, rx = tied ? xid : -1, rb = tied ? bid : 0x7FFFFFFF;
+#pragma unroll
+        for (int o = 1; o < GL; o <<= 1) {
+            const int t0 = __shfl_xor(rg, o), t1 = __shfl_xor(rx, o), t2 = __shfl_xor(rb, o);
+            rg = min(rg, t0); rx = max(rx, t1); rb = min(rb, t2);
+        }
+        const bool any_cand = Grp<GL>::ballot(bhas) != 0;
+        const int win = rg != 0x7FFFFFFF ? rg : rx;            // neighbour id to merge with (if any_cand)
+        double st[9], c[3], n[3], m; int mN;
+        {
+            // the winner's fit from the lane that holds it (groups without one read a dummy lane and ignore it)
+            const unsigned long long wm = Grp<GL>::ballot(tied && bid == win);
+            const int src = gb + (wm ? __ffsll((long long)wm) - 1 : 0);
+#pragma unroll
+            for (int q = 0; q < 9; q++) st[q] = __shfl(bst[q], src);
+#pragma unroll
+            for (int q = 0; q < 3; q++) { c[q] = __shfl(bc[q], src); n[q] = __shfl(bn[q], src); }
+            m = __shfl(bm, src); mN = __shfl(bN, src);
+            // tie broken by the N-vs-mse clause towards a candidate whose fit no lane kept: fit it again
+            const bool refit = any_cand && wm == 0;
+            if (__any(refit)) {
+                double lst[9]; int lN = 4;
+#pragma unroll
+                for (int q = 0; q < 9; q++) lst[q] = 0;
+                if (refit) {
+                    const double *nd = segD + (size_t)win * SEG_D;
+#pragma unroll
+                    for (int q = 0; q < 9; q++) lst[q] = ps[q] + nd[q];
+                    lN = pN + segI[(size_t)win * SEG_I];
+                }
+                double tc[3], tn[3], tm;
+                stats_compute_dev(lst, lN, tc, tn, tm);
+                if (refit) {
+#pragma unroll
+                    for (int q = 0; q < 9; q++) st[q] = lst[q];
+#pragma unroll
+                    for (int q = 0; q < 3; q++) { c[q] = tc[q]; n[q] = tn[q]; }
+                    m = tm; mN = lN;
+                }
+            }
         }
         PT(3)
         // ---- merge decision ----
-        int nb = 0, ncnt = 0, noff = 0; int *ni = segI;
+        const int nb = win;
+        int ncnt = 0, noff = 0; int *ni = segI;
         bool do_merge = false;
-        if (live && cand_k >= 0) {
-            nb = pool[poff + cand_k];
+        if (live && any_cand) {
             ni = segI + (size_t)nb * SEG_I;
             const double t = 1.6e-6 * c[2] * c[2] + 8.0;        // T_mse(P_MERGING)
             if (m < t * t) {
@@ -588,26 +645,61 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
         PT(4)
         if (__any(do_merge)) {
             PT_CNT(10, 1)
-            const bool staged = do_merge && pcnt <= LCG && ncnt <= LCG;
-            if (staged) {
-                for (int k = gl; k < pcnt; k += GL) lA[k] = pool[poff + k];
-                for (int k = gl; k < ncnt; k += GL) lB[k] = pool[noff + k];
-            }
-            __syncthreads();
             const int id = nseg;
             if (do_merge) nseg++;
             const int moff = pooltop;
-            if (do_merge && gl == 0) {
-                const int *LA = staged ? lA : pool + poff, *LB = staged ? lB : pool + noff;
-                int mcnt = 0, i = 0, j = 0;
-                while (i < pcnt || j < ncnt) {
-                    int v;
-                    if (j >= ncnt || (i < pcnt && LA[i] <= LB[j])) { v = LA[i]; if (j < ncnt && LB[j] == v) j++; i++; }
-                    else { v = LB[j]; j++; }
-                    if (v != p && v != nb) pool[moff + mcnt++] = v;
+            // new.nbs = (p.nbs U nb.nbs) \ {p, nb}.  Mark nb's neighbours with the new id (ids only grow, so
+            // marks never need clearing); pass A copies p's list and, per neighbour, rewrites that
+            // neighbour's own list (p -> new id; nb dropped when the mark says it holds both) and flips the
+            // mark to -id; pass B copies what is left of nb's list (mark still +id) and rewrites nb -> id.
+            for (int k = gl; __any(do_merge && k < ncnt); k += GL)
+                if (do_merge && k < ncnt) { const int v = pool[noff + k]; if (v != p) segI[(size_t)v * SEG_I + 7] = id; }
+            __syncthreads();
+            int mcnt = 0;
+            // pass A: p's neighbours except nb; a marked one is also nb's neighbour
+            for (int base = 0; __any(do_merge && base < pcnt); base += GL) {
+                const int k = base + gl;
+                int v = -1; bool keep = false;
+                if (do_merge && k < pcnt) { v = pool[poff + k]; keep = v != nb; }
+                const unsigned long long km = Grp<GL>::ballot(keep);
+                if (keep) {
+                    int *qi = segI + (size_t)v * SEG_I;
+                    const bool both = qi[7] == id;
+                    if (both) qi[7] = -id;                     // "already taken from p's list"
+                    pool[moff + mcnt + __popcll(km & lt_mask)] = v;
+                    // v's own list: p (and nb) -> the new id
+                    const int off = qi[3]; int cnt = qi[4];
+                    int found = 0;
+                    for (int x = 0; x < cnt; x++) {
+                        const int u = pool[off + x];
+                        if (u == p || u == nb) {
+                            if (!found) { pool[off + x] = id; found = 1; if (!both) break; }
+                            else { pool[off + x] = pool[off + cnt - 1]; cnt--; break; }
+                        }
+                    }
+                    qi[4] = cnt;
                 }
-                cN[gb] = mcnt;
+                mcnt += __popcll(km);
+            }
+            __syncthreads();                                   // pass A's marks / list edits before pass B reads them
+            // pass B: nb's neighbours except p and those already taken
+            for (int base = 0; __any(do_merge && base < ncnt); base += GL) {
+                const int k = base + gl;
+                int v = -1; bool keep = false;
+                if (do_merge && k < ncnt) { v = pool[noff + k]; keep = v != p && segI[(size_t)v * SEG_I + 7] != -id; }
+                const unsigned long long km = Grp<GL>::ballot(keep);
+                if (keep) {
+                    int *qi = segI + (size_t)v * SEG_I;
+                    pool[moff + mcnt + __popcll(km & lt_mask)] = v;
+                    const int off = qi[3], cnt = qi[4];
+                    for (int x = 0; x < cnt; x++) if (pool[off + x] == nb) { pool[off + x] = id; break; }
+                }
+                mcnt += __popcll(km);
+            }
+            PT(5)
+            if (do_merge && gl == 0) {
                 double *md = segD + (size_t)id * SEG_D;
+#pragma unroll
                 for (int q = 0; q < 9; q++) md[q] = st[q];
                 md[9] = c[0]; md[10] = c[1]; md[11] = c[2]; md[12] = n[0]; md[13] = n[1]; md[14] = n[2]; md[15] = m;
                 int *mi = segI + (size_t)id * SEG_I;
@@ -619,30 +711,23 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
                 }
                 pi[2] = 1; ni[2] = 1; pi[4] = 0; ni[4] = 0;
             }
+            if (do_merge) pooltop += pcnt + ncnt;
             __syncthreads();
-            PT(5)
+            PT(7)
             gheap_push<GL>(hkey, hid, hn, m, id, do_merge);
             __syncthreads();
             PT(6)
-            if (do_merge) {
-                const int mcnt = cN[gb];
-                pooltop += pcnt + ncnt;
-                // every neighbour of the new node: drop p / nb, append the new id (largest so far)
-                for (int k = gl; k < mcnt; k += GL) {
-                    int *qi = segI + (size_t)pool[moff + k] * SEG_I;
-                    nb_remove2(pool, qi, p, nb);
-                    pool[qi[3] + qi[4]] = id; qi[4]++;
-                }
-            }
-            __syncthreads();
         }
-        PT(7)
         const bool no_merge = live && !do_merge;
         if (__any(no_merge)) {
             PT_CNT(11, 1)
             if (no_merge) {
                 if (pN >= MIN_SUPPORT) { if (next < MAX_PLANES) { if (gl == 0) ext[next] = p; next++; } else flags |= 16; }
-                for (int k = gl; k < pcnt; k += GL) nb_remove2(pool, segI + (size_t)pool[poff + k] * SEG_I, p, -1);   // disconnectAllNbs
+                for (int k = gl; k < pcnt; k += GL) {                                      // disconnectAllNbs
+                    int *qi = segI + (size_t)pool[poff + k] * SEG_I;
+                    const int off = qi[3], cnt = qi[4];
+                    for (int x = 0; x < cnt; x++) if (pool[off + x] == p) { pool[off + x] = pool[off + cnt - 1]; qi[4] = cnt - 1; break; }
+                }
             }
             __syncthreads();
             if (no_merge && gl == 0) pi[4] = 0;
@@ -670,10 +755,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
 template <int GL>
 __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
 {
-    constexpr int NG = 64 / GL, LCG = LCAP / NG;
-    __shared__ double cm[64];
-    __shared__ int cN[64];
-    __shared__ int lAs[NG][LCG], lBs[NG][LCG];
+    constexpr int NG = 64 / GL;
     const int lane = threadIdx.x, gl = Grp<GL>::gl(), gid = lane / GL;
     int frame = blockIdx.x * NG + gid;
     const bool galive = frame < nframes;
@@ -761,7 +843,7 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
 #endif
     int nseg = nblk, pooltop = nblk * 4, next = 0, flags = 0;
     int *ext = a.extracted + (size_t)frame * 2 * MAX_PLANES;
-    ah_cluster_grouped<GL, LCG>(a, frame, hkey, hid, hn, nseg, pooltop, pool, pool2, ext, next, lAs[gid], lBs[gid], cm, cN, flags);
+    ah_cluster_grouped<GL>(a, frame, hkey, hid, hn, nseg, pooltop, pool, pool2, ext, next, flags);
     if (galive && gl == 0) {
         int *meta = a.meta + (size_t)frame * 16;
         meta[0] = nseg; meta[1] = pooltop; meta[2] = next; meta[3] = flags;
@@ -1218,9 +1300,10 @@ int peac_run(hvo_ctx *ctx, int n)
     a.c15 = P->c15; a.c60 = P->c60; a.hkey = P->d_hkey; a.hid = P->d_hid;
     id = hvo_prof_begin(ctx, "peac_cluster", st);
     {
-        static int gl = 0;
-        // 4 frames per wave pay off once the wave slots are saturated (measured: >= ~3000 resident frames)
-        if (!gl) { const char *e = getenv("HVO_PEAC_GL"); gl = e ? atoi(e) : -1; }
+        // 4 frames per wave pay off once the wave slots are saturated (measured: >= ~3000 resident frames);
+        // HVO_PEAC_GL forces a group width (tests run the 16-lane path on small batches with it)
+        const char *e = getenv("HVO_PEAC_GL");
+        const int gl = e ? atoi(e) : -1;
         const int use = gl > 0 ? gl : (n >= 3072 ? 16 : 64);
         if (use == 64) hipLaunchKernelGGL(k_peac_cluster<64>, dim3(n), dim3(64), 0, st, a, n);
         else if (use == 32) hipLaunchKernelGGL(k_peac_cluster<32>, dim3((n + 1) / 2), dim3(64), 0, st, a, n);
@@ -1236,8 +1319,8 @@ int peac_run(hvo_ctx *ctx, int n)
     r.blkmap = P->d_blkmap; r.isvalid = P->d_isvalid; r.state = P->d_state; r.queue = P->d_queue;
     r.qcap = P->qcap; r.plidmap = P->d_plidmap; r.planes = P->d_planes; r.c30 = P->c30;
     {
-        static int flood_t = 0;
-        if (!flood_t) { const char *e = getenv("HVO_FLOOD_T"); flood_t = e ? atoi(e) : -1; }
+        const char *e = getenv("HVO_FLOOD_T");
+        const int flood_t = e ? atoi(e) : -1;
         const int ft = flood_t > 0 ? flood_t : (n >= 3072 ? 256 : 512);
         if (ft == 64) hipLaunchKernelGGL(k_peac_flood<64>, dim3(n), dim3(64), 0, st, r, P->d_adj);
         else if (ft == 128) hipLaunchKernelGGL(k_peac_flood<128>, dim3(n), dim3(128), 0, st, r, P->d_adj);

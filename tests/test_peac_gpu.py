@@ -89,3 +89,45 @@ def test_peac_batch(hvo, orc, synth):
         lo, po = orc.peac(depth[b])
         assert res[b]["status"] == 0
         check(res[b]["labels"], res[b]["planes"], lo, po)
+
+
+@pytest.mark.parametrize("gl,flood_t", [(16, 256), (32, 128), (64, 1024)])
+def test_peac_batch_grouped_paths(hvo, orc, synth, monkeypatch, gl, flood_t):
+    """the configurations large batches select (several frames per wave in lockstep, smaller flood
+    blocks), forced on a small ragged batch: 6 frames = one full and one half-empty wave at 16 lanes"""
+    monkeypatch.setenv("HVO_PEAC_GL", str(gl))
+    monkeypatch.setenv("HVO_FLOOD_T", str(flood_t))
+    depth = np.stack([synth.make_depth(s) for s in (0x5EED0002, 0x5EED1000, 0x5EED1003, 77, 0x5EED1001, 0x5EED1002)])
+    # one exact plane (every candidate merge ties at mse ~ 0) rides along in the same wave
+    j = np.arange(640)[None, :]; i = np.arange(480)[:, None]
+    depth[4] = np.rint(2.0 / (0.1 * (j - 320.1) / 535.4 + 0.2 * (i - 247.6) / 539.2 + 1.0) * 5000).astype(np.uint16)
+    gray = np.zeros((6, 480, 640), np.uint8)
+    ctx = hvo.Context(max_batch=6)
+    try:
+        ctx.batch_upload(gray, depth)
+        ctx.batch_run(hvo.STAGE_PLANES)
+        res = ctx.batch_download(hvo.STAGE_PLANES)
+    finally:
+        ctx.close()
+    for b in range(6):
+        lo, po = orc.peac(depth[b])
+        assert res[b]["status"] == 0
+        check(res[b]["labels"], res[b]["planes"], lo, po)
+
+
+def test_peac_large_batch_adaptive(hvo, orc, synth):
+    """3072 resident frames (16 distinct, repeated): the batch size at which the grouped AHC and the small
+    flood blocks are selected by themselves; a sample of the results must equal the oracle's"""
+    gray, depth = synth.make_batch("std", 0x5EED1000, 16)
+    ctx = hvo.Context(max_batch=3072)
+    try:
+        ctx.batch_upload(gray, depth, repeat=192)
+        ctx.batch_run(hvo.STAGE_PLANES)
+        res = ctx.batch_download(hvo.STAGE_PLANES, n=40)
+    finally:
+        ctx.close()
+    ref = [orc.peac(depth[b]) for b in range(16)]
+    for b in range(40):
+        lo, po = ref[b % 16]
+        assert res[b]["status"] == 0
+        check(res[b]["labels"], res[b]["planes"], lo, po)
