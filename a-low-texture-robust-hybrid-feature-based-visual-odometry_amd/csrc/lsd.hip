@@ -806,8 +806,9 @@ int lsd_run(hvo_ctx *ctx, int n)
     g.stats = P->d_stats; g.kl_all = P->d_kl_all; g.kl = P->d_kl; g.fn = P->d_fn; g.nkl = P->d_nkl; g.flags = P->d_flags;
     g.sw = sw; g.sh = sh; g.nwords = P->nwords; g.w = w; g.h = h; g.nfeat = P->nfeat; g.kl_cap = P->nfeat;
     g.rho = P->rho; g.prec = P->prec; g.p = P->p; g.min_reg = P->min_reg;
-    const size_t lds = (size_t)P->nwords * 4;
+    size_t lds = (size_t)P->nwords * 4;
     if (lds > 150 * 1024) return HVO_ERR_UNSUPPORTED;
+    { const char *e = getenv("HVO_GROW_LDS_PAD"); if (e) lds += (size_t)atoi(e); }
     static size_t lds_set = 0;
     if (lds > 32 * 1024 && lds_set < lds) {
         HVO_HIP(hipFuncSetAttribute((const void *)k_lsd_grow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

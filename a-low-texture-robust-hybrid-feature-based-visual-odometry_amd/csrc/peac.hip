@@ -417,6 +417,21 @@ __device__ unsigned long long g_peac_t[32];
 #define PT_CNT(i, v)
 #define PT_FLUSH
 #endif
+// position(s) of `a` (and `b` when want2) in the unordered list pool[off .. off+cnt): the list is read
+// eight entries per round trip (lists are short; a one-by-one scan would pay one memory latency per entry)
+static __device__ __forceinline__ void list_find2(const int *pool, int off, int cnt, int a, int b, bool want2, int &i1, int &i2)
+{
+    i1 = -1; i2 = -1;
+    for (int x0 = 0; x0 < cnt; x0 += 8) {
+        int u[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) u[j] = x0 + j < cnt ? pool[off + x0 + j] : -1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (u[j] == a || u[j] == b) { if (i1 < 0) i1 = x0 + j; else i2 = x0 + j; }
+        if (i1 >= 0 && (!want2 || i2 >= 0)) break;
+    }
+}
+
 template <int GL> struct Grp {
     static_assert(GL == 16 || GL == 32 || GL == 64, "group width");
     static __device__ __forceinline__ int gl() { return threadIdx.x & (GL - 1); }
@@ -426,18 +441,19 @@ template <int GL> struct Grp {
     template <class T> static __device__ __forceinline__ T shfl(T v, int l) { return __shfl(v, gb() + l); }
 };
 
+#define GH_ARY 16         // arity of the grouped heap: one child per lane of the narrowest group
 template <int GL>
 static __device__ void gheap_sift_down(double *key, int *id, int n, int i, double k, int idv, bool act)
 {
     const int gl = Grp<GL>::gl();
     bool go = act;
     while (__any(go)) {
-        const int c0 = 8 * i + 1;
+        const int c0 = GH_ARY * i + 1;
         const bool cont = go && c0 < n;
         double ck = 1.0e308; int cid = 0x7FFFFFFF, ci = -1;
-        if (cont && gl < 8 && c0 + gl < n) { ci = c0 + gl; ck = key[ci]; cid = id[ci]; }
+        if (cont && gl < GH_ARY && c0 + gl < n) { ci = c0 + gl; ck = key[ci]; cid = id[ci]; }
 #pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
+        for (int o = 1; o < GH_ARY; o <<= 1) {
             const double ok = __shfl_xor(ck, o); const int oid = __shfl_xor(cid, o), oi = __shfl_xor(ci, o);
             if (oi >= 0 && (ci < 0 || hless(ok, oid, ck, cid))) { ck = ok; cid = oid; ci = oi; }
         }
@@ -457,7 +473,7 @@ static __device__ void gheap_push(double *key, int *id, int &n, double k, int id
     if (act) n++;
     bool go = act && i > 0;
     while (__any(go)) {
-        const int p = go ? (i - 1) / 8 : 0;
+        const int p = go ? (i - 1) / GH_ARY : 0;
         double pk = 0; int pid = 0;
         if (go) { pk = key[p]; pid = id[p]; }
         const bool mv = go && hless(k, idv, pk, pid);
@@ -668,16 +684,11 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
                     if (both) qi[7] = -id;                     // "already taken from p's list"
                     pool[moff + mcnt + __popcll(km & lt_mask)] = v;
                     // v's own list: p (and nb) -> the new id
-                    const int off = qi[3]; int cnt = qi[4];
-                    int found = 0;
-                    for (int x = 0; x < cnt; x++) {
-                        const int u = pool[off + x];
-                        if (u == p || u == nb) {
-                            if (!found) { pool[off + x] = id; found = 1; if (!both) break; }
-                            else { pool[off + x] = pool[off + cnt - 1]; cnt--; break; }
-                        }
-                    }
-                    qi[4] = cnt;
+                    const int off = qi[3], cnt = qi[4];
+                    int i1, i2;
+                    list_find2(pool, off, cnt, p, nb, both, i1, i2);
+                    if (i1 >= 0) pool[off + i1] = id;
+                    if (i2 >= 0) { if (i2 != cnt - 1) pool[off + i2] = pool[off + cnt - 1]; qi[4] = cnt - 1; }
                 }
                 mcnt += __popcll(km);
             }
@@ -692,7 +703,9 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
                     int *qi = segI + (size_t)v * SEG_I;
                     pool[moff + mcnt + __popcll(km & lt_mask)] = v;
                     const int off = qi[3], cnt = qi[4];
-                    for (int x = 0; x < cnt; x++) if (pool[off + x] == nb) { pool[off + x] = id; break; }
+                    int i1, i2;
+                    list_find2(pool, off, cnt, nb, nb, false, i1, i2);
+                    if (i1 >= 0) pool[off + i1] = id;
                 }
                 mcnt += __popcll(km);
             }
@@ -726,7 +739,9 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
                 for (int k = gl; k < pcnt; k += GL) {                                      // disconnectAllNbs
                     int *qi = segI + (size_t)pool[poff + k] * SEG_I;
                     const int off = qi[3], cnt = qi[4];
-                    for (int x = 0; x < cnt; x++) if (pool[off + x] == p) { pool[off + x] = pool[off + cnt - 1]; qi[4] = cnt - 1; break; }
+                    int i1, i2;
+                    list_find2(pool, off, cnt, p, p, false, i1, i2);
+                    if (i1 >= 0) { if (i1 != cnt - 1) pool[off + i1] = pool[off + cnt - 1]; qi[4] = cnt - 1; }
                 }
             }
             __syncthreads();
@@ -829,8 +844,8 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
     const unsigned long long t_in1 = clock64();
 #endif
     // Floyd heapify from the last parent down (each sift is group-cooperative)
-    for (int i = (nblk - 2) / 8; i >= 0; i--) {
-        const bool act = hn > 1 && i <= (hn - 2) / 8;
+    for (int i = (nblk - 2) / GH_ARY; i >= 0; i--) {
+        const bool act = hn > 1 && i <= (hn - 2) / GH_ARY;
         if (!__any(act)) continue;
         double k = 0; int id = 0;
         if (act) { k = hkey[i]; id = hid[i]; }
@@ -919,14 +934,16 @@ struct RfArgs {
 };
 
 // k_peac_flood: seeds + floodFill (AHCPlaneFitter.hpp:543-575, 428-476), FLOOD_T threads per frame.
-// Events = (queue entry, neighbour slot) in queue order.  A round takes the next FLOOD_T events that
-// existed when it started.  The part of an event that does not depend on the pixel's state (block
-// test, unprojection, point-plane distance) is evaluated for all events at once; the per-pixel
-// state machine (membership "trail", distMap) must see its events in queue order, so events that
-// hit the same pixel are serialised: an LDS hash groups the round's events by pixel, every event
-// learns its rank among the events of its pixel (ordered by event index), and sub-round r applies
-// the events of rank r.  Pushes are appended in event order with a block scan, which reproduces the
-// reference's queue order exactly.  Queue entries are packed plid<<26 | y<<13 | x.
+// Events = (queue entry, neighbour) in queue order.  A round takes the next FLOOD_T queue ENTRIES that
+// existed when it started; a thread owns one entry and its (up to) four neighbour events, so the
+// entry is decoded once, its plane is read once and the four pixel states are in flight together.
+// The part of an event that does not depend on the pixel's state (unprojection, point-plane distance)
+// is evaluated for all events at once; the per-pixel state machine (membership "trail", distMap)
+// must see its events in queue order, so events that hit the same pixel are serialised: an LDS hash
+// groups the round's events by pixel, every event learns its rank among the events of its pixel
+// (ordered by event index), and sub-round r applies the events of rank r, the state travelling from
+// rank to rank through LDS.  Pushes are appended in event order with a block scan, which reproduces
+// the reference's queue order exactly.  Queue entries are packed plid<<26 | y<<13 | x.
 #define FQ_PACK(x, y, pl) (((pl) << 26) | ((y) << 13) | (x))
 // workgroup barrier that orders LDS traffic only: outstanding global stores are not waited for
 static __device__ __forceinline__ void lds_barrier()
@@ -938,12 +955,14 @@ static __device__ __forceinline__ void lds_barrier()
 template <int FLOOD_T>
 __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long long *__restrict__ adj_out)
 {
-    constexpr int FLOOD_HS = FLOOD_T * 2, FLOOD_HL = 4;
+    constexpr int NEV = FLOOD_T * 4;              // events per round
+    constexpr int FLOOD_HS = NEV * 2, FLOOD_HL = 4;
     __shared__ double pl[MAX_PLANES][8];          // center[3], normal[3], mse, pad
     __shared__ unsigned long long adj[MAX_PLANES];
-    __shared__ int hkeys[FLOOD_HS], hcnt[FLOOD_HS], hlist[FLOOD_HS * FLOOD_HL];
-    __shared__ int evpix[FLOOD_T];                // the round's target pixels (rank fallback for crowded pixels)
-    __shared__ int hlab[FLOOD_HS]; __shared__ float hdist[FLOOD_HS];   // per-pixel state handed from rank to rank
+    __shared__ int hkeys[FLOOD_HS], hcnt[FLOOD_HS];
+    __shared__ __attribute__((aligned(8))) unsigned short hlist[FLOOD_HS * FLOOD_HL];
+    __shared__ uint2 hstate[FLOOD_HS];            // per-pixel state handed from rank to rank: (label, dist bits)
+    __shared__ int evpix[NEV];                    // the round's target pixels (rank fallback for crowded pixels)
     __shared__ int wsum[FLOOD_T / 64];
     __shared__ int s_nq, s_max[2];
     const ClArgs &a = r.c;
@@ -997,7 +1016,7 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
     if (nq > r.qcap) { nq = r.qcap; flags |= 32; }
     const double dfx = (double)r.fx, dfy = (double)r.fy, dcx = (double)r.cx, dcy = (double)r.cy, df = (double)r.dfac;
 #ifdef HVO_PEAC_TIMING
-    unsigned long long ft[6] = {0,0,0,0,0,0}, ftl = clock64();
+    unsigned long long ft[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, ftl = clock64();
 #define FT(i) { const unsigned long long t_ = clock64(); ft[i] += t_ - ftl; ftl = t_; }
 #else
 #define FT(i)
@@ -1018,123 +1037,147 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
             else if (trail < 0) nl = trail - 1;
         } else if (trail < 0) nl = trail - 1;
     };
-    long long ev = 0;
-    int par = 0, qpf = 0, pf_nq = 0;                     // queue entry prefetched for the next round, valid for k < pf_nq
-    while (ev < (long long)nq * 4) {
+    int kq = 0, par = 0, qpf = 0, pf_nq = 0;             // entry cursor; entry prefetched for the next round, valid for k < pf_nq
+    while (kq < nq) {
 #ifdef HVO_PEAC_TIMING
         ft[4]++;
 #endif
-        const long long avail = (long long)nq * 4 - ev;
-        const int nev = avail < FLOOD_T ? (int)avail : FLOOD_T;
+        const int nent = min(FLOOD_T, nq - kq);
         if (tid == 0) s_max[par ^ 1] = 1;
-        int cIdx = -1, plid = 0, cx_ = 0, cy_ = 0, trail0 = 0; unsigned sx0 = 0;
-        bool ok = false; float cdist = -1, dist0 = 0;
+        const int k = kq + tid;
+        const bool own = tid < nent;
+        int q = qpf;
+        if (own && k >= pf_nq) q = queue[k];
+        if (nent == FLOOD_T) { if (k + FLOOD_T < nq) qpf = queue[k + FLOOD_T]; pf_nq = nq; } else pf_nq = 0;
+        const int plid = (int)((unsigned)q >> 26);
+        const int sx = q & 8191, sy = (q >> 13) & 8191;
+        // getValid4Neighbor order: left, right, up, down
+        int cIdx[4], trail0[4]; unsigned sx0[4]; float dist0[4], cdist[4]; bool ok[4], pending[4], push[4];
         {
-            const long long e = ev + tid;
-            const int k = (int)(e >> 2), slot = (int)(e & 3);
-            int q = qpf;
-            if (tid < nev && k >= pf_nq) q = queue[k];
-            // next round's entries, if they exist already (they do while the frontier is long)
-            const int kn = (int)((e + FLOOD_T) >> 2);
-            if (nev == FLOOD_T) { if (kn < nq) qpf = queue[kn]; pf_nq = nq; } else pf_nq = 0;
-            if (tid < nev) {
-                plid = (int)((unsigned)q >> 26);
-                const int sx = q & 8191, sy = (q >> 13) & 8191;
-                // getValid4Neighbor order: left, right, up, down -- slot = index among the EXISTING neighbours
-                const int hasl = sx > 0, hasr = sx < w - 1, hasu = sy > 0, hasd = sy < h - 1;
-                int c = 0; bool hit = false;
-                cx_ = sx; cy_ = sy;
-                if (hasl) { if (c == slot) { cx_ = sx - 1; hit = true; } c++; }
-                if (hasr) { if (c == slot) { cx_ = sx + 1; hit = true; } c++; }
-                if (hasu) { if (c == slot) { cy_ = sy - 1; hit = true; } c++; }
-                if (hasd) { if (c == slot) { cy_ = sy + 1; hit = true; } c++; }
-                if (hit) {
-                    const int pix = cy_ * w + cx_;
-                    const uint2 st = state[pix];                           // the only scattered access of the event
-                    sx0 = st.x; trail0 = FS_LABEL(st.x); dist0 = __uint_as_float(st.y);
-                    if (!(st.x & FS_VALID)) {                              // pixel of a still-valid block: never touched
-                        cIdx = pix;
-                        const int d = (int)(st.x >> 16);
-                        if (d != 0) {
-                            const double z = (double)d * df;
-                            const double x = ((double)cx_ - dcx) * z / dfx, y = ((double)cy_ - dcy) * z / dfy;
-                            const double *P = pl[plid];
-                            const double sd = P[3] * (x - P[0]) + P[4] * (y - P[1]) + P[5] * (z - P[2]);
-                            cdist = (float)fabs(sd);
-                            ok = ((double)cdist * (double)cdist) < 9 * P[6] + 1e-5;
-                        }
+            const bool ex[4] = { own && sx > 0, own && sx < w - 1, own && sy > 0, own && sy < h - 1 };
+            const int px[4] = { sx - 1, sx + 1, sx, sx }, py[4] = { sy, sy, sy - 1, sy + 1 };
+            uint2 st[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { st[j] = make_uint2(FS_VALID, 0); if (ex[j]) st[j] = state[py[j] * w + px[j]]; }   // the only scattered reads
+            const double *P = pl[plid];
+            const double P0 = P[0], P1 = P[1], P2 = P[2], P3 = P[3], P4 = P[4], P5 = P[5], lim = 9 * P[6] + 1e-5;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                sx0[j] = st[j].x; trail0[j] = FS_LABEL(st[j].x); dist0[j] = __uint_as_float(st[j].y);
+                cIdx[j] = -1; ok[j] = false; cdist[j] = -1; push[j] = false;
+                if (!(st[j].x & FS_VALID)) {                               // pixels of still-valid blocks are never touched
+                    cIdx[j] = py[j] * w + px[j];
+                    const int d = (int)(st[j].x >> 16);
+                    if (d != 0) {
+                        const double z = (double)d * df;
+                        const double x = ((double)px[j] - dcx) * z / dfx, y = ((double)py[j] - dcy) * z / dfy;
+                        const double sd = P3 * (x - P0) + P4 * (y - P1) + P5 * (z - P2);
+                        cdist[j] = (float)fabs(sd);
+                        ok[j] = ((double)cdist[j] * (double)cdist[j]) < lim;
                     }
                 }
+                pending[j] = cIdx[j] >= 0;
             }
         }
-        bool pending = cIdx >= 0, push = false;
-        int hs = 0;
         FT(1)
         // ---- group the round's events by pixel ----
-        evpix[tid] = cIdx;
-        if (pending) {
-            hs = (int)(((unsigned)cIdx * 2654435761u) >> 20) & (FLOOD_HS - 1);
-            for (;;) {
-                const int old = atomicCAS(&hkeys[hs], -1, cIdx);
-                if (old == -1 || old == cIdx) break;
-                hs = (hs + 1) & (FLOOD_HS - 1);
+        int hs[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            evpix[tid * 4 + j] = cIdx[j];
+            hs[j] = 0;
+            if (pending[j]) {
+                int s = (int)(((unsigned)cIdx[j] * 2654435761u) >> 19) & (FLOOD_HS - 1);
+                for (;;) {
+                    const int old = atomicCAS(&hkeys[s], -1, cIdx[j]);
+                    if (old == -1 || old == cIdx[j]) break;
+                    s = (s + 1) & (FLOOD_HS - 1);
+                }
+                const int pos = atomicAdd(&hcnt[s], 1);
+                if (pos < FLOOD_HL) hlist[s * FLOOD_HL + pos] = (unsigned short)(tid * 4 + j);
+                hs[j] = s;
             }
-            const int pos = atomicAdd(&hcnt[hs], 1);
-            if (pos < FLOOD_HL) hlist[hs * FLOOD_HL + pos] = tid;
         }
+        FT(6)
         lds_barrier();
-        int rank = 0, cnt = 0;
-        if (pending) {
-            cnt = hcnt[hs];
-            if (cnt <= FLOOD_HL) { for (int i = 0; i < cnt; i++) rank += hlist[hs * FLOOD_HL + i] < tid; }
-            else { for (int t = 0; t < tid; t++) rank += evpix[t] == cIdx; }       // crowded pixel (rare)
+        FT(7)
+        int rank[4], cnt[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            rank[j] = 0; cnt[j] = 0;
+            if (pending[j]) {
+                const int e = tid * 4 + j;
+                cnt[j] = hcnt[hs[j]];
+                if (cnt[j] <= FLOOD_HL) {
+                    const uint2 L = *(const uint2 *)&hlist[hs[j] * FLOOD_HL];
+                    const int l0 = L.x & 0xFFFF, l1 = L.x >> 16, l2 = L.y & 0xFFFF, l3 = L.y >> 16;
+                    rank[j] = (l0 < e) + (cnt[j] > 1 && l1 < e) + (cnt[j] > 2 && l2 < e) + (cnt[j] > 3 && l3 < e);
+                } else { for (int t = 0; t < e; t++) rank[j] += evpix[t] == cIdx[j]; }      // crowded pixel (rare)
+            }
         }
+        FT(8)
         // ---- rank 0 works on the state fetched from memory; later ranks hand the state on through LDS,
         //      the last one writes it back ----
-        if (pending && rank == 0) {
-            pending = false;
-            int nl; float nd;
-            apply(trail0, dist0, plid, ok, cdist, nl, nd, push);
-            if (cnt > 1) { hlab[hs] = nl; hdist[hs] = nd; atomicMax(&s_max[par], cnt); }
-            else if (nl != trail0 || nd != dist0) state[cIdx] = make_uint2((sx0 & ~0xFFu) | ((unsigned)nl & 0xFFu), __float_as_uint(nd));
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (pending[j] && rank[j] == 0) {
+                pending[j] = false;
+                int nl; float nd;
+                apply(trail0[j], dist0[j], plid, ok[j], cdist[j], nl, nd, push[j]);
+                if (cnt[j] > 1) { hstate[hs[j]] = make_uint2((unsigned)nl, __float_as_uint(nd)); atomicMax(&s_max[par], cnt[j]); }
+                else if (nl != trail0[j] || nd != dist0[j]) state[cIdx[j]] = make_uint2((sx0[j] & ~0xFFu) | ((unsigned)nl & 0xFFu), __float_as_uint(nd));
+            }
         }
+        FT(9)
         lds_barrier();
         const int nsub = s_max[par];
         for (int rr = 1; rr < nsub; rr++) {
 #ifdef HVO_PEAC_TIMING
             ft[5]++;
 #endif
-            if (pending && rank == rr) {
-                pending = false;
-                int nl; float nd;
-                apply(hlab[hs], hdist[hs], plid, ok, cdist, nl, nd, push);
-                if (rr == cnt - 1) state[cIdx] = make_uint2((sx0 & ~0xFFu) | ((unsigned)nl & 0xFFu), __float_as_uint(nd));
-                else { hlab[hs] = nl; hdist[hs] = nd; }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (pending[j] && rank[j] == rr) {
+                    pending[j] = false;
+                    const uint2 hsv = hstate[hs[j]];
+                    int nl; float nd;
+                    apply((int)hsv.x, __uint_as_float(hsv.y), plid, ok[j], cdist[j], nl, nd, push[j]);
+                    if (rr == cnt[j] - 1) state[cIdx[j]] = make_uint2((sx0[j] & ~0xFFu) | ((unsigned)nl & 0xFFu), __float_as_uint(nd));
+                    else hstate[hs[j]] = make_uint2((unsigned)nl, __float_as_uint(nd));
+                }
             }
             lds_barrier();
         }
-        if (cIdx >= 0) { hkeys[hs] = -1; hcnt[hs] = 0; }                          // leave the hash empty for the next round
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (cIdx[j] >= 0) { hkeys[hs[j]] = -1; hcnt[hs[j]] = 0; }   // leave the hash empty for the next round
         FT(2)
-        // ---- ordered append: exclusive scan of `push` over the block ----
-        const unsigned long long bm = __ballot(push);
-        const int wcnt = __popcll(bm);
-        if (lane == 0) wsum[wv] = wcnt;
-        lds_barrier();
-        int base = 0, total = 0;
-        for (int i = 0; i < FLOOD_T / 64; i++) { const int v = wsum[i]; if (i < wv) base += v; total += v; }
-        if (push) {
-            const int pos = nq + base + __popcll(bm & ((1ull << lane) - 1));
-            if (pos < r.qcap) queue[pos] = FQ_PACK(cx_, cy_, plid);
+        // ---- ordered append: exclusive scan of the pushes over the block, in event order ----
+        int below = 0, wtot = 0;
+        const unsigned long long ltm = (1ull << lane) - 1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const unsigned long long bm = __ballot(push[j]); below += __popcll(bm & ltm); wtot += __popcll(bm); }
+        int base = 0, total = wtot;
+        if (FLOOD_T > 64) {
+            if (lane == 0) wsum[wv] = wtot;
+            lds_barrier();
+            total = 0;
+            for (int i = 0; i < FLOOD_T / 64; i++) { const int v = wsum[i]; if (i < wv) base += v; total += v; }
+        }
+        {
+            int pos = nq + base + below;
+            const int px[4] = { sx - 1, sx + 1, sx, sx }, py[4] = { sy, sy, sy - 1, sy + 1 };
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (push[j]) { if (pos < r.qcap) queue[pos] = FQ_PACK(px[j], py[j], plid); pos++; }
         }
         nq += total;
         if (nq > r.qcap) { nq = r.qcap; flags |= 32; }
-        ev += nev;
+        kq += nent;
         par ^= 1;
-        __syncthreads();                                 // drains this round's label / dist / queue stores
+        __syncthreads();                                 // drains this round's state / queue stores
         FT(3)
     }
 #ifdef HVO_PEAC_TIMING
-    if (tid == 0) { for (int q = 0; q < 6; q++) atomicAdd(&g_peac_t[16 + q], ft[q]); atomicAdd(&g_peac_t[22], (unsigned long long)nq); atomicAdd(&g_peac_t[23], 1ull); }
+    if (tid == 0) { for (int q = 0; q < 6; q++) atomicAdd(&g_peac_t[16 + q], ft[q]); for (int q = 6; q < 12; q++) atomicAdd(&g_peac_t[18 + q], ft[q]); atomicAdd(&g_peac_t[22], (unsigned long long)nq); atomicAdd(&g_peac_t[23], 1ull); }
 #endif
     if (tid < MAX_PLANES) adj_out[(size_t)frame * MAX_PLANES + tid] = adj[tid];
     if (tid == 0) { meta[5] = nq; meta[7] = flags; }
@@ -1319,14 +1362,13 @@ int peac_run(hvo_ctx *ctx, int n)
     r.blkmap = P->d_blkmap; r.isvalid = P->d_isvalid; r.state = P->d_state; r.queue = P->d_queue;
     r.qcap = P->qcap; r.plidmap = P->d_plidmap; r.planes = P->d_planes; r.c30 = P->c30;
     {
+        // threads per frame (one queue entry = 4 events per thread and round); HVO_FLOOD_T overrides
         const char *e = getenv("HVO_FLOOD_T");
         const int flood_t = e ? atoi(e) : -1;
-        const int ft = flood_t > 0 ? flood_t : (n >= 3072 ? 256 : 512);
+        const int ft = flood_t > 0 ? flood_t : 128;
         if (ft == 64) hipLaunchKernelGGL(k_peac_flood<64>, dim3(n), dim3(64), 0, st, r, P->d_adj);
-        else if (ft == 128) hipLaunchKernelGGL(k_peac_flood<128>, dim3(n), dim3(128), 0, st, r, P->d_adj);
         else if (ft == 256) hipLaunchKernelGGL(k_peac_flood<256>, dim3(n), dim3(256), 0, st, r, P->d_adj);
-        else if (ft == 1024) hipLaunchKernelGGL(k_peac_flood<1024>, dim3(n), dim3(1024), 0, st, r, P->d_adj);
-        else hipLaunchKernelGGL(k_peac_flood<512>, dim3(n), dim3(512), 0, st, r, P->d_adj);
+        else hipLaunchKernelGGL(k_peac_flood<128>, dim3(n), dim3(128), 0, st, r, P->d_adj);
     }
     hipLaunchKernelGGL(k_peac_final, dim3(n), dim3(64), 0, st, r, P->d_adj);
     hipLaunchKernelGGL(k_peac_relabel, dim3(64, n), dim3(256), 0, st, P->d_state, P->d_labels, P->d_plidmap, P->w * P->h);

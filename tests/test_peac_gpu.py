@@ -91,7 +91,7 @@ def test_peac_batch(hvo, orc, synth):
         check(res[b]["labels"], res[b]["planes"], lo, po)
 
 
-@pytest.mark.parametrize("gl,flood_t", [(16, 256), (32, 128), (64, 1024)])
+@pytest.mark.parametrize("gl,flood_t", [(16, 64), (32, 128), (64, 256)])
 def test_peac_batch_grouped_paths(hvo, orc, synth, monkeypatch, gl, flood_t):
     """the configurations large batches select (several frames per wave in lockstep, smaller flood
     blocks), forced on a small ragged batch: 6 frames = one full and one half-empty wave at 16 lanes"""

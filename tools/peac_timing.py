@@ -54,10 +54,12 @@ def main():
     for i in range(8, 12):
         print("  %-18s %.1f per wave" % (NAMES[i], v[i] / nw))
     nf = max(v[23], 1)
-    ftot = v[16:20].sum()
+    ftot = v[16:20].sum()  # (election time excludes the sub-phases listed below)
     print("flood: frames %d, ticks per frame %.3e, queue entries per frame %.0f, rounds %.1f, sub-rounds %.1f" % (nf, ftot / nf, v[22] / nf, v[20] / nf, v[21] / nf))
     for i, nm in enumerate(["seeds", "event precompute", "election sub-rounds", "ordered append"]):
         print("  %-20s %6.2f %%" % (nm, 100 * v[16 + i] / ftot))
+    for i, nm in enumerate(["hash insert", "barrier A", "rank", "rank-0 apply", "(unused)", "(unused)"]):
+        print("    sub-phase %-14s %6.2f %% of flood" % (nm, 100 * v[24 + i] / max(ftot + v[24:30].sum(), 1)))
     ctx.close()
     shutil.rmtree(tmp, ignore_errors=True)
 
