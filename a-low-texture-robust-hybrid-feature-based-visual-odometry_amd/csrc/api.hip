@@ -2,6 +2,8 @@
 // checks, device selection, staging, and dispatch to the per-subsystem batch runners.
 // There is deliberately no CPU path: without a usable gfx950 device every call fails.
 #include "hvo_internal.hpp"
+#include <stdio.h>
+#include <stdlib.h>
 #include <math.h>
 #include <string.h>
 #include <new>
@@ -57,9 +59,12 @@ int hvo_create(const hvo_params *p, hvo_ctx **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) { delete ctx; return HVO_ERR_NO_DEVICE; }
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete ctx; return HVO_ERR_NO_DEVICE; }   // code object is gfx950 only
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->s_lsd, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->s_peac, hipStreamNonBlocking) != hipSuccess) { hvo_destroy(ctx); return HVO_ERR_HIP; }
+    // stream priorities (experiment knob HVO_PRIO="orb,lsd,peac", lower number = higher priority)
+    int pr[3] = { 0, -1, 1 };          // measured best: the LSD chain is the longest, the PEAC kernels fill in
+    { const char *e = getenv("HVO_PRIO"); if (e) sscanf(e, "%d,%d,%d", &pr[0], &pr[1], &pr[2]); }
+    if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, pr[0]) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->s_lsd, hipStreamNonBlocking, pr[1]) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->s_peac, hipStreamNonBlocking, pr[2]) != hipSuccess) { hvo_destroy(ctx); return HVO_ERR_HIP; }
     int rc = orb_init_tables(ctx);
     if (rc) { hvo_destroy(ctx); return rc; }
     *out = ctx;

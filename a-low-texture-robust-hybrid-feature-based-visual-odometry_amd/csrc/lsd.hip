@@ -37,7 +37,7 @@
 struct LsdPlan {
     int w = 0, h = 0, sw = 0, sh = 0, batch = 0, nfeat = 0, nwords = 0;
     double *d_tmp = nullptr, *d_blur = nullptr;            // w*h doubles each
-    double *d_modgrad = nullptr, *d_ang = nullptr, *d_cs = nullptr, *d_sn = nullptr;   // sw*sh
+    double4 *d_px = nullptr;           // sw*sh x {angle, cos, sin, modgrad}: one 32-byte record per scaled pixel
     unsigned *d_defined = nullptr;                          // bitmask, nwords per frame
     int *d_reg = nullptr;                                   // sw*sh ints
     float *d_segs = nullptr;                                // LSD_MAXSEG x 4
@@ -140,8 +140,7 @@ static __device__ __forceinline__ double scaled_at(const double *B, int w, int x
 __global__ __launch_bounds__(256) void k_lsd_resize_grad(const double *__restrict__ blur, int w, int h, int sw, int sh,
                                                          const int *__restrict__ xofs, const float *__restrict__ xa,
                                                          const int *__restrict__ yofs, const float *__restrict__ yb,
-                                                         double *__restrict__ modgrad, double *__restrict__ ang,
-                                                         double *__restrict__ cs, double *__restrict__ sn,
+                                                         double4 *__restrict__ px4,
                                                          unsigned *__restrict__ defined, int nwords, double rho)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
@@ -164,7 +163,7 @@ __global__ __launch_bounds__(256) void k_lsd_resize_grad(const double *__restric
                 def = true;
             }
         }
-        modgrad[o] = m; ang[o] = a; cs[o] = c; sn[o] = s;
+        px4[o] = make_double4(a, c, s, m);
     }
     // 256 threads = 8 words of 32 bits; rows are padded to a multiple of 32 bits in the mask
     const unsigned long long bal = __ballot(def);
@@ -179,7 +178,7 @@ __global__ __launch_bounds__(256) void k_lsd_resize_grad(const double *__restric
 // k_lsd_grow: the serial heart of LSD, one wave per frame
 // ------------------------------------------------------------------------------------------------
 struct GrowArgs {
-    const double *modgrad, *ang, *cs, *sn; const unsigned *defined; int *reg; float *segs;
+    const double4 *px4; const unsigned *defined; int *reg; float *segs;
     hvo_keyline *kl_all, *kl; double *fn; int *nkl; int *flags; long long *stats;
     int sw, sh, nwords, w, h, nfeat, kl_cap;
     double rho, prec, p; unsigned min_reg;
@@ -188,7 +187,7 @@ struct GrowArgs {
 struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy; };
 
 struct GrowState {
-    const double *modgrad, *ang, *cs, *sn; int *reg; unsigned *used; int *ring;
+    const double4 *px4; int *reg; unsigned *used; int *ring;      // px4: {angle, cos, sin, modgrad}
     int sw, sh, wpr;          // wpr = mask words per row
 };
 
@@ -213,6 +212,10 @@ static __device__ __forceinline__ double angle_diff_signed(double a, double b)
 // and the remaining lanes re-evaluate against the new angle.  Neighbours tested before the cursor are
 // never revisited, like the reference's single pass.
 #define GROW_SLOTS 4
+static __device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 static __device__ __forceinline__ bool lsd_aligned(double a, double theta, double prec)
 {
     double n_theta = theta - a;
@@ -225,7 +228,7 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
 {
     const int lane = threadIdx.x, sw = S.sw, sh = S.sh;
     const int sx0 = seed_xy & 0xFFFF, sy0 = seed_xy >> 16;
-    const double a0 = S.ang[sx0 + sy0 * sw];
+    const double a0 = S.px4[sx0 + sy0 * sw].x;
     double ra = a0;
     float sumdx = (float)cos(a0), sumdy = (float)sin(a0);
     if (lane == 0) { S.reg[0] = seed_xy; S.ring[0] = seed_xy; used_set(S, sx0, sy0); }
@@ -245,10 +248,12 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
                 const int idx = i + k;
                 const int pxy = (rs - idx <= LSD_RING) ? S.ring[idx & (LSD_RING - 1)] : S.reg[idx];
                 const int xx = (pxy & 0xFFFF) + jx, yy = (pxy >> 16) + jy;
-                if (xx >= 0 && yy >= 0 && xx < sw && yy < sh) {
-                    const int ad = xx + yy * sw;
-                    const double a = S.ang[ad];
-                    if (a != LSD_NOTDEF && !used_get(S, xx, yy)) { c[s] = (yy << 16) | xx; an[s] = a; cs[s] = S.cs[ad]; sn[s] = S.sn[ad]; valid[s] = true; }
+                // `used` starts as the complement of the "defined" mask, so one LDS bit test rejects both the
+                // pixels without a gradient angle and the ones already taken; only real candidates go to memory,
+                // and they fetch angle, cos and sin in one 32-byte record
+                if (xx >= 0 && yy >= 0 && xx < sw && yy < sh && !used_get(S, xx, yy)) {
+                    const double4 r = S.px4[xx + yy * sw];
+                    c[s] = (yy << 16) | xx; an[s] = r.x; cs[s] = r.y; sn[s] = r.z; valid[s] = true;
                 }
             }
         }
@@ -261,8 +266,9 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
                 const unsigned long long m = __ballot(al) & ~done_mask;
                 if (!m) break;
                 const int L = __ffsll((long long)m) - 1;
-                const int cA = __shfl(c[s], L);
-                const double csA = __shfl(cs[s], L), snA = __shfl(sn[s], L);
+                // L is wave-uniform: read lane L's registers directly instead of a cross-lane permute through LDS
+                const int cA = __builtin_amdgcn_readlane(c[s], L);
+                const double csA = readlane_f64(cs[s], L), snA = readlane_f64(sn[s], L);
                 if (lane == 0) { used_set(S, cA & 0xFFFF, cA >> 16); S.reg[rs] = cA; S.ring[rs & (LSD_RING - 1)] = cA; }
                 ++rs;
                 sumdx = (float)((double)sumdx + csA);
@@ -298,7 +304,7 @@ static __device__ void region2rect_wave(const GrowState &S, int reg_size, double
     for (int base = 0; base < reg_size; base += 64) {
         const int i = base + lane;
         double t0 = 0, t1 = 0, t2 = 0;
-        if (i < reg_size) { const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; const double wgt = S.modgrad[px + py * sw]; t0 = (double)px * wgt; t1 = (double)py * wgt; t2 = wgt; }
+        if (i < reg_size) { const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; const double wgt = S.px4[px + py * sw].w; t0 = (double)px * wgt; t1 = (double)py * wgt; t2 = wgt; }
         b0[lane] = t0; b1[lane] = t1; b2[lane] = t2;
         __syncthreads();
         if (lane == 0) seq_add3(b0, b1, b2, x, y, sum);
@@ -312,7 +318,7 @@ static __device__ void region2rect_wave(const GrowState &S, int reg_size, double
         const int i = base + lane;
         double t0 = 0, t1 = 0, t2 = 0;
         if (i < reg_size) {
-            const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; const double wgt = S.modgrad[px + py * sw];
+            const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; const double wgt = S.px4[px + py * sw].w;
             const double dx = (double)px - x, dy = (double)py - y;
             t0 = dy * dy * wgt; t1 = dx * dx * wgt; t2 = -(dx * dy * wgt);      // a -= b  ==  a += (-b), exactly
         }
@@ -365,7 +371,7 @@ static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle
     if (density >= density_th) return true;
     const int a0 = S.reg[0];
     const double xc = (double)(a0 & 0xFFFF), yc = (double)(a0 >> 16);
-    const double ang_c = S.ang[(a0 & 0xFFFF) + (a0 >> 16) * sw];
+    const double ang_c = S.px4[(a0 & 0xFFFF) + (a0 >> 16) * sw].x;
     double sum = 0, s_sum = 0, dummy = 0; int n = 0;
     for (int base = 0; base < reg_size; base += 64) {
         const int i = base + lane;
@@ -375,7 +381,7 @@ static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle
             n_addr[lane] = a;
             const double ddx = (double)px - xc, ddy = (double)py - yc;
             if (sqrt(ddx * ddx + ddy * ddy) < rec.width) {
-                const double ang_d = angle_diff_signed(S.ang[px + py * sw], ang_c);
+                const double ang_d = angle_diff_signed(S.px4[px + py * sw].x, ang_c);
                 t0 = ang_d; t1 = ang_d * ang_d; in = true;
             }
         }
@@ -449,11 +455,11 @@ __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
     const int sw = g.sw, sh = g.sh, wpr = (sw + 31) / 32, nwords = g.nwords;
     const size_t np = (size_t)sw * sh;
     GrowState S;
-    S.modgrad = g.modgrad + f * np; S.ang = g.ang + f * np; S.cs = g.cs + f * np; S.sn = g.sn + f * np;
+    S.px4 = g.px4 + f * np;
     S.reg = g.reg + f * np; S.used = used_lds; S.ring = ring; S.sw = sw; S.sh = sh; S.wpr = wpr;
     const unsigned *defined = g.defined + (size_t)f * nwords;
     float *segs = g.segs + (size_t)f * LSD_MAXSEG * 4;
-    for (int i = lane; i < nwords; i += 64) used_lds[i] = 0;
+    for (int i = lane; i < nwords; i += 64) used_lds[i] = ~defined[i];      // undefined pixels can never join a region
     __syncthreads();
     int nseg = 0, flags = 0;
     long long st_seeds = 0, st_pts = 0, st_tg = 0, st_tr = 0, st_tf = 0, st_big = 0;
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
         for (;;) {
             const int wi = wbase + lane;
             unsigned m = 0;
-            if (wi < nwords) m = defined[wi] & ~used_lds[wi];
+            if (wi < nwords) m = ~used_lds[wi];
             const unsigned long long nz = __ballot(m != 0);
             if (!nz) break;
             const int wl = __ffsll((long long)nz) - 1;
@@ -697,7 +703,7 @@ void lsd_free(hvo_ctx *ctx)
 {
     LsdPlan *P = plan_of(ctx);
     if (!P) return;
-    void *ptrs[] = { P->d_tmp, P->d_blur, P->d_modgrad, P->d_ang, P->d_cs, P->d_sn, P->d_defined, P->d_reg, P->d_segs, P->d_kl_all, P->d_kl,
+    void *ptrs[] = { P->d_tmp, P->d_blur, P->d_px, P->d_defined, P->d_reg, P->d_segs, P->d_kl_all, P->d_kl,
                      P->d_desc, P->d_fn, P->d_nkl, P->d_flags, P->d_b5, P->d_dx, P->d_dy, P->d_xofs, P->d_yofs, P->d_xa, P->d_yb, P->d_gL, P->d_gG, P->d_stats };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
@@ -759,7 +765,7 @@ static int lsd_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
     const size_t B = batch, npix = (size_t)w * h, nsp = (size_t)P->sw * P->sh;
 #define PA(ptr, n) HVO_HIP(hipMalloc((void **)&(ptr), (n)))
     PA(P->d_tmp, B * npix * 8); PA(P->d_blur, B * npix * 8);
-    PA(P->d_modgrad, B * nsp * 8); PA(P->d_ang, B * nsp * 8); PA(P->d_cs, B * nsp * 8); PA(P->d_sn, B * nsp * 8);
+    PA(P->d_px, B * nsp * sizeof(double4));
     PA(P->d_defined, B * P->nwords * 4); PA(P->d_reg, B * nsp * 4);
     PA(P->d_segs, B * LSD_MAXSEG * 16); PA(P->d_kl_all, B * LSD_MAXSEG * sizeof(hvo_keyline));
     PA(P->d_kl, B * P->nfeat * sizeof(hvo_keyline)); PA(P->d_desc, B * P->nfeat * 32); PA(P->d_fn, B * P->nfeat * 24);
@@ -798,11 +804,11 @@ int lsd_run(hvo_ctx *ctx, int n)
     id = hvo_prof_begin(ctx, "lsd_gradient", st);
     const int gx = (((sw + 31) & ~31) + 255) / 256;
     hipLaunchKernelGGL(k_lsd_resize_grad, dim3(gx, sh, n), dim3(256), 0, st, P->d_blur, w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb,
-                       P->d_modgrad, P->d_ang, P->d_cs, P->d_sn, P->d_defined, P->nwords, P->rho);
+                       P->d_px, P->d_defined, P->nwords, P->rho);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lsd_grow", st);
     GrowArgs g;
-    g.modgrad = P->d_modgrad; g.ang = P->d_ang; g.cs = P->d_cs; g.sn = P->d_sn; g.defined = P->d_defined; g.reg = P->d_reg; g.segs = P->d_segs;
+    g.px4 = P->d_px; g.defined = P->d_defined; g.reg = P->d_reg; g.segs = P->d_segs;
     g.stats = P->d_stats; g.kl_all = P->d_kl_all; g.kl = P->d_kl; g.fn = P->d_fn; g.nkl = P->d_nkl; g.flags = P->d_flags;
     g.sw = sw; g.sh = sh; g.nwords = P->nwords; g.w = w; g.h = h; g.nfeat = P->nfeat; g.kl_cap = P->nfeat;
     g.rho = P->rho; g.prec = P->prec; g.p = P->p; g.min_reg = P->min_reg;

@@ -465,6 +465,45 @@ static __device__ void gheap_sift_down(double *key, int *id, int n, int i, doubl
     if (act && gl == 0) { key[i] = k; id[i] = idv; }
 }
 
+// Optionally the top three levels of the 16-ary heap (1 + 16 + 256 entries) live in LDS.  Measured: no
+// gain for the kernel alone (the sift is bound by the cross-lane reduction, not by the loads) and a loss
+// for the whole front-end, because LDS is the resource k_lsd_grow exhausts while both kernels run.
+#ifndef GH_TOP
+#define GH_TOP 0            // 273 = cache three levels; 0 = heap entirely in global memory (see note)
+#endif
+struct GHeap {
+    double *gk; int *gi;       // global arrays (entries >= GH_TOP are authoritative there)
+    double *lk; int *li;       // LDS copy of entries < GH_TOP (authoritative)
+    __device__ __forceinline__ double key(int i) const { return i < GH_TOP ? lk[i] : gk[i]; }
+    __device__ __forceinline__ int id(int i) const { return i < GH_TOP ? li[i] : gi[i]; }
+    __device__ __forceinline__ void set(int i, double k, int v) const { if (i < GH_TOP) { lk[i] = k; li[i] = v; } else { gk[i] = k; gi[i] = v; } }
+};
+// sift (k, idv) down from the root; returns the id that ends up AT the root, i.e. the next top
+template <int GL>
+static __device__ int gheap_sift_root(const GHeap &H, int n, double k, int idv, bool act)
+{
+    const int gl = Grp<GL>::gl();
+    int i = 0, root = idv;
+    bool go = act;
+    while (__any(go)) {
+        const int c0 = GH_ARY * i + 1;
+        const bool cont = go && c0 < n;
+        double ck = 1.0e308; int cid = 0x7FFFFFFF, ci = -1;
+        if (cont && gl < GH_ARY && c0 + gl < n) { ci = c0 + gl; ck = H.key(ci); cid = H.id(ci); }
+#pragma unroll
+        for (int o = 1; o < GH_ARY; o <<= 1) {
+            const double ok = __shfl_xor(ck, o); const int oid = __shfl_xor(cid, o), oi = __shfl_xor(ci, o);
+            if (oi >= 0 && (ci < 0 || hless(ok, oid, ck, cid))) { ck = ok; cid = oid; ci = oi; }
+        }
+        ck = Grp<GL>::shfl(ck, 0); cid = Grp<GL>::shfl(cid, 0); ci = Grp<GL>::shfl(ci, 0);
+        const bool mv = cont && ci >= 0 && hless(ck, cid, k, idv);
+        if (mv) { if (gl == 0) H.set(i, ck, cid); if (i == 0) root = cid; i = ci; }
+        go = mv;
+    }
+    if (act && gl == 0) H.set(i, k, idv);
+    return root;
+}
+
 template <int GL>
 static __device__ void gheap_push(double *key, int *id, int &n, double k, int idv, bool act)
 {
@@ -530,7 +569,7 @@ static __device__ void gpool_gc(int *segI, int nseg, int *&pool, int *&pool2, in
 // That is three reductions (min mse; min id with N >= mse; max id), so lists need no order, merging
 // two lists is mark / test / compact in parallel, and removing an id is replace-or-swap-with-last.
 template <int GL>
-static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hkey, int *hid, int &hn, int &nseg, int &pooltop,
+static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHeap &H, int &hn, int &nseg, int &pooltop,
                                           int *&pool, int *&pool2, int *ext, int &next, int &flags)
 {
     const int gl = Grp<GL>::gl(), gb = Grp<GL>::gb();
@@ -539,55 +578,67 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
     int *parent = a.parent + (size_t)frame * a.nblk, *dsize = a.dsize + (size_t)frame * a.nblk;
     const unsigned long long lt_mask = (1ull << gl) - 1;       // lanes of my group below me
     PT_DECL
+    // The heap is touched once per iteration: the popped root is only replaced at the end, by the merged
+    // node (merge) or by the last entry (no merge), with one sift-down that also yields the next top.
+    __syncthreads();
+    int ptop = hn > 0 ? H.id(0) : -1;
     while (__any(hn > 0)) {
         const bool act = hn > 0;
         PT_CNT(8, 1)
         const bool need_gc = act && pooltop > a.poolcap - 2 * a.nblk;
         if (__any(need_gc)) gpool_gc<GL>(segI, nseg, pool, pool2, pooltop, need_gc);
-        // ---- pop ----
+        __syncthreads();                                       // the previous iteration's stores (lists, records, heap)
         PT(0)
-        const int p = gheap_pop<GL>(hkey, hid, hn, act);
+        const int p = act ? ptop : -1;
+        double lastk = 0; int lastid = 0;
+        if (act) { lastk = H.key(hn - 1); lastid = H.id(hn - 1); }
         PT(1)
         int *pi = segI + (size_t)(p < 0 ? 0 : p) * SEG_I;
         const double *pd = segD + (size_t)(p < 0 ? 0 : p) * SEG_D;
         const bool live = act && pi[2] == 0;                   // skip nouse nodes (lazy deletion)
-        const int pcnt = live ? pi[4] : 0, poff = pi[3], pN = pi[0];
+        const int pcnt = live ? pi[4] : 0, poff = pi[3], pN = pi[0], prid = pi[1];
         double ps[9], pn[3];                                   // popped node: sums and normal (uniform per group)
 #pragma unroll
         for (int q = 0; q < 9; q++) ps[q] = pd[q];
         pn[0] = pd[12]; pn[1] = pd[13]; pn[2] = pd[14];
         // ---- evaluate the merge with every neighbour, one candidate per lane; each lane keeps its best ----
         bool bhas = false; double bm = 0; int bid = 0x7FFFFFFF, bN = 0, gid = 0x7FFFFFFF, xid = -1;
+        int brid = 0, bnoff = 0, bncnt = 0;                    // the candidate's rid and list, fetched with its sums
         double bst[9], bc[3] = { 0, 0, 0 }, bn[3] = { 0, 0, 0 };
 #pragma unroll
         for (int q = 0; q < 9; q++) bst[q] = 0;
+        const int a0 = gl < pcnt ? pool[poff + gl] : -1;       // first chunk of p's list, reused by the merge
         PT(2)
         for (int base = 0; __any(base < pcnt); base += GL) {
             PT_CNT(9, 1)
             const int k = base + gl;
-            double lst[9]; int lN = 4, nb = 0; bool has = false;
+            double lst[9]; int lN = 4, nb = 0, nrid = 0, noff_ = 0, ncnt_ = 0; bool has = false;
 #pragma unroll
             for (int q = 0; q < 9; q++) lst[q] = 0;
             if (k < pcnt) {
-                nb = pool[poff + k];
+                nb = base == 0 ? a0 : pool[poff + k];
                 const double *nd = segD + (size_t)nb * SEG_D;
+                const int *nI = segI + (size_t)nb * SEG_I;
+                const int nN = nI[0]; nrid = nI[1]; noff_ = nI[3]; ncnt_ = nI[4];
                 if (!(fabs(pn[0] * nd[12] + pn[1] * nd[13] + pn[2] * nd[14]) < a.c60)) {      // T_ang(P_MERGING)
 #pragma unroll
                     for (int q = 0; q < 9; q++) lst[q] = ps[q] + nd[q];
-                    lN = pN + segI[(size_t)nb * SEG_I];
+                    lN = pN + nN;
                     has = true;
                 }
             }
             // one 3x3 eigen-solve pass serves every group (uniform call: no divergence inside)
             if (__any(has)) {
                 double tc[3], tn[3], tm;
+                PT(2)
                 stats_compute_dev(lst, lN, tc, tn, tm);
+                PT(4)
                 if (has) {
                     const bool good = (double)lN >= tm, better = !bhas || tm < bm, equal = bhas && tm == bm;
                     if (better) { gid = good ? nb : 0x7FFFFFFF; xid = nb; }
                     else if (equal) { if (good && nb < gid) gid = nb; if (nb > xid) xid = nb; }
                     if (better || (equal && nb < bid)) {                   // payload follows (mse, id)
-                        bid = nb; bN = lN;
+                        bid = nb; bN = lN; brid = nrid; bnoff = noff_; bncnt = ncnt_;
 #pragma unroll
                         for (int q = 0; q < 9; q++) bst[q] = lst[q];
 #pragma unroll
@@ -603,15 +654,15 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
 #pragma unroll
         for (int o = 1; o < GL; o <<= 1) { const double t = __shfl_xor(gmin, o); gmin = t < gmin ? t : gmin; }
         const bool tied = bhas && bm == gmin;
-        int rg = tied ? gid : 0x7FFFFFFF, rx = tied ? xid : -1, rb = tied ? bid : 0x7FFFFFFF;
+        int rg = tied ? gid : 0x7FFFFFFF, rx = tied ? xid : -1;
 #pragma unroll
         for (int o = 1; o < GL; o <<= 1) {
-            const int t0 = __shfl_xor(rg, o), t1 = __shfl_xor(rx, o), t2 = __shfl_xor(rb, o);
-            rg = min(rg, t0); rx = max(rx, t1); rb = min(rb, t2);
+            const int t0 = __shfl_xor(rg, o), t1 = __shfl_xor(rx, o);
+            rg = min(rg, t0); rx = max(rx, t1);
         }
         const bool any_cand = Grp<GL>::ballot(bhas) != 0;
         const int win = rg != 0x7FFFFFFF ? rg : rx;            // neighbour id to merge with (if any_cand)
-        double st[9], c[3], n[3], m; int mN;
+        double st[9], c[3], n[3], m; int mN, nrid, noff, ncnt;
         {
             // the winner's fit from the lane that holds it (groups without one read a dummy lane and ignore it)
             const unsigned long long wm = Grp<GL>::ballot(tied && bid == win);
@@ -621,6 +672,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
 #pragma unroll
             for (int q = 0; q < 3; q++) { c[q] = __shfl(bc[q], src); n[q] = __shfl(bn[q], src); }
             m = __shfl(bm, src); mN = __shfl(bN, src);
+            nrid = __shfl(brid, src); noff = __shfl(bnoff, src); ncnt = __shfl(bncnt, src);
             // tie broken by the N-vs-mse clause towards a candidate whose fit no lane kept: fit it again
             const bool refit = any_cand && wm == 0;
             if (__any(refit)) {
@@ -629,9 +681,10 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
                 for (int q = 0; q < 9; q++) lst[q] = 0;
                 if (refit) {
                     const double *nd = segD + (size_t)win * SEG_D;
+                    const int *nI = segI + (size_t)win * SEG_I;
 #pragma unroll
                     for (int q = 0; q < 9; q++) lst[q] = ps[q] + nd[q];
-                    lN = pN + segI[(size_t)win * SEG_I];
+                    lN = pN + nI[0]; nrid = nI[1]; noff = nI[3]; ncnt = nI[4];
                 }
                 double tc[3], tn[3], tm;
                 stats_compute_dev(lst, lN, tc, tn, tm);
@@ -647,66 +700,64 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
         PT(3)
         // ---- merge decision ----
         const int nb = win;
-        int ncnt = 0, noff = 0; int *ni = segI;
         bool do_merge = false;
         if (live && any_cand) {
-            ni = segI + (size_t)nb * SEG_I;
             const double t = 1.6e-6 * c[2] * c[2] + 8.0;        // T_mse(P_MERGING)
             if (m < t * t) {
-                ncnt = ni[4]; noff = ni[3];
                 if (nseg >= a.segcap || pooltop + pcnt + ncnt > a.poolcap) flags |= 8;     // capacity: keep the node unmerged
                 else do_merge = true;
             }
         }
+        if (!do_merge) ncnt = 0;
+        const int id = nseg;
         PT(4)
         if (__any(do_merge)) {
             PT_CNT(10, 1)
-            const int id = nseg;
             if (do_merge) nseg++;
             const int moff = pooltop;
-            // new.nbs = (p.nbs U nb.nbs) \ {p, nb}.  Mark nb's neighbours with the new id (ids only grow, so
-            // marks never need clearing); pass A copies p's list and, per neighbour, rewrites that
-            // neighbour's own list (p -> new id; nb dropped when the mark says it holds both) and flips the
-            // mark to -id; pass B copies what is left of nb's list (mark still +id) and rewrites nb -> id.
-            for (int k = gl; __any(do_merge && k < ncnt); k += GL)
-                if (do_merge && k < ncnt) { const int v = pool[noff + k]; if (v != p) segI[(size_t)v * SEG_I + 7] = id; }
-            __syncthreads();
+            // new.nbs = (p.nbs U nb.nbs) \ {p, nb}, and every member's own list gets p / nb replaced by the
+            // new id.  Pass B walks nb's list: a member that also holds p is left to pass A (read only here);
+            // the others are copied and get nb -> id.  Pass A walks p's list: copy, p -> id, nb dropped.
+            // B only writes lists of nodes that are not p's neighbours and reads the others before A writes
+            // them, so no ordering beyond program order is needed.
+            int qa_off = 0, qa_cnt = 0;                         // pass A's first round trip, started early
+            if (do_merge && a0 >= 0 && a0 != nb) { const int *qi = segI + (size_t)a0 * SEG_I; qa_off = qi[3]; qa_cnt = qi[4]; }
             int mcnt = 0;
-            // pass A: p's neighbours except nb; a marked one is also nb's neighbour
+            for (int base = 0; __any(base < ncnt); base += GL) {
+                const int k = base + gl;
+                int v = -1; bool keep = false;
+                if (k < ncnt) {
+                    v = pool[noff + k];
+                    if (v != p) {
+                        const int *qi = segI + (size_t)v * SEG_I;
+                        const int off = qi[3], cnt = qi[4];
+                        int i1, i2;
+                        list_find2(pool, off, cnt, nb, p, true, i1, i2);
+                        if (i2 < 0) { keep = true; if (i1 >= 0) pool[off + i1] = id; }
+                    }
+                }
+                const unsigned long long km = Grp<GL>::ballot(keep);
+                if (keep) pool[moff + mcnt + __popcll(km & lt_mask)] = v;
+                mcnt += __popcll(km);
+            }
             for (int base = 0; __any(do_merge && base < pcnt); base += GL) {
                 const int k = base + gl;
                 int v = -1; bool keep = false;
-                if (do_merge && k < pcnt) { v = pool[poff + k]; keep = v != nb; }
-                const unsigned long long km = Grp<GL>::ballot(keep);
-                if (keep) {
-                    int *qi = segI + (size_t)v * SEG_I;
-                    const bool both = qi[7] == id;
-                    if (both) qi[7] = -id;                     // "already taken from p's list"
-                    pool[moff + mcnt + __popcll(km & lt_mask)] = v;
-                    // v's own list: p (and nb) -> the new id
-                    const int off = qi[3], cnt = qi[4];
-                    int i1, i2;
-                    list_find2(pool, off, cnt, p, nb, both, i1, i2);
-                    if (i1 >= 0) pool[off + i1] = id;
-                    if (i2 >= 0) { if (i2 != cnt - 1) pool[off + i2] = pool[off + cnt - 1]; qi[4] = cnt - 1; }
+                if (do_merge && k < pcnt) {
+                    v = base == 0 ? a0 : pool[poff + k];
+                    if (v != nb) {
+                        keep = true;
+                        int *qi = segI + (size_t)v * SEG_I;
+                        int off = qa_off, cnt = qa_cnt;
+                        if (base != 0) { off = qi[3]; cnt = qi[4]; }
+                        int i1, i2;
+                        list_find2(pool, off, cnt, p, nb, true, i1, i2);
+                        if (i1 >= 0) pool[off + i1] = id;
+                        if (i2 >= 0) { if (i2 != cnt - 1) pool[off + i2] = pool[off + cnt - 1]; qi[4] = cnt - 1; }
+                    }
                 }
-                mcnt += __popcll(km);
-            }
-            __syncthreads();                                   // pass A's marks / list edits before pass B reads them
-            // pass B: nb's neighbours except p and those already taken
-            for (int base = 0; __any(do_merge && base < ncnt); base += GL) {
-                const int k = base + gl;
-                int v = -1; bool keep = false;
-                if (do_merge && k < ncnt) { v = pool[noff + k]; keep = v != p && segI[(size_t)v * SEG_I + 7] != -id; }
                 const unsigned long long km = Grp<GL>::ballot(keep);
-                if (keep) {
-                    int *qi = segI + (size_t)v * SEG_I;
-                    pool[moff + mcnt + __popcll(km & lt_mask)] = v;
-                    const int off = qi[3], cnt = qi[4];
-                    int i1, i2;
-                    list_find2(pool, off, cnt, nb, nb, false, i1, i2);
-                    if (i1 >= 0) pool[off + i1] = id;
-                }
+                if (keep) pool[moff + mcnt + __popcll(km & lt_mask)] = v;
                 mcnt += __popcll(km);
             }
             PT(5)
@@ -716,38 +767,44 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, double *hk
                 for (int q = 0; q < 9; q++) md[q] = st[q];
                 md[9] = c[0]; md[10] = c[1]; md[11] = c[2]; md[12] = n[0]; md[13] = n[1]; md[14] = n[2]; md[15] = m;
                 int *mi = segI + (size_t)id * SEG_I;
-                mi[0] = mN; mi[1] = pN >= ni[0] ? pi[1] : ni[1]; mi[2] = 0; mi[3] = moff; mi[4] = mcnt; mi[5] = pcnt + ncnt; mi[6] = 1; mi[7] = 0;
-                int xr = ds_find_ro(parent, pi[1]), yr = ds_find_ro(parent, ni[1]);       // ds.Union(pa.rid, pb.rid)
+                mi[0] = mN; mi[1] = pN >= mN - pN ? prid : nrid; mi[2] = 0; mi[3] = moff; mi[4] = mcnt; mi[5] = pcnt + ncnt; mi[6] = 1; mi[7] = 0;
+                int xr = ds_find_ro(parent, prid), yr = ds_find_ro(parent, nrid);          // ds.Union(pa.rid, pb.rid)
                 if (xr != yr) {
                     if (dsize[xr] < dsize[yr]) { parent[xr] = yr; dsize[yr] += dsize[xr]; }
                     else { parent[yr] = xr; dsize[xr] += dsize[yr]; }
                 }
+                int *ni = segI + (size_t)nb * SEG_I;
                 pi[2] = 1; ni[2] = 1; pi[4] = 0; ni[4] = 0;
             }
             if (do_merge) pooltop += pcnt + ncnt;
-            __syncthreads();
             PT(7)
-            gheap_push<GL>(hkey, hid, hn, m, id, do_merge);
-            __syncthreads();
-            PT(6)
         }
         const bool no_merge = live && !do_merge;
         if (__any(no_merge)) {
             PT_CNT(11, 1)
             if (no_merge) {
                 if (pN >= MIN_SUPPORT) { if (next < MAX_PLANES) { if (gl == 0) ext[next] = p; next++; } else flags |= 16; }
-                for (int k = gl; k < pcnt; k += GL) {                                      // disconnectAllNbs
-                    int *qi = segI + (size_t)pool[poff + k] * SEG_I;
-                    const int off = qi[3], cnt = qi[4];
-                    int i1, i2;
-                    list_find2(pool, off, cnt, p, p, false, i1, i2);
-                    if (i1 >= 0) { if (i1 != cnt - 1) pool[off + i1] = pool[off + cnt - 1]; qi[4] = cnt - 1; }
+                for (int base = 0; base < pcnt; base += GL) {                              // disconnectAllNbs
+                    const int k = base + gl;
+                    if (k < pcnt) {
+                        int *qi = segI + (size_t)(base == 0 ? a0 : pool[poff + k]) * SEG_I;
+                        const int off = qi[3], cnt = qi[4];
+                        int i1, i2;
+                        list_find2(pool, off, cnt, p, p, false, i1, i2);
+                        if (i1 >= 0) { if (i1 != cnt - 1) pool[off + i1] = pool[off + cnt - 1]; qi[4] = cnt - 1; }
+                    }
                 }
+                if (gl == 0) pi[4] = 0;
             }
-            __syncthreads();
-            if (no_merge && gl == 0) pi[4] = 0;
-            __syncthreads();
         }
+        // ---- the heap: the merged node, or the last entry, replaces the popped root ----
+        {
+            double k = m; int idv = id; bool sift = do_merge;
+            if (act && !do_merge) { hn--; k = lastk; idv = lastid; sift = hn > 0; }
+            ptop = gheap_sift_root<GL>(H, hn, k, idv, sift);
+            if (!sift) ptop = -1;
+        }
+        PT(6)
     }
     // std::sort by N descending, ties -> extraction order (stable insertion sort)
     __syncthreads();
@@ -771,6 +828,8 @@ template <int GL>
 __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
 {
     constexpr int NG = 64 / GL;
+    __shared__ double lks[NG][GH_TOP + 1];
+    __shared__ int lis[NG][GH_TOP + 1];
     const int lane = threadIdx.x, gl = Grp<GL>::gl(), gid = lane / GL;
     int frame = blockIdx.x * NG + gid;
     const bool galive = frame < nframes;
@@ -858,7 +917,10 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
 #endif
     int nseg = nblk, pooltop = nblk * 4, next = 0, flags = 0;
     int *ext = a.extracted + (size_t)frame * 2 * MAX_PLANES;
-    ah_cluster_grouped<GL>(a, frame, hkey, hid, hn, nseg, pooltop, pool, pool2, ext, next, flags);
+    GHeap H; H.gk = hkey; H.gi = hid; H.lk = lks[gid]; H.li = lis[gid];
+    __syncthreads();
+    for (int i = gl; i < min(hn, GH_TOP); i += GL) { H.lk[i] = hkey[i]; H.li[i] = hid[i]; }
+    ah_cluster_grouped<GL>(a, frame, H, hn, nseg, pooltop, pool, pool2, ext, next, flags);
     if (galive && gl == 0) {
         int *meta = a.meta + (size_t)frame * 16;
         meta[0] = nseg; meta[1] = pooltop; meta[2] = next; meta[3] = flags;

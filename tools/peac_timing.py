@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
-NAMES = ["nomerge+gc", "pop", "load popped", "evaluate", "decision", "list merge", "push", "nb update",
+NAMES = ["sync+gc", "last-entry load", "eval: loads", "eval: reduce+bcast", "eval: eigen-solve (+decision)", "list merge", "push", "nb update",
          "#iters", "#eval passes", "#merge iters", "#nomerge iters", "init edges+lists", "heapify", "#waves"]
 
 
