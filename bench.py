@@ -62,6 +62,22 @@ def algorithmic_bytes(group, w, h, nkp, nlines):
     return table.get(group, 0), 4 * S + 60 * nkp
 
 
+def hbm_traffic(group, B, width):
+    """HBM bytes per launch of a kernel group from the PMC counters (FETCH_SIZE + WRITE_SIZE, collected in
+    separate rocprofv3 --pmc passes of this same command and committed as profiles/r01_hbm_traffic.json --
+    counters cannot be read from inside the process).  None when the committed measurement does not
+    cover this configuration."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            t = json.load(f)
+        if t.get("frames_per_launch") != B or width != 640 or group not in t["bytes_per_frame"]:
+            return None
+        e = t["bytes_per_frame"][group]
+        return int((e["fetch"] + e["write"]) * B)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(stages, gray, depth, budget_s=12.0):
     """time the CPU oracle (scalar port, 1 thread) on a bounded sample of the same workload"""
     orc = ge.oracle()
@@ -174,7 +190,7 @@ def main():
             per_frame, pass_bytes = algorithmic_bytes(dom, args.width, args.height, nkp, nlines)
             ach = per_frame * B / (groups[dom] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": hbm_traffic(dom, B, args.width),
                     "bytes_per_launch": int(per_frame * B), "ms_per_launch": round(groups[dom], 4)}
             orb_ms = sum(v for k, v in groups.items() if k in ("orb_pyramid", "orb_fast_cells", "orb_blur", "orb_brief", "orb_orient"))
             if orb_ms > 0:
