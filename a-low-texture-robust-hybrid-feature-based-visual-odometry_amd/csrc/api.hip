@@ -64,7 +64,10 @@ int hvo_create(const hvo_params *p, hvo_ctx **out)
     { const char *e = getenv("HVO_PRIO"); if (e) sscanf(e, "%d,%d,%d", &pr[0], &pr[1], &pr[2]); }
     if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, pr[0]) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->s_lsd, hipStreamNonBlocking, pr[1]) != hipSuccess ||
-        hipStreamCreateWithPriority(&ctx->s_peac, hipStreamNonBlocking, pr[2]) != hipSuccess) { hvo_destroy(ctx); return HVO_ERR_HIP; }
+        hipStreamCreateWithPriority(&ctx->s_peac, hipStreamNonBlocking, pr[2]) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lsd_pre, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fast, hipEventDisableTiming) != hipSuccess) { hvo_destroy(ctx); return HVO_ERR_HIP; }
+    { const char *e = getenv("HVO_SCHED"); if (e) ctx->sched = atoi(e); }
     int rc = orb_init_tables(ctx);
     if (rc) { hvo_destroy(ctx); return rc; }
     *out = ctx;
@@ -87,6 +90,8 @@ void hvo_destroy(hvo_ctx *ctx)
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->s_lsd) (void)hipStreamDestroy(ctx->s_lsd);
     if (ctx->s_peac) (void)hipStreamDestroy(ctx->s_peac);
+    if (ctx->ev_lsd_pre) (void)hipEventDestroy(ctx->ev_lsd_pre);
+    if (ctx->ev_fast) (void)hipEventDestroy(ctx->ev_fast);
     delete ctx;
 }
 
@@ -135,8 +140,23 @@ int hvo_batch_run(hvo_ctx *ctx, unsigned stages)
         if (!ctx->have_depth) return HVO_ERR_INVALID_ARG;
         rc = peac_run(ctx, ctx->batch_n); if (rc) return rc;
     }
-    if (stages & HVO_STAGE_LSD) { rc = lsd_run(ctx, ctx->batch_n); if (rc) return rc; }
-    if (stages & HVO_STAGE_ORB) { rc = orb_run(ctx, ctx->batch_n); if (rc) return rc; }
+    // Overlap policy.  k_lsd_grow takes almost all of a CU's LDS for >100 ms; streaming kernels gain nothing
+    // from running side by side; the latency-bound kernels (k_lsd_grow, k_peac_cluster) leave most issue
+    // slots idle.  sched 2: ORB starts at once and its only LDS kernel (k_fast_cells) is ordered BEFORE
+    // k_lsd_grow, the rest of ORB then runs underneath it.  sched 1: ORB waits for the LSD preamble.
+    // sched 0: no cross-stream ordering.
+    ctx->lsd_pre_recorded = ctx->fast_recorded = false;
+    const bool want_orb = (stages & HVO_STAGE_ORB) != 0, want_lsd = (stages & HVO_STAGE_LSD) != 0;
+    if (ctx->sched == 2 && want_orb && !ctx->serialize) {
+        rc = orb_run(ctx, ctx->batch_n); if (rc) return rc;                 // records ev_fast
+        if (want_lsd) { rc = lsd_run(ctx, ctx->batch_n); if (rc) return rc; }   // k_lsd_grow waits for ev_fast
+    } else {
+        if (want_lsd) { rc = lsd_run(ctx, ctx->batch_n); if (rc) return rc; }
+        if (want_orb) {
+            if (ctx->sched == 1 && ctx->lsd_pre_recorded && !ctx->serialize) HVO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_lsd_pre, 0));
+            rc = orb_run(ctx, ctx->batch_n); if (rc) return rc;
+        }
+    }
     HVO_HIP(hipStreamSynchronize(ctx->s_peac));
     HVO_HIP(hipStreamSynchronize(ctx->s_lsd));
     HVO_HIP(hipStreamSynchronize(ctx->stream));

@@ -68,6 +68,11 @@ struct hvo_ctx {
     hipStream_t stream = nullptr;          // ORB + matching + uploads
     hipStream_t s_lsd = nullptr;           // LSD/LBD kernels   } the three subsystems are independent and run
     hipStream_t s_peac = nullptr;          // PEAC kernels      } concurrently, like Frame.cc:210-215's threads
+    hipEvent_t ev_lsd_pre = nullptr;       // recorded on s_lsd when the streaming LSD kernels are done (before k_lsd_grow)
+    bool lsd_pre_recorded = false;
+    hipEvent_t ev_fast = nullptr;          // recorded on the ORB stream after k_fast_cells (the only ORB kernel that needs LDS)
+    bool fast_recorded = false;
+    int sched = 1;                         // overlap policy of hvo_batch_run, see api.hip
     std::string last_error;
     OrbPlan orb;
     // ORB tables

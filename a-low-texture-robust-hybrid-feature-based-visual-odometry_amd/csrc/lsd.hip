@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_lsd_resize_grad(const double *__restric
 // k_lsd_grow: the serial heart of LSD, one wave per frame
 // ------------------------------------------------------------------------------------------------
 struct GrowArgs {
-    const double4 *px4; const unsigned *defined; int *reg; float *segs;
+    const double4 *px4; unsigned *avail; int *reg; float *segs;
     hvo_keyline *kl_all, *kl; double *fn; int *nkl; int *flags; long long *stats;
     int sw, sh, nwords, w, h, nfeat, kl_cap;
     double rho, prec, p; unsigned min_reg;
@@ -187,13 +187,21 @@ struct GrowArgs {
 struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy; };
 
 struct GrowState {
-    const double4 *px4; int *reg; unsigned *used; int *ring;      // px4: {angle, cos, sin, modgrad}
+    const double4 *px4; int *reg; unsigned *avail; int *ring;     // px4: {angle, cos, sin, modgrad}
     int sw, sh, wpr;          // wpr = mask words per row
 };
 
-static __device__ __forceinline__ bool used_get(const GrowState &S, int x, int y) { return (S.used[y * S.wpr + (x >> 5)] >> (x & 31)) & 1u; }
-static __device__ __forceinline__ void used_set(const GrowState &S, int x, int y) { S.used[y * S.wpr + (x >> 5)] |= 1u << (x & 31); }
-static __device__ __forceinline__ void used_clr(const GrowState &S, int x, int y) { S.used[y * S.wpr + (x >> 5)] &= ~(1u << (x & 31)); }
+// The "available" mask (bit = pixel has a gradient angle and is not in a region yet) lives in GLOBAL memory:
+// k_lsd_resize_grad writes it as the "defined" mask, k_lsd_grow consumes it in place.  Keeping it out of
+// LDS (24.5 KB per frame at 640x480) is what lets a CU hold 20+ frames instead of 5 -- the kernel is bound
+// by one wave's dependent-instruction latency, so frames in flight are its only source of throughput --
+// and leaves the LDS to the kernels that need it (k_fast_cells, k_peac_flood).  Reads bypass the per-CU
+// L1 (agent-scope atomic loads); updates are L2 atomics without return, made visible to the wave's later
+// reads by the vmcnt(0) of the __syncthreads() that closes every growing round.
+static __device__ __forceinline__ unsigned avail_word(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ bool used_get(const GrowState &S, int x, int y) { return !((avail_word(&S.avail[y * S.wpr + (x >> 5)]) >> (x & 31)) & 1u); }
+static __device__ __forceinline__ void used_set(const GrowState &S, int x, int y) { __hip_atomic_fetch_and(&S.avail[y * S.wpr + (x >> 5)], ~(1u << (x & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ void used_clr(const GrowState &S, int x, int y) { __hip_atomic_fetch_or(&S.avail[y * S.wpr + (x >> 5)], 1u << (x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 static __device__ __forceinline__ double angle_diff_signed(double a, double b)
 {
@@ -248,9 +256,8 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
                 const int idx = i + k;
                 const int pxy = (rs - idx <= LSD_RING) ? S.ring[idx & (LSD_RING - 1)] : S.reg[idx];
                 const int xx = (pxy & 0xFFFF) + jx, yy = (pxy >> 16) + jy;
-                // `used` starts as the complement of the "defined" mask, so one LDS bit test rejects both the
-                // pixels without a gradient angle and the ones already taken; only real candidates go to memory,
-                // and they fetch angle, cos and sin in one 32-byte record
+                // one bit test rejects both the pixels without a gradient angle and the ones already taken; only
+                // real candidates fetch their record (angle, cos, sin in one 32-byte access)
                 if (xx >= 0 && yy >= 0 && xx < sw && yy < sh && !used_get(S, xx, yy)) {
                     const double4 r = S.px4[xx + yy * sw];
                     c[s] = (yy << 16) | xx; an[s] = r.x; cs[s] = r.y; sn[s] = r.z; valid[s] = true;
@@ -388,11 +395,8 @@ static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle
         b0[lane] = t0; b1[lane] = t1; b2[lane] = 0;
         n += __popcll(__ballot(in));
         __syncthreads();
-        if (lane == 0) {
-            const int m = min(64, reg_size - base);
-            for (int q = 0; q < m; q++) used_clr(S, n_addr[q] & 0xFFFF, n_addr[q] >> 16);
-            seq_add3(b0, b1, b2, sum, s_sum, dummy);
-        }
+        if (i < reg_size) used_clr(S, n_addr[lane] & 0xFFFF, n_addr[lane] >> 16);
+        if (lane == 0) seq_add3(b0, b1, b2, sum, s_sum, dummy);
         __syncthreads();
     }
     double tau = 0;
@@ -447,7 +451,6 @@ static __device__ __forceinline__ int line_count(float x1, float y1, float x2, f
 
 __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
 {
-    extern __shared__ unsigned used_lds[];
     __shared__ double b0[64], b1[64], b2[64];
     __shared__ int n_addr[64];
     __shared__ int ring[LSD_RING];
@@ -456,20 +459,17 @@ __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
     const size_t np = (size_t)sw * sh;
     GrowState S;
     S.px4 = g.px4 + f * np;
-    S.reg = g.reg + f * np; S.used = used_lds; S.ring = ring; S.sw = sw; S.sh = sh; S.wpr = wpr;
-    const unsigned *defined = g.defined + (size_t)f * nwords;
+    S.reg = g.reg + f * np; S.avail = g.avail + (size_t)f * nwords; S.ring = ring; S.sw = sw; S.sh = sh; S.wpr = wpr;
     float *segs = g.segs + (size_t)f * LSD_MAXSEG * 4;
-    for (int i = lane; i < nwords; i += 64) used_lds[i] = ~defined[i];      // undefined pixels can never join a region
-    __syncthreads();
     int nseg = 0, flags = 0;
     long long st_seeds = 0, st_pts = 0, st_tg = 0, st_tr = 0, st_tf = 0, st_big = 0;
     const long long t_begin = wall_clock64();
-    // seeds in raster order: words of (defined & ~used), 64 words per step
+    // seeds in raster order: words of the available mask, 64 words per step
     for (int wbase = 0; wbase < nwords; wbase += 64) {
         for (;;) {
             const int wi = wbase + lane;
             unsigned m = 0;
-            if (wi < nwords) m = ~used_lds[wi];
+            if (wi < nwords) m = avail_word(&S.avail[wi]);
             const unsigned long long nz = __ballot(m != 0);
             if (!nz) break;
             const int wl = __ffsll((long long)nz) - 1;
@@ -806,21 +806,15 @@ int lsd_run(hvo_ctx *ctx, int n)
     hipLaunchKernelGGL(k_lsd_resize_grad, dim3(gx, sh, n), dim3(256), 0, st, P->d_blur, w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb,
                        P->d_px, P->d_defined, P->nwords, P->rho);
     hvo_prof_end(ctx, id);
+    if (ctx->ev_lsd_pre && !ctx->serialize) { HVO_HIP(hipEventRecord(ctx->ev_lsd_pre, st)); ctx->lsd_pre_recorded = true; }
+    if (ctx->sched == 2 && ctx->fast_recorded && !ctx->serialize) HVO_HIP(hipStreamWaitEvent(st, ctx->ev_fast, 0));
     id = hvo_prof_begin(ctx, "lsd_grow", st);
     GrowArgs g;
-    g.px4 = P->d_px; g.defined = P->d_defined; g.reg = P->d_reg; g.segs = P->d_segs;
+    g.px4 = P->d_px; g.avail = P->d_defined; g.reg = P->d_reg; g.segs = P->d_segs;
     g.stats = P->d_stats; g.kl_all = P->d_kl_all; g.kl = P->d_kl; g.fn = P->d_fn; g.nkl = P->d_nkl; g.flags = P->d_flags;
     g.sw = sw; g.sh = sh; g.nwords = P->nwords; g.w = w; g.h = h; g.nfeat = P->nfeat; g.kl_cap = P->nfeat;
     g.rho = P->rho; g.prec = P->prec; g.p = P->p; g.min_reg = P->min_reg;
-    size_t lds = (size_t)P->nwords * 4;
-    if (lds > 150 * 1024) return HVO_ERR_UNSUPPORTED;
-    { const char *e = getenv("HVO_GROW_LDS_PAD"); if (e) lds += (size_t)atoi(e); }
-    static size_t lds_set = 0;
-    if (lds > 32 * 1024 && lds_set < lds) {
-        HVO_HIP(hipFuncSetAttribute((const void *)k_lsd_grow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
-    hipLaunchKernelGGL(k_lsd_grow, dim3(n), dim3(64), lds, st, g);
+    hipLaunchKernelGGL(k_lsd_grow, dim3(n), dim3(64), 0, st, g);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lbd_sobel", st);
     hipLaunchKernelGGL(k_lbd_blur5, dim3((w + 255) / 256, (h + 7) / 8, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_b5, w, h, P->k5[0], P->k5[1], P->k5[2]);

@@ -927,6 +927,7 @@ int orb_run(hvo_ctx *ctx, int n)
         hipLaunchKernelGGL(k_fast_cells<HVO_CELL_TILE>, dim3((P.ncells + 3) / 4, n), dim3(256), 0, st, P.d_pyr, P.pyr_bytes, P.d_lev, P.d_cells, P.ncells,
                            P.d_cell_kp, P.d_cell_cnt, ctx->p.orb_ini_th_fast, ctx->p.orb_min_th_fast, P.d_flags);
     hvo_prof_end(ctx, id);
+    if (ctx->ev_fast && !ctx->serialize) { HVO_HIP(hipEventRecord(ctx->ev_fast, st)); ctx->fast_recorded = true; }
     id = hvo_prof_begin(ctx, "orb_octree", st);
     OctArgs oa;
     oa.lev = P.d_lev; oa.cell_kp = P.d_cell_kp; oa.cell_cnt = P.d_cell_cnt; oa.ncells = P.ncells;

@@ -442,6 +442,23 @@ template <int GL> struct Grp {
     template <class T> static __device__ __forceinline__ T shfl(T v, int l) { return __shfl(v, gb() + l); }
 };
 
+// Butterfly partner inside a 16-lane row through DPP (a VALU move) instead of a permute through LDS.
+// STEP 1,2: quad_perm xor; STEP 4: row_half_mirror; STEP 8: row_mirror.  The mirrors pair lane i with
+// 7-i / 15-i rather than i^4 / i^8, which is the same for an all-reduce of a commutative operation whose
+// earlier steps made each quad / half-row uniform.  Steps >= 16 (wider groups) fall back to ds_bpermute.
+template <int STEP> static __device__ __forceinline__ int row_partner(int v)
+{
+    if (STEP == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);
+    if (STEP == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);
+    if (STEP == 4) return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);
+    if (STEP == 8) return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false);
+    return __shfl_xor(v, STEP);
+}
+template <int STEP> static __device__ __forceinline__ double row_partner(double v)
+{
+    return __hiloint2double(row_partner<STEP>(__double2hiint(v)), row_partner<STEP>(__double2loint(v)));
+}
+
 #define GH_ARY 16         // arity of the grouped heap: one child per lane of the narrowest group
 template <int GL>
 static __device__ void gheap_sift_down(double *key, int *id, int n, int i, double k, int idv, bool act)
@@ -491,12 +508,12 @@ static __device__ int gheap_sift_root(const GHeap &H, int n, double k, int idv, 
         const bool cont = go && c0 < n;
         double ck = 1.0e308; int cid = 0x7FFFFFFF, ci = -1;
         if (cont && gl < GH_ARY && c0 + gl < n) { ci = c0 + gl; ck = H.key(ci); cid = H.id(ci); }
-#pragma unroll
-        for (int o = 1; o < GH_ARY; o <<= 1) {
-            const double ok = __shfl_xor(ck, o); const int oid = __shfl_xor(cid, o), oi = __shfl_xor(ci, o);
-            if (oi >= 0 && (ci < 0 || hless(ok, oid, ck, cid))) { ck = ok; cid = oid; ci = oi; }
-        }
-        ck = Grp<GL>::shfl(ck, 0); cid = Grp<GL>::shfl(cid, 0); ci = Grp<GL>::shfl(ci, 0);
+#define GH_STEP(o) { const double ok = row_partner<o>(ck); const int oid = row_partner<o>(cid), oi = row_partner<o>(ci); \
+                     if (oi >= 0 && (ci < 0 || hless(ok, oid, ck, cid))) { ck = ok; cid = oid; ci = oi; } }
+        GH_STEP(1) GH_STEP(2) GH_STEP(4) GH_STEP(8)
+#undef GH_STEP
+        // every lane of the first 16-lane row now holds the minimum; wider groups broadcast it
+        if (GL != 16) { ck = Grp<GL>::shfl(ck, 0); cid = Grp<GL>::shfl(cid, 0); ci = Grp<GL>::shfl(ci, 0); }
         const bool mv = cont && ci >= 0 && hless(ck, cid, k, idv);
         if (mv) { if (gl == 0) H.set(i, ck, cid); if (i == 0) root = cid; i = ci; }
         go = mv;
@@ -652,15 +669,14 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
         }
         // ---- group reductions: min mse, then the tie rule ----
         double gmin = bhas ? bm : 1.7976931348623157e308;
-#pragma unroll
-        for (int o = 1; o < GL; o <<= 1) { const double t = __shfl_xor(gmin, o); gmin = t < gmin ? t : gmin; }
+#define GM_STEP(o) if (o < GL) { const double t = row_partner<o>(gmin); gmin = t < gmin ? t : gmin; }
+        GM_STEP(1) GM_STEP(2) GM_STEP(4) GM_STEP(8) GM_STEP(16) GM_STEP(32)
+#undef GM_STEP
         const bool tied = bhas && bm == gmin;
         int rg = tied ? gid : 0x7FFFFFFF, rx = tied ? xid : -1;
-#pragma unroll
-        for (int o = 1; o < GL; o <<= 1) {
-            const int t0 = __shfl_xor(rg, o), t1 = __shfl_xor(rx, o);
-            rg = min(rg, t0); rx = max(rx, t1);
-        }
+#define GM_STEP(o) if (o < GL) { const int t0 = row_partner<o>(rg), t1 = row_partner<o>(rx); rg = min(rg, t0); rx = max(rx, t1); }
+        GM_STEP(1) GM_STEP(2) GM_STEP(4) GM_STEP(8) GM_STEP(16) GM_STEP(32)
+#undef GM_STEP
         const bool any_cand = Grp<GL>::ballot(bhas) != 0;
         const int win = rg != 0x7FFFFFFF ? rg : rx;            // neighbour id to merge with (if any_cand)
         double st[9], c[3], n[3], m; int mN, nrid, noff, ncnt;
