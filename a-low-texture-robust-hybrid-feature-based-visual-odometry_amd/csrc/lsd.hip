@@ -267,23 +267,72 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
 #pragma unroll
         for (int s = 0; s < GROW_SLOTS; s++) {
             if (s * 7 >= cnt) break;                 // no pending points in this slot (uniform)
-            unsigned long long done_mask = 0;        // lanes already passed in this slot
+            // The reference walks the slot's neighbours in lane order; each one it adds changes the region
+            // angle that the later ones are tested against.  Instead of one wave-wide step per added pixel the
+            // walk is SPECULATED: assume every neighbour aligned with the current angle gets added, compute
+            // the running sums in that order (a short scalar chain), let every such lane evaluate the angle
+            // after its own addition in parallel, then let every lane re-take its decision with the angle
+            // that would be in force when the cursor reaches it.  Everything before the first lane whose
+            // decision differs from the assumption is exactly what the sequential walk does and is committed
+            // at once; the walk resumes at that lane.  Mismatches need a candidate within rounding of the
+            // tolerance, so a slot is normally done in one pass.
+            unsigned long long todo = ~0ull;         // lanes the cursor has not passed yet
             for (;;) {
-                const bool al = valid[s] && lsd_aligned(an[s], ra, prec);
-                const unsigned long long m = __ballot(al) & ~done_mask;
-                if (!m) break;
-                const int L = __ffsll((long long)m) - 1;
-                // L is wave-uniform: read lane L's registers directly instead of a cross-lane permute through LDS
-                const int cA = __builtin_amdgcn_readlane(c[s], L);
-                const double csA = readlane_f64(cs[s], L), snA = readlane_f64(sn[s], L);
-                if (lane == 0) { used_set(S, cA & 0xFFFF, cA >> 16); S.reg[rs] = cA; S.ring[rs & (LSD_RING - 1)] = cA; }
-                ++rs;
-                sumdx = (float)((double)sumdx + csA);
-                sumdy = (float)((double)sumdy + snA);
-                ra = (double)fatan2_deg(sumdy, sumdx) * (LSD_PI / 180);
+                const bool al0 = valid[s] && lsd_aligned(an[s], ra, prec);
+                const unsigned long long A = __ballot(al0) & todo;
+                if (!A) break;
+                // running sums over A in lane order; a later lane looking at the same pixel as an assumed
+                // addition cannot be added any more and drops out of the assumption
+                float psx = sumdx, psy = sumdy, my_sx = 0, my_sy = 0;
+                unsigned long long rem = A, Aeff = 0, dropm = 0;
+                while (rem) {
+                    const int L = __ffsll((long long)rem) - 1;
+                    rem &= rem - 1;
+                    const int cA = __builtin_amdgcn_readlane(c[s], L);
+                    psx = (float)((double)psx + readlane_f64(cs[s], L));
+                    psy = (float)((double)psy + readlane_f64(sn[s], L));
+                    if (lane == L) { my_sx = psx; my_sy = psy; }
+                    Aeff |= 1ull << L;
+                    const unsigned long long same = __ballot(c[s] == cA);
+                    rem &= ~same; dropm |= same & ~((2ull << L) - 1);
+                }
+                const double my_ra = (double)fatan2_deg(my_sy, my_sx) * (LSD_PI / 180);     // meaningful on Aeff lanes
+                // angle in force when the cursor reaches this lane: the one after the nearest assumed addition below it
+                const unsigned long long below = Aeff & ((1ull << lane) - 1);
+                const int src = below ? 63 - __clzll((long long)below) : lane;
+                const double ra_src = __shfl(my_ra, src);          // unconditional: every source lane must be active
+                const double ra_at = below ? ra_src : ra;
+                // a lane that dropped out because of an assumed addition below it stays out (that addition is
+                // committed whenever the cursor gets this far)
+                const bool spec = (Aeff >> lane) & 1ull;
+                const bool dropped = (dropm >> lane) & 1ull;
+                const bool act = !dropped && valid[s] && lsd_aligned(an[s], ra_at, prec);
+                const unsigned long long mis = __ballot(act != spec) & todo;
+                const int m = mis ? __ffsll((long long)mis) - 1 : 64;
+                const unsigned long long C = m >= 64 ? Aeff : (Aeff & ((1ull << m) - 1));  // committed additions
+                if (C) {
+                    const int nC = __popcll(C);
+                    if ((C >> lane) & 1ull) {
+                        const int pos = rs + __popcll(C & ((1ull << lane) - 1));
+                        used_set(S, c[s] & 0xFFFF, c[s] >> 16); S.reg[pos] = c[s]; S.ring[pos & (LSD_RING - 1)] = c[s];
+                    }
+                    const int last = 63 - __clzll((long long)C);
+                    sumdx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_sx), last));
+                    sumdy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_sy), last));
+                    ra = readlane_f64(my_ra, last);
+                    rs += nC;
+                    // the committed pixels are no candidates any more, in any slot
+                    unsigned long long cc = C;
+                    while (cc) {
+                        const int L = __ffsll((long long)cc) - 1;
+                        cc &= cc - 1;
+                        const int cA = __builtin_amdgcn_readlane(c[s], L);
 #pragma unroll
-                for (int t = 0; t < GROW_SLOTS; t++) if (c[t] == cA) valid[t] = false;
-                done_mask = (L == 63) ? ~0ull : ((1ull << (L + 1)) - 1);
+                        for (int t = 0; t < GROW_SLOTS; t++) if (c[t] == cA) valid[t] = false;
+                    }
+                }
+                if (m >= 64) break;
+                todo = ~((1ull << m) - 1);           // resume at the lane whose decision differed
             }
         }
         i += cnt;

@@ -105,7 +105,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="frames resident per GPU per step (multiple of 16)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames resident per GPU per step (multiple of 16); 0 = the largest of 8192/4096/2048/1024 that fits in 85 %% of the free HBM")
     ap.add_argument("--stages", default="orb,lsd,planes")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
@@ -133,6 +134,15 @@ def main():
         mask |= {"orb": hvo.STAGE_ORB, "lsd": hvo.STAGE_LSD, "planes": hvo.STAGE_PLANES}[s]
 
     B = args.batch
+    if B <= 0:
+        # 28.5 MB per resident 640x480 frame (profiles/r01_hbm_footprint.txt); more frames in flight = more latency hiding
+        free_b, _ = torch.cuda.mem_get_info()
+        per_frame = 28.5e6 * (args.width * args.height) / (640.0 * 480.0)
+        B = next((c for c in (8192, 4096, 2048, 1024) if c * per_frame <= 0.85 * free_b), 512)
+        if dist is not None:                 # every rank must run the same workload
+            t = torch.tensor([B], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            B = int(t.item())
     ndistinct = min(B, 16)
     g0, d0 = synth.make_batch("std", 0x5EED1000 + 1000 * rank, ndistinct, args.width, args.height)
     reps = max(1, B // ndistinct)
