@@ -679,21 +679,21 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
 #undef GM_STEP
         const bool any_cand = Grp<GL>::ballot(bhas) != 0;
         const int win = rg != 0x7FFFFFFF ? rg : rx;            // neighbour id to merge with (if any_cand)
-        double st[9], c[3], n[3], m; int mN, nrid, noff, ncnt;
+        // Only the quantities the group decides on are made uniform (mse, centre z, the partner's list); the
+        // fit itself stays in the lane that computed it, and that lane writes the merged node's record.
+        double m, c2; int noff, ncnt;
+        bool is_w;                                             // this lane holds the winning fit in b*
         {
-            // the winner's fit from the lane that holds it (groups without one read a dummy lane and ignore it)
             const unsigned long long wm = Grp<GL>::ballot(tied && bid == win);
-            const int src = gb + (wm ? __ffsll((long long)wm) - 1 : 0);
-#pragma unroll
-            for (int q = 0; q < 9; q++) st[q] = __shfl(bst[q], src);
-#pragma unroll
-            for (int q = 0; q < 3; q++) { c[q] = __shfl(bc[q], src); n[q] = __shfl(bn[q], src); }
-            m = __shfl(bm, src); mN = __shfl(bN, src);
-            nrid = __shfl(brid, src); noff = __shfl(bnoff, src); ncnt = __shfl(bncnt, src);
+            const int wl = wm ? __ffsll((long long)wm) - 1 : 0, src = gb + wl;
+            is_w = wm != 0 && gl == wl;
+            m = __shfl(bm, src); c2 = __shfl(bc[2], src);
+            noff = __shfl(bnoff, src); ncnt = __shfl(bncnt, src);
             // tie broken by the N-vs-mse clause towards a candidate whose fit no lane kept: fit it again
+            // (uniformly over the group; lane 0 of the group then owns it)
             const bool refit = any_cand && wm == 0;
             if (__any(refit)) {
-                double lst[9]; int lN = 4;
+                double lst[9]; int lN = 4, rrid = 0, roff = 0, rcnt = 0;
 #pragma unroll
                 for (int q = 0; q < 9; q++) lst[q] = 0;
                 if (refit) {
@@ -701,16 +701,17 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
                     const int *nI = segI + (size_t)win * SEG_I;
 #pragma unroll
                     for (int q = 0; q < 9; q++) lst[q] = ps[q] + nd[q];
-                    lN = pN + nI[0]; nrid = nI[1]; noff = nI[3]; ncnt = nI[4];
+                    lN = pN + nI[0]; rrid = nI[1]; roff = nI[3]; rcnt = nI[4];
                 }
                 double tc[3], tn[3], tm;
                 stats_compute_dev(lst, lN, tc, tn, tm);
                 if (refit) {
 #pragma unroll
-                    for (int q = 0; q < 9; q++) st[q] = lst[q];
+                    for (int q = 0; q < 9; q++) bst[q] = lst[q];
 #pragma unroll
-                    for (int q = 0; q < 3; q++) { c[q] = tc[q]; n[q] = tn[q]; }
-                    m = tm; mN = lN;
+                    for (int q = 0; q < 3; q++) { bc[q] = tc[q]; bn[q] = tn[q]; }
+                    bm = tm; bN = lN; brid = rrid; m = tm; c2 = tc[2]; noff = roff; ncnt = rcnt;
+                    is_w = gl == 0;
                 }
             }
         }
@@ -719,7 +720,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
         const int nb = win;
         bool do_merge = false;
         if (live && any_cand) {
-            const double t = 1.6e-6 * c[2] * c[2] + 8.0;        // T_mse(P_MERGING)
+            const double t = 1.6e-6 * c2 * c2 + 8.0;            // T_mse(P_MERGING)
             if (m < t * t) {
                 if (nseg >= a.segcap || pooltop + pcnt + ncnt > a.poolcap) flags |= 8;     // capacity: keep the node unmerged
                 else do_merge = true;
@@ -778,14 +779,14 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
                 mcnt += __popcll(km);
             }
             PT(5)
-            if (do_merge && gl == 0) {
+            if (do_merge && is_w) {
                 double *md = segD + (size_t)id * SEG_D;
 #pragma unroll
-                for (int q = 0; q < 9; q++) md[q] = st[q];
-                md[9] = c[0]; md[10] = c[1]; md[11] = c[2]; md[12] = n[0]; md[13] = n[1]; md[14] = n[2]; md[15] = m;
+                for (int q = 0; q < 9; q++) md[q] = bst[q];
+                md[9] = bc[0]; md[10] = bc[1]; md[11] = bc[2]; md[12] = bn[0]; md[13] = bn[1]; md[14] = bn[2]; md[15] = bm;
                 int *mi = segI + (size_t)id * SEG_I;
-                mi[0] = mN; mi[1] = pN >= mN - pN ? prid : nrid; mi[2] = 0; mi[3] = moff; mi[4] = mcnt; mi[5] = pcnt + ncnt; mi[6] = 1; mi[7] = 0;
-                int xr = ds_find_ro(parent, prid), yr = ds_find_ro(parent, nrid);          // ds.Union(pa.rid, pb.rid)
+                mi[0] = bN; mi[1] = pN >= bN - pN ? prid : brid; mi[2] = 0; mi[3] = moff; mi[4] = mcnt; mi[5] = pcnt + ncnt; mi[6] = 1; mi[7] = 0;
+                int xr = ds_find_ro(parent, prid), yr = ds_find_ro(parent, brid);          // ds.Union(pa.rid, pb.rid)
                 if (xr != yr) {
                     if (dsize[xr] < dsize[yr]) { parent[xr] = yr; dsize[yr] += dsize[xr]; }
                     else { parent[yr] = xr; dsize[xr] += dsize[yr]; }
