@@ -1024,6 +1024,9 @@ struct RfArgs {
 // (ordered by event index), and sub-round r applies the events of rank r, the state travelling from
 // rank to rank through LDS.  Pushes are appended in event order with a block scan, which reproduces
 // the reference's queue order exactly.  Queue entries are packed plid<<26 | y<<13 | x.
+#ifndef FLOOD_HS_MUL
+#define FLOOD_HS_MUL 1      // hash slots per event: 1 = table as large as the round (8 workgroups per CU), 2 = half-empty table (5 per CU)
+#endif
 #define FQ_PACK(x, y, pl) (((pl) << 26) | ((y) << 13) | (x))
 // workgroup barrier that orders LDS traffic only: outstanding global stores are not waited for
 static __device__ __forceinline__ void lds_barrier()
@@ -1036,7 +1039,7 @@ template <int FLOOD_T>
 __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long long *__restrict__ adj_out)
 {
     constexpr int NEV = FLOOD_T * 4;              // events per round
-    constexpr int FLOOD_HS = NEV * 2, FLOOD_HL = 4;
+    constexpr int FLOOD_HS = NEV * FLOOD_HS_MUL, FLOOD_HL = 4;
     __shared__ double pl[MAX_PLANES][8];          // center[3], normal[3], mse, pad
     __shared__ unsigned long long adj[MAX_PLANES];
     __shared__ int hkeys[FLOOD_HS], hcnt[FLOOD_HS];
@@ -1445,7 +1448,7 @@ int peac_run(hvo_ctx *ctx, int n)
         // threads per frame (one queue entry = 4 events per thread and round); HVO_FLOOD_T overrides
         const char *e = getenv("HVO_FLOOD_T");
         const int flood_t = e ? atoi(e) : -1;
-        const int ft = flood_t > 0 ? flood_t : 128;
+        const int ft = flood_t > 0 ? flood_t : 256;
         if (ft == 64) hipLaunchKernelGGL(k_peac_flood<64>, dim3(n), dim3(64), 0, st, r, P->d_adj);
         else if (ft == 256) hipLaunchKernelGGL(k_peac_flood<256>, dim3(n), dim3(256), 0, st, r, P->d_adj);
         else hipLaunchKernelGGL(k_peac_flood<128>, dim3(n), dim3(128), 0, st, r, P->d_adj);
