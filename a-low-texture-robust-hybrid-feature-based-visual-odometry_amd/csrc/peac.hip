@@ -496,14 +496,16 @@ struct GHeap {
     __device__ __forceinline__ int id(int i) const { return i < GH_TOP ? li[i] : gi[i]; }
     __device__ __forceinline__ void set(int i, double k, int v) const { if (i < GH_TOP) { lk[i] = k; li[i] = v; } else { gk[i] = k; gi[i] = v; } }
 };
-// sift (k, idv) down from the root; returns the id that ends up AT the root, i.e. the next top
-template <int GL>
-static __device__ int gheap_sift_root(const GHeap &H, int n, double k, int idv, bool act)
+// sift (k, idv) down from the root; returns the id that ends up AT the root, i.e. the next top.  The root is
+// known after the first level: on_root(root) is called there, so that the caller's loads for the next
+// iteration travel underneath the remaining levels.
+template <int GL, class F>
+static __device__ int gheap_sift_root(const GHeap &H, int n, double k, int idv, bool act, F on_root)
 {
     const int gl = Grp<GL>::gl();
-    int i = 0, root = idv;
-    bool go = act;
-    while (__any(go)) {
+    int i = 0, root = act ? idv : -1;
+    bool go = act, first = true;
+    do {
         const int c0 = GH_ARY * i + 1;
         const bool cont = go && c0 < n;
         double ck = 1.0e308; int cid = 0x7FFFFFFF, ci = -1;
@@ -517,7 +519,8 @@ static __device__ int gheap_sift_root(const GHeap &H, int n, double k, int idv, 
         const bool mv = cont && ci >= 0 && hless(ck, cid, k, idv);
         if (mv) { if (gl == 0) H.set(i, ck, cid); if (i == 0) root = cid; i = ci; }
         go = mv;
-    }
+        if (first) { on_root(root); first = false; }
+    } while (__any(go));
     if (act && gl == 0) H.set(i, k, idv);
     return root;
 }
@@ -600,32 +603,45 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
     // node (merge) or by the last entry (no merge), with one sift-down that also yields the next top.
     __syncthreads();
     int ptop = hn > 0 ? H.id(0) : -1;
+    // the popped node's record (sums, normal, list) is fetched one iteration ahead, underneath the sift-down
+    double nps[9], npn[3]; int n_nouse = 1, n_cnt = 0, n_off = 0, n_N = 0, n_rid = 0, a0n = -1;
+    auto fetch_next = [&](int r) {
+        const int q = r < 0 ? 0 : r;
+        const int *qi = segI + (size_t)q * SEG_I;
+        const double *qd = segD + (size_t)q * SEG_D;
+        n_nouse = qi[2]; n_cnt = qi[4]; n_off = qi[3]; n_N = qi[0]; n_rid = qi[1];
+#pragma unroll
+        for (int q2 = 0; q2 < 9; q2++) nps[q2] = qd[q2];
+        npn[0] = qd[12]; npn[1] = qd[13]; npn[2] = qd[14];
+    };
+    fetch_next(ptop);
+    a0n = gl < n_cnt ? pool[n_off + gl] : -1;
     while (__any(hn > 0)) {
         const bool act = hn > 0;
         PT_CNT(8, 1)
         const bool need_gc = act && pooltop > a.poolcap - 2 * a.nblk;
-        if (__any(need_gc)) gpool_gc<GL>(segI, nseg, pool, pool2, pooltop, need_gc);
-        __syncthreads();                                       // the previous iteration's stores (lists, records, heap)
+        if (__any(need_gc)) {
+            gpool_gc<GL>(segI, nseg, pool, pool2, pooltop, need_gc);       // relocates the lists: fetch the list again
+            n_off = segI[(size_t)(ptop < 0 ? 0 : ptop) * SEG_I + 3];
+            a0n = gl < n_cnt ? pool[n_off + gl] : -1;
+        }
         PT(0)
         const int p = act ? ptop : -1;
-        double lastk = 0; int lastid = 0;
-        if (act) { lastk = H.key(hn - 1); lastid = H.id(hn - 1); }
         PT(1)
         int *pi = segI + (size_t)(p < 0 ? 0 : p) * SEG_I;
-        const double *pd = segD + (size_t)(p < 0 ? 0 : p) * SEG_D;
-        const bool live = act && pi[2] == 0;                   // skip nouse nodes (lazy deletion)
-        const int pcnt = live ? pi[4] : 0, poff = pi[3], pN = pi[0], prid = pi[1];
+        const bool live = act && n_nouse == 0;                 // skip nouse nodes (lazy deletion)
+        const int pcnt = live ? n_cnt : 0, poff = n_off, pN = n_N, prid = n_rid;
         double ps[9], pn[3];                                   // popped node: sums and normal (uniform per group)
 #pragma unroll
-        for (int q = 0; q < 9; q++) ps[q] = pd[q];
-        pn[0] = pd[12]; pn[1] = pd[13]; pn[2] = pd[14];
+        for (int q = 0; q < 9; q++) ps[q] = nps[q];
+        pn[0] = npn[0]; pn[1] = npn[1]; pn[2] = npn[2];
+        const int a0 = gl < pcnt ? a0n : -1;                   // first chunk of p's list, reused by the merge
         // ---- evaluate the merge with every neighbour, one candidate per lane; each lane keeps its best ----
         bool bhas = false; double bm = 0; int bid = 0x7FFFFFFF, bN = 0, gid = 0x7FFFFFFF, xid = -1;
         int brid = 0, bnoff = 0, bncnt = 0;                    // the candidate's rid and list, fetched with its sums
         double bst[9], bc[3] = { 0, 0, 0 }, bn[3] = { 0, 0, 0 };
 #pragma unroll
         for (int q = 0; q < 9; q++) bst[q] = 0;
-        const int a0 = gl < pcnt ? pool[poff + gl] : -1;       // first chunk of p's list, reused by the merge
         PT(2)
         for (int base = 0; __any(base < pcnt); base += GL) {
             PT_CNT(9, 1)
@@ -816,11 +832,13 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
             }
         }
         // ---- the heap: the merged node, or the last entry, replaces the popped root ----
+        __syncthreads();                                       // this iteration's records / lists and the previous sift's heap stores
         {
             double k = m; int idv = id; bool sift = do_merge;
-            if (act && !do_merge) { hn--; k = lastk; idv = lastid; sift = hn > 0; }
-            ptop = gheap_sift_root<GL>(H, hn, k, idv, sift);
+            if (act && !do_merge) { hn--; k = H.key(hn); idv = H.id(hn); sift = hn > 0; }
+            ptop = gheap_sift_root<GL>(H, hn, k, idv, sift, fetch_next);
             if (!sift) ptop = -1;
+            a0n = gl < n_cnt ? pool[n_off + gl] : -1;
         }
         PT(6)
     }
