@@ -22,7 +22,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_LIBPATH = os.path.join(_CSRC, "libhvo.so")
+# HVO_LIB: developer knob, points the binding at an experimental build of the same library (A/B measurements)
+_LIBPATH = os.environ.get("HVO_LIB") or os.path.join(_CSRC, "libhvo.so")
 _LIB = None
 
 HVO_OK = 0

@@ -643,14 +643,16 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
 #pragma unroll
         for (int q = 0; q < 9; q++) bst[q] = 0;
         PT(2)
+        int id_cur = a0;                                        // ids of the next chunk are fetched one pass ahead
         for (int base = 0; __any(base < pcnt); base += GL) {
             PT_CNT(9, 1)
             const int k = base + gl;
+            const int id_nxt = k + GL < pcnt ? pool[poff + k + GL] : -1;
             double lst[9]; int lN = 4, nb = 0, nrid = 0, noff_ = 0, ncnt_ = 0; bool has = false;
 #pragma unroll
             for (int q = 0; q < 9; q++) lst[q] = 0;
             if (k < pcnt) {
-                nb = base == 0 ? a0 : pool[poff + k];
+                nb = id_cur;
                 const double *nd = segD + (size_t)nb * SEG_D;
                 const int *nI = segI + (size_t)nb * SEG_I;
                 const int nN = nI[0]; nrid = nI[1]; noff_ = nI[3]; ncnt_ = nI[4];
@@ -682,6 +684,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
                     bhas = true;
                 }
             }
+            id_cur = id_nxt;
         }
         // ---- group reductions: min mse, then the tie rule ----
         double gmin = bhas ? bm : 1.7976931348623157e308;
@@ -861,6 +864,9 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
 // k_peac_cluster: initGraph edges + main ahCluster, 64/GL frames per wave
 // ------------------------------------------------------------------------------------------------
 template <int GL>
+#ifdef HVO_CLUSTER_WPE
+__attribute__((amdgpu_waves_per_eu(HVO_CLUSTER_WPE, HVO_CLUSTER_WPE)))
+#endif
 __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
 {
     constexpr int NG = 64 / GL;
