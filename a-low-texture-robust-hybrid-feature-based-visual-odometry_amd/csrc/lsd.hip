@@ -12,12 +12,13 @@
 // Kernels
 //   k_lsd_blur_h / k_lsd_blur_v   GaussianBlur 7x7 sigma 0.75 on the CV_64F image (row / column pass)
 //   k_lsd_resize_grad             0.8x INTER_LINEAR resize (double) fused with ll_angle: gradient norm,
-//                                 level-line angle, per-pixel cos/sin of the angle, "defined" bitmask
+//                                 one {angle, cos, sin, |grad|} record per pixel, "defined" bitmask
 //   k_lsd_grow                    one wave per frame: raster-order seeds, region_grow, region2rect,
-//                                 refine / reduce_region_radius; neighbourhoods of up to 7 pending
-//                                 region points are fetched per memory round trip, decisions are
-//                                 taken in the reference's sequential order; emits segments,
-//                                 key-lines, the top-N selection and the line functions
+//                                 refine / reduce_region_radius; neighbourhoods of up to 28 pending
+//                                 region points are fetched per round (availability mask in global
+//                                 memory, one 32-byte record per candidate), the reference's sequential
+//                                 add-and-update walk is speculated, verified and committed in batches;
+//                                 emits segments, key-lines, the top-N selection and the line functions
 //   k_lbd_blur5 / k_lbd_sobel     GaussianBlur 5x5 sigma 1 (u8 fixed point) and Sobel dx, dy (s16)
 //   k_lbd_desc                    one 64-thread workgroup per line: 63 row sums, 9 band sums,
 //                                 normalisation, 32-byte binary descriptor
@@ -189,6 +190,9 @@ struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy; };
 struct GrowState {
     const double4 *px4; int *reg; unsigned *avail; int *ring;     // px4: {angle, cos, sin, modgrad}
     int sw, sh, wpr;          // wpr = mask words per row
+#ifdef HVO_LSD_TIMING
+    long long t_gather, t_add, n_rounds;      // diagnostics build (tools/lsd_timing.py)
+#endif
 };
 
 // The "available" mask (bit = pixel has a gradient angle and is not in a region yet) lives in GLOBAL memory:
@@ -245,6 +249,9 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
     int i = 0;
     const int k0 = lane / 9, j0 = lane - 9 * k0, jx = j0 / 3 - 1, jy = j0 - 3 * (j0 / 3) - 1;   // lane -> (point, neighbour)
     while (i < rs) {
+#ifdef HVO_LSD_TIMING
+        const long long tg0 = clock64();
+#endif
         const int cnt = min(7 * GROW_SLOTS, rs - i);
         int c[GROW_SLOTS]; double an[GROW_SLOTS], cs[GROW_SLOTS], sn[GROW_SLOTS]; bool valid[GROW_SLOTS];
 #pragma unroll
@@ -264,6 +271,10 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
                 }
             }
         }
+#ifdef HVO_LSD_TIMING
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const long long tg1 = clock64();
+#endif
 #pragma unroll
         for (int s = 0; s < GROW_SLOTS; s++) {
             if (s * 7 >= cnt) break;                 // no pending points in this slot (uniform)
@@ -335,6 +346,9 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
                 todo = ~((1ull << m) - 1);           // resume at the lane whose decision differed
             }
         }
+#ifdef HVO_LSD_TIMING
+        S.t_gather += tg1 - tg0; S.t_add += clock64() - tg1; S.n_rounds++;
+#endif
         i += cnt;
         __syncthreads();
     }
@@ -510,6 +524,9 @@ __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
     S.px4 = g.px4 + f * np;
     S.reg = g.reg + f * np; S.avail = g.avail + (size_t)f * nwords; S.ring = ring; S.sw = sw; S.sh = sh; S.wpr = wpr;
     float *segs = g.segs + (size_t)f * LSD_MAXSEG * 4;
+#ifdef HVO_LSD_TIMING
+    S.t_gather = S.t_add = S.n_rounds = 0;
+#endif
     int nseg = 0, flags = 0;
     long long st_seeds = 0, st_pts = 0, st_tg = 0, st_tr = 0, st_tf = 0, st_big = 0;
     const long long t_begin = wall_clock64();
@@ -600,6 +617,9 @@ __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
         g.nkl[f] = n; g.flags[f] = flags;
         long long *st = g.stats + (size_t)f * 8;
         st[0] = st_seeds; st[1] = st_pts; st[2] = st_big; st[3] = st_tg; st[4] = st_tr; st[5] = st_tf; st[6] = wall_clock64() - t_begin; st[7] = nseg;
+#ifdef HVO_LSD_TIMING
+        st[2] = S.n_rounds; st[4] = S.t_gather; st[5] = S.t_add;      // diagnostics build: rounds, gather ticks, add ticks
+#endif
     }
 }
 

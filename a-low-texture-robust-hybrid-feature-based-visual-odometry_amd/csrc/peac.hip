@@ -6,11 +6,12 @@
 //   k_peac_blocks    readDepthImage fused with the PlaneSeg block constructor + Stats::compute
 //                    (PlaneExtractor.cpp:42-56, AHCPlaneSeg.hpp:210-285, 125-156): the 7.4 MB fp64
 //                    cloud is never materialised, each 10x10 block is unprojected on the fly
-//   k_peac_cluster   initGraph edges (AHCPlaneFitter.hpp:894-954) + ahCluster (983-1189); one wave
-//                    per frame, min-MSE heap in LDS, candidate merges evaluated one per lane
-//   k_peac_blkmap    findBlockMembership (485-587): block erosion, coarse labels
-//   k_peac_flood     seed queue + floodFill (428-476): 1024 threads per frame, 1024 queue events per
-//                    round, same-pixel events serialised through an LDS hash
+//   k_peac_cluster   initGraph edges (AHCPlaneFitter.hpp:894-954) + ahCluster (983-1189); 16 lanes per
+//                    frame (4 frames per wave in lockstep), 16-ary min-MSE heap in global memory touched
+//                    once per iteration, candidate merges evaluated one per lane, unordered neighbour sets
+//   k_peac_blkmap    findBlockMembership (485-587): block erosion, packed per-pixel flood state
+//   k_peac_flood     seed queue + floodFill (428-476): a thread owns a queue entry and its four neighbour
+//                    events, same-pixel events ordered by rank through an LDS hash
 //   k_peac_final     last merge round + plidmap (299-340), one wave per frame
 //   k_peac_relabel   membership relabel (353-365), negative "trail" counters reported as -1
 //
@@ -523,38 +524,6 @@ static __device__ int gheap_sift_root(const GHeap &H, int n, double k, int idv, 
     } while (__any(go));
     if (act && gl == 0) H.set(i, k, idv);
     return root;
-}
-
-template <int GL>
-static __device__ void gheap_push(double *key, int *id, int &n, double k, int idv, bool act)
-{
-    const int gl = Grp<GL>::gl();
-    int i = n;
-    if (act) n++;
-    bool go = act && i > 0;
-    while (__any(go)) {
-        const int p = go ? (i - 1) / GH_ARY : 0;
-        double pk = 0; int pid = 0;
-        if (go) { pk = key[p]; pid = id[p]; }
-        const bool mv = go && hless(k, idv, pk, pid);
-        if (mv) { if (gl == 0) { key[i] = pk; id[i] = pid; } i = p; }
-        go = mv && i > 0;
-    }
-    if (act && gl == 0) { key[i] = k; id[i] = idv; }
-}
-
-template <int GL>
-static __device__ int gheap_pop(double *key, int *id, int &n, bool act)
-{
-    int top = -1;
-    double k = 0; int idv = 0;
-    if (act) { top = id[0]; n--; }
-    const bool need = act && n > 0;
-    if (need) { k = key[n]; idv = id[n]; }
-    __syncthreads();
-    gheap_sift_down<GL>(key, id, n, 0, k, idv, need);
-    __syncthreads();
-    return top;
 }
 
 template <int GL>
