@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (rehearsal of the N>1 path on a 1-GPU box)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -119,11 +121,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"     # where the two scalar reductions live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     ge.build() if not os.path.exists(os.path.join(ge.PKG_DIR, "csrc", "libhvo.so")) else None
     hvo = ge.package()
@@ -140,7 +148,7 @@ def main():
         per_frame = 28.5e6 * (args.width * args.height) / (640.0 * 480.0)
         B = next((c for c in (8192, 4096, 2048, 1024) if c * per_frame <= 0.85 * free_b), 512)
         if dist is not None:                 # every rank must run the same workload
-            t = torch.tensor([B], dtype=torch.int64, device="cuda")
+            t = torch.tensor([B], dtype=torch.int64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             B = int(t.item())
     ndistinct = min(B, 16)
@@ -168,7 +176,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
