@@ -44,6 +44,7 @@ EXPORTS = [
     "hvo_abi_version", "hvo_default_params", "hvo_create", "hvo_destroy", "hvo_strerror", "hvo_last_error",
     "hvo_extract_orb", "hvo_extract_lsd", "hvo_compute_planes",
     "hvo_hamming_matrix", "hvo_hamming_knn2", "hvo_match_nnr", "hvo_search_by_projection", "hvo_stereo_from_rgbd",
+    "hvo_undistort_keypoints", "hvo_image_bounds", "hvo_assign_features_to_grid", "hvo_assign_lines_to_grid",
     "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch",
     "hvo_profile_last", "hvo_profile_enable",
 ]
@@ -110,6 +111,10 @@ def lib():
                                     C.POINTER(C.c_int)]
         L.hvo_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_void_p] * 4 + [C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.hvo_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        L.hvo_undistort_keypoints.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.hvo_image_bounds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.hvo_assign_features_to_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.hvo_assign_lines_to_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.hvo_batch_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameIn), C.c_int, C.c_int]
         L.hvo_batch_run.argtypes = [C.c_void_p, C.c_uint]
         L.hvo_batch_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameOut)]
@@ -236,6 +241,35 @@ class Context:
         ur = np.zeros(len(kp), np.float32); z = np.zeros(len(kp), np.float32)
         self._chk(lib().hvo_stereo_from_rgbd(self.h, _p(kp), _p(kp_un), len(kp), _p(depth), w, h, depth.strides[0], bf, _p(ur), _p(z)), "stereo_from_rgbd")
         return ur, z
+
+    # ---- Frame post-processing ----
+    def undistort_keypoints(self, kp, dist5):
+        """Frame::UndistortKeyPoints (src/Frame.cc:1701-1731); dist5 = (k1, k2, p1, p2, k3)"""
+        kp = np.ascontiguousarray(kp); out = np.zeros_like(kp); d = np.ascontiguousarray(dist5, np.float32)
+        assert d.shape == (5,)
+        self._chk(lib().hvo_undistort_keypoints(self.h, _p(kp), len(kp), _p(d), _p(out)), "undistort_keypoints")
+        return out
+
+    def image_bounds(self, w, h, dist5):
+        """Frame::ComputeImageBounds (src/Frame.cc:1733-1762) -> (mnMinX, mnMaxX, mnMinY, mnMaxY)"""
+        d = np.ascontiguousarray(dist5, np.float32); b = np.zeros(4, np.float32)
+        self._chk(lib().hvo_image_bounds(self.h, w, h, _p(d), _p(b)), "image_bounds")
+        return b
+
+    def assign_features_to_grid(self, kp_un, bounds4):
+        """Frame::AssignFeaturesToGrid (src/Frame.cc:832-847) as CSR (cell = col*48 + row)"""
+        kp_un = np.ascontiguousarray(kp_un); b = np.ascontiguousarray(bounds4, np.float32)
+        start = np.zeros(64 * 48 + 1, np.int32); items = np.zeros(max(len(kp_un), 1), np.int32); n = C.c_int(0)
+        self._chk(lib().hvo_assign_features_to_grid(self.h, _p(kp_un), len(kp_un), _p(b), _p(start), _p(items), C.byref(n)), "assign_features_to_grid")
+        return start, items[: n.value]
+
+    def assign_lines_to_grid(self, kl, bounds4, cap=None):
+        """Frame::AssignFeaturesToGridForLine (src/Frame.cc:849-872) as CSR"""
+        kl = np.ascontiguousarray(kl); b = np.ascontiguousarray(bounds4, np.float32)
+        cap = cap if cap is not None else max(len(kl), 1) * 128
+        start = np.zeros(64 * 48 + 1, np.int32); items = np.zeros(max(cap, 1), np.int32); n = C.c_int(0)
+        self._chk(lib().hvo_assign_lines_to_grid(self.h, _p(kl), len(kl), _p(b), _p(start), _p(items), cap, C.byref(n)), "assign_lines_to_grid")
+        return start, items[: n.value]
 
     # ---- batch ----
     def batch_upload(self, gray, depth=None, repeat=1):

@@ -209,6 +209,46 @@ int hvo_extract_orb(hvo_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
     return out.status;
 }
 
+int hvo_undistort_keypoints(hvo_ctx *ctx, const hvo_keypoint *kp, int n, const float dist5[5], hvo_keypoint *kp_un)
+{
+    if (!ctx || n < 0 || !dist5) return HVO_ERR_INVALID_ARG;
+    if (n == 0) return HVO_OK;
+    if (!kp || !kp_un) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    return frame_undistort(ctx, kp, n, dist5, kp_un);
+}
+
+int hvo_image_bounds(hvo_ctx *ctx, int w, int h, const float dist5[5], float bounds4[4])
+{
+    if (!ctx || !dist5 || !bounds4 || w <= 0 || h <= 0) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    return frame_image_bounds(ctx, w, h, dist5, bounds4);
+}
+
+int hvo_assign_features_to_grid(hvo_ctx *ctx, const hvo_keypoint *kp_un, int n, const float bounds4[4],
+                                int32_t *cell_start, int32_t *cell_items, int *n_assigned)
+{
+    if (!ctx || n < 0 || !bounds4 || !cell_start || !n_assigned) return HVO_ERR_INVALID_ARG;
+    *n_assigned = 0;
+    if (!(bounds4[1] > bounds4[0]) || !(bounds4[3] > bounds4[2])) return HVO_ERR_INVALID_ARG;
+    if (n == 0) { memset(cell_start, 0, (HVO_GRID_COLS * HVO_GRID_ROWS + 1) * sizeof(int32_t)); return HVO_OK; }
+    if (!kp_un || !cell_items) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    return frame_points_to_grid(ctx, kp_un, n, bounds4, cell_start, cell_items, n_assigned);
+}
+
+int hvo_assign_lines_to_grid(hvo_ctx *ctx, const hvo_keyline *kl, int n, const float bounds4[4],
+                             int32_t *cell_start, int32_t *cell_items, int cap, int *n_items)
+{
+    if (!ctx || n < 0 || cap < 0 || !bounds4 || !cell_start || !n_items) return HVO_ERR_INVALID_ARG;
+    *n_items = 0;
+    if (!(bounds4[1] > bounds4[0]) || !(bounds4[3] > bounds4[2])) return HVO_ERR_INVALID_ARG;
+    if (n == 0) { memset(cell_start, 0, (HVO_GRID_COLS * HVO_GRID_ROWS + 1) * sizeof(int32_t)); return HVO_OK; }
+    if (!kl || (cap > 0 && !cell_items)) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    return frame_lines_to_grid(ctx, kl, n, bounds4, cell_start, cell_items, cap, n_items);
+}
+
 int hvo_hamming_matrix(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *d)
 {
     if (!ctx || nq < 0 || nt < 0) return HVO_ERR_INVALID_ARG;

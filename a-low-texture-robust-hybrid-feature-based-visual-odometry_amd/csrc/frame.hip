@@ -1,0 +1,191 @@
+// frame.hip -- Frame post-processing of the front-end's outputs for gfx950:
+//   k_undistort          Frame::UndistortKeyPoints (reference src/Frame.cc:1701-1731): cv::undistortPoints,
+//                        OpenCV 3.2.0 fixed-point iteration in fp64, one thread per key point
+//   k_point_cells        Frame::PosInGrid (1680-1690): grid cell of every undistorted key point
+//   k_line_cells         ORB_SLAM2::LineIterator (src/lineIterator.cpp:34-76) over the 64x48 grid, one thread
+//                        per key line, (cell, line) pairs in visiting order
+//   k_cells_to_csr       Frame::AssignFeaturesToGrid / AssignFeaturesToGridForLine (832-872) as CSR: one
+//                        workgroup, a thread owns a few cells and walks the item list in push order, so the
+//                        per-cell order is the reference's without sorting or atomics
+// Same operation order as oracle/frame.c (-ffp-contract=off).
+#include "hvo_internal.hpp"
+#include <string.h>
+
+#define GRID_COLS 64
+#define GRID_ROWS 48
+#define GRID_CELLS (GRID_COLS * GRID_ROWS)
+#define LINE_CELL_CAP 128          // cells one key line can visit: <= max(64, 48) + 2
+
+__global__ __launch_bounds__(256) void k_undistort(const hvo_keypoint *__restrict__ kp, int n, double fx, double fy, double cx, double cy,
+                                                   double k0, double k1, double p1, double p2, double k4, hvo_keypoint *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    hvo_keypoint k = kp[i];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    double x = k.x, y = k.y;
+    x = (x - cx) * ifx; y = (y - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
+        const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x) + 0 * r2 + 0 * r2 * r2;
+        const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y + 0 * r2 + 0 * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0 * y + cx, yy = 0 * x + fy * y + cy, ww = 1. / (0 * x + 0 * y + 1);
+    k.x = (float)(xx * ww); k.y = (float)(yy * ww);
+    out[i] = k;
+}
+
+__global__ __launch_bounds__(256) void k_point_cells(const hvo_keypoint *__restrict__ kp, int n, float minx, float miny, float winv, float hinv,
+                                                     int *__restrict__ cell)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int px = (int)roundf(__fmul_rn(__fsub_rn(kp[i].x, minx), winv)), py = (int)roundf(__fmul_rn(__fsub_rn(kp[i].y, miny), hinv));
+    cell[i] = (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) ? -1 : px * GRID_ROWS + py;
+}
+
+__global__ __launch_bounds__(64) void k_line_cells(const hvo_keyline *__restrict__ kl, int n, float winv, float hinv, int *__restrict__ cell)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    double x1 = (double)__fmul_rn(kl[i].sx, winv), y1 = (double)__fmul_rn(kl[i].sy, hinv);
+    double x2 = (double)__fmul_rn(kl[i].ex, winv), y2 = (double)__fmul_rn(kl[i].ey, hinv);
+    const bool steep = fabs(y2 - y1) > fabs(x2 - x1);
+    double t;
+    if (steep) { t = x1; x1 = y1; y1 = t; t = x2; x2 = y2; y2 = t; }
+    if (x1 > x2) { t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; }
+    const double dx = x2 - x1, dy = fabs(y2 - y1);
+    double error = dx / 2.0;
+    const int ystep = (y1 < y2) ? 1 : -1;
+    int x = (int)x1, y = (int)y1, m = 0;
+    const int maxX = (int)x2;
+    int *out = cell + (size_t)i * LINE_CELL_CAP;
+    while (x <= maxX && m < LINE_CELL_CAP) {
+        const int gx = steep ? y : x, gy = steep ? x : y;
+        out[m++] = (gx < 0 || gx >= GRID_COLS || gy < 0 || gy >= GRID_ROWS) ? -1 : gx * GRID_ROWS + gy;
+        error -= dy;
+        if (error < 0) { y += ystep; error += dx; }
+        x++;
+    }
+    for (; m < LINE_CELL_CAP; m++) out[m] = -1;
+}
+
+// items: n_items cell ids in push order (-1 = not assigned); item i reports index i / per_item.
+// One workgroup of 1024 threads, 3 cells per thread: count, block scan, fill.
+__global__ __launch_bounds__(1024) void k_cells_to_csr(const int *__restrict__ cell, int n_items, int per_item,
+                                                       int *__restrict__ cell_start, int *__restrict__ cell_items, int cap, int *__restrict__ total_out)
+{
+    __shared__ int wsum[16];
+    __shared__ int s_total;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c0 = tid * 3;
+    int cnt[3] = { 0, 0, 0 };
+    for (int i = 0; i < n_items; i++) {
+        const int c = cell[i] - c0;                       // uniform address: broadcast load
+        if (c >= 0 && c < 3) cnt[c]++;
+    }
+    const int mine = cnt[0] + cnt[1] + cnt[2];
+    int incl = mine;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < 16; w++) { const int v = wsum[w]; if (w < wv) base += v; total += v; }
+    int pos[3];
+    pos[0] = base + incl - mine; pos[1] = pos[0] + cnt[0]; pos[2] = pos[1] + cnt[1];
+    for (int q = 0; q < 3; q++) cell_start[c0 + q] = pos[q];
+    if (tid == 1023) { cell_start[GRID_CELLS] = total; *total_out = total; }
+    for (int i = 0; i < n_items; i++) {
+        const int c = cell[i] - c0;
+        if (c >= 0 && c < 3) { if (pos[c] < cap) cell_items[pos[c]] = i / per_item; pos[c]++; }
+    }
+    (void)s_total;
+}
+
+static int grid_csr(hvo_ctx *ctx, const int *d_cell, int n_items, int per_item, int32_t *cell_start, int32_t *cell_items, int cap, int *n_out)
+{
+    int *d_start = nullptr, *d_items = nullptr, *d_total = nullptr;
+    int rc = HVO_OK, total = 0;
+    if (hipMalloc((void **)&d_start, (GRID_CELLS + 1) * sizeof(int)) != hipSuccess || hipMalloc((void **)&d_items, (size_t)(cap > 0 ? cap : 1) * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&d_total, sizeof(int)) != hipSuccess) rc = HVO_ERR_HIP;
+    if (!rc) {
+        hipLaunchKernelGGL(k_cells_to_csr, dim3(1), dim3(1024), 0, ctx->stream, d_cell, n_items, per_item, d_start, d_items, cap, d_total);
+        (void)hipMemcpyAsync(cell_start, d_start, (GRID_CELLS + 1) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = HVO_ERR_HIP;
+        if (!rc && total > 0 && hipMemcpy(cell_items, d_items, (size_t)(total < cap ? total : cap) * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = HVO_ERR_HIP;
+    }
+    if (d_start) (void)hipFree(d_start);
+    if (d_items) (void)hipFree(d_items);
+    if (d_total) (void)hipFree(d_total);
+    *n_out = total;
+    if (!rc && total > cap) rc = HVO_ERR_CAPACITY;
+    return rc;
+}
+
+int frame_undistort(hvo_ctx *ctx, const hvo_keypoint *kp, int n, const float *dist5, hvo_keypoint *kp_un)
+{
+    if (dist5[0] == 0.0f) { memcpy(kp_un, kp, (size_t)n * sizeof(hvo_keypoint)); return HVO_OK; }     // Frame.cc:1703-1707
+    hvo_keypoint *d_in = nullptr, *d_out = nullptr;
+    int rc = HVO_OK;
+    if (hipMalloc((void **)&d_in, (size_t)n * sizeof(hvo_keypoint)) != hipSuccess || hipMalloc((void **)&d_out, (size_t)n * sizeof(hvo_keypoint)) != hipSuccess) rc = HVO_ERR_HIP;
+    if (!rc) {
+        (void)hipMemcpyAsync(d_in, kp, (size_t)n * sizeof(hvo_keypoint), hipMemcpyHostToDevice, ctx->stream);
+        hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_in, n, (double)ctx->p.fx, (double)ctx->p.fy, (double)ctx->p.cx, (double)ctx->p.cy,
+                           (double)dist5[0], (double)dist5[1], (double)dist5[2], (double)dist5[3], (double)dist5[4], d_out);
+        (void)hipMemcpyAsync(kp_un, d_out, (size_t)n * sizeof(hvo_keypoint), hipMemcpyDeviceToHost, ctx->stream);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = HVO_ERR_HIP;
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+int frame_image_bounds(hvo_ctx *ctx, int w, int h, const float *dist5, float *bounds4)
+{
+    if (dist5[0] == 0.0f) { bounds4[0] = 0.f; bounds4[1] = (float)w; bounds4[2] = 0.f; bounds4[3] = (float)h; return HVO_OK; }
+    hvo_keypoint c[4], o[4];
+    memset(c, 0, sizeof(c));
+    c[1].x = (float)w; c[2].y = (float)h; c[3].x = (float)w; c[3].y = (float)h;
+    const int rc = frame_undistort(ctx, c, 4, dist5, o);
+    if (rc) return rc;
+    bounds4[0] = fminf(o[0].x, o[2].x); bounds4[1] = fmaxf(o[1].x, o[3].x);
+    bounds4[2] = fminf(o[0].y, o[1].y); bounds4[3] = fmaxf(o[2].y, o[3].y);
+    return HVO_OK;
+}
+
+int frame_points_to_grid(hvo_ctx *ctx, const hvo_keypoint *kp_un, int n, const float *b, int32_t *cell_start, int32_t *cell_items, int *n_out)
+{
+    const float winv = (float)GRID_COLS / (b[1] - b[0]), hinv = (float)GRID_ROWS / (b[3] - b[2]);
+    hvo_keypoint *d_kp = nullptr; int *d_cell = nullptr;
+    int rc = HVO_OK;
+    if (hipMalloc((void **)&d_kp, (size_t)n * sizeof(hvo_keypoint)) != hipSuccess || hipMalloc((void **)&d_cell, (size_t)n * sizeof(int)) != hipSuccess) rc = HVO_ERR_HIP;
+    if (!rc) {
+        (void)hipMemcpyAsync(d_kp, kp_un, (size_t)n * sizeof(hvo_keypoint), hipMemcpyHostToDevice, ctx->stream);
+        hipLaunchKernelGGL(k_point_cells, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_kp, n, b[0], b[2], winv, hinv, d_cell);
+        rc = grid_csr(ctx, d_cell, n, 1, cell_start, cell_items, n, n_out);
+    }
+    if (d_kp) (void)hipFree(d_kp);
+    if (d_cell) (void)hipFree(d_cell);
+    return rc;
+}
+
+int frame_lines_to_grid(hvo_ctx *ctx, const hvo_keyline *kl, int n, const float *b, int32_t *cell_start, int32_t *cell_items, int cap, int *n_out)
+{
+    const float winv = (float)GRID_COLS / (b[1] - b[0]), hinv = (float)GRID_ROWS / (b[3] - b[2]);
+    hvo_keyline *d_kl = nullptr; int *d_cell = nullptr;
+    int rc = HVO_OK;
+    if (hipMalloc((void **)&d_kl, (size_t)n * sizeof(hvo_keyline)) != hipSuccess || hipMalloc((void **)&d_cell, (size_t)n * LINE_CELL_CAP * sizeof(int)) != hipSuccess) rc = HVO_ERR_HIP;
+    if (!rc) {
+        (void)hipMemcpyAsync(d_kl, kl, (size_t)n * sizeof(hvo_keyline), hipMemcpyHostToDevice, ctx->stream);
+        hipLaunchKernelGGL(k_line_cells, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_kl, n, winv, hinv, d_cell);
+        rc = grid_csr(ctx, d_cell, n * LINE_CELL_CAP, LINE_CELL_CAP, cell_start, cell_items, cap, n_out);
+    }
+    if (d_kl) (void)hipFree(d_kl);
+    if (d_cell) (void)hipFree(d_cell);
+    return rc;
+}

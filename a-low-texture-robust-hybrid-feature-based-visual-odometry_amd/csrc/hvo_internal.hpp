@@ -141,6 +141,12 @@ int match_search_by_projection(hvo_ctx *ctx, const uint8_t *q_desc, int nq, cons
 int match_stereo_from_rgbd(hvo_ctx *ctx, const hvo_keypoint *kp, const hvo_keypoint *kpun, int n, const uint16_t *depth, int w, int h, int stride,
                            float bf, float *uright, float *zdepth);
 
+// frame.hip
+int frame_undistort(hvo_ctx *ctx, const hvo_keypoint *kp, int n, const float *dist5, hvo_keypoint *kp_un);
+int frame_image_bounds(hvo_ctx *ctx, int w, int h, const float *dist5, float *bounds4);
+int frame_points_to_grid(hvo_ctx *ctx, const hvo_keypoint *kp_un, int n, const float *bounds4, int32_t *cell_start, int32_t *cell_items, int *n_out);
+int frame_lines_to_grid(hvo_ctx *ctx, const hvo_keyline *kl, int n, const float *bounds4, int32_t *cell_start, int32_t *cell_items, int cap, int *n_out);
+
 // peac.hip
 int peac_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h);
 int peac_run(hvo_ctx *ctx, int n);

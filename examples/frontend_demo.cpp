@@ -31,6 +31,17 @@ int main(int argc, char **argv)
         hvo::LSDmatcher lm(orb.ctx());
         std::vector<int> m12;
         int nm = lm.match(desc.data(), (int)kps.size(), desc.data(), (int)kps.size(), 0.9f, m12);
+        // what the Frame constructor does next (Frame.cc:231-262): undistort, image bounds, feature grids
+        hvo::FrameGrid fg(orb.ctx());
+        const float dist[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };           // TUM3.yaml:13-17
+        std::vector<hvo::KeyPoint> kps_un; float b[4];
+        fg.UndistortKeyPoints(kps, dist, kps_un);
+        fg.ComputeImageBounds(W, H, dist, b[0], b[1], b[2], b[3]);
+        std::vector<int> gstart, gitems, lstart, litems;
+        fg.AssignFeaturesToGrid(kps_un, b, gstart, gitems);
+        fg.AssignFeaturesToGridForLine(kls, b, lstart, litems);
+        printf("grid %zu %016llx linegrid %zu %016llx ", gitems.size(), (unsigned long long)fnv(gitems.data(), gitems.size() * 4),
+               litems.size(), (unsigned long long)fnv(litems.data(), litems.size() * 4));
         printf("kp %zu desc %016llx lines %zu ldesc %016llx planes %d labels %016llx matches %d\n", kps.size(),
                (unsigned long long)fnv(desc.data(), desc.size()), kls.size(), (unsigned long long)fnv(ldesc.data(), ldesc.size()),
                planes.plane_num_, (unsigned long long)fnv(planes.membership.data(), planes.membership.size() * 4), nm);

@@ -148,6 +148,26 @@ int hvo_search_by_projection(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const 
                              const uint8_t *t_desc, int nt, float mnMinX, float mnMinY, float mnMaxX, float mnMaxY,
                              int th_high, int check_orientation, int32_t *match_idx, int32_t *match_dist, int *n_matches);
 
+/* ---- Frame post-processing of the outputs above ----------------------------------------
+ * dist5 = {k1, k2, p1, p2, k3} (Camera.k1.. of the settings file; k3 = 0 when absent); the intrinsics are the
+ * context's (hvo_params fx, fy, cx, cy).  The 64 x 48 grids (FRAME_GRID_COLS x FRAME_GRID_ROWS) are returned as
+ * CSR: cell = col * 48 + row (the reference's mGrid[col][row]), cell_start has 64*48+1 entries, cell_items holds
+ * feature indices in the reference's push order. */
+#define HVO_GRID_COLS 64
+#define HVO_GRID_ROWS 48
+/* Frame::UndistortKeyPoints (reference src/Frame.cc:1701-1731): k1 == 0 copies the key points (1703-1707), else
+ * cv::undistortPoints(pts, K, dist, Mat(), K) replaces x, y and keeps the other fields. */
+int hvo_undistort_keypoints(hvo_ctx *ctx, const hvo_keypoint *kp, int n, const float dist5[5], hvo_keypoint *kp_un);
+/* Frame::ComputeImageBounds (reference src/Frame.cc:1733-1762): bounds4 = {mnMinX, mnMaxX, mnMinY, mnMaxY} */
+int hvo_image_bounds(hvo_ctx *ctx, int w, int h, const float dist5[5], float bounds4[4]);
+/* Frame::AssignFeaturesToGrid (reference src/Frame.cc:832-847, PosInGrid 1680-1690); cell_items needs n entries */
+int hvo_assign_features_to_grid(hvo_ctx *ctx, const hvo_keypoint *kp_un, int n, const float bounds4[4],
+                                int32_t *cell_start, int32_t *cell_items, int *n_assigned);
+/* Frame::AssignFeaturesToGridForLine (reference src/Frame.cc:849-872, src/lineIterator.cpp:34-76); a line enters
+ * every cell its Bresenham walk visits; HVO_ERR_CAPACITY (with *n_items = the needed count) if cap is too small */
+int hvo_assign_lines_to_grid(hvo_ctx *ctx, const hvo_keyline *kl, int n, const float bounds4[4],
+                             int32_t *cell_start, int32_t *cell_items, int cap, int *n_items);
+
 /* Frame::ComputeStereoFromRGBD (reference src/Frame.cc:1940-1961): uright[i] = kp_un[i].x - bf/d and zdepth[i] = d
  * where d = depth(v,u) * depth_map_factor at the truncated key-point position, if 0 < d < 7; else -1. */
 int hvo_stereo_from_rgbd(hvo_ctx *ctx, const hvo_keypoint *kp, const hvo_keypoint *kp_un, int n,

@@ -154,6 +154,42 @@ private:
     std::unique_ptr<Context> ctx_;
 };
 
+// Frame post-processing of the extractor outputs: what the Frame constructor does right after
+// ExtractORB / ExtractLSD (Frame.cc:231-262): UndistortKeyPoints, ComputeImageBounds, AssignFeaturesToGrid,
+// AssignFeaturesToGridForLine.  Grids are CSR (cell = col * 48 + row), see hvo.h.
+class FrameGrid {
+public:
+    static const int COLS = HVO_GRID_COLS, ROWS = HVO_GRID_ROWS;
+    explicit FrameGrid(hvo_ctx *ctx) : ctx_(ctx) {}
+    void UndistortKeyPoints(const std::vector<KeyPoint> &keys, const float distCoef[5], std::vector<KeyPoint> &keysUn) const
+    {
+        keysUn.resize(keys.size());
+        check(hvo_undistort_keypoints(ctx_, keys.data(), (int)keys.size(), distCoef, keysUn.data()), "hvo_undistort_keypoints");
+    }
+    void ComputeImageBounds(int cols, int rows, const float distCoef[5], float &mnMinX, float &mnMaxX, float &mnMinY, float &mnMaxY) const
+    {
+        float b[4]; check(hvo_image_bounds(ctx_, cols, rows, distCoef, b), "hvo_image_bounds");
+        mnMinX = b[0]; mnMaxX = b[1]; mnMinY = b[2]; mnMaxY = b[3];
+    }
+    // mGrid[col][row] == items[start[col*48+row] .. start[col*48+row+1])
+    void AssignFeaturesToGrid(const std::vector<KeyPoint> &keysUn, const float bounds[4], std::vector<int> &start, std::vector<int> &items) const
+    {
+        start.assign(COLS * ROWS + 1, 0); items.assign(keysUn.size() ? keysUn.size() : 1, 0);
+        int n = 0;
+        check(hvo_assign_features_to_grid(ctx_, keysUn.data(), (int)keysUn.size(), bounds, start.data(), items.data(), &n), "hvo_assign_features_to_grid");
+        items.resize(n);
+    }
+    void AssignFeaturesToGridForLine(const std::vector<KeyLine> &keylines, const float bounds[4], std::vector<int> &start, std::vector<int> &items) const
+    {
+        start.assign(COLS * ROWS + 1, 0); items.assign(keylines.size() * 128 + 1, 0);
+        int n = 0;
+        check(hvo_assign_lines_to_grid(ctx_, keylines.data(), (int)keylines.size(), bounds, start.data(), items.data(), (int)items.size(), &n), "hvo_assign_lines_to_grid");
+        items.resize(n);
+    }
+private:
+    hvo_ctx *ctx_;
+};
+
 class ORBmatcher {
 public:
     static const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;       // ORBmatcher.cc:37-39

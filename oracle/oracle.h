@@ -132,6 +132,19 @@ int  orc_search_by_projection(const uint8_t *q_desc, int nq, const float *q_u, c
 void orc_stereo_from_rgbd(const void *kp, const void *kp_un, int n, const uint16_t *depth, int w, int h, int stride_bytes,
                           float depth_factor, float bf, float *uright, float *zdepth);
 
+
+/* ---------------- Frame post-processing (frame.c) ---------------- */
+/* cv::undistortPoints(src, dst, K, dist, Mat(), K), OpenCV 3.2.0 (ASSUMED); dist5 = k1 k2 p1 p2 k3 */
+void orc_undistort_points(const float *xy_in, int n, float fx, float fy, float cx, float cy, const float *dist5, float *xy_out);
+/* Frame::UndistortKeyPoints (src/Frame.cc:1701-1731) */
+void orc_undistort_keypoints(const orc_keypoint *kp, int n, float fx, float fy, float cx, float cy, const float *dist5, orc_keypoint *kp_un);
+/* Frame::ComputeImageBounds (src/Frame.cc:1733-1762): {mnMinX, mnMaxX, mnMinY, mnMaxY} */
+void orc_image_bounds(int w, int h, float fx, float fy, float cx, float cy, const float *dist5, float *bounds4);
+/* Frame::AssignFeaturesToGrid (src/Frame.cc:832-847, 1680-1690) as CSR, cell = col*48 + row */
+int  orc_assign_features_to_grid(const orc_keypoint *kp_un, int n, const float *bounds4, int32_t *cell_start, int32_t *cell_items);
+/* Frame::AssignFeaturesToGridForLine (src/Frame.cc:849-872, src/lineIterator.cpp:34-76) as CSR */
+int  orc_assign_lines_to_grid(const orc_keyline *kl, int n, const float *bounds4, int32_t *cell_start, int32_t *cell_items, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -296,3 +296,43 @@ def stereo_from_rgbd(kp, kp_un, depth, depth_factor, bf):
     L.orc_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     L.orc_stereo_from_rgbd(_p(kp), _p(kp_un), len(kp), _p(depth), w, h, depth.strides[0], depth_factor, bf, _p(ur), _p(z))
     return ur, z
+
+
+# ---------------- Frame post-processing (frame.c) ----------------
+def undistort_keypoints(kp, fx, fy, cx, cy, dist5):
+    kp = np.ascontiguousarray(kp); out = np.zeros_like(kp)
+    d = np.ascontiguousarray(dist5, np.float32)
+    L = lib()
+    L.orc_undistort_keypoints.restype = None
+    L.orc_undistort_keypoints.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p]
+    L.orc_undistort_keypoints(_p(kp), len(kp), fx, fy, cx, cy, _p(d), _p(out))
+    return out
+
+
+def image_bounds(w, h, fx, fy, cx, cy, dist5):
+    d = np.ascontiguousarray(dist5, np.float32); b = np.zeros(4, np.float32)
+    L = lib()
+    L.orc_image_bounds.restype = None
+    L.orc_image_bounds.argtypes = [C.c_int, C.c_int] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p]
+    L.orc_image_bounds(w, h, fx, fy, cx, cy, _p(d), _p(b))
+    return b
+
+
+def assign_features_to_grid(kp_un, bounds4):
+    kp_un = np.ascontiguousarray(kp_un); b = np.ascontiguousarray(bounds4, np.float32)
+    start = np.zeros(64 * 48 + 1, np.int32); items = np.zeros(max(len(kp_un), 1), np.int32)
+    L = lib()
+    L.orc_assign_features_to_grid.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = L.orc_assign_features_to_grid(_p(kp_un), len(kp_un), _p(b), _p(start), _p(items))
+    return start, items[:n]
+
+
+def assign_lines_to_grid(kl, bounds4, cap=None):
+    kl = np.ascontiguousarray(kl); b = np.ascontiguousarray(bounds4, np.float32)
+    cap = cap if cap is not None else max(len(kl), 1) * 128
+    start = np.zeros(64 * 48 + 1, np.int32); items = np.zeros(cap, np.int32)
+    L = lib()
+    L.orc_assign_lines_to_grid.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    n = L.orc_assign_lines_to_grid(_p(kl), len(kl), _p(b), _p(start), _p(items), cap)
+    return start, items[:max(n, 0)], n
+

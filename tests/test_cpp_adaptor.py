@@ -37,6 +37,13 @@ def test_cpp_demo_matches_oracle(tmp_path, orc, synth):
     kl_o, ld_o, _ = orc.line_extract(g)
     lab_o, pl_o = orc.peac(d)
     nm, _ = orc.match_nnr(d_o, d_o, 0.9)
+    # "grid N hash linegrid N hash kp N desc H lines N ldesc H planes N labels H matches N"
+    b = orc.image_bounds(640, 480, 535.4, 539.2, 320.1, 247.6, [0] * 5)
+    _, gi = orc.assign_features_to_grid(kp_o, b)
+    _, li, _ = orc.assign_lines_to_grid(kl_o, b)
+    assert int(out[1]) == len(gi) and int(out[2], 16) == _fnv(gi.tobytes())
+    assert int(out[4]) == len(li) and int(out[5], 16) == _fnv(li.tobytes())
+    out = out[6:]
     assert int(out[1]) == len(kp_o) and int(out[3], 16) == _fnv(d_o.tobytes())
     assert int(out[5]) == len(kl_o) and int(out[7], 16) == _fnv(ld_o.tobytes())
     assert int(out[9]) == len(pl_o) and int(out[11], 16) == _fnv(lab_o.tobytes())
