@@ -28,6 +28,7 @@ _LIB = None
 
 HVO_OK = 0
 STAGE_ORB, STAGE_LSD, STAGE_PLANES, STAGE_ALL = 1, 2, 4, 7
+STAGE_LSD_CULL = 8        # STAGE_LSD followed by Frame::cullingLine (merged lines replace the extractor's)
 
 KEYPOINT_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                         ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
@@ -45,6 +46,7 @@ EXPORTS = [
     "hvo_extract_orb", "hvo_extract_lsd", "hvo_compute_planes",
     "hvo_hamming_matrix", "hvo_hamming_knn2", "hvo_match_nnr", "hvo_search_by_projection", "hvo_stereo_from_rgbd",
     "hvo_undistort_keypoints", "hvo_image_bounds", "hvo_assign_features_to_grid", "hvo_assign_lines_to_grid",
+    "hvo_extract_lsd_culled", "hvo_set_line_culling",
     "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch",
     "hvo_profile_last", "hvo_profile_enable",
 ]
@@ -111,6 +113,8 @@ def lib():
                                     C.POINTER(C.c_int)]
         L.hvo_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_void_p] * 4 + [C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.hvo_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        L.hvo_extract_lsd_culled.argtypes = L.hvo_extract_lsd.argtypes
+        L.hvo_set_line_culling.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
         L.hvo_undistort_keypoints.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.hvo_image_bounds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.hvo_assign_features_to_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
@@ -175,7 +179,8 @@ class Context:
         self._chk(lib().hvo_extract_orb(self.h, _p(gray), w, h, gray.strides[0], _p(kp), _p(desc), cap, C.byref(n)), "extract_orb")
         return kp[: n.value].copy(), desc[: n.value].copy()
 
-    def extract_lsd(self, gray, cap=None):
+    def extract_lsd(self, gray, cap=None, culled=False):
+        """LINEextractor::operator(); culled=True: Frame::ExtractLSD up to and including cullingLine (Frame.cc:895-934)"""
         if gray is None or gray.size == 0:
             return np.zeros(0, KEYLINE_DT), np.zeros((0, 32), np.uint8), np.zeros((0, 3))
         if gray.dtype != np.uint8 or gray.ndim != 2:
@@ -185,8 +190,13 @@ class Context:
         cap = cap or max(self.params.lsd_nfeatures, 1)
         kl = np.zeros(cap, KEYLINE_DT); desc = np.zeros((cap, 32), np.uint8); fn = np.zeros((cap, 3), np.float64)
         n = C.c_int(0)
-        self._chk(lib().hvo_extract_lsd(self.h, _p(gray), w, h, gray.strides[0], _p(kl), _p(desc), _p(fn), cap, C.byref(n)), "extract_lsd")
+        fnc = lib().hvo_extract_lsd_culled if culled else lib().hvo_extract_lsd
+        self._chk(fnc(self.h, _p(gray), w, h, gray.strides[0], _p(kl), _p(desc), _p(fn), cap, C.byref(n)), "extract_lsd")
         return kl[: n.value].copy(), desc[: n.value].copy(), fn[: n.value].copy()
+
+    def set_line_culling(self, dis=5.0, angle_deg=2.5, endpoint_dis=15.0):
+        """parameters of Frame::cullingLine (Frame.cc:934)"""
+        self._chk(lib().hvo_set_line_culling(self.h, dis, angle_deg, endpoint_dis), "set_line_culling")
 
     def compute_planes(self, depth, cap=64):
         if depth.dtype != np.uint16 or depth.ndim != 2:
@@ -305,7 +315,7 @@ class Context:
             if stages & STAGE_ORB:
                 r["kp"] = np.zeros(kcap, KEYPOINT_DT); r["desc"] = np.zeros((kcap, 32), np.uint8)
                 fo[b].kp = r["kp"].ctypes.data; fo[b].desc = r["desc"].ctypes.data; fo[b].kp_cap = kcap
-            if stages & STAGE_LSD:
+            if stages & (STAGE_LSD | STAGE_LSD_CULL):
                 r["kl"] = np.zeros(lcap, KEYLINE_DT); r["ldesc"] = np.zeros((lcap, 32), np.uint8); r["linefn"] = np.zeros((lcap, 3))
                 fo[b].kl = r["kl"].ctypes.data; fo[b].ldesc = r["ldesc"].ctypes.data; fo[b].linefn = r["linefn"].ctypes.data
                 fo[b].kl_cap = lcap

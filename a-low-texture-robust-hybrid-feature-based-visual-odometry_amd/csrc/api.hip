@@ -146,12 +146,14 @@ int hvo_batch_run(hvo_ctx *ctx, unsigned stages)
     // k_lsd_grow, the rest of ORB then runs underneath it.  sched 1: ORB waits for the LSD preamble.
     // sched 0: no cross-stream ordering.
     ctx->lsd_pre_recorded = ctx->fast_recorded = false;
-    const bool want_orb = (stages & HVO_STAGE_ORB) != 0, want_lsd = (stages & HVO_STAGE_LSD) != 0;
+    const bool want_cull = (stages & HVO_STAGE_LSD_CULL) != 0;
+    const bool want_orb = (stages & HVO_STAGE_ORB) != 0, want_lsd = (stages & HVO_STAGE_LSD) != 0 || want_cull;
+    if (want_lsd) ctx->last_cull = want_cull;
     if (ctx->sched == 2 && want_orb && !ctx->serialize) {
         rc = orb_run(ctx, ctx->batch_n); if (rc) return rc;                 // records ev_fast
-        if (want_lsd) { rc = lsd_run(ctx, ctx->batch_n); if (rc) return rc; }   // k_lsd_grow waits for ev_fast
+        if (want_lsd) { rc = lsd_run(ctx, ctx->batch_n, want_cull); if (rc) return rc; }   // k_lsd_grow waits for ev_fast
     } else {
-        if (want_lsd) { rc = lsd_run(ctx, ctx->batch_n); if (rc) return rc; }
+        if (want_lsd) { rc = lsd_run(ctx, ctx->batch_n, want_cull); if (rc) return rc; }
         if (want_orb) {
             if (ctx->sched == 1 && ctx->lsd_pre_recorded && !ctx->serialize) HVO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_lsd_pre, 0));
             rc = orb_run(ctx, ctx->batch_n); if (rc) return rc;
@@ -176,7 +178,7 @@ int hvo_batch_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
     bool want_pl = false, want_kl = false;
     for (int f = 0; f < n; f++) { want_pl |= (out[f].labels || out[f].planes); want_kl |= (out[f].kl != nullptr); }
     if (want_pl) { rc = peac_download(ctx, n, out); if (rc) return rc; }
-    if (want_kl) { rc = lsd_download(ctx, n, out); if (rc) return rc; }
+    if (want_kl) { rc = lsd_download(ctx, n, out, ctx->last_cull); if (rc) return rc; }
     return HVO_OK;
 }
 

@@ -73,6 +73,8 @@ struct hvo_ctx {
     hipEvent_t ev_fast = nullptr;          // recorded on the ORB stream after k_fast_cells (the only ORB kernel that needs LDS)
     bool fast_recorded = false;
     int sched = 1;                         // overlap policy of hvo_batch_run, see api.hip
+    double cull_dis = 5.0, cull_angle = 2.5, cull_endpoint = 15.0;   // Frame::cullingLine(im, 5, 2.5, 15, 30), Frame.cc:934
+    bool last_cull = false;                // the resident batch was run with HVO_STAGE_LSD_CULL
     std::string last_error;
     OrbPlan orb;
     // ORB tables
@@ -154,8 +156,8 @@ int peac_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
 void peac_free(hvo_ctx *ctx);
 
 // lsd.hip (+ lbd)
-int lsd_run(hvo_ctx *ctx, int n);
-int lsd_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
+int lsd_run(hvo_ctx *ctx, int n, bool cull = false);
+int lsd_download(hvo_ctx *ctx, int n, hvo_frame_out *out, bool culled = false);
 void lsd_free(hvo_ctx *ctx);
 
 static inline hipStream_t hvo_stream_lsd(hvo_ctx *c) { return c->serialize ? c->stream : c->s_lsd; }

@@ -44,6 +44,7 @@ struct LsdPlan {
     float *d_segs = nullptr;                                // LSD_MAXSEG x 4
     hvo_keyline *d_kl_all = nullptr;                        // LSD_MAXSEG
     hvo_keyline *d_kl = nullptr; uint8_t *d_desc = nullptr; double *d_fn = nullptr; int *d_nkl = nullptr; int *d_flags = nullptr;
+    hvo_keyline *d_kl2 = nullptr; uint8_t *d_desc2 = nullptr; double *d_fn2 = nullptr; int *d_nkl2 = nullptr;   // after cullingLine
     uint8_t *d_b5 = nullptr; int16_t *d_dx = nullptr, *d_dy = nullptr;
     int *d_xofs = nullptr, *d_yofs = nullptr; float *d_xa = nullptr, *d_yb = nullptr;   // resize tables
     double k7[4] = { 0, 0, 0, 0 };                          // gaussian taps (double): k[0..3], symmetric
@@ -765,6 +766,188 @@ __global__ __launch_bounds__(64) void k_lbd_desc(const int16_t *__restrict__ dxI
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_cull_lines: Frame::cullingLine (reference src/Frame.cc:952-1116), one wave per frame.
+//   step 1 (pair scan, 956-1027): leaders in ascending index; a leader's candidates j > i are tested 64 at a
+//           time, the accepted ones are appended in ascending j (ballot order = the reference's push order)
+//   step 2 (1030-1056): every leader folds MergeTwoLines over its members (one leader per lane)
+//   step 3 (1062-1092): new KeyLines, stable rank sort by response, class_id = rank, line functions
+// The second LBD pass (1094-1096) is a k_lbd_desc launch on the result.
+// ------------------------------------------------------------------------------------------------
+#define CULL_MAXL 512
+struct CullArgs {
+    const hvo_keyline *kl; const double *fn; const int *nkl; hvo_keyline *tmp; hvo_keyline *kl_out; double *fn_out; int *nkl_out;
+    int cap, tmp_stride, w, h; double dis, cos_th, endpoint_dis;
+};
+
+static __device__ double cull_point_line_distance(const float *l, float px, float py)                  // Frame.cc:1117-1126
+{
+    const double x0 = (double)px, y0 = (double)py, x1 = l[0], y1 = l[1], x2 = l[2], y2 = l[3];
+    return fabs((y2 - y1) * x0 + (x1 - x2) * y0 + ((x2 * y1) - (x1 * y2))) / sqrt((y2 - y1) * (y2 - y1) + (x1 - x2) * (x1 - x2));
+}
+static __device__ double cull_two_line_angle(const double *f1, const double *f2)                       // Frame.cc:1127-1140, as written
+{
+    double v1[3] = { f1[0], f1[1], f1[2] }, v2[3] = { f2[0], f2[1], f2[2] };
+    v1[0] /= v1[2]; v1[1] /= v1[2];
+    v2[0] /= v2[2]; v2[1] /= v2[2];
+    const double a0 = v1[0] / v1[2], a1 = v1[1] / v1[2], b0 = v2[0] / v2[2], b1 = v2[1] / v2[2];
+    const double a = a0 * b0 + a1 * b1;
+    const double b = sqrt(a0 * a0 + a1 * a1), c = sqrt(b0 * b0 + b1 * b1);
+    return fabs(a / (b * c));
+}
+static __device__ void cull_merge_two_lines(const float *l1, const float *l2, float *out)               // Frame.cc:1141-1202
+{
+    const double PI = 3.1415926535897932384626433832795;
+    const float ax = l1[0], ay = l1[1], bx = l1[2], by = l1[3], cx = l2[0], cy = l2[1], dx = l2[2], dy = l2[3];
+    const float dlix = __fsub_rn(bx, ax), dliy = __fsub_rn(by, ay), dljx = __fsub_rn(dx, cx), dljy = __fsub_rn(dy, cy);
+    const double li = sqrt((double)__fmul_rn(dlix, dlix) + (double)__fmul_rn(dliy, dliy));
+    const double lj = sqrt((double)__fmul_rn(dljx, dljx) + (double)__fmul_rn(dljy, dljy));
+    const double xg = (li * (double)__fadd_rn(ax, bx) + lj * (double)__fadd_rn(cx, dx)) / (double)(2.0 * (li + lj));
+    const double yg = (li * (double)__fadd_rn(ay, by) + lj * (double)__fadd_rn(cy, dy)) / (double)(2.0 * (li + lj));
+    const double thi = dlix == 0.0f ? PI / 2.0 : atan((double)__fdiv_rn(dliy, dlix));
+    const double thj = dljx == 0.0f ? PI / 2.0 : atan((double)__fdiv_rn(dljy, dljx));
+    double thr;
+    if (fabs(thi - thj) <= PI / 2.0) thr = (li * thi + lj * thj) / (li + lj);
+    else { const double tmp = thj - PI * (thj / fabs(thj)); thr = li * thi + lj * tmp; thr /= (li + lj); }
+    const double s = sin(thr), c = cos(thr);
+    const double axg = ((double)ay - yg) * s + ((double)ax - xg) * c, bxg = ((double)by - yg) * s + ((double)bx - xg) * c;
+    const double cxg = ((double)cy - yg) * s + ((double)cx - xg) * c, dxg = ((double)dy - yg) * s + ((double)dx - xg) * c;
+    const double d1 = fmin(axg, fmin(bxg, fmin(cxg, dxg))), d2 = fmax(axg, fmax(bxg, fmax(cxg, dxg)));
+    out[0] = (float)(d1 * c + xg); out[1] = (float)(d1 * s + yg); out[2] = (float)(d2 * c + xg); out[3] = (float)(d2 * s + yg);
+}
+// cv::LineIterator(img, Point(p1), Point(p2), 8).count with cv::clipLine (OpenCV 3.2.0, ASSUMED)
+static __device__ int cull_line_count(int w, int h, float fx1, float fy1, float fx2, float fy2)
+{
+    long long x1 = __float2int_rn(fx1), y1 = __float2int_rn(fy1), x2 = __float2int_rn(fx2), y2 = __float2int_rn(fy2);
+    if ((unsigned long long)x1 >= (unsigned long long)w || (unsigned long long)x2 >= (unsigned long long)w ||
+        (unsigned long long)y1 >= (unsigned long long)h || (unsigned long long)y2 >= (unsigned long long)h) {
+        const long long right = w - 1, bottom = h - 1;
+        int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+        int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            long long a;
+            if (c1 & 12) { a = c1 < 8 ? 0 : bottom; x1 += (a - y1) * (x2 - x1) / (y2 - y1); y1 = a; c1 = (x1 < 0) + (x1 > right) * 2; }
+            if (c2 & 12) { a = c2 < 8 ? 0 : bottom; x2 += (a - y2) * (x2 - x1) / (y2 - y1); y2 = a; c2 = (x2 < 0) + (x2 > right) * 2; }
+            if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+                if (c1) { a = c1 == 1 ? 0 : right; y1 += (a - x1) * (y2 - y1) / (x2 - x1); x1 = a; c1 = 0; }
+                if (c2) { a = c2 == 1 ? 0 : right; y2 += (a - x2) * (y2 - y1) / (x2 - x1); x2 = a; c2 = 0; }
+            }
+        }
+        if ((c1 | c2) != 0) return 0;
+    }
+    const long long dx = llabs(x2 - x1), dy = llabs(y2 - y1);
+    return (int)((dx > dy ? dx : dy) + 1);
+}
+
+__global__ __launch_bounds__(64) void k_cull_lines(CullArgs a)
+{
+    __shared__ float ep[CULL_MAXL][4];            // end points of the input lines
+    __shared__ double fnl[CULL_MAXL][3];
+    __shared__ unsigned char tag[CULL_MAXL];
+    __shared__ short grp[CULL_MAXL]; __shared__ short gstart[CULL_MAXL + 1];
+    __shared__ float nl[CULL_MAXL][4];            // merged / surviving segments
+    __shared__ float resp[CULL_MAXL];
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int n = min(a.nkl[f], CULL_MAXL);
+    const hvo_keyline *kl = a.kl + (size_t)f * a.cap;
+    const double *fn = a.fn + (size_t)f * a.cap * 3;
+    for (int i = lane; i < n; i += 64) {
+        ep[i][0] = kl[i].sx; ep[i][1] = kl[i].sy; ep[i][2] = kl[i].ex; ep[i][3] = kl[i].ey;
+        fnl[i][0] = fn[3 * i]; fnl[i][1] = fn[3 * i + 1]; fnl[i][2] = fn[3 * i + 2];
+        tag[i] = 0;
+    }
+    __syncthreads();
+    // ---- step 1 ----
+    int ngrp = 0;
+    for (int i = 0; i < n; i++) {
+        if (lane == 0) gstart[i] = (short)ngrp;
+        if (tag[i]) continue;                     // uniform (LDS broadcast)
+        const float *e1 = ep[i];
+        const float m12x = (float)((double)__fadd_rn(e1[0], e1[2]) * 0.5), m12y = (float)((double)__fadd_rn(e1[1], e1[3]) * 0.5);
+        bool any = false;
+        for (int base = i + 1; base < n; base += 64) {
+            const int j = base + lane;
+            bool acc = false;
+            if (j < n && !tag[j]) {
+                const float *e2 = ep[j];
+                float m21x = (float)((double)__fadd_rn(e2[2], e2[0]) * 0.5), m21y = (float)((double)__fadd_rn(e2[3], e2[1]) * 0.5);
+                m21x = __fadd_rn(m21x, e2[0]); m21y = __fadd_rn(m21y, e2[1]);                  // Frame.cc:977, as written
+                const double dis12 = cull_point_line_distance(e2, m12x, m12y), dis21 = cull_point_line_distance(e1, m21x, m21y);
+                if ((dis12 < a.dis || dis21 < a.dis) && cull_two_line_angle(fnl[i], fnl[j]) > a.cos_th) {
+                    double bx[4] = { (double)e1[0], (double)e1[2], (double)e2[0], (double)e2[2] }, by[4] = { (double)e1[1], (double)e1[3], (double)e2[1], (double)e2[3] };
+#pragma unroll
+                    for (int p = 1; p < 4; p++) for (int q = p; q > 0; q--) {
+                        if (bx[q - 1] > bx[q]) { const double t = bx[q]; bx[q] = bx[q - 1]; bx[q - 1] = t; }
+                        if (by[q - 1] > by[q]) { const double t = by[q]; by[q] = by[q - 1]; by[q - 1] = t; }
+                    }
+                    const double dx = bx[3] - bx[0], dy = by[3] - by[0];
+                    const double dx1 = fabs((double)e1[0] - (double)e1[2]), dx2 = fabs((double)e2[0] - (double)e2[2]);
+                    const double dy1 = fabs((double)e1[1] - (double)e1[3]), dy2 = fabs((double)e2[1] - (double)e2[3]);
+                    acc = !(dx > dx1 + dx2 && bx[2] - bx[1] > a.endpoint_dis) && !(dy > dy1 + dy2 && by[2] - by[1] > a.endpoint_dis);
+                }
+            }
+            const unsigned long long m = __ballot(acc);
+            if (acc) { grp[ngrp + __popcll(m & ((1ull << lane) - 1))] = (short)j; tag[j] = 1; }
+            ngrp += __popcll(m);
+            any |= m != 0;
+        }
+        if (any && lane == 0) tag[i] = 1;
+        __syncthreads();
+    }
+    if (lane == 0) gstart[n] = (short)ngrp;
+    __syncthreads();
+    // ---- step 2: one leader per lane ----
+    int m = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        bool keep = false; float cur[4] = { 0, 0, 0, 0 };
+        if (i < n) {
+            const int g0 = gstart[i], g1 = gstart[i + 1];
+            cur[0] = ep[i][0]; cur[1] = ep[i][1]; cur[2] = ep[i][2]; cur[3] = ep[i][3];
+            for (int q = g0; q < g1; q++) { float r[4]; cull_merge_two_lines(cur, ep[grp[q]], r); cur[0] = r[0]; cur[1] = r[1]; cur[2] = r[2]; cur[3] = r[3]; }
+            keep = g1 > g0 || !tag[i];
+        }
+        const unsigned long long km = __ballot(keep);
+        if (keep) { const int p = m + __popcll(km & ((1ull << lane) - 1)); nl[p][0] = cur[0]; nl[p][1] = cur[1]; nl[p][2] = cur[2]; nl[p][3] = cur[3]; }
+        m += __popcll(km);
+    }
+    __syncthreads();
+    // ---- step 3: KeyLines, stable rank sort by response, line functions ----
+    hvo_keyline *tmp = a.tmp + (size_t)f * a.tmp_stride;
+    for (int i = lane; i < m; i += 64) {
+        hvo_keyline k;
+        k.sx = k.sox = nl[i][0]; k.sy = k.soy = nl[i][1]; k.ex = k.eox = nl[i][2]; k.ey = k.eoy = nl[i][3];
+        const double ddx = (double)__fsub_rn(nl[i][0], nl[i][2]), ddy = (double)__fsub_rn(nl[i][1], nl[i][3]);
+        k.length = (float)sqrt(ddx * ddx + ddy * ddy);
+        k.octave = 0;
+        k.angle = (float)atan2((double)__fsub_rn(k.ey, k.sy), (double)__fsub_rn(k.ex, k.sx));
+        k.size = __fmul_rn(__fsub_rn(k.ex, k.sx), __fsub_rn(k.ey, k.sy));
+        k.pt_x = __fdiv_rn(__fadd_rn(k.ex, k.sx), 2.f); k.pt_y = __fdiv_rn(__fadd_rn(k.ey, k.sy), 2.f);
+        k.num_pixels = cull_line_count(a.w, a.h, nl[i][0], nl[i][1], nl[i][2], nl[i][3]);
+        k.response = __fdiv_rn(k.length, (float)(a.w > a.h ? a.w : a.h));
+        k.class_id = -1;
+        tmp[i] = k; resp[i] = k.response;
+    }
+    __syncthreads();
+    hvo_keyline *out = a.kl_out + (size_t)f * a.cap;
+    double *fo = a.fn_out + (size_t)f * a.cap * 3;
+    for (int i = lane; i < m; i += 64) {
+        const float r = resp[i];
+        int rank = 0;
+        for (int q = 0; q < m; q++) { const float rq = resp[q]; rank += (rq > r) || (rq == r && q < i); }
+        hvo_keyline k = tmp[i]; k.class_id = rank;
+        if (rank < a.cap) {
+            out[rank] = k;
+            const double sx = k.sx, sy = k.sy, ex = k.ex, ey = k.ey;
+            const double l0 = sy * 1.0 - 1.0 * ey, l1 = 1.0 * ex - sx * 1.0, l2 = sx * ey - sy * ex;
+            const double nrm = sqrt(l0 * l0 + l1 * l1);
+            fo[3 * rank] = l0 / nrm; fo[3 * rank + 1] = l1 / nrm; fo[3 * rank + 2] = l2 / nrm;
+        }
+    }
+    if (lane == 0) a.nkl_out[f] = m;
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -772,7 +955,7 @@ void lsd_free(hvo_ctx *ctx)
 {
     LsdPlan *P = plan_of(ctx);
     if (!P) return;
-    void *ptrs[] = { P->d_tmp, P->d_blur, P->d_px, P->d_defined, P->d_reg, P->d_segs, P->d_kl_all, P->d_kl,
+    void *ptrs[] = { P->d_kl2, P->d_desc2, P->d_fn2, P->d_nkl2, P->d_tmp, P->d_blur, P->d_px, P->d_defined, P->d_reg, P->d_segs, P->d_kl_all, P->d_kl,
                      P->d_desc, P->d_fn, P->d_nkl, P->d_flags, P->d_b5, P->d_dx, P->d_dy, P->d_xofs, P->d_yofs, P->d_xa, P->d_yb, P->d_gL, P->d_gG, P->d_stats };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
@@ -839,6 +1022,7 @@ static int lsd_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_segs, B * LSD_MAXSEG * 16); PA(P->d_kl_all, B * LSD_MAXSEG * sizeof(hvo_keyline));
     PA(P->d_kl, B * P->nfeat * sizeof(hvo_keyline)); PA(P->d_desc, B * P->nfeat * 32); PA(P->d_fn, B * P->nfeat * 24);
     PA(P->d_nkl, B * 4); PA(P->d_flags, B * 4);
+    PA(P->d_kl2, B * P->nfeat * sizeof(hvo_keyline)); PA(P->d_desc2, B * P->nfeat * 32); PA(P->d_fn2, B * P->nfeat * 24); PA(P->d_nkl2, B * 4);
     PA(P->d_b5, B * npix); PA(P->d_dx, B * npix * 2); PA(P->d_dy, B * npix * 2);
     PA(P->d_xofs, P->sw * 4); PA(P->d_yofs, P->sh * 4); PA(P->d_xa, P->sw * 8); PA(P->d_yb, P->sh * 8);
     PA(P->d_gL, 21 * 4); PA(P->d_gG, 63 * 4); PA(P->d_stats, B * 64);
@@ -854,7 +1038,7 @@ static int lsd_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
     return HVO_OK;
 }
 
-int lsd_run(hvo_ctx *ctx, int n)
+int lsd_run(hvo_ctx *ctx, int n, bool cull)
 {
     // input: level 0 of the ORB pyramid slab (the uploaded gray image)
     OrbPlan &O = ctx->orb;
@@ -892,16 +1076,28 @@ int lsd_run(hvo_ctx *ctx, int n)
     id = hvo_prof_begin(ctx, "lbd_desc", st);
     hipLaunchKernelGGL(k_lbd_desc, dim3(P->nfeat, n), dim3(64), 0, st, P->d_dx, P->d_dy, w, h, P->d_kl, P->d_nkl, P->nfeat, P->d_gL, P->d_gG, P->d_desc);
     hvo_prof_end(ctx, id);
+    if (cull) {                                     // Frame::cullingLine + the second LBD pass (Frame.cc:934, 952-1116)
+        if (P->nfeat > CULL_MAXL) return HVO_ERR_UNSUPPORTED;
+        id = hvo_prof_begin(ctx, "lsd_cull", st);
+        CullArgs c;
+        c.kl = P->d_kl; c.fn = P->d_fn; c.nkl = P->d_nkl; c.tmp = P->d_kl_all; c.tmp_stride = LSD_MAXSEG; c.kl_out = P->d_kl2; c.fn_out = P->d_fn2; c.nkl_out = P->d_nkl2;
+        c.cap = P->nfeat; c.w = w; c.h = h; c.dis = ctx->cull_dis; c.cos_th = cos(ctx->cull_angle * 0.0174533); c.endpoint_dis = ctx->cull_endpoint;
+        hipLaunchKernelGGL(k_cull_lines, dim3(n), dim3(64), 0, st, c);
+        hipLaunchKernelGGL(k_lbd_desc, dim3(P->nfeat, n), dim3(64), 0, st, P->d_dx, P->d_dy, w, h, P->d_kl2, P->d_nkl2, P->nfeat, P->d_gL, P->d_gG, P->d_desc2);
+        hvo_prof_end(ctx, id);
+    }
     HVO_HIP(hipGetLastError());
     return HVO_OK;
 }
 
-int lsd_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
+int lsd_download(hvo_ctx *ctx, int n, hvo_frame_out *out, bool culled)
 {
     LsdPlan *P = plan_of(ctx);
     if (!P) return HVO_ERR_INVALID_ARG;
+    const hvo_keyline *d_kl = culled ? P->d_kl2 : P->d_kl; const uint8_t *d_desc = culled ? P->d_desc2 : P->d_desc;
+    const double *d_fn = culled ? P->d_fn2 : P->d_fn; const int *d_nkl = culled ? P->d_nkl2 : P->d_nkl;
     std::vector<int> nk(n), fl(n);
-    HVO_HIP(hipMemcpyAsync(nk.data(), P->d_nkl, n * sizeof(int), hipMemcpyDeviceToHost, ctx->s_lsd));
+    HVO_HIP(hipMemcpyAsync(nk.data(), d_nkl, n * sizeof(int), hipMemcpyDeviceToHost, ctx->s_lsd));
     HVO_HIP(hipMemcpyAsync(fl.data(), P->d_flags, n * sizeof(int), hipMemcpyDeviceToHost, ctx->s_lsd));
     HVO_HIP(hipStreamSynchronize(ctx->s_lsd));
     for (int f = 0; f < n; f++) {
@@ -910,9 +1106,9 @@ int lsd_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
         if (out[f].kl) {
             if (m > out[f].kl_cap) { m = out[f].kl_cap; out[f].status = HVO_ERR_CAPACITY; }
             if (m > 0) {
-                HVO_HIP(hipMemcpyAsync(out[f].kl, P->d_kl + (size_t)f * P->nfeat, (size_t)m * sizeof(hvo_keyline), hipMemcpyDeviceToHost, ctx->s_lsd));
-                if (out[f].ldesc) HVO_HIP(hipMemcpyAsync(out[f].ldesc, P->d_desc + (size_t)f * P->nfeat * 32, (size_t)m * 32, hipMemcpyDeviceToHost, ctx->s_lsd));
-                if (out[f].linefn) HVO_HIP(hipMemcpyAsync(out[f].linefn, P->d_fn + (size_t)f * P->nfeat * 3, (size_t)m * 24, hipMemcpyDeviceToHost, ctx->s_lsd));
+                HVO_HIP(hipMemcpyAsync(out[f].kl, d_kl + (size_t)f * P->nfeat, (size_t)m * sizeof(hvo_keyline), hipMemcpyDeviceToHost, ctx->s_lsd));
+                if (out[f].ldesc) HVO_HIP(hipMemcpyAsync(out[f].ldesc, d_desc + (size_t)f * P->nfeat * 32, (size_t)m * 32, hipMemcpyDeviceToHost, ctx->s_lsd));
+                if (out[f].linefn) HVO_HIP(hipMemcpyAsync(out[f].linefn, d_fn + (size_t)f * P->nfeat * 3, (size_t)m * 24, hipMemcpyDeviceToHost, ctx->s_lsd));
             }
         }
         out[f].n_kl = m;
@@ -940,6 +1136,36 @@ extern "C" int hvo_extract_lsd(hvo_ctx *ctx, const uint8_t *gray, int w, int h, 
     if ((rc = lsd_download(ctx, 1, &out))) return rc;
     *n = out.n_kl;
     return out.status;
+}
+
+// Frame::ExtractLSD up to and including cullingLine (reference src/Frame.cc:895-934): LINEextractor, then the
+// merge of near-collinear segments with the second LBD pass
+extern "C" int hvo_extract_lsd_culled(hvo_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
+                                      hvo_keyline *kl, uint8_t *desc32, double *linefn3, int cap, int *n)
+{
+    if (!ctx || !n) return HVO_ERR_INVALID_ARG;
+    *n = 0;
+    if (!gray || w <= 0 || h <= 0) return HVO_OK;
+    if (!kl || !desc32 || !linefn3 || cap < 0 || stride < w) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    hvo_frame_in in; memset(&in, 0, sizeof(in));
+    in.gray = gray; in.gray_stride = stride;
+    int rc = orb_upload(ctx, 1, &in, w, h);
+    if (rc) return rc;
+    for (int i = 0; i < ctx->nprof; i++) ctx->prof[i].used = false;
+    if ((rc = lsd_run(ctx, 1, true))) return rc;
+    hvo_frame_out out; memset(&out, 0, sizeof(out));
+    out.kl = kl; out.ldesc = desc32; out.linefn = linefn3; out.kl_cap = cap;
+    if ((rc = lsd_download(ctx, 1, &out, true))) return rc;
+    *n = out.n_kl;
+    return out.status;
+}
+
+extern "C" int hvo_set_line_culling(hvo_ctx *ctx, double dis, double angle_deg, double endpoint_dis)
+{
+    if (!ctx || !(dis >= 0) || !(angle_deg >= 0) || !(endpoint_dis >= 0)) return HVO_ERR_INVALID_ARG;
+    ctx->cull_dis = dis; ctx->cull_angle = angle_deg; ctx->cull_endpoint = endpoint_dis;
+    return HVO_OK;
 }
 
 // diagnostics (not part of include/hvo.h): per-frame counters of the last k_lsd_grow launch:

@@ -148,6 +148,16 @@ int hvo_search_by_projection(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const 
                              const uint8_t *t_desc, int nt, float mnMinX, float mnMinY, float mnMaxX, float mnMaxY,
                              int th_high, int check_orientation, int32_t *match_idx, int32_t *match_dist, int *n_matches);
 
+/* Frame::ExtractLSD up to and including cullingLine (reference src/Frame.cc:895-934, 952-1116):
+ * the LINEextractor output, then near-collinear segments merged (PointLineDistance / TwoLineAngle /
+ * MergeTwoLines, 1117-1202), KeyLines rebuilt and re-sorted by response (class_id = rank), second LBD pass,
+ * line functions.  isLineGood (the 3-D line fit with rand()) is not part of it.  Same conventions as
+ * hvo_extract_lsd.  hvo_set_line_culling changes cullingLine's dis / angle (degrees) / endpoint_dis
+ * (defaults 5, 2.5, 15: Frame.cc:934). */
+int hvo_extract_lsd_culled(hvo_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
+                           hvo_keyline *kl, uint8_t *desc32, double *linefn3, int cap, int *n);
+int hvo_set_line_culling(hvo_ctx *ctx, double dis, double angle_deg, double endpoint_dis);
+
 /* ---- Frame post-processing of the outputs above ----------------------------------------
  * dist5 = {k1, k2, p1, p2, k3} (Camera.k1.. of the settings file; k3 = 0 when absent); the intrinsics are the
  * context's (hvo_params fx, fy, cx, cy).  The 64 x 48 grids (FRAME_GRID_COLS x FRAME_GRID_ROWS) are returned as
@@ -178,6 +188,7 @@ int hvo_stereo_from_rgbd(hvo_ctx *ctx, const hvo_keypoint *kp, const hvo_keypoin
 #define HVO_STAGE_LSD    2u
 #define HVO_STAGE_PLANES 4u
 #define HVO_STAGE_ALL    7u
+#define HVO_STAGE_LSD_CULL 8u    /* HVO_STAGE_LSD followed by Frame::cullingLine: the frame's kl / ldesc / linefn are the merged lines */
 
 typedef struct {
     const uint8_t  *gray;  int gray_stride;    /* bytes */

@@ -109,6 +109,20 @@ public:
         check(hvo_extract_lsd(ctx_->get(), image.data, image.width, image.height, image.stride, keylines.data(), descriptors.data(), lineVec2d.data(), cap, &n), "hvo_extract_lsd");
         keylines.resize(n); descriptors.resize((size_t)n * 32); lineVec2d.resize((size_t)n * 3);
     }
+    // Frame::ExtractLSD up to and including cullingLine(im, dis, angle, endpoint_dis, .) (Frame.cc:895-934, 952-1116):
+    // the extractor's lines with near-collinear segments merged, re-sorted, re-described
+    void ExtractLSDCulled(const Image8 &image, std::vector<KeyLine> &keylines, std::vector<uint8_t> &descriptors, std::vector<double> &lineVec2d,
+                          double dis = 5, double angle = 2.5, double endpoint_dis = 15)
+    {
+        keylines.clear(); descriptors.clear(); lineVec2d.clear();
+        if (image.empty()) return;
+        const int cap = nfeat_ > 0 ? nfeat_ : 1;
+        keylines.resize(cap); descriptors.resize((size_t)cap * 32); lineVec2d.resize((size_t)cap * 3);
+        int n = 0;
+        check(hvo_set_line_culling(ctx_->get(), dis, angle, endpoint_dis), "hvo_set_line_culling");
+        check(hvo_extract_lsd_culled(ctx_->get(), image.data, image.width, image.height, image.stride, keylines.data(), descriptors.data(), lineVec2d.data(), cap, &n), "hvo_extract_lsd_culled");
+        keylines.resize(n); descriptors.resize((size_t)n * 32); lineVec2d.resize((size_t)n * 3);
+    }
     int GetLevels() const { return numOctaves_; }
     float GetScaleFactor() const { return scale_; }
 private:

@@ -145,6 +145,11 @@ int  orc_assign_features_to_grid(const orc_keypoint *kp_un, int n, const float *
 /* Frame::AssignFeaturesToGridForLine (src/Frame.cc:849-872, src/lineIterator.cpp:34-76) as CSR */
 int  orc_assign_lines_to_grid(const orc_keyline *kl, int n, const float *bounds4, int32_t *cell_start, int32_t *cell_items, int cap);
 
+/* Frame::cullingLine (src/Frame.cc:952-1116; helpers 1117-1202), SURVEY.md 8f.2 */
+int  orc_line_iterator_count_clipped(int w, int h, float x1, float y1, float x2, float y2);
+int  orc_cull_lines(const uint8_t *gray, int w, int h, int stride, const orc_keyline *kl, const double *fn, int n,
+                    double dis, double angle_deg, double endpoint_dis, orc_keyline *kl_out, uint8_t *desc32, double *fn_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -336,3 +336,21 @@ def assign_lines_to_grid(kl, bounds4, cap=None):
     n = L.orc_assign_lines_to_grid(_p(kl), len(kl), _p(b), _p(start), _p(items), cap)
     return start, items[:max(n, 0)], n
 
+
+def cull_lines(gray, kl, fn, dis=5.0, angle=2.5, endpoint_dis=15.0):
+    """Frame::cullingLine(im, 5, 2.5, 15, 30) (src/Frame.cc:934, 952-1116) -> (keylines, descriptors, line functions)"""
+    gray = np.ascontiguousarray(gray, np.uint8); kl = np.ascontiguousarray(kl); fn = np.ascontiguousarray(fn, np.float64)
+    h, w = gray.shape; n = len(kl)
+    out = np.zeros(max(n, 1), KEYLINE_DT); desc = np.zeros((max(n, 1), 32), np.uint8); fo = np.zeros((max(n, 1), 3))
+    L = lib()
+    L.orc_cull_lines.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]
+    m = L.orc_cull_lines(_p(gray), w, h, gray.strides[0], _p(kl), _p(fn), n, dis, angle, endpoint_dis, _p(out), _p(desc), _p(fo))
+    return out[:m], desc[:m], fo[:m]
+
+
+def line_iterator_count_clipped(w, h, x1, y1, x2, y2):
+    L = lib()
+    L.orc_line_iterator_count_clipped.argtypes = [C.c_int, C.c_int] + [C.c_float] * 4
+    return L.orc_line_iterator_count_clipped(w, h, x1, y1, x2, y2)
+

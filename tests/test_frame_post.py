@@ -100,3 +100,63 @@ def test_frame_post_edge_cases(hvo, gpu_ctx):
         gpu_ctx.assign_lines_to_grid(kl, b, cap=2)                                                      # HVO_ERR_CAPACITY
     with pytest.raises(hvo.HvoError):
         gpu_ctx.assign_features_to_grid(kp, np.array([0, 0, 0, 480], np.float32))                        # empty bounds
+
+
+# ---------------- Frame::cullingLine ----------------
+def test_oracle_culling_known_answers(orc, synth):
+    # cv::LineIterator count with clipping: inside -> max(|dx|,|dy|)+1; the image diagonal extended beyond the corners is
+    # clipped to the image; a segment entirely left of the image has no pixels
+    assert orc.line_iterator_count_clipped(640, 480, 10, 10, 20, 40) == 31
+    assert orc.line_iterator_count_clipped(640, 480, -10, 5, -3, 80) == 0
+    assert 0 < orc.line_iterator_count_clipped(640, 480, -10, -10, 700, 500) <= 640
+    g = np.full((480, 640), 128, np.uint8)
+    kl = np.zeros(3, orc.KEYLINE_DT)
+    # two collinear overlapping horizontal segments and one far away vertical one
+    kl["sx"], kl["sy"], kl["ex"], kl["ey"] = [100, 150, 400], [200, 200.5, 50], [200, 300, 400], [200, 200.5, 300]
+    fn = np.zeros((3, 3))
+    for i in range(3):
+        sx, sy, ex, ey = (float(kl[k][i]) for k in ("sx", "sy", "ex", "ey"))
+        l = np.array([sy - ey, ex - sx, sx * ey - sy * ex]); fn[i] = l / np.hypot(l[0], l[1])
+    out, desc, fo = orc.cull_lines(g, kl, fn)
+    assert len(out) == 2                                            # the two horizontal ones merged
+    assert out["class_id"].tolist() == [0, 1] and out["response"][0] >= out["response"][1]
+    horiz = out[np.abs(out["sy"] - 200) < 2][0]
+    assert abs(min(horiz["sx"], horiz["ex"]) - 100) < 1 and abs(max(horiz["sx"], horiz["ex"]) - 300) < 1   # spans both
+    vert = out[np.abs(out["sx"] - 400) < 1][0]
+    assert vert["num_pixels"] == 251 and np.isclose(vert["length"], 250)
+    assert np.allclose(fo[:, 0] ** 2 + fo[:, 1] ** 2, 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,seed", [("std", 0x5EED0002), ("std", 0x5EED1001), ("lowtex", 0x5EED0001)])
+def test_culling_parity(gpu_ctx, orc, synth, kind, seed):
+    g = synth.make_gray(kind, seed)
+    kl_o, d_o, fn_o = orc.line_extract(g)
+    ck_o, cd_o, cf_o = orc.cull_lines(g, kl_o, fn_o)
+    ck_g, cd_g, cf_g = gpu_ctx.extract_lsd(g, culled=True)
+    assert len(ck_g) == len(ck_o) and len(ck_o) <= len(kl_o)
+    for f in ck_o.dtype.names:
+        assert np.array_equal(ck_g[f], ck_o[f]), f
+    assert np.array_equal(cd_g, cd_o)
+    assert np.allclose(cf_g, cf_o, rtol=1e-12, atol=1e-12)
+    # the plain extractor output is unchanged by the extra stage
+    kl_g, d_g, _ = gpu_ctx.extract_lsd(g)
+    assert np.array_equal(kl_g["sx"], kl_o["sx"]) and np.array_equal(d_g, d_o)
+
+
+@pytest.mark.gpu
+def test_culling_batch_stage_and_params(hvo, orc, synth):
+    gray, depth = synth.make_batch("std", 0x5EED1000, 3)
+    ctx = hvo.Context(max_batch=3)
+    try:
+        ctx.set_line_culling(7.5, 3.0, 20.0)                          # the commented-out alternative at Frame.cc:935
+        ctx.batch_upload(gray, depth)
+        ctx.batch_run(hvo.STAGE_LSD_CULL)
+        res = ctx.batch_download(hvo.STAGE_LSD_CULL)
+    finally:
+        ctx.close()
+    for b in range(3):
+        kl_o, _, fn_o = orc.line_extract(gray[b])
+        ck_o, cd_o, _ = orc.cull_lines(gray[b], kl_o, fn_o, 7.5, 3.0, 20.0)
+        assert res[b]["status"] == 0 and len(res[b]["kl"]) == len(ck_o)
+        assert np.array_equal(res[b]["kl"]["sx"], ck_o["sx"]) and np.array_equal(res[b]["ldesc"], cd_o)
