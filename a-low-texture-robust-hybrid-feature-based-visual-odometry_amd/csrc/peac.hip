@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
     constexpr int NEV = FLOOD_T * 4;              // events per round
     constexpr int FLOOD_HS = NEV * FLOOD_HS_MUL, FLOOD_HL = 4;
     __shared__ double pl[MAX_PLANES][8];          // center[3], normal[3], mse, pad
-    __shared__ unsigned long long adj[MAX_PLANES];
+    __shared__ unsigned long long adj[MAX_PLANES], simok[MAX_PLANES];
     __shared__ int hkeys[FLOOD_HS], hcnt[FLOOD_HS];
     __shared__ __attribute__((aligned(8))) unsigned short hlist[FLOOD_HS * FLOOD_HL];
     __shared__ uint2 hstate[FLOOD_HS];            // per-pixel state handed from rank to rank: (label, dist bits)
@@ -1058,6 +1058,17 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
     }
     for (int i = tid; i < FLOOD_HS; i += FLOOD_T) { hkeys[i] = -1; hcnt[i] = 0; }
     if (tid < 2) s_max[tid] = 1;
+    __syncthreads();
+    // which pairs of planes count as adjacent when they meet on a pixel (|n_p . n_q| >= cos 30 deg,
+    // AHCPlaneFitter.hpp:457-462): evaluated once per pair instead of once per contested event
+    if (tid < MAX_PLANES) {
+        unsigned long long m = 0;
+        if (tid < nold) for (int q = 0; q < nold; q++) {
+            const double *P = pl[tid], *Q = pl[q];
+            if (fabs(P[3] * Q[3] + P[4] * Q[4] + P[5] * Q[5]) >= r.c30) m |= 1ull << q;
+        }
+        simok[tid] = m;
+    }
     // ---- seeds in block raster order: count, scan, write (wave 0) ----
     if (wv == 0) {
         int nq = 0;
@@ -1098,20 +1109,15 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
 #define FT(i)
 #endif
     FT(0)
-    // state machine of one event on its pixel (AHCPlaneFitter.hpp:445-470): (trail, dcur) -> (nl, nd), push
+    // state machine of one event on its pixel (AHCPlaneFitter.hpp:445-470): (trail, dcur) -> (nl, nd), push.
+    // Written with selects; the only branch left is the rare "two planes meet" adjacency update.
     auto apply = [&](int trail, float dcur, int plid, bool ok, float cdist, int &nl, float &nd, bool &push) {
-        nl = trail; nd = dcur;
-        if (trail <= -6 || (trail >= 0 && trail == plid)) return;
-        if (ok) {
-            if (trail >= 0) {
-                const double *Q = pl[trail], *P = pl[plid];
-                if (fabs(P[3] * Q[3] + P[4] * Q[4] + P[5] * Q[5]) >= r.c30) {
-                    atomicOr(&adj[trail], 1ull << plid); atomicOr(&adj[plid], 1ull << trail);
-                }
-            }
-            if (cdist < dcur) { nl = plid; nd = cdist; push = true; }
-            else if (trail < 0) nl = trail - 1;
-        } else if (trail < 0) nl = trail - 1;
+        const bool live = !(trail <= -6 || trail == plid);                 // trail == plid implies trail >= 0
+        const bool closer = live && ok && cdist < dcur;
+        if (live && ok && trail >= 0 && ((simok[plid] >> trail) & 1ull)) { atomicOr(&adj[trail], 1ull << plid); atomicOr(&adj[plid], 1ull << trail); }
+        nl = closer ? plid : ((live && trail < 0) ? trail - 1 : trail);
+        nd = closer ? cdist : dcur;
+        push = push || closer;
     };
     int kq = 0, par = 0, qpf = 0, pf_nq = 0;             // entry cursor; entry prefetched for the next round, valid for k < pf_nq
     while (kq < nq) {
