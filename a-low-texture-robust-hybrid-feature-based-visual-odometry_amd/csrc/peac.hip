@@ -608,9 +608,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
         // ---- evaluate the merge with every neighbour, one candidate per lane; each lane keeps its best ----
         bool bhas = false; double bm = 0; int bid = 0x7FFFFFFF, bN = 0, gid = 0x7FFFFFFF, xid = -1;
         int brid = 0, bnoff = 0, bncnt = 0;                    // the candidate's rid and list, fetched with its sums
-        double bst[9], bc[3] = { 0, 0, 0 }, bn[3] = { 0, 0, 0 };
-#pragma unroll
-        for (int q = 0; q < 9; q++) bst[q] = 0;
+        double bc[3] = { 0, 0, 0 }, bn[3] = { 0, 0, 0 };        // (the merged sums are re-formed when the record is written)
         PT(2)
         int id_cur = a0;                                        // ids of the next chunk are fetched one pass ahead
         for (int base = 0; __any(base < pcnt); base += GL) {
@@ -644,8 +642,6 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
                     else if (equal) { if (good && nb < gid) gid = nb; if (nb > xid) xid = nb; }
                     if (better || (equal && nb < bid)) {                   // payload follows (mse, id)
                         bid = nb; bN = lN; brid = nrid; bnoff = noff_; bncnt = ncnt_;
-#pragma unroll
-                        for (int q = 0; q < 9; q++) bst[q] = lst[q];
 #pragma unroll
                         for (int q = 0; q < 3; q++) { bc[q] = tc[q]; bn[q] = tn[q]; }
                     }
@@ -695,10 +691,8 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
                 stats_compute_dev(lst, lN, tc, tn, tm);
                 if (refit) {
 #pragma unroll
-                    for (int q = 0; q < 9; q++) bst[q] = lst[q];
-#pragma unroll
                     for (int q = 0; q < 3; q++) { bc[q] = tc[q]; bn[q] = tn[q]; }
-                    bm = tm; bN = lN; brid = rrid; m = tm; c2 = tc[2]; noff = roff; ncnt = rcnt;
+                    bm = tm; bN = lN; brid = rrid; bid = win; m = tm; c2 = tc[2]; noff = roff; ncnt = rcnt;
                     is_w = gl == 0;
                 }
             }
@@ -769,8 +763,9 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
             PT(5)
             if (do_merge && is_w) {
                 double *md = segD + (size_t)id * SEG_D;
+                const double *wd = segD + (size_t)bid * SEG_D;                                // sums of the merge = p's + the partner's
 #pragma unroll
-                for (int q = 0; q < 9; q++) md[q] = bst[q];
+                for (int q = 0; q < 9; q++) md[q] = ps[q] + wd[q];
                 md[9] = bc[0]; md[10] = bc[1]; md[11] = bc[2]; md[12] = bn[0]; md[13] = bn[1]; md[14] = bn[2]; md[15] = bm;
                 int *mi = segI + (size_t)id * SEG_I;
                 mi[0] = bN; mi[1] = pN >= bN - pN ? prid : brid; mi[2] = 0; mi[3] = moff; mi[4] = mcnt; mi[5] = pcnt + ncnt; mi[6] = 1; mi[7] = 0;
