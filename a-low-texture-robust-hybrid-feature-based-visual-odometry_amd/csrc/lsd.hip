@@ -10,7 +10,7 @@
 //   normalised 2-D line functions (LineExtractor.cpp:367-377)
 //
 // Kernels
-//   k_lsd_blur_h / k_lsd_blur_v   GaussianBlur 7x7 sigma 0.75 on the CV_64F image (row / column pass)
+//   k_lsd_blur                    GaussianBlur 7x7 sigma 0.75 on the CV_64F image (row and column pass fused)
 //   k_lsd_resize_grad             0.8x INTER_LINEAR resize (double) fused with ll_angle: gradient norm,
 //                                 one {angle, cos, sin, |grad|} record per pixel, "defined" bitmask
 //   k_lsd_grow                    one wave per frame: raster-order seeds, region_grow, region2rect,
@@ -37,7 +37,7 @@
 
 struct LsdPlan {
     int w = 0, h = 0, sw = 0, sh = 0, batch = 0, nfeat = 0, nwords = 0;
-    double *d_tmp = nullptr, *d_blur = nullptr;            // w*h doubles each
+    double *d_blur = nullptr;                               // w*h doubles
     double4 *d_px = nullptr;           // sw*sh x {angle, cos, sin, modgrad}: one 32-byte record per scaled pixel
     unsigned *d_defined = nullptr;                          // bitmask, nwords per frame
     int *d_reg = nullptr;                                   // sw*sh ints
@@ -83,14 +83,22 @@ static __device__ __forceinline__ float fatan2_deg(float y, float x)
 // Gaussian blur 7x7 on the double image.  Row pass: s = k0*S[0]; s += k[i]*S[i] (RowFilter order);
 // column pass: s = kc*S[0]; s += k[j]*(S[+j] + S[-j]) (SymmColumnFilter order).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lsd_blur_h(const uint8_t *__restrict__ gray, size_t gframe, int gpitch,
-                                                    double *__restrict__ tmp, int w, int h, double k0, double k1, double k2, double k3)
+// Both passes in one kernel: a thread owns a column and LSD_BLUR_ROWS output rows, forms the row-pass value of
+// the LSD_BLUR_ROWS + 6 source rows it needs (7 cached byte loads each) and runs the column pass over that
+// register window.  The fp64 intermediate image (2.4 MB per frame written and read back) does not exist.
+#define LSD_BLUR_ROWS 16
+__global__ __launch_bounds__(256) void k_lsd_blur(const uint8_t *__restrict__ gray, size_t gframe, int gpitch,
+                                                  double *__restrict__ blur, int w, int h, double k0, double k1, double k2, double k3)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, f = blockIdx.z;
     if (x >= w) return;
     const int xm3 = refl(x - 3, w), xm2 = refl(x - 2, w), xm1 = refl(x - 1, w), xp1 = refl(x + 1, w), xp2 = refl(x + 2, w), xp3 = refl(x + 3, w);
-    for (int y = blockIdx.y * 8; y < min(h, blockIdx.y * 8 + 8); y++) {     // 8 rows per thread: fewer, fatter workgroups
-        const uint8_t *S = gray + (size_t)f * gframe + (size_t)y * gpitch;
+    const uint8_t *G = gray + (size_t)f * gframe;
+    const int yb = blockIdx.y * LSD_BLUR_ROWS;
+    double v[LSD_BLUR_ROWS + 6];                       // row-pass values of rows yb-3 .. yb+ROWS+2 of this column
+#pragma unroll
+    for (int j = 0; j < LSD_BLUR_ROWS + 6; j++) {
+        const uint8_t *S = G + (size_t)refl(min(yb + j - 3, h + 2), h) * gpitch;
         double s = k0 * (double)S[xm3];
         s += k1 * (double)S[xm2];
         s += k2 * (double)S[xm1];
@@ -98,22 +106,10 @@ __global__ __launch_bounds__(256) void k_lsd_blur_h(const uint8_t *__restrict__ 
         s += k2 * (double)S[xp1];
         s += k1 * (double)S[xp2];
         s += k0 * (double)S[xp3];
-        tmp[((size_t)f * h + y) * w + x] = s;
+        v[j] = s;
     }
-}
-
-__global__ __launch_bounds__(256) void k_lsd_blur_v(const double *__restrict__ tmp, double *__restrict__ blur, int w, int h,
-                                                    double k0, double k1, double k2, double k3)
-{
-    const int x = blockIdx.x * 256 + threadIdx.x, f = blockIdx.z;
-    if (x >= w) return;
-    const double *T = tmp + (size_t)f * h * w;
-    const int yb = blockIdx.y * 8;
-    double v[14];                                      // rows yb-3 .. yb+10 of this column, loaded once
 #pragma unroll
-    for (int j = 0; j < 14; j++) v[j] = T[(size_t)refl(min(yb + j - 3, h + 2), h) * w + x];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < LSD_BLUR_ROWS; j++) {
         const int y = yb + j;
         if (y >= h) break;
         double s = k3 * v[j + 3];
@@ -955,7 +951,7 @@ void lsd_free(hvo_ctx *ctx)
 {
     LsdPlan *P = plan_of(ctx);
     if (!P) return;
-    void *ptrs[] = { P->d_kl2, P->d_desc2, P->d_fn2, P->d_nkl2, P->d_tmp, P->d_blur, P->d_px, P->d_defined, P->d_reg, P->d_segs, P->d_kl_all, P->d_kl,
+    void *ptrs[] = { P->d_kl2, P->d_desc2, P->d_fn2, P->d_nkl2, P->d_blur, P->d_px, P->d_defined, P->d_reg, P->d_segs, P->d_kl_all, P->d_kl,
                      P->d_desc, P->d_fn, P->d_nkl, P->d_flags, P->d_b5, P->d_dx, P->d_dy, P->d_xofs, P->d_yofs, P->d_xa, P->d_yb, P->d_gL, P->d_gG, P->d_stats };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
@@ -1016,7 +1012,7 @@ static int lsd_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
     for (int i = 0; i < 63; i++) gGf[i] = (float)P->gG[i];
     const size_t B = batch, npix = (size_t)w * h, nsp = (size_t)P->sw * P->sh;
 #define PA(ptr, n) HVO_HIP(hipMalloc((void **)&(ptr), (n)))
-    PA(P->d_tmp, B * npix * 8); PA(P->d_blur, B * npix * 8);
+    PA(P->d_blur, B * npix * 8);
     PA(P->d_px, B * nsp * sizeof(double4));
     PA(P->d_defined, B * P->nwords * 4); PA(P->d_reg, B * nsp * 4);
     PA(P->d_segs, B * LSD_MAXSEG * 16); PA(P->d_kl_all, B * LSD_MAXSEG * sizeof(hvo_keyline));
@@ -1051,8 +1047,8 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     const uint8_t *gray = O.d_pyr + O.lev[0].img_off;
     const int gpitch = O.lev[0].pitch;
     int id = hvo_prof_begin(ctx, "lsd_blur_scale", st);
-    hipLaunchKernelGGL(k_lsd_blur_h, dim3((w + 255) / 256, (h + 7) / 8, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_tmp, w, h, P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
-    hipLaunchKernelGGL(k_lsd_blur_v, dim3((w + 255) / 256, (h + 7) / 8, n), dim3(256), 0, st, P->d_tmp, P->d_blur, w, h, P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
+    hipLaunchKernelGGL(k_lsd_blur, dim3((w + 255) / 256, (h + LSD_BLUR_ROWS - 1) / LSD_BLUR_ROWS, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_blur, w, h,
+                       P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lsd_gradient", st);
     const int gx = (((sw + 31) & ~31) + 255) / 256;
