@@ -135,40 +135,61 @@ static __device__ __forceinline__ double scaled_at(const double *B, int w, int x
     return t0 * b0 + t1 * b1;
 }
 
+// One workgroup = 256 consecutive pixels of one scaled row.  A thread forms the two scaled values of its
+// column (rows y, y+1) and reads its right neighbour's from LDS, so a scaled value is interpolated ~1.25 times
+// instead of 4.  Only ~15 % of the pixels have a gradient above the threshold: they are compacted through LDS
+// and the expensive part (double cos / sin of the level-line angle) runs on dense lanes only.
 __global__ __launch_bounds__(256) void k_lsd_resize_grad(const double *__restrict__ blur, int w, int h, int sw, int sh,
                                                          const int *__restrict__ xofs, const float *__restrict__ xa,
                                                          const int *__restrict__ yofs, const float *__restrict__ yb,
                                                          double4 *__restrict__ px4,
                                                          unsigned *__restrict__ defined, int nwords, double rho)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    __shared__ double sv0[257], sv1[257];
+    __shared__ double la[256], lm[256]; __shared__ unsigned short lx[256];
+    __shared__ int wcnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x0 = blockIdx.x * 256, x = x0 + tid, y = blockIdx.y, f = blockIdx.z;
     const double *B = blur + (size_t)f * w * h;
+    const bool row1 = y + 1 < sh;
+    double v0 = 0, v1 = 0;
+    if (x < sw) { v0 = scaled_at(B, w, x, y, xofs, xa, yofs, yb, w); if (row1) v1 = scaled_at(B, w, x, y + 1, xofs, xa, yofs, yb, w); }
+    sv0[tid] = v0; sv1[tid] = v1;
+    if (tid == 0) {
+        const int xe = x0 + 256;
+        sv0[256] = xe < sw ? scaled_at(B, w, xe, y, xofs, xa, yofs, yb, w) : 0;
+        sv1[256] = xe < sw && row1 ? scaled_at(B, w, xe, y + 1, xofs, xa, yofs, yb, w) : 0;
+    }
+    __syncthreads();
     bool def = false;
+    double a = LSD_NOTDEF, m = 0;
     if (x < sw) {
-        const size_t o = ((size_t)f * sh + y) * sw + x;
-        double a = LSD_NOTDEF, m = 0, c = 0, s = 0;
         if (x < sw - 1 && y < sh - 1) {
-            const double v00 = scaled_at(B, w, x, y, xofs, xa, yofs, yb, w), v10 = scaled_at(B, w, x + 1, y, xofs, xa, yofs, yb, w);
-            const double v01 = scaled_at(B, w, x, y + 1, xofs, xa, yofs, yb, w), v11 = scaled_at(B, w, x + 1, y + 1, xofs, xa, yofs, yb, w);
+            const double v00 = v0, v10 = sv0[tid + 1], v01 = v1, v11 = sv1[tid + 1];
             const double DA = v11 - v00, BC = v10 - v01;
             const double gx = DA + BC, gy = DA - BC;
             m = sqrt((gx * gx + gy * gy) / 4);
-            if (!(m <= rho)) {
-                a = (double)fatan2_deg((float)gx, (float)-gy) * (LSD_PI / 180);
-                // region_grow accumulates cos(float(angle)) / sin(float(angle)) evaluated in double
-                const double af = (double)(float)a;
-                c = cos(af); s = sin(af);
-                def = true;
-            }
+            if (!(m <= rho)) { a = (double)fatan2_deg((float)gx, (float)-gy) * (LSD_PI / 180); def = true; }
         }
-        px4[o] = make_double4(a, c, s, m);
+        // records of pixels without a gradient angle are never read (the availability mask filters them): not written
     }
     // 256 threads = 8 words of 32 bits; rows are padded to a multiple of 32 bits in the mask
     const unsigned long long bal = __ballot(def);
-    const int lane = threadIdx.x & 63;
     if (x < ((sw + 31) & ~31)) {
         const int word = (y * ((sw + 31) / 32)) + (x >> 5);
         if ((lane & 31) == 0) defined[(size_t)f * nwords + word] = (unsigned)(bal >> (lane & 32));
+    }
+    // compaction of the defined pixels, then cos / sin on dense lanes
+    if (lane == 0) wcnt[wv] = __popcll(bal);
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int i = 0; i < 4; i++) { const int c = wcnt[i]; if (i < wv) base += c; total += c; }
+    if (def) { const int p = base + __popcll(bal & ((1ull << lane) - 1)); la[p] = a; lm[p] = m; lx[p] = (unsigned short)tid; }
+    __syncthreads();
+    if (tid < total) {
+        // region_grow accumulates cos(float(angle)) / sin(float(angle)) evaluated in double
+        const double aa = la[tid], af = (double)(float)aa;
+        px4[((size_t)f * sh + y) * sw + x0 + lx[tid]] = make_double4(aa, cos(af), sin(af), lm[tid]);
     }
 }
 
