@@ -1442,7 +1442,8 @@ int peac_run(hvo_ctx *ctx, int n)
         // threads per frame (one queue entry = 4 events per thread and round); HVO_FLOOD_T overrides
         const char *e = getenv("HVO_FLOOD_T");
         const int flood_t = e ? atoi(e) : -1;
-        const int ft = flood_t > 0 ? flood_t : 256;
+        // measured: 256 threads per frame up to ~4096 resident frames, one wave per frame (less LDS, all frames in flight) beyond
+        const int ft = flood_t > 0 ? flood_t : (n >= 6144 ? 64 : 256);
         if (ft == 64) hipLaunchKernelGGL(k_peac_flood<64>, dim3(n), dim3(64), 0, st, r, P->d_adj);
         else if (ft == 256) hipLaunchKernelGGL(k_peac_flood<256>, dim3(n), dim3(256), 0, st, r, P->d_adj);
         else hipLaunchKernelGGL(k_peac_flood<128>, dim3(n), dim3(128), 0, st, r, P->d_adj);
