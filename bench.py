@@ -78,6 +78,21 @@ def hbm_traffic(group, B, width):
         return None
 
 
+def issue_utilisation(frames_per_s):
+    """The step is bound by instruction issue, not by HBM: with the committed SQ_ACTIVE_INST_ANY per frame
+    (profiles/r01_issue_utilisation.json, quad-cycles) this reports how much of the 1024 SIMDs' issue capacity the
+    measured rate corresponds to.  Extra keys of the roofline object; empty when the profile is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_issue_utilisation.json")) as f:
+            t = json.load(f)
+        q, qv = t["per_frame_total"]["sq_active_inst_any"], t["per_frame_total"]["sq_active_inst_valu"]
+        cap = t["simds"] * t["clock_hz"]
+        return {"issue_quad_cycles_per_frame": int(q), "issue_frac": round(q * 4.0 * frames_per_s / cap, 4),
+                "valu_frac": round(qv * 4.0 * frames_per_s / cap, 4)}
+    except (OSError, ValueError, KeyError):
+        return {}
+
+
 def cpu_baseline(stages, gray, depth, budget_s=12.0):
     """time the CPU oracle (scalar port, 1 thread) on a bounded sample of the same workload"""
     orc = ge.oracle()
@@ -210,6 +225,7 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": hbm_traffic(dom, B, args.width),
                     "bytes_per_launch": int(per_frame * B), "ms_per_launch": round(groups[dom], 4)}
+            roof.update(issue_utilisation(value))
             orb_ms = sum(v for k, v in groups.items() if k in ("orb_pyramid", "orb_fast_cells", "orb_blur", "orb_brief", "orb_orient"))
             if orb_ms > 0:
                 roof["orb_pyramid_brief_pass_GBps"] = round(pass_bytes * B / (orb_ms * 1e-3) / 1e9, 2)
