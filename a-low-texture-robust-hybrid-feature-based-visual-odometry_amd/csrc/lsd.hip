@@ -14,7 +14,7 @@
 //   k_lsd_resize_grad             0.8x INTER_LINEAR resize (double) fused with ll_angle: gradient norm,
 //                                 one {angle, cos, sin, |grad|} record per pixel, "defined" bitmask
 //   k_lsd_grow                    one wave per frame: raster-order seeds, region_grow, region2rect,
-//                                 refine / reduce_region_radius; neighbourhoods of up to 28 pending
+//                                 refine / reduce_region_radius; neighbourhoods of up to 7 pending
 //                                 region points are fetched per round (availability mask in global
 //                                 memory, one 32-byte record per candidate), the reference's sequential
 //                                 add-and-update walk is speculated, verified and committed in batches;
@@ -234,14 +234,14 @@ static __device__ __forceinline__ double angle_diff_signed(double a, double b)
 }
 
 // region_grow (OpenCV 3.2 lsd.cpp).  Region points are stored packed (y << 16 | x).
-// Per round the wave fetches the 3x3 neighbourhoods of up to 28 pending region points (4 slots of 64
+// Per round the wave fetches the 3x3 neighbourhoods of up to 7 pending region points (4 slots of 64
 // lanes, slot-major = the reference's visiting order: point index, then x outer / y inner).  The
 // sequential decisions are then taken without a scalar scan: every lane holds "valid & aligned with
 // the current region angle" for its neighbour, a ballot yields the first such neighbour at or after the
 // cursor -- exactly the next pixel the reference would add -- the region angle is updated uniformly,
 // and the remaining lanes re-evaluate against the new angle.  Neighbours tested before the cursor are
 // never revisited, like the reference's single pass.
-#define GROW_SLOTS 4
+#define GROW_SLOTS 1          // measured: 1 -> 21.5k, 2 -> 21.4k, 4 -> 21.1k frames/s (pending points per round average 3; unused slots still cost code)
 static __device__ __forceinline__ double readlane_f64(double v, int l)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
