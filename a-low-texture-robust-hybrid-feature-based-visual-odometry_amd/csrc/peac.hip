@@ -435,7 +435,7 @@ static __device__ __forceinline__ void list_find2(const int *pool, int off, int 
 }
 
 template <int GL> struct Grp {
-    static_assert(GL == 16 || GL == 32 || GL == 64, "group width");
+    static_assert(GL == 8 || GL == 16 || GL == 32 || GL == 64, "group width");
     static __device__ __forceinline__ int gl() { return threadIdx.x & (GL - 1); }
     static __device__ __forceinline__ int gb() { return threadIdx.x & 63 & ~(GL - 1); }
     static __device__ __forceinline__ unsigned long long ballot(bool p)
@@ -460,7 +460,8 @@ template <int STEP> static __device__ __forceinline__ double row_partner(double 
     return __hiloint2double(row_partner<STEP>(__double2hiint(v)), row_partner<STEP>(__double2loint(v)));
 }
 
-#define GH_ARY 16         // arity of the grouped heap: one child per lane of the narrowest group
+// arity of the grouped heap: one child per lane, at most a DPP row
+#define GH_ARY (GL < 16 ? GL : 16)
 template <int GL>
 static __device__ void gheap_sift_down(double *key, int *id, int n, int i, double k, int idv, bool act)
 {
@@ -513,10 +514,10 @@ static __device__ int gheap_sift_root(const GHeap &H, int n, double k, int idv, 
         if (cont && gl < GH_ARY && c0 + gl < n) { ci = c0 + gl; ck = H.key(ci); cid = H.id(ci); }
 #define GH_STEP(o) { const double ok = row_partner<o>(ck); const int oid = row_partner<o>(cid), oi = row_partner<o>(ci); \
                      if (oi >= 0 && (ci < 0 || hless(ok, oid, ck, cid))) { ck = ok; cid = oid; ci = oi; } }
-        GH_STEP(1) GH_STEP(2) GH_STEP(4) GH_STEP(8)
+        GH_STEP(1) GH_STEP(2) GH_STEP(4) if (GH_ARY > 8) GH_STEP(8)
 #undef GH_STEP
-        // every lane of the first 16-lane row now holds the minimum; wider groups broadcast it
-        if (GL != 16) { ck = Grp<GL>::shfl(ck, 0); cid = Grp<GL>::shfl(cid, 0); ci = Grp<GL>::shfl(ci, 0); }
+        // every lane of the first GH_ARY lanes now holds the minimum; wider groups broadcast it
+        if (GL > 16) { ck = Grp<GL>::shfl(ck, 0); cid = Grp<GL>::shfl(cid, 0); ci = Grp<GL>::shfl(ci, 0); }
         const bool mv = cont && ci >= 0 && hless(ck, cid, k, idv);
         if (mv) { if (gl == 0) H.set(i, ck, cid); if (i == 0) root = cid; i = ci; }
         go = mv;
@@ -1427,6 +1428,7 @@ int peac_run(hvo_ctx *ctx, int n)
         const int use = gl > 0 ? gl : (n >= 3072 ? 16 : 64);
         if (use == 64) hipLaunchKernelGGL(k_peac_cluster<64>, dim3(n), dim3(64), 0, st, a, n);
         else if (use == 32) hipLaunchKernelGGL(k_peac_cluster<32>, dim3((n + 1) / 2), dim3(64), 0, st, a, n);
+        else if (use == 8) hipLaunchKernelGGL(k_peac_cluster<8>, dim3((n + 7) / 8), dim3(64), 0, st, a, n);
         else hipLaunchKernelGGL(k_peac_cluster<16>, dim3((n + 3) / 4), dim3(64), 0, st, a, n);
     }
     hvo_prof_end(ctx, id);
