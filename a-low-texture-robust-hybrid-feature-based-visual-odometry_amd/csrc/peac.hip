@@ -1157,6 +1157,12 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                 pending[j] = cIdx[j] >= 0;
             }
         }
+#ifdef HVO_PEAC_TIMING
+        { int np_ = 0, nl_ = 0;
+          for (int j = 0; j < 4; j++) { np_ += pending[j]; nl_ += pending[j] && trail0[j] > -6 && trail0[j] != plid; }
+          for (int o = 32; o > 0; o >>= 1) { np_ += __shfl_xor(np_, o); nl_ += __shfl_xor(nl_, o); }
+          if (lane == 0) { atomicAdd(&g_peac_t[30], (unsigned long long)np_); atomicAdd(&g_peac_t[31], (unsigned long long)nl_); } }
+#endif
         FT(1)
         // ---- group the round's events by pixel ----
         int hs[4];

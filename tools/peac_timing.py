@@ -58,6 +58,8 @@ def main():
     print("flood: frames %d, ticks per frame %.3e, queue entries per frame %.0f, rounds %.1f, sub-rounds %.1f" % (nf, ftot / nf, v[22] / nf, v[20] / nf, v[21] / nf))
     for i, nm in enumerate(["seeds", "event precompute", "election sub-rounds", "ordered append"]):
         print("  %-20s %6.2f %%" % (nm, 100 * v[16 + i] / ftot))
+    print("  events per frame: %.0f (4 per queue entry), pending (target exists, not in a valid block) %.0f, of them not trivially no-op (trail > -6 and trail != plane) %.0f"
+          % (4 * v[22] / nf, v[30] / nf, v[31] / nf))
     for i, nm in enumerate(["hash insert", "barrier A", "rank", "rank-0 apply", "(unused)", "(unused)"]):
         print("    sub-phase %-14s %6.2f %% of flood" % (nm, 100 * v[24 + i] / max(ftot + v[24:30].sum(), 1)))
     ctx.close()
