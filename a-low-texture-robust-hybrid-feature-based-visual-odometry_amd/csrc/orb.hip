@@ -218,31 +218,63 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
         }
     }
     __syncthreads();
-    // ---- strict 3x3 NMS, 64 raster-consecutive pixels per step; survivors = ballot ----
+    // ---- strict 3x3 NMS and emission.  Only phase-A survivors can have a score, and their list is already in
+    //      raster order, so both walk the candidate list (a step or two) instead of the whole interior; the
+    //      full-raster walk remains for the pathological tile whose list overflowed. ----
     int n_ini = 0;
-    {
-        int yy = lane / iw, xx = lane - yy * iw, st = 0;
-        for (int p0 = 0; p0 < P; p0 += 64, st++) {
+    uint32_t *out = cell_kp + ((size_t)frame * ncells + cell) * HVO_CELL_CAP;
+    int pos = 0;
+    if (ncand <= CAND_CAP) {
+        int st = 0;
+        for (int base = 0; base < ncand; base += 64, st++) {
+            const int i = base + lane;
             bool ok = false; int v = 0;
-            if (p0 + lane < P) {
-                const uint8_t *s = S0 + (yy + 3) * TP + xx + 3;
-                v = s[0];
+            if (i < ncand) {
+                const int xy = cand_[wv][i];
+                const uint8_t *sp = S0 + (xy >> 8) * TP + (xy & 0xFF);
+                v = sp[0];
                 // neighbours outside the interior region are never written -> 0, like the zeroed score
                 // rows/columns of the reference's per-view FAST call
-                ok = v != 0 && v > s[-1] && v > s[1] && v > s[-TP - 1] && v > s[-TP] && v > s[-TP + 1] &&
-                     v > s[TP - 1] && v > s[TP] && v > s[TP + 1];
+                ok = v != 0 && v > sp[-1] && v > sp[1] && v > sp[-TP - 1] && v > sp[-TP] && v > sp[-TP + 1] &&
+                     v > sp[TP - 1] && v > sp[TP] && v > sp[TP + 1];
             }
             const unsigned long long mm = __ballot(ok), mi = __ballot(ok && v >= iniTh);
             n_ini += __popcll(mi);
             if (lane == 0) { sm_min[wv][st] = mm; sm_ini[wv][st] = mi; }
-            xx += adv_x; yy += adv_y; if (xx >= iw) { xx -= iw; yy++; }
         }
-    }
-    __syncthreads();
-    const bool use_ini = n_ini > 0;                            // iniThFAST survivors, else the minThFAST fallback
-    uint32_t *out = cell_kp + ((size_t)frame * ncells + cell) * HVO_CELL_CAP;
-    int pos = 0;
-    {
+        __syncthreads();
+        const bool use_ini = n_ini > 0;                        // iniThFAST survivors, else the minThFAST fallback
+        st = 0;
+        for (int base = 0; base < ncand; base += 64, st++) {
+            const unsigned long long m = use_ini ? sm_ini[wv][st] : sm_min[wv][st];
+            if (m) {
+                if (live && ((m >> lane) & 1ull)) {
+                    const int xy = cand_[wv][base + lane], x = xy & 0xFF, y = xy >> 8;
+                    const int p = pos + __popcll(m & ((1ull << lane) - 1));
+                    if (p < HVO_CELL_CAP) out[p] = (uint32_t)(x + c.ox) | ((uint32_t)(y + c.oy) << 12) | ((uint32_t)S0[y * TP + x] << 24);
+                }
+                pos += __popcll(m);
+            }
+        }
+    } else {
+        {
+            int yy = lane / iw, xx = lane - yy * iw, st = 0;
+            for (int p0 = 0; p0 < P; p0 += 64, st++) {
+                bool ok = false; int v = 0;
+                if (p0 + lane < P) {
+                    const uint8_t *sp = S0 + (yy + 3) * TP + xx + 3;
+                    v = sp[0];
+                    ok = v != 0 && v > sp[-1] && v > sp[1] && v > sp[-TP - 1] && v > sp[-TP] && v > sp[-TP + 1] &&
+                         v > sp[TP - 1] && v > sp[TP] && v > sp[TP + 1];
+                }
+                const unsigned long long mm = __ballot(ok), mi = __ballot(ok && v >= iniTh);
+                n_ini += __popcll(mi);
+                if (lane == 0) { sm_min[wv][st] = mm; sm_ini[wv][st] = mi; }
+                xx += adv_x; yy += adv_y; if (xx >= iw) { xx -= iw; yy++; }
+            }
+        }
+        __syncthreads();
+        const bool use_ini = n_ini > 0;
         int yy = lane / iw, xx = lane - yy * iw, st = 0;
         for (int p0 = 0; p0 < P; p0 += 64, st++) {
             const unsigned long long m = use_ini ? sm_ini[wv][st] : sm_min[wv][st];
