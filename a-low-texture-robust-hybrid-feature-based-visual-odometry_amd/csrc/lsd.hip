@@ -45,7 +45,7 @@ struct LsdPlan {
     hvo_keyline *d_kl_all = nullptr;                        // LSD_MAXSEG
     hvo_keyline *d_kl = nullptr; uint8_t *d_desc = nullptr; double *d_fn = nullptr; int *d_nkl = nullptr; int *d_flags = nullptr;
     hvo_keyline *d_kl2 = nullptr; uint8_t *d_desc2 = nullptr; double *d_fn2 = nullptr; int *d_nkl2 = nullptr;   // after cullingLine
-    uint8_t *d_b5 = nullptr; int16_t *d_dx = nullptr, *d_dy = nullptr;
+    uint8_t *d_b5 = nullptr; short2 *d_dxy = nullptr;       // Sobel (dx, dy) interleaved
     int *d_xofs = nullptr, *d_yofs = nullptr; float *d_xa = nullptr, *d_yb = nullptr;   // resize tables
     double k7[4] = { 0, 0, 0, 0 };                          // gaussian taps (double): k[0..3], symmetric
     int k5[3] = { 0, 0, 0 };
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256) void k_lbd_blur5(const uint8_t *__restrict__ g
     }
 }
 
-__global__ __launch_bounds__(256) void k_lbd_sobel(const uint8_t *__restrict__ b5, int16_t *__restrict__ dx, int16_t *__restrict__ dy, int w, int h)
+__global__ __launch_bounds__(256) void k_lbd_sobel(const uint8_t *__restrict__ b5, short2 *__restrict__ dxy, int w, int h)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, f = blockIdx.z;
     if (x >= w) return;
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void k_lbd_sobel(const uint8_t *__restrict__ b
     const int gx = (R0[xp] - R0[xm]) + 2 * (R1[xp] - R1[xm]) + (R2[xp] - R2[xm]);
     const int gy = (R2[xm] + 2 * R2[x] + R2[xp]) - (R0[xm] + 2 * R0[x] + R0[xp]);
     const size_t o = ((size_t)f * h + y) * w + x;
-    dx[o] = (int16_t)gx; dy[o] = (int16_t)gy;
+    dxy[o] = make_short2((short)gx, (short)gy);       // interleaved: the descriptor fetches both with one access
     }
 }
 
@@ -686,7 +686,7 @@ __constant__ int c_lbd_comb[32][2] = {
     { 2, 3 }, { 2, 4 }, { 2, 5 }, { 2, 6 }, { 2, 7 }, { 2, 8 }, { 3, 4 }, { 3, 5 }, { 3, 6 }, { 3, 7 }, { 3, 8 },
     { 4, 5 }, { 4, 6 }, { 4, 7 }, { 4, 8 }, { 5, 6 }, { 5, 7 }, { 5, 8 }, { 6, 7 }, { 6, 8 }, { 7, 8 } };
 
-__global__ __launch_bounds__(64) void k_lbd_desc(const int16_t *__restrict__ dxImg, const int16_t *__restrict__ dyImg, int w, int h,
+__global__ __launch_bounds__(64) void k_lbd_desc(const short2 *__restrict__ dxyImg, int w, int h,
                                                  const hvo_keyline *__restrict__ kls, const int *__restrict__ nkl, int kl_cap,
                                                  const float *__restrict__ gL, const float *__restrict__ gG, uint8_t *__restrict__ desc)
 {
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(64) void k_lbd_desc(const int16_t *__restrict__ dxI
     const int line = blockIdx.x, f = blockIdx.y, t = threadIdx.x;
     if (line >= nkl[f]) return;
     const hvo_keyline kl = kls[(size_t)f * kl_cap + line];
-    const int16_t *DX = dxImg + (size_t)f * w * h, *DY = dyImg + (size_t)f * w * h;
+    const short2 *DXY = dxyImg + (size_t)f * w * h;
     const short imageWidth = (short)(w - 1), imageHeight = (short)(h - 1);
     const short halfHeight = 31;
     const short lengthOfLSP = (short)kl.num_pixels;
@@ -713,11 +713,14 @@ __global__ __launch_bounds__(64) void k_lbd_desc(const int16_t *__restrict__ dxI
         float sCorX = sCorX0, sCorY = sCorY0;
         float pL = 0, nL = 0, pO = 0, nO = 0;
         for (short wID = 0; wID < lengthOfLSP; wID++) {
-            short tc = (short)round((double)sCorX);
+            // (short)round((double)v) of the reference: a float's nearest integer (ties away from zero) is the
+            // same whether it is formed in float or in double
+            short tc = (short)roundf(sCorX);
             const short xCor = (tc < 0) ? 0 : (tc > imageWidth) ? imageWidth : tc;
-            tc = (short)round((double)sCorY);
+            tc = (short)roundf(sCorY);
             const short yCor = (tc < 0) ? 0 : (tc > imageHeight) ? imageHeight : tc;
-            const float ddx = (float)DX[(int)yCor * w + xCor], ddy = (float)DY[(int)yCor * w + xCor];
+            const short2 g2 = DXY[(int)yCor * w + xCor];
+            const float ddx = (float)g2.x, ddy = (float)g2.y;
             const float gDL = __fadd_rn(__fmul_rn(ddx, dL0), __fmul_rn(ddy, dL1));
             const float gDO = __fadd_rn(__fmul_rn(ddx, dO0), __fmul_rn(ddy, dO1));
             if (gDL > 0) pL = __fadd_rn(pL, gDL); else nL = __fsub_rn(nL, gDL);
@@ -973,7 +976,7 @@ void lsd_free(hvo_ctx *ctx)
     LsdPlan *P = plan_of(ctx);
     if (!P) return;
     void *ptrs[] = { P->d_kl2, P->d_desc2, P->d_fn2, P->d_nkl2, P->d_blur, P->d_px, P->d_defined, P->d_reg, P->d_segs, P->d_kl_all, P->d_kl,
-                     P->d_desc, P->d_fn, P->d_nkl, P->d_flags, P->d_b5, P->d_dx, P->d_dy, P->d_xofs, P->d_yofs, P->d_xa, P->d_yb, P->d_gL, P->d_gG, P->d_stats };
+                     P->d_desc, P->d_fn, P->d_nkl, P->d_flags, P->d_b5, P->d_dxy, P->d_xofs, P->d_yofs, P->d_xa, P->d_yb, P->d_gL, P->d_gG, P->d_stats };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
     ctx->lsd = nullptr;
@@ -1040,7 +1043,7 @@ static int lsd_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_kl, B * P->nfeat * sizeof(hvo_keyline)); PA(P->d_desc, B * P->nfeat * 32); PA(P->d_fn, B * P->nfeat * 24);
     PA(P->d_nkl, B * 4); PA(P->d_flags, B * 4);
     PA(P->d_kl2, B * P->nfeat * sizeof(hvo_keyline)); PA(P->d_desc2, B * P->nfeat * 32); PA(P->d_fn2, B * P->nfeat * 24); PA(P->d_nkl2, B * 4);
-    PA(P->d_b5, B * npix); PA(P->d_dx, B * npix * 2); PA(P->d_dy, B * npix * 2);
+    PA(P->d_b5, B * npix); PA(P->d_dxy, B * npix * sizeof(short2));
     PA(P->d_xofs, P->sw * 4); PA(P->d_yofs, P->sh * 4); PA(P->d_xa, P->sw * 8); PA(P->d_yb, P->sh * 8);
     PA(P->d_gL, 21 * 4); PA(P->d_gG, 63 * 4); PA(P->d_stats, B * 64);
 #undef PA
@@ -1088,10 +1091,10 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lbd_sobel", st);
     hipLaunchKernelGGL(k_lbd_blur5, dim3((w + 255) / 256, (h + 7) / 8, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_b5, w, h, P->k5[0], P->k5[1], P->k5[2]);
-    hipLaunchKernelGGL(k_lbd_sobel, dim3((w + 255) / 256, (h + 7) / 8, n), dim3(256), 0, st, P->d_b5, P->d_dx, P->d_dy, w, h);
+    hipLaunchKernelGGL(k_lbd_sobel, dim3((w + 255) / 256, (h + 7) / 8, n), dim3(256), 0, st, P->d_b5, P->d_dxy, w, h);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lbd_desc", st);
-    hipLaunchKernelGGL(k_lbd_desc, dim3(P->nfeat, n), dim3(64), 0, st, P->d_dx, P->d_dy, w, h, P->d_kl, P->d_nkl, P->nfeat, P->d_gL, P->d_gG, P->d_desc);
+    hipLaunchKernelGGL(k_lbd_desc, dim3(P->nfeat, n), dim3(64), 0, st, P->d_dxy, w, h, P->d_kl, P->d_nkl, P->nfeat, P->d_gL, P->d_gG, P->d_desc);
     hvo_prof_end(ctx, id);
     if (cull) {                                     // Frame::cullingLine + the second LBD pass (Frame.cc:934, 952-1116)
         if (P->nfeat > CULL_MAXL) return HVO_ERR_UNSUPPORTED;
@@ -1100,7 +1103,7 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
         c.kl = P->d_kl; c.fn = P->d_fn; c.nkl = P->d_nkl; c.tmp = P->d_kl_all; c.tmp_stride = LSD_MAXSEG; c.kl_out = P->d_kl2; c.fn_out = P->d_fn2; c.nkl_out = P->d_nkl2;
         c.cap = P->nfeat; c.w = w; c.h = h; c.dis = ctx->cull_dis; c.cos_th = cos(ctx->cull_angle * 0.0174533); c.endpoint_dis = ctx->cull_endpoint;
         hipLaunchKernelGGL(k_cull_lines, dim3(n), dim3(64), 0, st, c);
-        hipLaunchKernelGGL(k_lbd_desc, dim3(P->nfeat, n), dim3(64), 0, st, P->d_dx, P->d_dy, w, h, P->d_kl2, P->d_nkl2, P->nfeat, P->d_gL, P->d_gG, P->d_desc2);
+        hipLaunchKernelGGL(k_lbd_desc, dim3(P->nfeat, n), dim3(64), 0, st, P->d_dxy, w, h, P->d_kl2, P->d_nkl2, P->nfeat, P->d_gL, P->d_gG, P->d_desc2);
         hvo_prof_end(ctx, id);
     }
     HVO_HIP(hipGetLastError());
