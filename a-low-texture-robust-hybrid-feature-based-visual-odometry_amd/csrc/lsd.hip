@@ -644,25 +644,32 @@ __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
 // ------------------------------------------------------------------------------------------------
 // LBD: blur 5x5 (u8 fixed point, same rounding rules as the ORB blur), Sobel, descriptor
 // ------------------------------------------------------------------------------------------------
+#define LBD_BLUR_ROWS 16
 __global__ __launch_bounds__(256) void k_lbd_blur5(const uint8_t *__restrict__ gray, size_t gframe, int gpitch,
                                                    uint8_t *__restrict__ out, int w, int h, int k0, int k1, int k2)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, f = blockIdx.z;
     if (x >= w) return;
     const uint8_t *G = gray + (size_t)f * gframe;
-    const int kk[5] = { k0, k1, k2, k1, k0 };
-    for (int y = blockIdx.y * 8; y < min(h, blockIdx.y * 8 + 8); y++) {
-    int s = 0;
+    const int xm2 = refl(x - 2, w), xm1 = refl(x - 1, w), xp1 = refl(x + 1, w), xp2 = refl(x + 2, w);
+    const int yb = blockIdx.y * LBD_BLUR_ROWS;
+    // row-pass values of the LBD_BLUR_ROWS + 4 source rows this column needs, each formed once
+    int r[LBD_BLUR_ROWS + 4];
 #pragma unroll
-    for (int j = 0; j < 5; j++) {
-        const uint8_t *R = G + (size_t)refl(y + j - 2, h) * gpitch;
-        const int r = k0 * (R[refl(x - 2, w)] + R[refl(x + 2, w)]) + k1 * (R[refl(x - 1, w)] + R[refl(x + 1, w)]) + k2 * R[x];
-        s += kk[j] * r;
+    for (int j = 0; j < LBD_BLUR_ROWS + 4; j++) {
+        const uint8_t *R = G + (size_t)refl(min(yb + j - 2, h + 1), h) * gpitch;
+        r[j] = k0 * (R[xm2] + R[xp2]) + k1 * (R[xm1] + R[xp1]) + k2 * R[x];
     }
-    int q;
-    if (x < (w & ~3)) { q = s >> 16; const int rem = s & 0xFFFF; if (rem > 32768 || (rem == 32768 && (q & 1))) q++; }
-    else q = (s + 32768) >> 16;
-    out[((size_t)f * h + y) * w + x] = (uint8_t)min(q, 255);
+    const bool vec = x < (w & ~3);                  // OpenCV's SSE2 column path (round half to even) vs its scalar tail
+#pragma unroll
+    for (int j = 0; j < LBD_BLUR_ROWS; j++) {
+        const int y = yb + j;
+        if (y >= h) break;
+        const int s = k0 * r[j] + k1 * r[j + 1] + k2 * r[j + 2] + k1 * r[j + 3] + k0 * r[j + 4];
+        int q;
+        if (vec) { q = s >> 16; const int rem = s & 0xFFFF; if (rem > 32768 || (rem == 32768 && (q & 1))) q++; }
+        else q = (s + 32768) >> 16;
+        out[((size_t)f * h + y) * w + x] = (uint8_t)min(q, 255);
     }
 }
 
@@ -1090,7 +1097,7 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     hipLaunchKernelGGL(k_lsd_grow, dim3(n), dim3(64), 0, st, g);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lbd_sobel", st);
-    hipLaunchKernelGGL(k_lbd_blur5, dim3((w + 255) / 256, (h + 7) / 8, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_b5, w, h, P->k5[0], P->k5[1], P->k5[2]);
+    hipLaunchKernelGGL(k_lbd_blur5, dim3((w + 255) / 256, (h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_b5, w, h, P->k5[0], P->k5[1], P->k5[2]);
     hipLaunchKernelGGL(k_lbd_sobel, dim3((w + 255) / 256, (h + 7) / 8, n), dim3(256), 0, st, P->d_b5, P->d_dxy, w, h);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lbd_desc", st);
