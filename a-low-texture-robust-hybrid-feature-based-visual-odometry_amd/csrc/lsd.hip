@@ -679,12 +679,22 @@ __global__ __launch_bounds__(256) void k_lbd_sobel(const uint8_t *__restrict__ b
     if (x >= w) return;
     const uint8_t *B = b5 + (size_t)f * w * h;
     const int xm = refl(x - 1, w), xp = refl(x + 1, w);
-    for (int y = blockIdx.y * 8; y < min(h, blockIdx.y * 8 + 8); y++) {
-    const uint8_t *R0 = B + (size_t)refl(y - 1, h) * w, *R1 = B + (size_t)y * w, *R2 = B + (size_t)refl(y + 1, h) * w;
-    const int gx = (R0[xp] - R0[xm]) + 2 * (R1[xp] - R1[xm]) + (R2[xp] - R2[xm]);
-    const int gy = (R2[xm] + 2 * R2[x] + R2[xp]) - (R0[xm] + 2 * R0[x] + R0[xp]);
-    const size_t o = ((size_t)f * h + y) * w + x;
-    dxy[o] = make_short2((short)gx, (short)gy);       // interleaved: the descriptor fetches both with one access
+    const int yb = blockIdx.y * LBD_BLUR_ROWS;
+    // per source row: horizontal difference and horizontal (1 2 1) sum, each formed once
+    int hd[LBD_BLUR_ROWS + 2], hs[LBD_BLUR_ROWS + 2];
+#pragma unroll
+    for (int j = 0; j < LBD_BLUR_ROWS + 2; j++) {
+        const uint8_t *R = B + (size_t)refl(min(yb + j - 1, h), h) * w;
+        const int a = R[xm], c = R[x], e = R[xp];
+        hd[j] = e - a; hs[j] = a + 2 * c + e;
+    }
+#pragma unroll
+    for (int j = 0; j < LBD_BLUR_ROWS; j++) {
+        const int y = yb + j;
+        if (y >= h) break;
+        const int gx = hd[j] + 2 * hd[j + 1] + hd[j + 2];
+        const int gy = hs[j + 2] - hs[j];
+        dxy[((size_t)f * h + y) * w + x] = make_short2((short)gx, (short)gy);       // interleaved: the descriptor fetches both with one access
     }
 }
 
@@ -1098,7 +1108,7 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lbd_sobel", st);
     hipLaunchKernelGGL(k_lbd_blur5, dim3((w + 255) / 256, (h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_b5, w, h, P->k5[0], P->k5[1], P->k5[2]);
-    hipLaunchKernelGGL(k_lbd_sobel, dim3((w + 255) / 256, (h + 7) / 8, n), dim3(256), 0, st, P->d_b5, P->d_dxy, w, h);
+    hipLaunchKernelGGL(k_lbd_sobel, dim3((w + 255) / 256, (h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS, n), dim3(256), 0, st, P->d_b5, P->d_dxy, w, h);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lbd_desc", st);
     hipLaunchKernelGGL(k_lbd_desc, dim3(P->nfeat, n), dim3(64), 0, st, P->d_dxy, w, h, P->d_kl, P->d_nkl, P->nfeat, P->d_gL, P->d_gG, P->d_desc);
