@@ -160,3 +160,19 @@ def test_culling_batch_stage_and_params(hvo, orc, synth):
         ck_o, cd_o, _ = orc.cull_lines(gray[b], kl_o, fn_o, 7.5, 3.0, 20.0)
         assert res[b]["status"] == 0 and len(res[b]["kl"]) == len(ck_o)
         assert np.array_equal(res[b]["kl"]["sx"], ck_o["sx"]) and np.array_equal(res[b]["ldesc"], cd_o)
+
+
+@pytest.mark.gpu
+def test_culling_parity_1280(hvo, orc, synth):
+    g = synth.make_gray("std", 0x5EED0003, 1280, 960)
+    kl_o, d_o, fn_o = orc.line_extract(g)
+    ck_o, cd_o, cf_o = orc.cull_lines(g, kl_o, fn_o)
+    ctx = hvo.Context()
+    try:
+        ck_g, cd_g, cf_g = ctx.extract_lsd(g, culled=True)
+    finally:
+        ctx.close()
+    assert len(ck_g) == len(ck_o)
+    for f in ck_o.dtype.names:
+        assert np.array_equal(ck_g[f], ck_o[f]), f
+    assert np.array_equal(cd_g, cd_o) and np.allclose(cf_g, cf_o, rtol=1e-12, atol=1e-12)
