@@ -40,6 +40,7 @@ static __device__ __forceinline__ unsigned long long lanemask_lt()
 // =====================================================================================
 // K1: pyramid level l from level l-1 (cv::resize INTER_LINEAR u8, 11-bit fixed point)
 // =====================================================================================
+#define RESIZE_ROWS 16
 __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, size_t frame_stride,
                                                 LevelGeom S, LevelGeom D,
                                                 const int *__restrict__ xofs, const int *__restrict__ xalpha,
@@ -60,9 +61,10 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, size_
         a0[i] = (short)(xa & 0xFFFF); a1[i] = (short)(xa >> 16);
         sx1[i] = min(sx[i] + 1, S.w - 1);                       // a1 == 0 whenever sx+1 is outside
     }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int dy = (blockIdx.y * blockDim.y + threadIdx.y) * 4 + r;
+    // RESIZE_ROWS rows per thread: the launch is dispatch bound with small workgroups (~6 ns per workgroup)
+#pragma unroll 4
+    for (int r = 0; r < RESIZE_ROWS; r++) {
+        const int dy = (blockIdx.y * blockDim.y + threadIdx.y) * RESIZE_ROWS + r;
         if (dy >= D.h) break;
         const int yo = yofs[dy];
         const int sy0 = yo & 0xFFFF, sy1 = yo >> 16;
@@ -946,7 +948,7 @@ int orb_run(hvo_ctx *ctx, int n)
     int id = hvo_prof_begin(ctx, "orb_pyramid", st);
     for (int l = 1; l < nl; l++) {
         const LevelGeom &S = P.lev[l - 1], &D = P.lev[l];
-        dim3 blk(64, 4), grd((D.w + 255) / 256, (D.h + 15) / 16, n);
+        dim3 blk(64, 4), grd((D.w + 255) / 256, (D.h + 4 * RESIZE_ROWS - 1) / (4 * RESIZE_ROWS), n);
         hipLaunchKernelGGL(k_resize, grd, blk, 0, st, P.d_pyr, P.pyr_bytes, S, D, P.d_rs_xofs + D.rs_off, P.d_rs_xalpha + D.rs_off,
                            P.d_rs_yofs + D.ry_off, P.d_rs_ybeta + D.ry_off);
     }

@@ -230,7 +230,7 @@ def main():
             if orb_ms > 0:
                 roof["orb_pyramid_brief_pass_GBps"] = round(pass_bytes * B / (orb_ms * 1e-3) / 1e9, 2)
         out = {
-            "metric": "RGB-D frames/sec (640\u00d7480, 1k ORB + LSD + PEAC) at 1/2/4/8 GPUs",      # BASELINE.json's metric, verbatim "value": round(value, 2), "unit": "frames/s",
+            "metric": "RGB-D frames/sec (640\u00d7480, 1k ORB + LSD + PEAC) at 1/2/4/8 GPUs", "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16 integer + f32/f64",
             "data": "synthetic",
