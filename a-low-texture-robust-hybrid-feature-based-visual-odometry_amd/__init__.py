@@ -46,7 +46,7 @@ EXPORTS = [
     "hvo_extract_orb", "hvo_extract_lsd", "hvo_compute_planes",
     "hvo_hamming_matrix", "hvo_hamming_knn2", "hvo_match_nnr", "hvo_search_by_projection", "hvo_stereo_from_rgbd",
     "hvo_undistort_keypoints", "hvo_image_bounds", "hvo_assign_features_to_grid", "hvo_assign_lines_to_grid",
-    "hvo_extract_lsd_culled", "hvo_set_line_culling",
+    "hvo_extract_lsd_culled", "hvo_set_line_culling", "hvo_search_by_projection_map",
     "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch",
     "hvo_profile_last", "hvo_profile_enable",
 ]
@@ -112,6 +112,7 @@ def lib():
         L.hvo_match_nnr.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
                                     C.POINTER(C.c_int)]
         L.hvo_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_void_p] * 4 + [C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.hvo_search_by_projection_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p] * 4 + [C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.hvo_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         L.hvo_extract_lsd_culled.argtypes = L.hvo_extract_lsd.argtypes
         L.hvo_set_line_culling.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
@@ -242,6 +243,23 @@ class Context:
                                                  _p(q_ur), _p(q_angle), _p(q_blocks), _p(t_kp), _p(t_uright), _p(t_occupied), _p(t_desc), nt,
                                                  bounds[0], bounds[1], bounds[2], bounds[3], th_high, 1 if check_orientation else 0,
                                                  _p(mi), _p(md), C.byref(n)), "search_by_projection")
+        return n.value, mi, md
+
+    def search_by_projection_map(self, q_desc, q_u, q_v, q_radius, q_min_level, q_max_level, q_ur, q_blocks,
+                                 t_kp, t_uright, t_occupied, t_desc, bounds, th_high=100, nn_ratio=0.8):
+        """ORBmatcher::SearchByProjection(F, vpMapPoints, th) core (src/ORBmatcher.cc:45-132) -> (nmatches, match_idx, match_dist)"""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        q_desc = np.ascontiguousarray(q_desc, np.uint8); t_desc = np.ascontiguousarray(t_desc, np.uint8)
+        nq, nt = len(q_desc), len(t_desc)
+        q_u, q_v, q_radius, q_ur = map(f32, (q_u, q_v, q_radius, q_ur))
+        q_min_level = np.ascontiguousarray(q_min_level, np.int32); q_max_level = np.ascontiguousarray(q_max_level, np.int32)
+        q_blocks = np.ascontiguousarray(q_blocks, np.uint8); t_occupied = np.ascontiguousarray(t_occupied, np.uint8)
+        t_kp = np.ascontiguousarray(t_kp); t_uright = f32(t_uright)
+        mi = np.zeros(nq, np.int32); md = np.zeros(nq, np.int32); n = C.c_int(0)
+        self._chk(lib().hvo_search_by_projection_map(self.h, _p(q_desc), nq, _p(q_u), _p(q_v), _p(q_radius), _p(q_min_level), _p(q_max_level), _p(q_ur),
+                                                     _p(q_blocks), _p(t_kp), _p(t_uright), _p(t_occupied), _p(t_desc), nt,
+                                                     bounds[0], bounds[1], bounds[2], bounds[3], th_high, nn_ratio, _p(mi), _p(md), C.byref(n)),
+                  "search_by_projection_map")
         return n.value, mi, md
 
     def stereo_from_rgbd(self, kp, kp_un, depth, bf):

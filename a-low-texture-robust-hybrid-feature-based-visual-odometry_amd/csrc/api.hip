@@ -369,6 +369,55 @@ int hvo_search_by_projection(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const 
     return status;
 }
 
+int hvo_search_by_projection_map(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
+                                 const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur, const uint8_t *q_blocks,
+                                 const hvo_keypoint *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
+                                 float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, int th_high, float nn_ratio,
+                                 int32_t *match_idx, int32_t *match_dist, int *n_matches)
+{
+    if (!ctx || !n_matches || nq < 0 || nt < 0) return HVO_ERR_INVALID_ARG;
+    *n_matches = 0;
+    if (nq == 0) return HVO_OK;
+    if (!q_desc || !q_u || !q_v || !q_radius || !q_min_level || !q_max_level || !q_blocks || !match_idx || !match_dist) return HVO_ERR_INVALID_ARG;
+    for (int i = 0; i < nq; i++) { match_idx[i] = -1; match_dist[i] = 256; }
+    if (nt == 0) return HVO_OK;
+    if (!t_kp || !t_desc || nt > 65535 || !(mnMaxX > mnMinX) || !(mnMaxY > mnMinY)) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    std::vector<unsigned long long> keys((size_t)nq * HVO_SBP_K);
+    std::vector<int> cnt(nq);
+    // Same ranked candidates as hvo_search_by_projection; the sequential pass (ORBmatcher.cc:50-128) takes the best and
+    // the second best still-free candidate of every query (ranking order = the reference's first-minimum-wins order).
+    std::vector<uint8_t> occ(nt, 0);
+    if (t_occupied) for (int j = 0; j < nt; j++) occ[j] = t_occupied[j] ? 1 : 0;
+    int nm = 0, start = 0;
+    while (start < nq) {
+        const int m = nq - start;
+        int rc = match_search_by_projection(ctx, q_desc + (size_t)start * 32, m, q_u + start, q_v + start, q_radius + start, q_min_level + start,
+                                            q_max_level + start, q_ur ? q_ur + start : nullptr, t_kp, t_uright, occ.data(), t_desc, nt,
+                                            mnMinX, mnMinY, mnMaxX, mnMaxY, keys.data(), cnt.data());
+        if (rc) return rc;
+        int i = start;
+        for (; i < nq; i++) {
+            const unsigned long long *kq = &keys[(size_t)(i - start) * HVO_SBP_K];
+            const int total = cnt[i - start], navail = total < HVO_SBP_K ? total : HVO_SBP_K;
+            int k1 = -1, k2 = -1;
+            for (int k = 0; k < navail; k++) if (!occ[(int)(kq[k] & 0xFFFF)]) { if (k1 < 0) k1 = k; else { k2 = k; break; } }
+            if (k2 < 0 && total > HVO_SBP_K) break;                         // fewer than two free among the ranked ones: re-rank from query i
+            if (k1 < 0) continue;
+            const int j = (int)(kq[k1] & 0xFFFF), d = (int)(kq[k1] >> 32);
+            if (d >= 256 || d > th_high) continue;                         // bestDist starts at 256 and only strictly smaller distances enter
+            int d2 = 256, lvl2 = -1;
+            if (k2 >= 0 && (int)(kq[k2] >> 32) < 256) { d2 = (int)(kq[k2] >> 32); lvl2 = t_kp[(int)(kq[k2] & 0xFFFF)].octave; }
+            if (t_kp[j].octave == lvl2 && (float)d > nn_ratio * (float)d2) continue;
+            match_idx[i] = j; match_dist[i] = d; nm++;
+            if (q_blocks[i]) occ[j] = 1;
+        }
+        start = i;
+    }
+    *n_matches = nm;
+    return HVO_OK;
+}
+
 int hvo_stereo_from_rgbd(hvo_ctx *ctx, const hvo_keypoint *kp, const hvo_keypoint *kp_un, int n, const uint16_t *depth, int w, int h, int stride,
                          float bf, float *uright, float *zdepth)
 {

@@ -178,6 +178,16 @@ int hvo_assign_features_to_grid(hvo_ctx *ctx, const hvo_keypoint *kp_un, int n, 
 int hvo_assign_lines_to_grid(hvo_ctx *ctx, const hvo_keyline *kl, int n, const float bounds4[4],
                              int32_t *cell_start, int32_t *cell_items, int cap, int *n_items);
 
+/* ORBmatcher::SearchByProjection(Frame &F, vpMapPoints, th) core (reference src/ORBmatcher.cc:45-132), the local-map
+ * variant: one query per map point in view (projected u, v = mTrackProjX/Y; radius = RadiusByViewingCos * th *
+ * scale[level]; levels [level-1, level]; ur = mTrackProjXR), best and second-best distance, accepted if best <= th_high
+ * and not (both in the same octave && best > nn_ratio * second) (:117-124).  t_occupied / q_blocks as above. */
+int hvo_search_by_projection_map(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
+                                 const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur, const uint8_t *q_blocks,
+                                 const hvo_keypoint *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
+                                 float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, int th_high, float nn_ratio,
+                                 int32_t *match_idx, int32_t *match_dist, int *n_matches);
+
 /* Frame::ComputeStereoFromRGBD (reference src/Frame.cc:1940-1961): uright[i] = kp_un[i].x - bf/d and zdepth[i] = d
  * where d = depth(v,u) * depth_map_factor at the truncated key-point position, if 0 < d < 7; else -1. */
 int hvo_stereo_from_rgbd(hvo_ctx *ctx, const hvo_keypoint *kp, const hvo_keypoint *kp_un, int n,

@@ -234,6 +234,21 @@ public:
                                        match_idx.data(), dist.data(), &n), "hvo_search_by_projection");
         return n;
     }
+    // SearchByProjection(F, vpMapPoints, th) core (ORBmatcher.cc:45-132): best / second best with the same-octave
+    // ratio test (mfNNratio); see hvo.h.  Returns the number of matches.
+    int SearchByProjectionMap(const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
+                              const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur, const uint8_t *q_blocks,
+                              const KeyPoint *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
+                              float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, float nnratio, std::vector<int> &match_idx) const
+    {
+        match_idx.assign(nq, -1);
+        std::vector<int> dist(nq);
+        int n = 0;
+        check(hvo_search_by_projection_map(ctx_, q_desc, nq, q_u, q_v, q_radius, q_min_level, q_max_level, q_ur, q_blocks, t_kp, t_uright,
+                                           t_occupied, t_desc, nt, mnMinX, mnMinY, mnMaxX, mnMaxY, TH_HIGH, nnratio,
+                                           match_idx.data(), dist.data(), &n), "hvo_search_by_projection_map");
+        return n;
+    }
 private:
     hvo_ctx *ctx_;
 };

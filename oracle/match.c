@@ -172,3 +172,69 @@ void orc_stereo_from_rgbd(const void *kp_, const void *kpun_, int n, const uint1
         if (d > 0 && d < 7.0) { zdepth[i] = d; uright[i] = kpu[i].x - bf / d; }
     }
 }
+
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th) core (src/ORBmatcher.cc:45-132):
+ * the local-map variant.  One query per map point that is in view (:52-56): projected (u, v) = mTrackProjX/Y,
+ * radius = r * scale[level] (:63-70), levels [level-1, level] (:71), ur = mTrackProjXR; best and second-best Hamming
+ * distance with their octaves; accepted if best <= TH_HIGH and not (same octave && best > mfNNratio * second)
+ * (:117-124).  A feature whose map point has observations is skipped (:89-91): t_occupied, and q_blocks[i] marks
+ * a query whose map point has observations (it then blocks the feature it is assigned to). */
+int orc_search_by_projection_map(const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
+                                 const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur, const uint8_t *q_blocks,
+                                 const void *t_kp_, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
+                                 float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, int th_high, float nn_ratio,
+                                 int32_t *match_idx, int32_t *match_dist)
+{
+    const kp_t *t_kp = (const kp_t *)t_kp_;
+    const float invW = (float)GRID_COLS / (mnMaxX - mnMinX), invH = (float)GRID_ROWS / (mnMaxY - mnMinY);
+    int *cell_of = (int *)malloc(sizeof(int) * (nt + 1));
+    for (int i = 0; i < nt; i++) {
+        int px = (int)round((t_kp[i].x - mnMinX) * invW), py = (int)round((t_kp[i].y - mnMinY) * invH);
+        cell_of[i] = (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) ? -1 : px * GRID_ROWS + py;
+    }
+    uint8_t *occ = (uint8_t *)calloc(nt + 1, 1);
+    for (int i = 0; i < nt; i++) occ[i] = t_occupied ? t_occupied[i] : 0;
+    int nmatches = 0;
+    for (int i = 0; i < nq; i++) {
+        match_idx[i] = -1; match_dist[i] = 256;
+        const float x = q_u[i], y = q_v[i], r = q_radius[i];
+        const int minLevel = q_min_level[i], maxLevel = q_max_level[i];
+        int nMinCellX = (int)floorf((x - mnMinX - r) * invW); if (nMinCellX < 0) nMinCellX = 0;
+        if (nMinCellX >= GRID_COLS) continue;
+        int nMaxCellX = (int)ceilf((x - mnMinX + r) * invW); if (nMaxCellX > GRID_COLS - 1) nMaxCellX = GRID_COLS - 1;
+        if (nMaxCellX < 0) continue;
+        int nMinCellY = (int)floorf((y - mnMinY - r) * invH); if (nMinCellY < 0) nMinCellY = 0;
+        if (nMinCellY >= GRID_ROWS) continue;
+        int nMaxCellY = (int)ceilf((y - mnMinY + r) * invH); if (nMaxCellY > GRID_ROWS - 1) nMaxCellY = GRID_ROWS - 1;
+        if (nMaxCellY < 0) continue;
+        const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+                for (int j = 0; j < nt; j++) {
+                    if (cell_of[j] != ix * GRID_ROWS + iy) continue;
+                    if (bCheckLevels) {
+                        if (t_kp[j].octave < minLevel) continue;
+                        if (maxLevel >= 0 && t_kp[j].octave > maxLevel) continue;
+                    }
+                    const float distx = t_kp[j].x - x, disty = t_kp[j].y - y;
+                    if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
+                    if (occ[j]) continue;
+                    if (t_uright && t_uright[j] > 0 && q_ur) {
+                        const float er = fabsf(q_ur[i] - t_uright[j]);
+                        if (er > r) continue;
+                    }
+                    const int dist = orc_descriptor_distance(q_desc + 32 * (size_t)i, t_desc + 32 * (size_t)j);
+                    if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = t_kp[j].octave; bestIdx = j; }
+                    else if (dist < bestDist2) { bestLevel2 = t_kp[j].octave; bestDist2 = dist; }
+                }
+        if (bestDist <= th_high) {
+            if (bestLevel == bestLevel2 && (float)bestDist > nn_ratio * (float)bestDist2) continue;
+            match_idx[i] = bestIdx; match_dist[i] = bestDist; nmatches++;
+            if (q_blocks[i]) occ[bestIdx] = 1;
+        }
+    }
+    free(cell_of); free(occ);
+    return nmatches;
+}
+

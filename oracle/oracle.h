@@ -128,6 +128,12 @@ int  orc_search_by_projection(const uint8_t *q_desc, int nq, const float *q_u, c
                               const void *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
                               float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, int th_high, int check_orientation,
                               int32_t *match_idx, int32_t *match_dist);
+/* ORBmatcher::SearchByProjection(F, vpMapPoints, th) core (src/ORBmatcher.cc:45-132): best / second best + ratio */
+int  orc_search_by_projection_map(const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
+                                  const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur, const uint8_t *q_blocks,
+                                  const void *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
+                                  float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, int th_high, float nn_ratio,
+                                  int32_t *match_idx, int32_t *match_dist);
 /* Frame::ComputeStereoFromRGBD (src/Frame.cc:1940-1961) */
 void orc_stereo_from_rgbd(const void *kp, const void *kp_un, int n, const uint16_t *depth, int w, int h, int stride_bytes,
                           float depth_factor, float bf, float *uright, float *zdepth);

@@ -354,3 +354,22 @@ def line_iterator_count_clipped(w, h, x1, y1, x2, y2):
     L.orc_line_iterator_count_clipped.argtypes = [C.c_int, C.c_int] + [C.c_float] * 4
     return L.orc_line_iterator_count_clipped(w, h, x1, y1, x2, y2)
 
+
+def search_by_projection_map(q_desc, q_u, q_v, q_radius, q_min_level, q_max_level, q_ur, q_blocks,
+                             t_kp, t_uright, t_occupied, t_desc, bounds, th_high=100, nn_ratio=0.8):
+    """ORBmatcher::SearchByProjection(F, vpMapPoints, th) core (src/ORBmatcher.cc:45-132) -> (nmatches, match_idx, match_dist)"""
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    q_desc = np.ascontiguousarray(q_desc, np.uint8); t_desc = np.ascontiguousarray(t_desc, np.uint8)
+    nq, nt = len(q_desc), len(t_desc)
+    q_u, q_v, q_radius, q_ur = map(f32, (q_u, q_v, q_radius, q_ur))
+    q_min_level = np.ascontiguousarray(q_min_level, np.int32); q_max_level = np.ascontiguousarray(q_max_level, np.int32)
+    q_blocks = np.ascontiguousarray(q_blocks, np.uint8); t_occupied = np.ascontiguousarray(t_occupied, np.uint8)
+    t_kp = np.ascontiguousarray(t_kp); t_uright = f32(t_uright)
+    mi = np.zeros(nq, np.int32); md = np.zeros(nq, np.int32)
+    L = lib()
+    L.orc_search_by_projection_map.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p] * 4 + [C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    n = L.orc_search_by_projection_map(_p(q_desc), nq, _p(q_u), _p(q_v), _p(q_radius), _p(q_min_level), _p(q_max_level), _p(q_ur),
+                                       _p(q_blocks), _p(t_kp), _p(t_uright), _p(t_occupied), _p(t_desc), nt,
+                                       bounds[0], bounds[1], bounds[2], bounds[3], th_high, nn_ratio, _p(mi), _p(md))
+    return n, mi, md
+

@@ -58,3 +58,34 @@ def test_stereo_from_rgbd(gpu_ctx, orc, synth):
     ug, zg = gpu_ctx.stereo_from_rgbd(kp, kp, d, float(bf))
     assert np.array_equal(zg, zo) and np.array_equal(ug, uo)
     assert (zo > 0).mean() > 0.8 and np.all((zo == -1) | ((zo > 0) & (zo < 7)))     # gate 0 < d < 7 (Frame.cc:1955)
+
+
+@pytest.mark.parametrize("th,occupied_frac,dup,ratio", [(4, 0.0, False, 0.8), (2, 0.3, False, 0.6), (8, 0.0, True, 0.9)])
+def test_search_by_projection_map_parity(gpu_ctx, orc, synth, th, occupied_frac, dup, ratio):
+    """local-map variant (ORBmatcher.cc:45-132): best / second best with the same-octave ratio test"""
+    kp1, d1, kp2, d2 = _scene(orc, synth, seed=0x5EED0004)
+    rng = np.random.default_rng(9)
+    n1 = len(kp1)
+    lvl = kp1["octave"].astype(np.int32)
+    scale = np.float32(1.2) ** lvl.astype(np.float32)
+    q_u = kp1["x"] + 3 + rng.normal(0, 1.5, n1).astype(np.float32)
+    q_v = kp1["y"] + 2 + rng.normal(0, 1.5, n1).astype(np.float32)
+    r = np.where(rng.uniform(size=n1) < 0.5, 2.5, 4.0).astype(np.float32)            # RadiusByViewingCos (:134-140)
+    q_radius = (r * np.float32(th) * scale).astype(np.float32)
+    q_min = (lvl - 1).astype(np.int32); q_max = lvl.copy()                            # GetFeaturesInArea(.., level-1, level)
+    q_ur = (q_u - 40.0 / rng.uniform(1, 4, n1)).astype(np.float32)
+    q_blocks = (rng.uniform(size=n1) < 0.8).astype(np.uint8)
+    t_uright = np.where(rng.uniform(size=len(kp2)) < 0.7, kp2["x"] - 40.0 / rng.uniform(1, 4, len(kp2)), -1).astype(np.float32)
+    t_occ = (rng.uniform(size=len(kp2)) < occupied_frac).astype(np.uint8)
+    qd = d1.copy()
+    if dup:
+        q_u[1::2] = q_u[0::2][: len(q_u[1::2])]; q_v[1::2] = q_v[0::2][: len(q_v[1::2])]
+        qd[1::2] = qd[0::2][: len(qd[1::2])]
+    args = (qd, q_u, q_v, q_radius, q_min, q_max, q_ur, q_blocks, kp2, t_uright, t_occ, d2, BOUNDS)
+    no, io, do = orc.search_by_projection_map(*args, th_high=100, nn_ratio=ratio)
+    ng, ig, dg = gpu_ctx.search_by_projection_map(*args, th_high=100, nn_ratio=ratio)
+    assert no > 30
+    assert ng == no and np.array_equal(ig, io) and np.array_equal(dg[ig >= 0], do[io >= 0])
+    # the ratio test must have rejected something the plain best-match rule accepts
+    n_plain, _, _ = orc.search_by_projection_map(*args, th_high=100, nn_ratio=10.0)
+    assert n_plain >= no
