@@ -46,7 +46,7 @@ EXPORTS = [
     "hvo_extract_orb", "hvo_extract_lsd", "hvo_compute_planes",
     "hvo_hamming_matrix", "hvo_hamming_knn2", "hvo_match_nnr", "hvo_search_by_projection", "hvo_stereo_from_rgbd",
     "hvo_undistort_keypoints", "hvo_image_bounds", "hvo_assign_features_to_grid", "hvo_assign_lines_to_grid",
-    "hvo_extract_lsd_culled", "hvo_set_line_culling", "hvo_search_by_projection_map",
+    "hvo_extract_lsd_culled", "hvo_set_line_culling", "hvo_search_by_projection_map", "hvo_frame_bf_match", "hvo_search_double",
     "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch",
     "hvo_profile_last", "hvo_profile_enable",
 ]
@@ -112,6 +112,8 @@ def lib():
         L.hvo_match_nnr.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
                                     C.POINTER(C.c_int)]
         L.hvo_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_void_p] * 4 + [C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.hvo_frame_bf_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_int)]
+        L.hvo_search_double.argtypes = L.hvo_frame_bf_match.argtypes
         L.hvo_search_by_projection_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p] * 4 + [C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.hvo_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         L.hvo_extract_lsd_culled.argtypes = L.hvo_extract_lsd.argtypes
@@ -244,6 +246,14 @@ class Context:
                                                  bounds[0], bounds[1], bounds[2], bounds[3], th_high, 1 if check_orientation else 0,
                                                  _p(mi), _p(md), C.byref(n)), "search_by_projection")
         return n.value, mi, md
+
+    def frame_bf_match(self, d1, d2, TH=50.0, nnratio=0.9, mutual=False):
+        """LSDmatcher::FrameBFMatch (LSDmatcher.cpp:942-966); mutual=True: SearchDouble's two-way check (902-939)"""
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        m = np.full(max(len(d1), 1), -1, np.int32); n = C.c_int(0)
+        fn = lib().hvo_search_double if mutual else lib().hvo_frame_bf_match
+        self._chk(fn(self.h, _p(d1), len(d1), _p(d2), len(d2), TH, nnratio, _p(m), C.byref(n)), "frame_bf_match")
+        return n.value, m[: len(d1)]
 
     def search_by_projection_map(self, q_desc, q_u, q_v, q_radius, q_min_level, q_max_level, q_ur, q_blocks,
                                  t_kp, t_uright, t_occupied, t_desc, bounds, th_high=100, nn_ratio=0.8):

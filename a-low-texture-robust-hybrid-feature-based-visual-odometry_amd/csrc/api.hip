@@ -3,6 +3,8 @@
 // There is deliberately no CPU path: without a usable gfx950 device every call fails.
 #include "hvo_internal.hpp"
 #include <stdio.h>
+#include <algorithm>
+#include <math.h>
 #include <stdlib.h>
 #include <math.h>
 #include <string.h>
@@ -291,6 +293,59 @@ int hvo_match_nnr(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, in
         m12[i] = -1;
         if (n2 >= 2 && (float)dist[2 * i] < (float)dist[2 * i + 1] * nnr) { m12[i] = idx[2 * i]; m++; }
     }
+    *n_matches = m;
+    return HVO_OK;
+}
+
+// LSDmatcher::FrameBFMatch (LSDmatcher.cpp:942-966) on a knn-2 table: lineDescriptorMAD's nn12 threshold
+// (1110-1135; medians are order statistics, the sorts' tie order cannot change them) and the three tests
+static void frame_bf_epilogue(const int32_t *idx2, const int32_t *dist2, int n1, float TH, float nnratio, int32_t *m12)
+{
+    std::vector<float> v(n1);
+    for (int i = 0; i < n1; i++) v[i] = (float)dist2[2 * i + 1] - (float)dist2[2 * i];
+    std::nth_element(v.begin(), v.begin() + n1 / 2, v.end(), [](float a, float b) { return a > b; });        // descending order
+    const double nn12_median = (double)v[n1 / 2];
+    for (int i = 0; i < n1; i++) v[i] = fabsf((float)((double)((float)dist2[2 * i + 1] - (float)dist2[2 * i]) - nn12_median));
+    std::nth_element(v.begin(), v.begin() + n1 / 2, v.end());
+    double nn12_th = 1.4826 * (double)v[n1 / 2];
+    nn12_th = nn12_th * 0.5;
+    for (int i = 0; i < n1; i++) {
+        const float d0 = (float)dist2[2 * i], d1 = (float)dist2[2 * i + 1];
+        const double dist_12 = (double)(d1 - d0);
+        m12[i] = (dist_12 > nn12_th && d0 < TH && d0 < nnratio * d1) ? idx2[2 * i] : -1;
+    }
+}
+
+int hvo_frame_bf_match(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float th, float nnratio,
+                       int32_t *m12, int *n_matches)
+{
+    if (!ctx || !m12 || !n_matches || n1 < 0 || n2 < 0) return HVO_ERR_INVALID_ARG;
+    *n_matches = 0;
+    for (int i = 0; i < n1; i++) m12[i] = -1;
+    if (n1 == 0 || n2 < 2) return HVO_OK;                        // knnMatch(k = 2) needs two train descriptors
+    std::vector<int32_t> idx((size_t)n1 * 2), dist((size_t)n1 * 2);
+    int rc = hvo_hamming_knn2(ctx, d1, n1, d2, n2, idx.data(), dist.data());
+    if (rc) return rc;
+    frame_bf_epilogue(idx.data(), dist.data(), n1, th, nnratio, m12);
+    int m = 0; for (int i = 0; i < n1; i++) m += m12[i] >= 0;
+    *n_matches = m;
+    return HVO_OK;
+}
+
+int hvo_search_double(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float th, float nnratio,
+                      int32_t *m12, int *n_matches)
+{
+    if (!ctx || !m12 || !n_matches || n1 < 0 || n2 < 0) return HVO_ERR_INVALID_ARG;
+    *n_matches = 0;
+    for (int i = 0; i < n1; i++) m12[i] = -1;
+    if (n1 == 0 || n2 == 0) return HVO_OK;                       // LSDmatcher.cpp:910-911
+    std::vector<int32_t> m21(n2);
+    int a = 0, b = 0;
+    int rc = hvo_frame_bf_match(ctx, d1, n1, d2, n2, th, nnratio, m12, &a);
+    if (rc) return rc;
+    if ((rc = hvo_frame_bf_match(ctx, d2, n2, d1, n1, th, nnratio, m21.data(), &b))) return rc;
+    int m = 0;
+    for (int i = 0; i < n1; i++) { const int j = m12[i]; if (j >= 0) { if (m21[j] != i) m12[i] = -1; else m++; } }
     *n_matches = m;
     return HVO_OK;
 }

@@ -134,6 +134,15 @@ int hvo_hamming_knn2(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, i
 int hvo_match_nnr(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float nnr,
                   int32_t *matches12, int *n_matches);
 
+/* LSDmatcher::FrameBFMatch(ldesc1, ldesc2, LineMatches, TH) (reference src/LSDmatcher.cpp:942-966): knnMatch(k = 2),
+ * lineDescriptorMAD's nn12 threshold (1110-1135), accepted if d1 - d0 > threshold && d0 < th && d0 < nnratio * d1.
+ * hvo_search_double = the core of LSDmatcher::SearchDouble / SearchByDescriptor (902-939, 865-899): FrameBFMatch in both
+ * directions (the reference uses two threads), i -> j kept only if j -> i. */
+int hvo_frame_bf_match(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float th, float nnratio,
+                       int32_t *matches12, int *n_matches);
+int hvo_search_double(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float th, float nnratio,
+                      int32_t *matches12, int *n_matches);
+
 /* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, mono) core (reference src/ORBmatcher.cc:1353-1497,
  * Frame::GetFeaturesInArea src/Frame.cc:1502-1555).  One query per last-frame map point that passed the
  * projection tests (:1381-1404): projected (u,v), radius = th * scale[octave], octave band [min,max] with

@@ -256,6 +256,21 @@ private:
 class LSDmatcher {
 public:
     static const int TH_HIGH = 80, TH_LOW = 50;                            // LSDmatcher.cpp:12-14
+    // FrameBFMatch(ldesc1, ldesc2, LineMatches, TH) (LSDmatcher.cpp:942-966)
+    void FrameBFMatch(const uint8_t *ldesc1, int n1, const uint8_t *ldesc2, int n2, std::vector<int> &LineMatches, float TH, float nnratio) const
+    {
+        LineMatches.assign(n1 > 0 ? n1 : 1, -1); int n = 0;
+        check(hvo_frame_bf_match(ctx_, ldesc1, n1, ldesc2, n2, TH, nnratio, LineMatches.data(), &n), "hvo_frame_bf_match");
+        LineMatches.resize(n1);
+    }
+    // SearchDouble(InitialFrame, CurrentFrame, LineMatches) core (LSDmatcher.cpp:902-939): two-way FrameBFMatch at TH_LOW
+    int SearchDouble(const uint8_t *ldesc1, int n1, const uint8_t *ldesc2, int n2, std::vector<int> &LineMatches, float nnratio) const
+    {
+        LineMatches.assign(n1 > 0 ? n1 : 1, -1); int n = 0;
+        check(hvo_search_double(ctx_, ldesc1, n1, ldesc2, n2, (float)TH_LOW, nnratio, LineMatches.data(), &n), "hvo_search_double");
+        LineMatches.resize(n1);
+        return n;
+    }
     explicit LSDmatcher(hvo_ctx *ctx) : ctx_(ctx) {}
     // int match(desc1, desc2, nnr, matches_12) -> matchNNR (LSDmatcher.cpp:828-863, 803-826)
     int match(const uint8_t *desc1, int n1, const uint8_t *desc2, int n2, float nnr, std::vector<int> &matches_12) const

@@ -238,3 +238,57 @@ int orc_search_by_projection_map(const uint8_t *q_desc, int nq, const float *q_u
     return nmatches;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * LSDmatcher::FrameBFMatch (src/LSDmatcher.cpp:942-966) with lineDescriptorMAD (1110-1135) and the mutual
+ * check of LSDmatcher::SearchDouble (902-939).  knnMatch(k=2) per query; nn12 threshold = 0.5 * 1.4826 * median
+ * absolute deviation of (d1 - d0); accepted if d1 - d0 > threshold && d0 < TH && d0 < mfNNratio * d1.
+ * Medians are order statistics, so the unstable std::sort calls cannot change them.
+ * ---------------------------------------------------------------------------------------------- */
+static int cmp_float_asc(const void *a, const void *b) { const float x = *(const float *)a, y = *(const float *)b; return (x > y) - (x < y); }
+static int cmp_float_desc(const void *a, const void *b) { return -cmp_float_asc(a, b); }
+
+/* the epilogue on a knn-2 table (shared with the HIP library's host side in spirit, not in code) */
+static void frame_bf_from_knn2(const int32_t *idx2, const int32_t *dist2, int n1, float TH, float nnratio, int32_t *m12)
+{
+    float *v = (float *)malloc(sizeof(float) * (n1 + 1));
+    for (int i = 0; i < n1; i++) v[i] = (float)dist2[2 * i + 1] - (float)dist2[2 * i];
+    qsort(v, n1, sizeof(float), cmp_float_desc);                            /* conpare_descriptor_by_NN12_dist: descending */
+    const double nn12_median = (double)v[n1 / 2];
+    for (int i = 0; i < n1; i++) v[i] = fabsf((float)((double)((float)dist2[2 * i + 1] - (float)dist2[2 * i]) - nn12_median));
+    qsort(v, n1, sizeof(float), cmp_float_asc);
+    double nn12_th = 1.4826 * (double)v[n1 / 2];
+    nn12_th = nn12_th * 0.5;
+    for (int i = 0; i < n1; i++) {
+        const float d0 = (float)dist2[2 * i], d1 = (float)dist2[2 * i + 1];
+        const double dist_12 = (double)(d1 - d0);
+        m12[i] = (dist_12 > nn12_th && d0 < TH && d0 < nnratio * d1) ? idx2[2 * i] : -1;
+    }
+    free(v);
+}
+
+int orc_frame_bf_match(const uint8_t *d1, int n1, const uint8_t *d2, int n2, float TH, float nnratio, int32_t *m12)
+{
+    for (int i = 0; i < n1; i++) m12[i] = -1;
+    if (n1 <= 0 || n2 < 2) return 0;                                         /* knnMatch(k=2) needs two train descriptors */
+    int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * 4 * n1), *dist = idx + 2 * n1;
+    orc_hamming_knn2(d1, n1, d2, n2, idx, dist);
+    frame_bf_from_knn2(idx, dist, n1, TH, nnratio, m12);
+    free(idx);
+    int m = 0; for (int i = 0; i < n1; i++) m += m12[i] >= 0;
+    return m;
+}
+
+/* LSDmatcher::SearchDouble core: FrameBFMatch both ways (TH_LOW), keep i -> j only if j -> i */
+int orc_search_double(const uint8_t *d1, int n1, const uint8_t *d2, int n2, float TH, float nnratio, int32_t *m12)
+{
+    for (int i = 0; i < n1; i++) m12[i] = -1;
+    if (n1 == 0 || n2 == 0) return 0;
+    int32_t *m21 = (int32_t *)malloc(sizeof(int32_t) * (n2 + 1));
+    orc_frame_bf_match(d1, n1, d2, n2, TH, nnratio, m12);
+    orc_frame_bf_match(d2, n2, d1, n1, TH, nnratio, m21);
+    int m = 0;
+    for (int i = 0; i < n1; i++) { const int j = m12[i]; if (j >= 0) { if (m21[j] != i) m12[i] = -1; else m++; } }
+    free(m21);
+    return m;
+}
+

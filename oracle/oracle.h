@@ -121,6 +121,10 @@ void orc_hamming_matrix(const uint8_t *q, int nq, const uint8_t *t, int nt, uint
 /* LSDmatcher::matchNNR */
 int  orc_match_nnr(const uint8_t *d1, int n1, const uint8_t *d2, int n2, float nnr, int32_t *m12);
 
+/* LSDmatcher::FrameBFMatch (src/LSDmatcher.cpp:942-966, lineDescriptorMAD 1110-1135) and SearchDouble's mutual check (902-939) */
+int  orc_frame_bf_match(const uint8_t *d1, int n1, const uint8_t *d2, int n2, float TH, float nnratio, int32_t *m12);
+int  orc_search_double(const uint8_t *d1, int n1, const uint8_t *d2, int n2, float TH, float nnratio, int32_t *m12);
+
 /* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, mono) core (src/ORBmatcher.cc:1353-1497) */
 int  orc_search_by_projection(const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
                               const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur, const float *q_angle,

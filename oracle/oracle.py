@@ -373,3 +373,14 @@ def search_by_projection_map(q_desc, q_u, q_v, q_radius, q_min_level, q_max_leve
                                        bounds[0], bounds[1], bounds[2], bounds[3], th_high, nn_ratio, _p(mi), _p(md))
     return n, mi, md
 
+
+def frame_bf_match(d1, d2, TH=50.0, nnratio=0.9, mutual=False):
+    """LSDmatcher::FrameBFMatch (mutual=False) / SearchDouble core (mutual=True) -> (nmatches, matches12)"""
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    m = np.full(max(len(d1), 1), -1, np.int32)
+    L = lib()
+    fn = L.orc_search_double if mutual else L.orc_frame_bf_match
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    n = fn(_p(d1), len(d1), _p(d2), len(d2), TH, nnratio, _p(m))
+    return n, m[: len(d1)]
+

@@ -49,3 +49,21 @@ def test_match_nnr(gpu_ctx, orc, hvo):
         no, mo = orc.match_nnr(d1, d2, nnr)
         assert ng == no and np.array_equal(mg, mo)
     assert hvo.ORBmatcher(gpu_ctx).DescriptorDistance(d1[0], d1[1]) == int(orc.hamming_matrix(d1[:1], d1[1:2])[0, 0])
+
+
+@pytest.mark.parametrize("mutual", [False, True])
+def test_frame_bf_match_parity(gpu_ctx, orc, synth, mutual):
+    """LSDmatcher::FrameBFMatch / SearchDouble core (LSDmatcher.cpp:942-966, 902-939, lineDescriptorMAD 1110-1135)"""
+    g1 = synth.make_gray("std", 0x5EED0002)
+    g2 = np.roll(np.roll(g1, 2, axis=0), 3, axis=1)
+    _, d1, _ = orc.line_extract(g1); _, d2, _ = orc.line_extract(g2)
+    for th, ratio in ((50.0, 0.9), (80.0, 0.75)):
+        no, mo = orc.frame_bf_match(d1, d2, th, ratio, mutual)
+        ng, mg = gpu_ctx.frame_bf_match(d1, d2, th, ratio, mutual)
+        assert ng == no and np.array_equal(mg, mo)
+    assert orc.frame_bf_match(d1, d2, 80.0, 0.9, mutual)[0] > 10
+    # fewer than two train descriptors: knnMatch(k=2) cannot rank -> no matches
+    n, m = gpu_ctx.frame_bf_match(d1, d2[:1], 50.0, 0.9, mutual)
+    assert n == 0 and np.all(m == -1)
+    n, m = gpu_ctx.frame_bf_match(d1[:0], d2, 50.0, 0.9, mutual)
+    assert n == 0 and len(m) == 0
