@@ -11,6 +11,12 @@
  *                                          reference src/PlaneExtractor.cpp:26,60 (include/PlaneExtractor.h:50-54)
  *   ORBmatcher::DescriptorDistance         reference src/ORBmatcher.cc:1676    (include/ORBmatcher.h:44)
  *   LSDmatcher::match / matchNNR           reference src/LSDmatcher.cpp:828 / :803 (include/LSDmatcher.h:43)
+ *   LSDmatcher::FrameBFMatch / SearchDouble reference src/LSDmatcher.cpp:942 / :902
+ *   ORBmatcher::SearchByProjection         reference src/ORBmatcher.cc:1353 (frame to frame) and :45 (local map)
+ * and, of the Frame constructor's post-processing:
+ *   Frame::cullingLine                     reference src/Frame.cc:952
+ *   Frame::UndistortKeyPoints / ComputeImageBounds / ComputeStereoFromRGBD / AssignFeaturesToGrid(ForLine)
+ *                                          reference src/Frame.cc:1701 / 1733 / 1940 / 832 / 849
  *
  * The reference has no FFI of its own (single C++ process); INTEGRATION.md shows the
  * adaptor a maintainer adds to Frame.cc to call these entry points.
