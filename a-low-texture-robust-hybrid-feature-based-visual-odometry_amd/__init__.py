@@ -211,6 +211,15 @@ class Context:
         self._chk(lib().hvo_compute_planes(self.h, _p(depth), w, h, depth.strides[0], _p(labels), _p(planes), cap, C.byref(n)), "compute_planes")
         return labels, planes[: n.value].copy()
 
+    def peac_stats(self, frame=0):
+        """diagnostics (not part of the reference interface): bookkeeping words of the last plane run of `frame`"""
+        L = lib()
+        L.hvo_debug_peac_stats.argtypes = [C.c_void_p, C.c_int, C.c_void_p]; L.hvo_debug_peac_stats.restype = C.c_int
+        m = np.zeros(16, np.int32)
+        self._chk(L.hvo_debug_peac_stats(self.h, frame, _p(m)), "peac_stats")
+        return {"segments": int(m[0]), "coarse_planes": int(m[2]), "flags": int(m[3]), "planes": int(m[4]), "queue_entries": int(m[5]),
+                "flood_rounds": int(m[8]), "flood_ranked_rounds": int(m[9]), "flood_serial_rounds": int(m[10])}
+
     # ---- matching ----
     def hamming_matrix(self, q, t):
         q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)

@@ -1004,17 +1004,28 @@ struct RfArgs {
 
 // k_peac_flood: seeds + floodFill (AHCPlaneFitter.hpp:543-575, 428-476), FLOOD_T threads per frame.
 // Events = (queue entry, neighbour) in queue order.  A round takes the next FLOOD_T queue ENTRIES that
-// existed when it started; a thread owns one entry and its (up to) four neighbour events, so the
-// entry is decoded once, its plane is read once and the four pixel states are in flight together.
-// The part of an event that does not depend on the pixel's state (unprojection, point-plane distance)
-// is evaluated for all events at once; the per-pixel state machine (membership "trail", distMap)
-// must see its events in queue order, so events that hit the same pixel are serialised: an LDS hash
-// groups the round's events by pixel, every event learns its rank among the events of its pixel
-// (ordered by event index), and sub-round r applies the events of rank r, the state travelling from
-// rank to rank through LDS.  Pushes are appended in event order with a block scan, which reproduces
-// the reference's queue order exactly.  Queue entries are packed plid<<26 | y<<13 | x.
+// existed when it started; a thread owns one entry and fetches the states of its (up to) four
+// neighbour pixels, the only scattered reads.  Two thirds of the events are no-ops that the state
+// fetched at the start of the round already proves to be no-ops:
+//   * trail <= -6 (given up) never changes again;
+//   * trail == plane ("passive"): the pixel already belongs to the event's plane with
+//     dist == cdist(plane, pixel).  Whatever other planes do to the pixel earlier in the same round,
+//     the event cannot win it back (their cdist is smaller), and its only possible side effect, the
+//     adjacency bit (label-at-that-time, plane), duplicates the bit the displacing event set itself -
+//     unless TWO different other planes changed the pixel before it in the same round.
+// The remaining "live" events are compacted in event order into LDS records and processed
+// ceil(live / FLOOD_T) at a time, so the expensive part (point-plane distance in double, grouping,
+// state machine, append) is issued for dense waves only.  An LDS hash groups the live events by
+// pixel.  If all live events of a pixel carry the same plane (the rule), the group has a closed form:
+// the first event either wins the pixel (the others then see trail == plane) or every event of the
+// group decrements the negative trail once (clamped at -6) / leaves a foreign label alone; only the
+// first event acts.  A round in which some pixel collects live events of two different planes, or
+// more than four live events, is "complex" (the passive events could matter, ranks would): it is
+// replayed by one thread in plain queue order, exactly like the reference loop.  Pushes are appended
+// in event order with a block scan, which reproduces the reference's queue order exactly.
+// Queue entries are packed plid<<26 | y<<13 | x.
 #ifndef FLOOD_HS_MUL
-#define FLOOD_HS_MUL 1      // hash slots per event: 1 = table as large as the round (8 workgroups per CU), 2 = half-empty table (5 per CU)
+#define FLOOD_HS_MUL 1      // hash slots per event
 #endif
 #define FQ_PACK(x, y, pl) (((pl) << 26) | ((y) << 13) | (x))
 // workgroup barrier that orders LDS traffic only: outstanding global stores are not waited for
@@ -1024,19 +1035,20 @@ static __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-template <int FLOOD_T>
+template <int FLOOD_T, int EPL>
 __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long long *__restrict__ adj_out)
 {
-    constexpr int NEV = FLOOD_T * 4;              // events per round
-    constexpr int FLOOD_HS = NEV * FLOOD_HS_MUL, FLOOD_HL = 4;
+    constexpr int NENT = FLOOD_T * EPL, NEV = NENT * 4;                        // queue entries / events per round (EPL entries per thread)
+    constexpr int FLOOD_HS = NEV * FLOOD_HS_MUL, FLOOD_HL = 4, FLOOD_NP = 4 * EPL;   // FLOOD_NP = passes that cover all NEV events
+    constexpr int NW = FLOOD_T / 64;
+    static_assert(NEV <= 1024, "the group lists hold 10-bit event indices");
     __shared__ double pl[MAX_PLANES][8];          // center[3], normal[3], mse, pad
     __shared__ unsigned long long adj[MAX_PLANES], simok[MAX_PLANES];
     __shared__ int hkeys[FLOOD_HS], hcnt[FLOOD_HS];
     __shared__ __attribute__((aligned(8))) unsigned short hlist[FLOOD_HS * FLOOD_HL];
-    __shared__ uint2 hstate[FLOOD_HS];            // per-pixel state handed from rank to rank: (label, dist bits)
-    __shared__ int evpix[NEV];                    // the round's target pixels (rank fallback for crowded pixels)
-    __shared__ int wsum[FLOOD_T / 64];
-    __shared__ int s_nq, s_max[2];
+    __shared__ uint4 rec[NEV];                    // the round's live events in event order: packed (plane, y, x) of the target pixel, its state word, its dist bits
+    __shared__ int wsum[EPL * NW], psum[FLOOD_NP * NW];
+    __shared__ int s_nq, s_cx[2];
     const ClArgs &a = r.c;
     const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int w = r.w, h = r.h, Nw = a.Nw, nblk = a.nblk;
@@ -1053,7 +1065,7 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
         if (tid < nold) { const double *sd = segD + (size_t)ext[tid] * SEG_D; for (int k = 0; k < 7; k++) pl[tid][k] = sd[9 + k]; }
     }
     for (int i = tid; i < FLOOD_HS; i += FLOOD_T) { hkeys[i] = -1; hcnt[i] = 0; }
-    if (tid < 2) s_max[tid] = 1;
+    if (tid < 2) s_cx[tid] = 0;
     __syncthreads();
     // which pairs of planes count as adjacent when they meet on a pixel (|n_p . n_q| >= cos 30 deg,
     // AHCPlaneFitter.hpp:457-462): evaluated once per pair instead of once per contested event
@@ -1105,153 +1117,263 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
 #define FT(i)
 #endif
     FT(0)
-    // state machine of one event on its pixel (AHCPlaneFitter.hpp:445-470): (trail, dcur) -> (nl, nd), push.
-    // Written with selects; the only branch left is the rare "two planes meet" adjacency update.
-    auto apply = [&](int trail, float dcur, int plid, bool ok, float cdist, int &nl, float &nd, bool &push) {
-        const bool live = !(trail <= -6 || trail == plid);                 // trail == plid implies trail >= 0
-        const bool closer = live && ok && cdist < dcur;
-        if (live && ok && trail >= 0 && ((simok[plid] >> trail) & 1ull)) { atomicOr(&adj[trail], 1ull << plid); atomicOr(&adj[plid], 1ull << trail); }
-        nl = closer ? plid : ((live && trail < 0) ? trail - 1 : trail);
-        nd = closer ? cdist : dcur;
-        push = push || closer;
+    // point-plane distance of pixel (px, py) with raw depth d to coarse plane P (AHCPlaneFitter.hpp:463-467)
+    auto geom = [&](const double *P, int px, int py, int d, float &cdist, bool &ok) {
+        cdist = -1; ok = false;
+        if (d != 0) {
+            const double z = (double)d * df;
+            const double x = ((double)px - dcx) * z / dfx, y = ((double)py - dcy) * z / dfy;
+            const double sd = P[3] * (x - P[0]) + P[4] * (y - P[1]) + P[5] * (z - P[2]);
+            cdist = (float)fabs(sd);
+            ok = ((double)cdist * (double)cdist) < 9 * P[6] + 1e-5;
+        }
     };
-    int kq = 0, par = 0, qpf = 0, pf_nq = 0;             // entry cursor; entry prefetched for the next round, valid for k < pf_nq
+    const unsigned long long ltm = (1ull << lane) - 1;
+    int kq = 0, par = 0, pf_nq = 0;                      // entry cursor; entries prefetched for the next round, valid for k < pf_nq
+    int n_rounds = 0, n_ranked = 0, n_serial = 0;        // diagnostics (hvo_debug_peac_stats)
+    int qpf[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) qpf[e] = 0;
     while (kq < nq) {
 #ifdef HVO_PEAC_TIMING
         ft[4]++;
 #endif
-        const int nent = min(FLOOD_T, nq - kq);
-        if (tid == 0) s_max[par ^ 1] = 1;
-        const int k = kq + tid;
-        const bool own = tid < nent;
-        int q = qpf;
-        if (own && k >= pf_nq) q = queue[k];
-        if (nent == FLOOD_T) { if (k + FLOOD_T < nq) qpf = queue[k + FLOOD_T]; pf_nq = nq; } else pf_nq = 0;
-        const int plid = (int)((unsigned)q >> 26);
-        const int sx = q & 8191, sy = (q >> 13) & 8191;
-        // getValid4Neighbor order: left, right, up, down
-        int cIdx[4], trail0[4]; unsigned sx0[4]; float dist0[4], cdist[4]; bool ok[4], pending[4], push[4];
+        const int nent = min(NENT, nq - kq);
+        n_rounds++;
+        if (tid == 0) s_cx[par ^ 1] = 0;
+        int q[EPL]; bool own[EPL];                       // thread tid owns entries kq + e * FLOOD_T + tid
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const int i = e * FLOOD_T + tid, k = kq + i;
+            own[e] = i < nent;
+            q[e] = qpf[e];
+            if (own[e] && k >= pf_nq) q[e] = queue[k];
+        }
+        if (nent == NENT) {
+#pragma unroll
+            for (int e = 0; e < EPL; e++) { const int k = kq + NENT + e * FLOOD_T + tid; if (k < nq) qpf[e] = queue[k]; }
+            pf_nq = nq;
+        } else pf_nq = 0;
+        // ---- fetch the four neighbour states (getValid4Neighbor order: left, right, up, down), keep the live events ----
+        int wtot = 0;
         {
-            const bool ex[4] = { own && sx > 0, own && sx < w - 1, own && sy > 0, own && sy < h - 1 };
-            const int px[4] = { sx - 1, sx + 1, sx, sx }, py[4] = { sy, sy, sy - 1, sy + 1 };
-            uint2 st[4];
+            uint2 st[EPL][4]; int below[EPL], etot[EPL], off[EPL];
 #pragma unroll
-            for (int j = 0; j < 4; j++) { st[j] = make_uint2(FS_VALID, 0); if (ex[j]) st[j] = state[py[j] * w + px[j]]; }   // the only scattered reads
-            const double *P = pl[plid];
-            const double P0 = P[0], P1 = P[1], P2 = P[2], P3 = P[3], P4 = P[4], P5 = P[5], lim = 9 * P[6] + 1e-5;
+            for (int e = 0; e < EPL; e++) {
+                const int sx = q[e] & 8191, sy = (q[e] >> 13) & 8191;
+                const bool ex[4] = { own[e] && sx > 0, own[e] && sx < w - 1, own[e] && sy > 0, own[e] && sy < h - 1 };
+                const int px[4] = { sx - 1, sx + 1, sx, sx }, py[4] = { sy, sy, sy - 1, sy + 1 };
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                sx0[j] = st[j].x; trail0[j] = FS_LABEL(st[j].x); dist0[j] = __uint_as_float(st[j].y);
-                cIdx[j] = -1; ok[j] = false; cdist[j] = -1; push[j] = false;
-                if (!(st[j].x & FS_VALID)) {                               // pixels of still-valid blocks are never touched
-                    cIdx[j] = py[j] * w + px[j];
-                    const int d = (int)(st[j].x >> 16);
-                    if (d != 0) {
-                        const double z = (double)d * df;
-                        const double x = ((double)px[j] - dcx) * z / dfx, y = ((double)py[j] - dcy) * z / dfy;
-                        const double sd = P3 * (x - P0) + P4 * (y - P1) + P5 * (z - P2);
-                        cdist[j] = (float)fabs(sd);
-                        ok[j] = ((double)cdist[j] * (double)cdist[j]) < lim;
-                    }
+                for (int j = 0; j < 4; j++) { st[e][j] = make_uint2(FS_VALID, 0); if (ex[j]) st[e][j] = state[py[j] * w + px[j]]; }   // the only scattered reads
+            }
+            unsigned actm = 0;
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                const int plid = (int)((unsigned)q[e] >> 26);
+                below[e] = 0; etot[e] = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int trail = FS_LABEL(st[e][j].x);
+                    const bool act = !(st[e][j].x & FS_VALID) && trail > -6 && trail != plid;     // pixels of still-valid blocks are never touched
+                    if (act) actm |= 1u << (e * 4 + j);
+                    const unsigned long long bm = __ballot(act);
+                    below[e] += __popcll(bm & ltm); etot[e] += __popcll(bm);
                 }
-                pending[j] = cIdx[j] >= 0;
+            }
+            // compact index = rank in event order (entry, neighbour): entries e * FLOOD_T + tid, so (e, wave, lane, j)
+            if (NW > 1) {
+                if (lane == 0) for (int e = 0; e < EPL; e++) wsum[e * NW + wv] = etot[e];
+                lds_barrier();
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                    off[e] = wtot;
+                    for (int i = 0; i < NW; i++) { const int v = wsum[e * NW + i]; if (i < wv) off[e] += v; wtot += v; }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPL; e++) { off[e] = wtot; wtot += etot[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                const int plid = (int)((unsigned)q[e] >> 26), sx = q[e] & 8191, sy = (q[e] >> 13) & 8191;
+                const int px[4] = { sx - 1, sx + 1, sx, sx }, py[4] = { sy, sy, sy - 1, sy + 1 };
+                int c = off[e] + below[e];
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (actm & (1u << (e * 4 + j))) { rec[c] = make_uint4((unsigned)FQ_PACK(px[j], py[j], plid), st[e][j].x, st[e][j].y, 0u); c++; }
             }
         }
+        lds_barrier();
+        const int na = __builtin_amdgcn_readfirstlane(wtot);
+        const int npass = (na + FLOOD_T - 1) / FLOOD_T;
 #ifdef HVO_PEAC_TIMING
-        { int np_ = 0, nl_ = 0;
-          for (int j = 0; j < 4; j++) { np_ += pending[j]; nl_ += pending[j] && trail0[j] > -6 && trail0[j] != plid; }
-          for (int o = 32; o > 0; o >>= 1) { np_ += __shfl_xor(np_, o); nl_ += __shfl_xor(nl_, o); }
-          if (lane == 0) { atomicAdd(&g_peac_t[30], (unsigned long long)np_); atomicAdd(&g_peac_t[31], (unsigned long long)nl_); } }
+        if (tid == 0) { atomicAdd(&g_peac_t[30], (unsigned long long)na); atomicAdd(&g_peac_t[31], (unsigned long long)npass); }
 #endif
         FT(1)
-        // ---- group the round's events by pixel ----
-        int hs[4];
+        // ---- live events, FLOOD_T at a time: distance, then group by pixel ----
+        unsigned eq[FLOOD_NP], es[FLOOD_NP]; float ed[FLOOD_NP], ecd[FLOOD_NP]; bool eok[FLOOD_NP], ev[FLOOD_NP], push[FLOOD_NP]; int hs[FLOOD_NP], eix[FLOOD_NP];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            evpix[tid * 4 + j] = cIdx[j];
-            hs[j] = 0;
-            if (pending[j]) {
-                int s = (int)(((unsigned)cIdx[j] * 2654435761u) >> 19) & (FLOOD_HS - 1);
-                for (;;) {
-                    const int old = atomicCAS(&hkeys[s], -1, cIdx[j]);
-                    if (old == -1 || old == cIdx[j]) break;
-                    s = (s + 1) & (FLOOD_HS - 1);
+        for (int p = 0; p < FLOOD_NP; p++) {
+            ev[p] = false; push[p] = false; eq[p] = 0; es[p] = 0; ed[p] = 0; ecd[p] = -1; eok[p] = false; hs[p] = 0; eix[p] = 0;
+            if (p < npass) {
+                const int c = p * FLOOD_T + tid;
+                ev[p] = c < na;
+                if (ev[p]) {
+                    const uint4 R = rec[c];
+                    eq[p] = R.x; es[p] = R.y; ed[p] = __uint_as_float(R.z);
+                    const int ep = (int)(R.x >> 26), ex_ = (int)(R.x & 8191u), ey = (int)((R.x >> 13) & 8191u);
+                    eix[p] = ey * w + ex_;
+                    geom(pl[ep], ex_, ey, (int)(R.y >> 16), ecd[p], eok[p]);
+                    int s = (int)(((unsigned)eix[p] * 2654435761u) >> 19) & (FLOOD_HS - 1);
+                    for (;;) {
+                        const int old = atomicCAS(&hkeys[s], -1, eix[p]);
+                        if (old == -1 || old == eix[p]) break;
+                        s = (s + 1) & (FLOOD_HS - 1);
+                    }
+                    const int pos = atomicAdd(&hcnt[s], 1);
+                    if (pos < FLOOD_HL) hlist[s * FLOOD_HL + pos] = (unsigned short)((ep << 10) | c);
+                    hs[p] = s;
                 }
-                const int pos = atomicAdd(&hcnt[s], 1);
-                if (pos < FLOOD_HL) hlist[s * FLOOD_HL + pos] = (unsigned short)(tid * 4 + j);
-                hs[j] = s;
             }
         }
-        FT(6)
         lds_barrier();
-        FT(7)
-        int rank[4], cnt[4];
+        // ---- first event of every pixel group, group size; groups that have no closed form flag the round ----
+        bool first[FLOOD_NP], multi[FLOOD_NP]; int cnt[FLOOD_NP]; int cx = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            rank[j] = 0; cnt[j] = 0;
-            if (pending[j]) {
-                const int e = tid * 4 + j;
-                cnt[j] = hcnt[hs[j]];
-                if (cnt[j] <= FLOOD_HL) {
-                    const uint2 L = *(const uint2 *)&hlist[hs[j] * FLOOD_HL];
-                    const int l0 = L.x & 0xFFFF, l1 = L.x >> 16, l2 = L.y & 0xFFFF, l3 = L.y >> 16;
-                    rank[j] = (l0 < e) + (cnt[j] > 1 && l1 < e) + (cnt[j] > 2 && l2 < e) + (cnt[j] > 3 && l3 < e);
-                } else { for (int t = 0; t < e; t++) rank[j] += evpix[t] == cIdx[j]; }      // crowded pixel (rare)
+        for (int p = 0; p < FLOOD_NP; p++) {
+            first[p] = false; multi[p] = false; cnt[p] = 1;
+            if (p < npass && ev[p]) {
+                cnt[p] = hcnt[hs[p]];
+                first[p] = true;
+                if (cnt[p] > FLOOD_HL) cx |= 2;
+                else if (cnt[p] > 1) {
+                    const uint2 L = *(const uint2 *)&hlist[hs[p] * FLOOD_HL];
+                    const unsigned me = ((eq[p] >> 26) << 10) | (unsigned)(p * FLOOD_T + tid);
+                    const unsigned l[4] = { L.x & 0xFFFFu, L.x >> 16, L.y & 0xFFFFu, L.y >> 16 };
+#pragma unroll
+                    for (int t = 0; t < 4; t++) if (t < cnt[p]) {
+                        if ((l[t] ^ me) >> 10) multi[p] = true;                    // another plane on the same pixel
+                        if ((l[t] & 1023u) < (me & 1023u)) first[p] = false;       // compact index == event order
+                    }
+                    // two planes racing for an unlabelled pixel: ranked replay by the group's first event (below);
+                    // on a labelled pixel the passive events of a third plane could matter: serial replay of the round
+                    if (multi[p]) cx |= FS_LABEL(es[p]) < 0 ? 1 : 2;
+                }
             }
         }
-        FT(8)
-        // ---- rank 0 works on the state fetched from memory; later ranks hand the state on through LDS,
-        //      the last one writes it back ----
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (pending[j] && rank[j] == 0) {
-                pending[j] = false;
-                int nl; float nd;
-                apply(trail0[j], dist0[j], plid, ok[j], cdist[j], nl, nd, push[j]);
-                if (cnt[j] > 1) { hstate[hs[j]] = make_uint2((unsigned)nl, __float_as_uint(nd)); atomicMax(&s_max[par], cnt[j]); }
-                else if (nl != trail0[j] || nd != dist0[j]) state[cIdx[j]] = make_uint2((sx0[j] & ~0xFFu) | ((unsigned)nl & 0xFFu), __float_as_uint(nd));
-            }
-        }
-        FT(9)
+        if (cx) atomicOr(&s_cx[par], cx);
         lds_barrier();
-        const int nsub = s_max[par];
-        for (int rr = 1; rr < nsub; rr++) {
+        const int cxr = s_cx[par];
+        const bool complex_round = (cxr & 2) != 0;
+#pragma unroll
+        for (int p = 0; p < FLOOD_NP; p++) if (p < npass && ev[p]) { hkeys[hs[p]] = -1; hcnt[hs[p]] = 0; }   // leave the hash empty for the next round
+        FT(2)
+        int total = 0;
+        if (!complex_round) {
+            // ---- closed form of a one-plane group, applied by its first event (AHCPlaneFitter.hpp:445-470) ----
+#pragma unroll
+            for (int p = 0; p < FLOOD_NP; p++) {
+                if (p < npass && first[p] && !multi[p]) {
+                    const int ep = (int)(eq[p] >> 26), trail = FS_LABEL(es[p]);
+                    const bool closer = eok[p] && ecd[p] < ed[p];
+                    if (eok[p] && trail >= 0 && ((simok[ep] >> trail) & 1ull)) { atomicOr(&adj[trail], 1ull << ep); atomicOr(&adj[ep], 1ull << trail); }
+                    const int nl = closer ? ep : (trail < 0 ? max(trail - cnt[p], -6) : trail);
+                    const float nd = closer ? ecd[p] : ed[p];
+                    push[p] = closer;
+                    if (nl != trail || closer) state[eix[p]] = make_uint2((es[p] & ~0xFFu) | ((unsigned)nl & 0xFFu), __float_as_uint(nd));
+                }
+            }
+            if (cxr & 1) {
+                n_ranked++;
+                // ---- groups with two planes on an unlabelled pixel: every event publishes its distance, the
+                //      group's first event replays the group in event order and hands the push flags back ----
+#ifdef HVO_PEAC_TIMING
+                ft[6]++;
+#endif
+#pragma unroll
+                for (int p = 0; p < FLOOD_NP; p++) if (p < npass && multi[p]) rec[p * FLOOD_T + tid].w = eok[p] ? __float_as_uint(ecd[p]) : 0xFFFFFFFFu;
+                lds_barrier();
+#pragma unroll
+                for (int p = 0; p < FLOOD_NP; p++) {
+                    if (p < npass && first[p] && multi[p]) {
+                        const uint2 L = *(const uint2 *)&hlist[hs[p] * FLOOD_HL];
+                        const unsigned l[4] = { L.x & 0xFFFFu, L.x >> 16, L.y & 0xFFFFu, L.y >> 16 };
+                        int trail = FS_LABEL(es[p]); float dist = ed[p];
+                        int last = -1;
+                        for (int it = 0; it < cnt[p]; it++) {
+                            unsigned best = 0; int c = 1 << 20;                     // next event of the group in event order
+#pragma unroll
+                            for (int t = 0; t < 4; t++) { const int ct = (int)(l[t] & 1023u); if (t < cnt[p] && ct > last && ct < c) { c = ct; best = l[t]; } }
+                            const int ep = (int)(best >> 10);
+                            last = c;
+                            const unsigned okcd = rec[c].w;
+                            const bool ok = okcd != 0xFFFFFFFFu; const float cd = __uint_as_float(okcd);
+                            const bool live = !(trail <= -6 || trail == ep);
+                            const bool closer = live && ok && cd < dist;
+                            if (live && ok && trail >= 0 && ((simok[ep] >> trail) & 1ull)) { atomicOr(&adj[trail], 1ull << ep); atomicOr(&adj[ep], 1ull << trail); }
+                            trail = closer ? ep : ((live && trail < 0) ? trail - 1 : trail);
+                            dist = closer ? cd : dist;
+                            rec[c].z = closer ? 1u : 0u;
+                        }
+                        state[eix[p]] = make_uint2((es[p] & ~0xFFu) | ((unsigned)trail & 0xFFu), __float_as_uint(dist));
+                    }
+                }
+                lds_barrier();
+#pragma unroll
+                for (int p = 0; p < FLOOD_NP; p++) if (p < npass && multi[p]) push[p] = rec[p * FLOOD_T + tid].z != 0u;
+            }
+            // ---- ordered append: exclusive scan of the pushes in compact (= event) order ----
+            unsigned long long bm[FLOOD_NP]; int off[FLOOD_NP];
+#pragma unroll
+            for (int p = 0; p < FLOOD_NP; p++) { bm[p] = 0; if (p < npass) bm[p] = __ballot(push[p]); }
+            if (NW > 1) {
+                if (lane == 0) for (int p = 0; p < FLOOD_NP; p++) psum[p * NW + wv] = __popcll(bm[p]);
+                lds_barrier();
+#pragma unroll
+                for (int p = 0; p < FLOOD_NP; p++) {
+                    off[p] = total;
+                    for (int i = 0; i < NW; i++) { const int v = psum[p * NW + i]; if (i < wv) off[p] += v; total += v; }
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < FLOOD_NP; p++) { off[p] = total; total += __popcll(bm[p]); }
+            }
+#pragma unroll
+            for (int p = 0; p < FLOOD_NP; p++) if (p < npass && push[p]) {
+                const int pos = nq + off[p] + __popcll(bm[p] & ltm);
+                if (pos < r.qcap) queue[pos] = (int)eq[p];
+            }
+        } else {
+            // ---- complex round: replay its entries in queue order on one thread (the reference loop) ----
+            n_serial++;
 #ifdef HVO_PEAC_TIMING
             ft[5]++;
 #endif
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (pending[j] && rank[j] == rr) {
-                    pending[j] = false;
-                    const uint2 hsv = hstate[hs[j]];
-                    int nl; float nd;
-                    apply((int)hsv.x, __uint_as_float(hsv.y), plid, ok[j], cdist[j], nl, nd, push[j]);
-                    if (rr == cnt[j] - 1) state[cIdx[j]] = make_uint2((sx0[j] & ~0xFFu) | ((unsigned)nl & 0xFFu), __float_as_uint(nd));
-                    else hstate[hs[j]] = make_uint2((unsigned)nl, __float_as_uint(nd));
+            if (tid == 0) {
+                int nqs = nq;
+                for (int e = 0; e < nent; e++) {
+                    const int qq = queue[kq + e];
+                    const int ep = (int)((unsigned)qq >> 26), x0 = qq & 8191, y0 = (qq >> 13) & 8191;
+                    for (int j = 0; j < 4; j++) {
+                        const int x = x0 + (j == 0 ? -1 : j == 1 ? 1 : 0), y = y0 + (j == 2 ? -1 : j == 3 ? 1 : 0);
+                        if (x < 0 || x >= w || y < 0 || y >= h) continue;
+                        const int ix = y * w + x;
+                        const uint2 s = state[ix];
+                        int trail = FS_LABEL(s.x); float dist = __uint_as_float(s.y);
+                        if ((s.x & FS_VALID) || trail <= -6 || trail == ep) continue;
+                        float cd; bool ok;
+                        geom(pl[ep], x, y, (int)(s.x >> 16), cd, ok);
+                        if (ok) {
+                            if (trail >= 0 && ((simok[ep] >> trail) & 1ull)) { atomicOr(&adj[trail], 1ull << ep); atomicOr(&adj[ep], 1ull << trail); }
+                            if (cd < dist) { trail = ep; dist = cd; if (nqs < r.qcap) queue[nqs] = FQ_PACK(x, y, ep); nqs++; }
+                            else if (trail < 0) trail -= 1;
+                        } else if (trail < 0) trail -= 1;
+                        state[ix] = make_uint2((s.x & ~0xFFu) | ((unsigned)trail & 0xFFu), __float_as_uint(dist));
+                    }
                 }
+                s_nq = nqs - nq;
             }
             lds_barrier();
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) if (cIdx[j] >= 0) { hkeys[hs[j]] = -1; hcnt[hs[j]] = 0; }   // leave the hash empty for the next round
-        FT(2)
-        // ---- ordered append: exclusive scan of the pushes over the block, in event order ----
-        int below = 0, wtot = 0;
-        const unsigned long long ltm = (1ull << lane) - 1;
-#pragma unroll
-        for (int j = 0; j < 4; j++) { const unsigned long long bm = __ballot(push[j]); below += __popcll(bm & ltm); wtot += __popcll(bm); }
-        int base = 0, total = wtot;
-        if (FLOOD_T > 64) {
-            if (lane == 0) wsum[wv] = wtot;
-            lds_barrier();
-            total = 0;
-            for (int i = 0; i < FLOOD_T / 64; i++) { const int v = wsum[i]; if (i < wv) base += v; total += v; }
-        }
-        {
-            int pos = nq + base + below;
-            const int px[4] = { sx - 1, sx + 1, sx, sx }, py[4] = { sy, sy, sy - 1, sy + 1 };
-#pragma unroll
-            for (int j = 0; j < 4; j++) if (push[j]) { if (pos < r.qcap) queue[pos] = FQ_PACK(px[j], py[j], plid); pos++; }
+            total = s_nq;
         }
         nq += total;
         if (nq > r.qcap) { nq = r.qcap; flags |= 32; }
@@ -1264,7 +1386,7 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
     if (tid == 0) { for (int q = 0; q < 6; q++) atomicAdd(&g_peac_t[16 + q], ft[q]); for (int q = 6; q < 12; q++) atomicAdd(&g_peac_t[18 + q], ft[q]); atomicAdd(&g_peac_t[22], (unsigned long long)nq); atomicAdd(&g_peac_t[23], 1ull); }
 #endif
     if (tid < MAX_PLANES) adj_out[(size_t)frame * MAX_PLANES + tid] = adj[tid];
-    if (tid == 0) { meta[5] = nq; meta[7] = flags; }
+    if (tid == 0) { meta[5] = nq; meta[7] = flags; meta[8] = n_rounds; meta[9] = n_ranked; meta[10] = n_serial; }
 }
 
 // k_peac_final: one last merge round over the still-valid coarse planes, plidmap, plane records
@@ -1452,9 +1574,12 @@ int peac_run(hvo_ctx *ctx, int n)
         const int flood_t = e ? atoi(e) : -1;
         // measured: 256 threads per frame up to ~4096 resident frames, one wave per frame (less LDS, all frames in flight) beyond
         const int ft = flood_t > 0 ? flood_t : (n >= 6144 ? 64 : 256);
-        if (ft == 64) hipLaunchKernelGGL(k_peac_flood<64>, dim3(n), dim3(64), 0, st, r, P->d_adj);
-        else if (ft == 256) hipLaunchKernelGGL(k_peac_flood<256>, dim3(n), dim3(256), 0, st, r, P->d_adj);
-        else hipLaunchKernelGGL(k_peac_flood<128>, dim3(n), dim3(128), 0, st, r, P->d_adj);
+        const char *e2 = getenv("HVO_FLOOD_EPL");          // queue entries per thread and round (one-wave variant only)
+        const int fe = e2 ? atoi(e2) : 1;
+        if (ft == 64 && fe == 2) hipLaunchKernelGGL((k_peac_flood<64, 2>), dim3(n), dim3(64), 0, st, r, P->d_adj);
+        else if (ft == 64) hipLaunchKernelGGL((k_peac_flood<64, 1>), dim3(n), dim3(64), 0, st, r, P->d_adj);
+        else if (ft == 256) hipLaunchKernelGGL((k_peac_flood<256, 1>), dim3(n), dim3(256), 0, st, r, P->d_adj);
+        else hipLaunchKernelGGL((k_peac_flood<128, 1>), dim3(n), dim3(128), 0, st, r, P->d_adj);
     }
     hipLaunchKernelGGL(k_peac_final, dim3(n), dim3(64), 0, st, r, P->d_adj);
     hipLaunchKernelGGL(k_peac_relabel, dim3(64, n), dim3(256), 0, st, P->d_state, P->d_labels, P->d_plidmap, P->w * P->h);
@@ -1505,6 +1630,18 @@ extern "C" int hvo_compute_planes(hvo_ctx *ctx, const uint16_t *depth, int w, in
     if ((rc = peac_download(ctx, 1, &out))) return rc;
     *n = out.n_planes;
     return out.status;
+}
+
+// diagnostics: the frame's 16 bookkeeping words of the last plane run: [0] AHC segments, [2] coarse planes, [3] capacity flags,
+// [4] final planes, [5] flood queue entries, [8] flood rounds, [9] rounds with ranked two-plane groups, [10] rounds replayed serially
+extern "C" int hvo_debug_peac_stats(hvo_ctx *ctx, int frame, int *out16)
+{
+    PeacPlan *P = ctx ? plan_of(ctx) : nullptr;
+    if (!P || !out16 || frame < 0 || frame >= P->batch) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    HVO_HIP(hipMemcpyAsync(out16, P->d_meta + (size_t)frame * 16, 16 * sizeof(int), hipMemcpyDeviceToHost, ctx->s_peac));
+    HVO_HIP(hipStreamSynchronize(ctx->s_peac));
+    return HVO_OK;
 }
 
 #ifdef HVO_PEAC_TIMING

@@ -59,6 +59,40 @@ def test_peac_holes_and_steps(gpu_ctx, orc):
     check(lg, pg, lo, po)
 
 
+def corner_depth(seed, noise, w=640, h=480, cu=320.0, cv=240.0):
+    """three planes meeting in one image point (a box corner pointing at the camera) + integer depth noise"""
+    j = (np.arange(w)[None, :] - cu) / 535.4; i = (np.arange(h)[:, None] - cv) / 539.2
+    zs = [2.0 / (a * j + b * i + 1.0) for a, b in ((0.9, 0.5), (-0.9, 0.5), (0.0, -1.0))]
+    z = np.minimum(np.minimum(zs[0], zs[1]), zs[2])
+    rng = np.random.default_rng(seed)
+    return (np.rint(z * 5000).astype(np.int32) + rng.integers(-noise, noise + 1, z.shape)).clip(1, 65535).astype(np.uint16)
+
+
+@pytest.mark.parametrize("seed,noise,cu,cv", [(1, 0, 320.0, 240.0), (2, 6, 320.0, 240.0), (3, 25, 323.0, 236.0), (4, 60, 317.5, 243.5)])
+def test_peac_three_plane_corner(gpu_ctx, orc, seed, noise, cu, cv):
+    """floodFill where three planes race for the same pixels: rounds whose pixel groups have no closed form are replayed
+    in rank order / serially (k_peac_flood); labels must still match the sequential loop bit for bit"""
+    d = corner_depth(seed, noise, cu=cu, cv=cv)
+    lo, po = orc.peac(d)
+    lg, pg = gpu_ctx.compute_planes(d)
+    assert len(po) >= 3
+    check(lg, pg, lo, po)
+
+
+def test_peac_flood_replay_paths_are_exercised(gpu_ctx, orc, synth):
+    """the parity scenes must reach all three ways k_peac_flood resolves a round (closed form, ranked, serial replay)"""
+    ranked = serial = rounds = 0
+    scenes = [synth.make_depth(s) for s in (0x5EED0002, 0x5EED1000, 0x5EED1003, 77)] + [corner_depth(3, 25, cu=323.0, cv=236.0), corner_depth(4, 60, cu=317.5, cv=243.5)]
+    for d in scenes:
+        lo, po = orc.peac(d)
+        lg, pg = gpu_ctx.compute_planes(d)
+        check(lg, pg, lo, po)
+        st = gpu_ctx.peac_stats(0)
+        assert st["flags"] == 0
+        rounds += st["flood_rounds"]; ranked += st["flood_ranked_rounds"]; serial += st["flood_serial_rounds"]
+    assert rounds > 1000 and ranked > 0 and serial > 0, (rounds, ranked, serial)
+
+
 def test_peac_1280(hvo, orc, synth):
     d = synth.make_depth(0x5EED0003, 1280, 960)
     K = synth.intrinsics(1280, 960)

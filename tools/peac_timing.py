@@ -55,13 +55,11 @@ def main():
         print("  %-18s %.1f per wave" % (NAMES[i], v[i] / nw))
     nf = max(v[23], 1)
     ftot = v[16:20].sum()  # (election time excludes the sub-phases listed below)
-    print("flood: frames %d, ticks per frame %.3e, queue entries per frame %.0f, rounds %.1f, sub-rounds %.1f" % (nf, ftot / nf, v[22] / nf, v[20] / nf, v[21] / nf))
-    for i, nm in enumerate(["seeds", "event precompute", "election sub-rounds", "ordered append"]):
-        print("  %-20s %6.2f %%" % (nm, 100 * v[16 + i] / ftot))
-    print("  events per frame: %.0f (4 per queue entry), pending (target exists, not in a valid block) %.0f, of them not trivially no-op (trail > -6 and trail != plane) %.0f"
-          % (4 * v[22] / nf, v[30] / nf, v[31] / nf))
-    for i, nm in enumerate(["hash insert", "barrier A", "rank", "rank-0 apply", "(unused)", "(unused)"]):
-        print("    sub-phase %-14s %6.2f %% of flood" % (nm, 100 * v[24 + i] / max(ftot + v[24:30].sum(), 1)))
+    print("flood: frames %d, ticks per frame %.3e, queue entries per frame %.0f, rounds %.1f, rounds with ranked two-plane groups %.2f, rounds replayed serially %.2f" % (nf, ftot / nf, v[22] / nf, v[20] / nf, v[24] / nf, v[21] / nf))
+    for i, nm in enumerate(["seeds", "state fetch + compaction", "distance + grouping", "apply + ordered append"]):
+        print("  %-26s %6.2f %%" % (nm, 100 * v[16 + i] / ftot))
+    print("  events per frame: %.0f (4 per queue entry), live (compacted) %.0f, passes per round %.2f"
+          % (4 * v[22] / nf, v[30] / nf, v[31] / max(v[20], 1)))
     ctx.close()
     shutil.rmtree(tmp, ignore_errors=True)
 
