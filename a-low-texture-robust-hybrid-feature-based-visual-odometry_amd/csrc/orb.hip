@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     __shared__ __attribute__((aligned(16))) uint8_t sc_[4][TILE * TP];
     __shared__ unsigned long long sm_min[4][NSTEP], sm_ini[4][NSTEP];
     __shared__ unsigned short cand_[4][CAND_CAP];              // packed y << 8 | x
+    __shared__ unsigned short pend_[4][128];                   // stage-1 survivors waiting for the rest of the pre-test
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int frame = blockIdx.y;
     int cell = blockIdx.x * 4 + wv;
@@ -171,8 +172,34 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     // A 9-arc of the 16-ring contains ring pixel k or k+8 for every k, and all its pixels are on the
     // same side of the centre, so with cls = 1 (darker than v - t) | 2 (brighter than v + t):
     //   AND over the 8 opposite pairs of (cls[k] | cls[k+8]) != 0     (the test cv::FAST itself uses)
+    // Stage 1 (the vertical pair 0 | 8) runs over the raster, 64 pixels a step; ~15 % of the pixels pass it but
+    // nearly every step has a lane that does, so the other seven pairs are not chained behind it under
+    // predication: survivors are queued (raster order) and the rest of the test runs on full waves of 64.
     int ncand = 0;
     {
+        unsigned short *pend = pend_[wv];
+        int npend = 0;
+        auto rest = [&](int cnt) {                         // pairs 4|12, 2|10, 6|14, 1|9, 3|11, 5|13, 7|15 for pend[0, cnt)
+            bool pass = false; int xy = 0;
+            if (lane < cnt) {
+                xy = pend[lane];
+                const uint8_t *q = T0 + (xy >> 8) * TP + (xy & 0xFF);
+                const int v = q[0], lo = v - minTh, hi = v + minTh;
+#define CLS(o) ((q[o] < lo ? 1 : 0) | (q[o] > hi ? 2 : 0))
+                int d = CLS(3 * TP) | CLS(-3 * TP);
+                d &= CLS(3) | CLS(-3);
+                d &= CLS(2 * TP + 2) | CLS(-2 * TP - 2);
+                d &= CLS(-2 * TP + 2) | CLS(2 * TP - 2);
+                d &= CLS(3 * TP + 1) | CLS(-3 * TP - 1);
+                d &= CLS(TP + 3) | CLS(-TP - 3);
+                d &= CLS(-TP + 3) | CLS(TP - 3);
+                d &= CLS(-3 * TP + 1) | CLS(3 * TP - 1);
+                pass = d != 0;
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass) { const int p = ncand + __popcll(m & ((1ull << lane) - 1)); if (p < CAND_CAP) cand_[wv][p] = (unsigned short)xy; }
+            ncand += __popcll(m);
+        };
         int yy = lane / iw, xx = lane - yy * iw;
         for (int p0 = 0; p0 < P; p0 += 64) {
             bool pass = false;
@@ -180,29 +207,21 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
             if (p0 + lane < P) {
                 const uint8_t *q = T0 + y * TP + x;
                 const int v = q[0], lo = v - minTh, hi = v + minTh;
-#define CLS(o) ((q[o] < lo ? 1 : 0) | (q[o] > hi ? 2 : 0))
-                int d = CLS(3 * TP) | CLS(-3 * TP);                       // ring 0 | 8
-                if (d) {
-                    d &= CLS(3) | CLS(-3);                                // ring 4 | 12
-                    if (d) {
-                        d &= CLS(2 * TP + 2) | CLS(-2 * TP - 2);          // 2 | 10
-                        d &= CLS(-2 * TP + 2) | CLS(2 * TP - 2);          // 6 | 14
-                        if (d) {
-                            d &= CLS(3 * TP + 1) | CLS(-3 * TP - 1);      // 1 | 9
-                            d &= CLS(TP + 3) | CLS(-TP - 3);              // 3 | 11
-                            d &= CLS(-TP + 3) | CLS(TP - 3);              // 5 | 13
-                            d &= CLS(-3 * TP + 1) | CLS(3 * TP - 1);      // 7 | 15
-                            pass = d != 0;
-                        }
-                    }
-                }
+                pass = (CLS(3 * TP) | CLS(-3 * TP)) != 0;                 // ring 0 | 8
 #undef CLS
             }
             const unsigned long long m = __ballot(pass);
-            if (pass) { const int p = ncand + __popcll(m & ((1ull << lane) - 1)); if (p < CAND_CAP) cand_[wv][p] = (unsigned short)((y << 8) | x); }
-            ncand += __popcll(m);
+            if (pass) pend[npend + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)((y << 8) | x);
+            npend += __popcll(m);
+            if (npend >= 64) {                                 // a full wave of survivors: finish their test
+                rest(64);
+                npend -= 64;
+                const int t = lane < npend ? pend[64 + lane] : 0;
+                if (lane < npend) pend[lane] = (unsigned short)t;
+            }
             xx += adv_x; yy += adv_y; if (xx >= iw) { xx -= iw; yy++; }
         }
+        if (npend > 0) rest(npend);
     }
     __syncthreads();
     // ---- phase B: exact score of the candidates, one per lane (~250 instructions each) ----

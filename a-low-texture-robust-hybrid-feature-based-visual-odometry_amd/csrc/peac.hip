@@ -10,8 +10,9 @@
 //                    frame (4 frames per wave in lockstep), 16-ary min-MSE heap in global memory touched
 //                    once per iteration, candidate merges evaluated one per lane, unordered neighbour sets
 //   k_peac_blkmap    findBlockMembership (485-587): block erosion, packed per-pixel flood state
-//   k_peac_flood     seed queue + floodFill (428-476): a thread owns a queue entry and its four neighbour
-//                    events, same-pixel events ordered by rank through an LDS hash
+//   k_peac_flood     seed queue + floodFill (428-476): a thread owns a queue entry and fetches its four neighbour
+//                    states; the live third of the events is compacted and resolved per pixel group through an
+//                    LDS hash (closed form for one-plane groups, ranked / serial replay for the rest)
 //   k_peac_final     last merge round + plidmap (299-340), one wave per frame
 //   k_peac_relabel   membership relabel (353-365), negative "trail" counters reported as -1
 //
@@ -835,6 +836,9 @@ __attribute__((amdgpu_waves_per_eu(HVO_CLUSTER_WPE, HVO_CLUSTER_WPE)))
 __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
 {
     constexpr int NG = 64 / GL;
+#ifdef HVO_CLUSTER_INFLATE      // experiment: allocate more registers without using them (tools/build_variant.sh)
+    asm volatile("v_mov_b32 v231, 0" ::: "v231");
+#endif
     __shared__ double lks[NG][GH_TOP + 1];
     __shared__ int lis[NG][GH_TOP + 1];
     const int lane = threadIdx.x, gl = Grp<GL>::gl(), gid = lane / GL;

@@ -78,18 +78,22 @@ def hbm_traffic(group, B, width):
         return None
 
 
-def issue_utilisation(frames_per_s):
-    """The step is bound by instruction issue, not by HBM: with the committed SQ_ACTIVE_INST_ANY per frame
-    (profiles/r01_issue_utilisation.json, quad-cycles) this reports how much of the 1024 SIMDs' issue capacity the
-    measured rate corresponds to.  Extra keys of the roofline object; empty when the profile is absent."""
+def sq_utilisation(frames_per_s):
+    """What the step spends on the SIMDs, from the committed SQ counters per frame (profiles/r01_sq_utilisation.json;
+    SQ_* count quad-cycles summed over waves): the VALU pipes' busy fraction at the measured rate (VALU instructions of
+    different waves of a SIMD cannot overlap, so this is a true pipe utilisation), the mean number of resident waves per
+    SIMD, and the share of a wave's life with an instruction in flight.  The step is NOT HBM bound; it is a set of
+    dependent-latency chains.  Extra keys of the roofline object; empty when the profile is absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_issue_utilisation.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_sq_utilisation.json")) as f:
             t = json.load(f)
-        q, qv = t["per_frame_total"]["sq_active_inst_any"], t["per_frame_total"]["sq_active_inst_valu"]
-        cap = t["simds"] * t["clock_hz"]
-        return {"issue_quad_cycles_per_frame": int(q), "issue_frac": round(q * 4.0 * frames_per_s / cap, 4),
-                "valu_frac": round(qv * 4.0 * frames_per_s / cap, 4)}
-    except (OSError, ValueError, KeyError):
+        tot = t["per_frame_total"]
+        cap = t["simds"] * t["clock_hz"] / 4.0                     # SIMD quad-cycles per second
+        return {"valu_busy_frac": round(tot["sq_active_inst_valu"] * frames_per_s / cap, 4),
+                "resident_waves_per_simd": round(tot["sq_wave_cycles"] * frames_per_s / cap, 3),
+                "wave_time_with_inst_active": round(tot["sq_active_inst_any"] / tot["sq_wave_cycles"], 4),
+                "valu_quad_cycles_per_frame": int(tot["sq_active_inst_valu"])}
+    except (OSError, ValueError, KeyError, ZeroDivisionError):
         return {}
 
 
@@ -225,7 +229,7 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": hbm_traffic(dom, B, args.width),
                     "bytes_per_launch": int(per_frame * B), "ms_per_launch": round(groups[dom], 4)}
-            roof.update(issue_utilisation(value))
+            roof.update(sq_utilisation(value))
             orb_ms = sum(v for k, v in groups.items() if k in ("orb_pyramid", "orb_fast_cells", "orb_blur", "orb_brief", "orb_orient"))
             if orb_ms > 0:
                 roof["orb_pyramid_brief_pass_GBps"] = round(pass_bytes * B / (orb_ms * 1e-3) / 1e9, 2)
