@@ -530,6 +530,9 @@ static __device__ __forceinline__ int line_count(float x1, float y1, float x2, f
     return (dx > dy ? dx : dy) + 1;
 }
 
+#ifdef HVO_WPE_GROW
+__attribute__((amdgpu_waves_per_eu(HVO_WPE_GROW)))
+#endif
 __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
 {
     __shared__ double b0[64], b1[64], b2[64];
@@ -645,6 +648,9 @@ __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
 // LBD: blur 5x5 (u8 fixed point, same rounding rules as the ORB blur), Sobel, descriptor
 // ------------------------------------------------------------------------------------------------
 #define LBD_BLUR_ROWS 16
+#ifdef HVO_WPE_BLUR5
+__attribute__((amdgpu_waves_per_eu(HVO_WPE_BLUR5)))
+#endif
 __global__ __launch_bounds__(256) void k_lbd_blur5(const uint8_t *__restrict__ gray, size_t gframe, int gpitch,
                                                    uint8_t *__restrict__ out, int w, int h, int k0, int k1, int k2)
 {

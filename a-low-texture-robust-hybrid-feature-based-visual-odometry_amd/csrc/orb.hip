@@ -41,6 +41,9 @@ static __device__ __forceinline__ unsigned long long lanemask_lt()
 // K1: pyramid level l from level l-1 (cv::resize INTER_LINEAR u8, 11-bit fixed point)
 // =====================================================================================
 #define RESIZE_ROWS 16
+#ifdef HVO_WPE_RESIZE
+__attribute__((amdgpu_waves_per_eu(HVO_WPE_RESIZE)))
+#endif
 __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, size_t frame_stride,
                                                 LevelGeom S, LevelGeom D,
                                                 const int *__restrict__ xofs, const int *__restrict__ xalpha,
@@ -126,6 +129,9 @@ static __device__ __forceinline__ int fast_score(const uint8_t *tile, int tp, in
 // wide) and a ballot over a step is already in emission order -- no atomics or scans.  The tile keeps
 // the 4-byte phase it has in global memory so loads and LDS stores are whole dwords.
 template <int TILE>
+#ifdef HVO_WPE_FAST
+__attribute__((amdgpu_waves_per_eu(HVO_WPE_FAST)))
+#endif
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, size_t frame_stride,
                                                     const LevelGeom *__restrict__ lev,
                                                     const CellDesc *__restrict__ cells, int ncells,
@@ -648,6 +654,9 @@ static __device__ __forceinline__ void blur_row_sums(const BlurWin &W, unsigned 
     hs[3] = (int)__builtin_amdgcn_udot4(W.W1, klo, __builtin_amdgcn_udot4(W.W2, khi, 0u, false), false);
 }
 
+#ifdef HVO_WPE_BLUR7
+__attribute__((amdgpu_waves_per_eu(HVO_WPE_BLUR7)))
+#endif
 __global__ __launch_bounds__(256) void k_blur7(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, size_t frame_stride,
                                                const LevelGeom *__restrict__ lev, const int4 *__restrict__ tiles,
                                                int k0, int k1, int k2, int k3)

@@ -117,6 +117,9 @@ static __device__ void stats_compute_dev(const double *st, int N, double center[
 // ------------------------------------------------------------------------------------------------
 // k_peac_blocks: one thread per 10x10 block
 // ------------------------------------------------------------------------------------------------
+#ifdef HVO_WPE_BLOCKS
+__attribute__((amdgpu_waves_per_eu(HVO_WPE_BLOCKS)))
+#endif
 __global__ __launch_bounds__(64) void k_peac_blocks(const uint16_t *__restrict__ depth, size_t dframe, int pitch,
                                                     int w, int h, int Nw, int nblk,
                                                     float fx, float fy, float cx, float cy, float dfac,
@@ -1040,6 +1043,9 @@ static __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 template <int FLOOD_T, int EPL>
+#ifdef HVO_WPE_FLOOD
+__attribute__((amdgpu_waves_per_eu(HVO_WPE_FLOOD)))
+#endif
 __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long long *__restrict__ adj_out)
 {
     constexpr int NENT = FLOOD_T * EPL, NEV = NENT * 4;                        // queue entries / events per round (EPL entries per thread)
