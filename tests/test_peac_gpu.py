@@ -79,6 +79,26 @@ def test_peac_three_plane_corner(gpu_ctx, orc, seed, noise, cu, cv):
     check(lg, pg, lo, po)
 
 
+@pytest.mark.parametrize("flood_t,epl", [(64, 1), (64, 2), (128, 1)])
+def test_peac_three_plane_corner_flood_variants(hvo, orc, monkeypatch, flood_t, epl):
+    """the one-wave flood variants large batches select, on the scenes that need the ranked and the serial replay"""
+    monkeypatch.setenv("HVO_FLOOD_T", str(flood_t))
+    monkeypatch.setenv("HVO_FLOOD_EPL", str(epl))
+    ctx = hvo.Context()
+    try:
+        ranked = serial = 0
+        for seed, noise, cu, cv in ((3, 25, 323.0, 236.0), (4, 60, 317.5, 243.5)):
+            d = corner_depth(seed, noise, cu=cu, cv=cv)
+            lo, po = orc.peac(d)
+            lg, pg = ctx.compute_planes(d)
+            check(lg, pg, lo, po)
+            st = ctx.peac_stats(0)
+            ranked += st["flood_ranked_rounds"]; serial += st["flood_serial_rounds"]
+        assert ranked > 0 and serial > 0, (ranked, serial)
+    finally:
+        ctx.close()
+
+
 def test_peac_flood_replay_paths_are_exercised(gpu_ctx, orc, synth):
     """the parity scenes must reach all three ways k_peac_flood resolves a round (closed form, ranked, serial replay)"""
     ranked = serial = rounds = 0
