@@ -99,6 +99,53 @@ def test_peac_three_plane_corner_flood_variants(hvo, orc, monkeypatch, flood_t, 
         ctx.close()
 
 
+def polyhedron_depth(seed, w=640, h=480):
+    """random convex polyhedral surface (lower envelope of 3-6 planes through random image points), depth noise of a random
+    amplitude, random rectangular holes and a few dropped pixels"""
+    rng = np.random.default_rng(seed)
+    j = (np.arange(w)[None, :] - 320.1) / 535.4; i = (np.arange(h)[:, None] - 247.6) / 539.2
+    z = np.full((h, w), np.inf)
+    for _ in range(int(rng.integers(3, 7))):
+        a, b = rng.uniform(-1.2, 1.2, 2); z0 = rng.uniform(1.2, 3.5)
+        ju, iv = rng.uniform(-0.4, 0.4), rng.uniform(-0.3, 0.3)
+        den = a * (j - ju) + b * (i - iv) + 1.0
+        zz = np.where(den > 0.2, z0 / np.maximum(den, 0.2), np.inf)
+        z = np.minimum(z, zz)
+    z = np.where(np.isfinite(z), z, 0.0).clip(0, 12.0)
+    noise = int(rng.integers(0, 16))
+    d = np.rint(z * 5000).astype(np.int64) + (rng.integers(-noise, noise + 1, z.shape) if noise else 0)
+    d = np.where(z > 0, d.clip(1, 65535), 0)
+    for _ in range(int(rng.integers(0, 4))):
+        y0, x0 = int(rng.integers(0, h - 40)), int(rng.integers(0, w - 40))
+        d[y0:y0 + int(rng.integers(5, 40)), x0:x0 + int(rng.integers(5, 40))] = 0
+    d[rng.random(d.shape) < 0.0003] = 0
+    return d.astype(np.uint16)
+
+
+@pytest.mark.parametrize("flood_t", [256, 64])
+def test_peac_random_polyhedra(hvo, orc, monkeypatch, flood_t):
+    """randomised scenes with several plane intersections, holes and noise: labels and planes must match the sequential
+    reference loop on every one of them (both flood layouts)"""
+    monkeypatch.setenv("HVO_FLOOD_T", str(flood_t))
+    seeds = list(range(100, 116))
+    depth = np.stack([polyhedron_depth(s) for s in seeds])
+    gray = np.zeros((len(seeds), 480, 640), np.uint8)
+    ctx = hvo.Context(max_batch=len(seeds))
+    try:
+        ctx.batch_upload(gray, depth)
+        ctx.batch_run(hvo.STAGE_PLANES)
+        res = ctx.batch_download(hvo.STAGE_PLANES)
+        nplanes = 0
+        for f, s in enumerate(seeds):
+            lo, po = orc.peac(depth[f])
+            assert res[f]["status"] == 0, (s, res[f]["status"])
+            check(res[f]["labels"], res[f]["planes"], lo, po)
+            nplanes += len(po)
+        assert nplanes >= 2 * len(seeds)      # the scenes are not degenerate
+    finally:
+        ctx.close()
+
+
 def test_peac_flood_replay_paths_are_exercised(gpu_ctx, orc, synth):
     """the parity scenes must reach all three ways k_peac_flood resolves a round (closed form, ranked, serial replay)"""
     ranked = serial = rounds = 0
