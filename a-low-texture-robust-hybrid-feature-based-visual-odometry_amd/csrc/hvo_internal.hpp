@@ -44,6 +44,7 @@ struct OrbPlan {
     LevelGeom lev[HVO_MAX_LEVELS];
     int ncells = 0, cand_total = 0, node_total = 0, kp_total = 0, ntiles = 0, max_cell = 0;
     size_t pyr_bytes = 0;               // per frame
+    bool resize_dw[HVO_MAX_LEVELS] = {};  // level is produced by k_resize_dw (dword loads) instead of k_resize
     int kp_cap = 0;                     // output capacity per frame
     // device
     LevelGeom *d_lev = nullptr;
