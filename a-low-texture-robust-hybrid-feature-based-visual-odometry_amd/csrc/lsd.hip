@@ -523,11 +523,30 @@ static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle
 }
 
 // cv::LineIterator(...).count for clamped float end points: Point2f -> Point rounds half to even
-static __device__ __forceinline__ int line_count(float x1, float y1, float x2, float y2)
+// checkLineExtremes (LSDDetector_custom.cpp:76-102) leaves end points in (n-1, n) untouched and Point2f -> Point rounds
+// them to n, so cv::LineIterator clips here too (LSDDetector_custom.cpp:187)
+// cv::LineIterator(img, Point(p1), Point(p2), 8).count with cv::clipLine (OpenCV 3.2.0, ASSUMED)
+static __device__ int cull_line_count(int w, int h, float fx1, float fy1, float fx2, float fy2)
 {
-    const int ax = __float2int_rn(x1), ay = __float2int_rn(y1), bx = __float2int_rn(x2), by = __float2int_rn(y2);
-    const int dx = abs(bx - ax), dy = abs(by - ay);
-    return (dx > dy ? dx : dy) + 1;
+    long long x1 = __float2int_rn(fx1), y1 = __float2int_rn(fy1), x2 = __float2int_rn(fx2), y2 = __float2int_rn(fy2);
+    if ((unsigned long long)x1 >= (unsigned long long)w || (unsigned long long)x2 >= (unsigned long long)w ||
+        (unsigned long long)y1 >= (unsigned long long)h || (unsigned long long)y2 >= (unsigned long long)h) {
+        const long long right = w - 1, bottom = h - 1;
+        int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+        int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            long long a;
+            if (c1 & 12) { a = c1 < 8 ? 0 : bottom; x1 += (a - y1) * (x2 - x1) / (y2 - y1); y1 = a; c1 = (x1 < 0) + (x1 > right) * 2; }
+            if (c2 & 12) { a = c2 < 8 ? 0 : bottom; x2 += (a - y2) * (x2 - x1) / (y2 - y1); y2 = a; c2 = (x2 < 0) + (x2 > right) * 2; }
+            if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+                if (c1) { a = c1 == 1 ? 0 : right; y1 += (a - x1) * (y2 - y1) / (x2 - x1); x1 = a; c1 = 0; }
+                if (c2) { a = c2 == 1 ? 0 : right; y2 += (a - x2) * (y2 - y1) / (x2 - x1); x2 = a; c2 = 0; }
+            }
+        }
+        if ((c1 | c2) != 0) return 0;
+    }
+    const long long dx = llabs(x2 - x1), dy = llabs(y2 - y1);
+    return (int)((dx > dy ? dx : dy) + 1);
 }
 
 #ifdef HVO_WPE_GROW
@@ -601,7 +620,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
         kl.sx = e0; kl.sy = e1; kl.ex = e2; kl.ey = e3; kl.sox = e0; kl.soy = e1; kl.eox = e2; kl.eoy = e3;
         const double ddx = (double)__fsub_rn(e0, e2), ddy = (double)__fsub_rn(e1, e3);
         kl.length = (float)sqrt(ddx * ddx + ddy * ddy);
-        kl.num_pixels = line_count(e0, e1, e2, e3);
+        kl.num_pixels = cull_line_count(g.w, g.h, e0, e1, e2, e3);
         kl.angle = (float)atan2((double)__fsub_rn(kl.ey, kl.sy), (double)__fsub_rn(kl.ex, kl.sx));
         kl.class_id = i; kl.octave = 0;
         kl.size = __fmul_rn(__fsub_rn(kl.ex, kl.sx), __fsub_rn(kl.ey, kl.sy));
@@ -701,6 +720,105 @@ __global__ __launch_bounds__(256) void k_lbd_sobel(const uint8_t *__restrict__ b
         const int gx = hd[j] + 2 * hd[j + 1] + hd[j + 2];
         const int gy = hs[j + 2] - hs[j];
         dxy[((size_t)f * h + y) * w + x] = make_short2((short)gx, (short)gy);       // interleaved: the descriptor fetches both with one access
+    }
+}
+
+// Blur and Sobel in one pass: a thread owns 4 adjacent columns and LBD_BLUR_ROWS output rows.  Per source row it
+// fetches three aligned dwords (pixels x0-4 .. x0+7; strips on the left / right image border assemble them byte by
+// byte with reflected indices) and forms the 5-tap row sums of the SIX columns x0-1 .. x0+4 with v_dot4 (the Sobel
+// needs the blurred neighbours of its own four); the last five row sums per column give one blurred row, the last
+// three blurred rows one Sobel row.  The u8 blurred image is never written.  Reflection of the blurred image at
+// the image border (refl(-1) = 1, refl(n) = n-2) is a substitution of the opposite neighbour.
+__global__ __launch_bounds__(256) void k_lbd_blur_sobel(const uint8_t *__restrict__ gray, size_t gframe, int gpitch,
+                                                        short2 *__restrict__ dxy, int w, int h, int k0, int k1, int k2)
+{
+    const int nstrip = (w + 3) >> 2, item = blockIdx.x * 256 + threadIdx.x, f = blockIdx.z;
+    const int rb = item / nstrip;
+    const int x0 = (item - rb * nstrip) * 4, yb = rb * LBD_BLUR_ROWS;
+    if (yb >= h) return;
+    const uint8_t *G = gray + (size_t)f * gframe;          // rows are 4-byte aligned (pitch % 64 == 0)
+    const bool interior = x0 >= 4 && x0 + 7 < gpitch && x0 + 6 < w;
+    const unsigned kA = (unsigned)k0 | ((unsigned)k1 << 8) | ((unsigned)k2 << 16) | ((unsigned)k1 << 24);
+    const int wv4 = w & ~3;
+    const int v0 = max(yb - 1, 0), v1 = min(yb + LBD_BLUR_ROWS, h - 1);      // blurred rows formed here
+    const int ylast = min(yb + LBD_BLUR_ROWS, h) - 1;
+    int rs[5][6];                                         // row sums of the last five source rows (oldest first)
+    int hd1[4], hs1[4], hd2[4], hs2[4];                    // Sobel row terms of blurred rows v-1 and v-2
+#pragma unroll
+    for (int j = 0; j < 4; j++) { hd1[j] = hs1[j] = hd2[j] = hs2[j] = 0; }
+#pragma unroll
+    for (int q = 0; q < 5; q++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) rs[q][c] = 0;
+    short2 *out = dxy + (size_t)f * h * w;
+    const bool vecst = (w & 3) == 0;                       // 16-byte stores need every row start aligned
+    for (int sr = v0 - 2; sr <= v1 + 2; sr++) {
+        const uint8_t *S = G + (size_t)refl(min(sr, h + 1), h) * gpitch;
+        unsigned W0, W1, W2;
+        if (interior) {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(S + x0 - 4);
+            W0 = p[0]; W1 = p[1]; W2 = p[2];
+        } else {
+            unsigned b[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) b[i] = S[refl(x0 - 4 + i, w)];
+            W0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+            W1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+            W2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) rs[q][c] = rs[q + 1][c];
+        // column c = pixel x0-1+c: taps at window bytes c+1 .. c+5 (window byte 0 = pixel x0-4)
+        rs[4][0] = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 1), kA, (unsigned)k0 * ((W1 >> 8) & 0xFFu), false);
+        rs[4][1] = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 2), kA, (unsigned)k0 * ((W1 >> 16) & 0xFFu), false);
+        rs[4][2] = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W1, W0, 3), kA, (unsigned)k0 * (W1 >> 24), false);
+        rs[4][3] = (int)__builtin_amdgcn_udot4(W1, kA, (unsigned)k0 * (W2 & 0xFFu), false);
+        rs[4][4] = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 1), kA, (unsigned)k0 * ((W2 >> 8) & 0xFFu), false);
+        rs[4][5] = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(W2, W1, 2), kA, (unsigned)k0 * ((W2 >> 16) & 0xFFu), false);
+        const int v = sr - 2;                              // blurred row completed by this source row
+        if (v < v0) continue;
+        int bl[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            const int sv = k0 * (rs[0][c] + rs[4][c]) + k1 * (rs[1][c] + rs[3][c]) + k2 * rs[2][c];
+            int q;
+            if (x0 - 1 + c < wv4) { q = sv >> 16; const int rem = sv & 0xFFFF; if (rem > 32768 || (rem == 32768 && (q & 1))) q++; }   // SSE2 column path: half to even
+            else q = (sv + 32768) >> 16;                                                                                                   // scalar tail
+            bl[c] = min(q, 255);
+        }
+        int hd0[4], hs0[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int x = x0 + j;
+            const int a = x == 0 ? bl[j + 2] : bl[j], e = x == w - 1 ? bl[j] : bl[j + 2];
+            hd0[j] = e - a; hs0[j] = a + 2 * bl[j + 1] + e;
+        }
+        // Sobel row y = v-1 from blurred rows v-2 (reflected at the top: row 1), v-1, v; the bottom row y = h-1 uses row h-2 twice
+        for (int pass = 0; pass < 2; pass++) {
+            const int y = pass == 0 ? v - 1 : v;
+            if (pass == 1 && !(v == h - 1)) break;
+            if (y < yb || y > ylast) continue;
+            short2 g[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int gx, gy;
+                if (pass == 0) {
+                    const int hdu = v >= 2 ? hd2[j] : hd0[j], hsu = v >= 2 ? hs2[j] : hs0[j];
+                    gx = hdu + 2 * hd1[j] + hd0[j]; gy = hs0[j] - hsu;
+                } else { gx = 2 * hd1[j] + 2 * hd0[j]; gy = 0; }         // rows (h-2, h-1, h-2)
+                g[j] = make_short2((short)gx, (short)gy);
+            }
+            short2 *o = out + (size_t)y * w + x0;
+            if (vecst) *reinterpret_cast<uint4 *>(o) = *reinterpret_cast<const uint4 *>(g);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (x0 + j < w) o[j] = g[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { hd2[j] = hd1[j]; hs2[j] = hs1[j]; hd1[j] = hd0[j]; hs1[j] = hs0[j]; }
     }
 }
 
@@ -859,30 +977,6 @@ static __device__ void cull_merge_two_lines(const float *l1, const float *l2, fl
     const double d1 = fmin(axg, fmin(bxg, fmin(cxg, dxg))), d2 = fmax(axg, fmax(bxg, fmax(cxg, dxg)));
     out[0] = (float)(d1 * c + xg); out[1] = (float)(d1 * s + yg); out[2] = (float)(d2 * c + xg); out[3] = (float)(d2 * s + yg);
 }
-// cv::LineIterator(img, Point(p1), Point(p2), 8).count with cv::clipLine (OpenCV 3.2.0, ASSUMED)
-static __device__ int cull_line_count(int w, int h, float fx1, float fy1, float fx2, float fy2)
-{
-    long long x1 = __float2int_rn(fx1), y1 = __float2int_rn(fy1), x2 = __float2int_rn(fx2), y2 = __float2int_rn(fy2);
-    if ((unsigned long long)x1 >= (unsigned long long)w || (unsigned long long)x2 >= (unsigned long long)w ||
-        (unsigned long long)y1 >= (unsigned long long)h || (unsigned long long)y2 >= (unsigned long long)h) {
-        const long long right = w - 1, bottom = h - 1;
-        int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
-        int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
-        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
-            long long a;
-            if (c1 & 12) { a = c1 < 8 ? 0 : bottom; x1 += (a - y1) * (x2 - x1) / (y2 - y1); y1 = a; c1 = (x1 < 0) + (x1 > right) * 2; }
-            if (c2 & 12) { a = c2 < 8 ? 0 : bottom; x2 += (a - y2) * (x2 - x1) / (y2 - y1); y2 = a; c2 = (x2 < 0) + (x2 > right) * 2; }
-            if ((c1 & c2) == 0 && (c1 | c2) != 0) {
-                if (c1) { a = c1 == 1 ? 0 : right; y1 += (a - x1) * (y2 - y1) / (x2 - x1); x1 = a; c1 = 0; }
-                if (c2) { a = c2 == 1 ? 0 : right; y2 += (a - x2) * (y2 - y1) / (x2 - x1); x2 = a; c2 = 0; }
-            }
-        }
-        if ((c1 | c2) != 0) return 0;
-    }
-    const long long dx = llabs(x2 - x1), dy = llabs(y2 - y1);
-    return (int)((dx > dy ? dx : dy) + 1);
-}
-
 __global__ __launch_bounds__(64) void k_cull_lines(CullArgs a)
 {
     __shared__ float ep[CULL_MAXL][4];            // end points of the input lines
@@ -1113,8 +1207,12 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     hipLaunchKernelGGL(k_lsd_grow, dim3(n), dim3(64), 0, st, g);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lbd_sobel", st);
-    hipLaunchKernelGGL(k_lbd_blur5, dim3((w + 255) / 256, (h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_b5, w, h, P->k5[0], P->k5[1], P->k5[2]);
-    hipLaunchKernelGGL(k_lbd_sobel, dim3((w + 255) / 256, (h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS, n), dim3(256), 0, st, P->d_b5, P->d_dxy, w, h);
+    if (getenv("HVO_LBD_SPLIT")) {                  // the two-kernel formulation (blurred u8 image materialised), kept for A/B runs
+        hipLaunchKernelGGL(k_lbd_blur5, dim3((w + 255) / 256, (h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_b5, w, h, P->k5[0], P->k5[1], P->k5[2]);
+        hipLaunchKernelGGL(k_lbd_sobel, dim3((w + 255) / 256, (h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS, n), dim3(256), 0, st, P->d_b5, P->d_dxy, w, h);
+    } else
+        hipLaunchKernelGGL(k_lbd_blur_sobel, dim3((((w + 3) / 4) * ((h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS) + 255) / 256, 1, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_dxy, w, h,
+                           P->k5[0], P->k5[1], P->k5[2]);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lbd_desc", st);
     hipLaunchKernelGGL(k_lbd_desc, dim3(P->nfeat, n), dim3(64), 0, st, P->d_dxy, w, h, P->d_kl, P->d_nkl, P->nfeat, P->d_gL, P->d_gG, P->d_desc);

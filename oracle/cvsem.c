@@ -271,16 +271,10 @@ int orc_fast9_16(const uint8_t *img, int stride, int vw, int vh, int threshold, 
     return n < cap ? n : cap;
 }
 
-/* cv::LineIterator(img, Point(p1), Point(p2), 8).count; Point2f->Point uses cvRound. The
- * reference clamps the end points into the image first (LSDDetector_custom.cpp:76-102). */
+/* cv::LineIterator(img, Point(p1), Point(p2), 8).count; Point2f->Point uses cvRound.  The reference clamps the
+ * end points into [0, n-1] as floats first (LSDDetector_custom.cpp:76-102), but an end point in (n-1, n), e.g.
+ * 641.5 for n = 642, passes that check and rounds to n: cv::LineIterator then clips the segment (cull.c). */
 int orc_line_iterator_count(int w, int h, float x1, float y1, float x2, float y2)
 {
-    int ax = orc_cvround_f(x1), ay = orc_cvround_f(y1), bx = orc_cvround_f(x2), by = orc_cvround_f(y2);
-    if ((unsigned)ax >= (unsigned)w || (unsigned)bx >= (unsigned)w ||
-        (unsigned)ay >= (unsigned)h || (unsigned)by >= (unsigned)h) {
-        /* cv::clipLine would be needed; callers never reach this (clamped inputs) */
-        return 0;
-    }
-    int dx = abs(bx - ax), dy = abs(by - ay);
-    return (dx > dy ? dx : dy) + 1;
+    return orc_line_iterator_count_clipped(w, h, x1, y1, x2, y2);
 }

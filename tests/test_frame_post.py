@@ -109,6 +109,9 @@ def test_oracle_culling_known_answers(orc, synth):
     assert orc.line_iterator_count_clipped(640, 480, 10, 10, 20, 40) == 31
     assert orc.line_iterator_count_clipped(640, 480, -10, 5, -3, 80) == 0
     assert 0 < orc.line_iterator_count_clipped(640, 480, -10, -10, 700, 500) <= 640
+    # an end point in (w-1, w) passes checkLineExtremes (LSDDetector_custom.cpp:76-102) and rounds to w: the segment
+    # (642, 279) - (623, 300) is clipped at x = 641 -> (641, 280) - (623, 300): max(18, 20) + 1 pixels, not 22 and not 0
+    assert orc.line_iterator_count_clipped(642, 400, np.float32(641.5019), np.float32(278.88806), np.float32(622.81824), np.float32(300.35803)) == 21
     g = np.full((480, 640), 128, np.uint8)
     kl = np.zeros(3, orc.KEYLINE_DT)
     # two collinear overlapping horizontal segments and one far away vertical one

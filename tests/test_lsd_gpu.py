@@ -28,6 +28,22 @@ def test_lines_parity_640(gpu_ctx, orc, synth, kind, seed):
     check(kl_g, d_g, fn_g, kl_o, d_o, fn_o)
 
 
+@pytest.mark.parametrize("hh,ww", [(397, 501), (479, 638), (400, 642)])
+def test_lines_odd_geometry(hvo, orc, synth, hh, ww):
+    """widths that are not a multiple of 4 (scalar tails of the LBD blur / Sobel strips, unaligned Sobel rows) and lines
+    that end at the right / bottom border"""
+    big = synth.make_gray("std", 11, 704, 480)
+    g = np.ascontiguousarray(big[:hh, :ww])
+    kl_o, d_o, fn_o = orc.line_extract(g)
+    ctx = hvo.Context()
+    try:
+        kl_g, d_g, fn_g = ctx.extract_lsd(g)
+    finally:
+        ctx.close()
+    assert len(kl_o) > 10
+    check(kl_g, d_g, fn_g, kl_o, d_o, fn_o)
+
+
 def test_lines_exactness_report(gpu_ctx, orc, synth):
     """how exact is 'within 1e-4'?  key-line floats are expected bit-equal on these frames"""
     g = synth.make_gray("std", 0x5EED0002)
