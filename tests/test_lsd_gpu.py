@@ -109,3 +109,58 @@ def test_lines_batch_and_all_stages(hvo, orc, synth):
         assert np.array_equal(res[b]["desc"], dd_o) and len(res[b]["kp"]) == len(kp_o)
         lo, po = orc.peac(depth[b])
         assert np.array_equal(res[b]["labels"], lo) and len(res[b]["planes"]) == len(po)
+
+
+def test_all_stages_batch_odd_geometry(hvo, orc, synth):
+    """the resident-batch path at a geometry where nothing is a multiple of anything: 3 frames of 501 x 397"""
+    gray0, depth0 = synth.make_batch("std", 0x5EED1000, 3)
+    gray = np.ascontiguousarray(gray0[:, :397, :501]); depth = np.ascontiguousarray(depth0[:, :397, :501])
+    ctx = hvo.Context(max_batch=3)
+    try:
+        ctx.batch_upload(gray, depth)
+        ctx.batch_run(hvo.STAGE_ALL)
+        res = ctx.batch_download(hvo.STAGE_ALL)
+    finally:
+        ctx.close()
+    o = orc.Orb()
+    for b in range(3):
+        assert res[b]["status"] == 0
+        kl_o, d_o, fn_o = orc.line_extract(gray[b])
+        check(res[b]["kl"], res[b]["ldesc"], res[b]["linefn"], kl_o, d_o, fn_o)
+        kp_o, dd_o = o.extract(gray[b])
+        assert np.array_equal(res[b]["desc"], dd_o) and len(res[b]["kp"]) == len(kp_o)
+        for f in ("x", "y", "octave"):
+            assert np.array_equal(res[b]["kp"][f], kp_o[f]), f
+        lo, po = orc.peac(depth[b])
+        assert np.array_equal(res[b]["labels"], lo) and len(res[b]["planes"]) == len(po)
+
+
+def test_all_stages_soak(hvo, orc, synth):
+    """40 more frames (24 'std', 16 'lowtex' scenes, fresh seeds) through the resident-batch path, every stage against the
+    oracle: the speculative region growing, the flood replay paths and the quadtree ties are data dependent"""
+    g1, d1 = synth.make_batch("std", 0xA11CE000, 24)
+    g2, d2 = synth.make_batch("lowtex", 0xB0B0000, 16)
+    gray = np.concatenate([g1, g2]); depth = np.concatenate([d1, d2])
+    n = len(gray)
+    ctx = hvo.Context(max_batch=n)
+    try:
+        ctx.batch_upload(gray, depth)
+        ctx.batch_run(hvo.STAGE_ALL)
+        res = ctx.batch_download(hvo.STAGE_ALL)
+    finally:
+        ctx.close()
+    o = orc.Orb()
+    bad = []
+    for b in range(n):
+        ok = res[b]["status"] == 0
+        kl_o, d_o, fn_o = orc.line_extract(gray[b])
+        ok = ok and len(res[b]["kl"]) == len(kl_o) and np.array_equal(res[b]["ldesc"], d_o) and np.array_equal(res[b]["kl"]["num_pixels"], kl_o["num_pixels"]) \
+            and np.allclose(res[b]["kl"]["sx"], kl_o["sx"], atol=TOL) and np.allclose(res[b]["kl"]["ey"], kl_o["ey"], atol=TOL)
+        kp_o, dd_o = o.extract(gray[b])
+        ok = ok and len(res[b]["kp"]) == len(kp_o) and np.array_equal(res[b]["desc"], dd_o) and np.array_equal(res[b]["kp"]["x"], kp_o["x"]) \
+            and np.array_equal(res[b]["kp"]["y"], kp_o["y"])
+        lo, po = orc.peac(depth[b])
+        ok = ok and np.array_equal(res[b]["labels"], lo) and len(res[b]["planes"]) == len(po)
+        if not ok:
+            bad.append(b)
+    assert not bad, bad

@@ -160,6 +160,21 @@ def test_peac_flood_replay_paths_are_exercised(gpu_ctx, orc, synth):
     assert rounds > 1000 and ranked > 0 and serial > 0, (rounds, ranked, serial)
 
 
+@pytest.mark.parametrize("hh,ww", [(397, 501), (473, 638), (480, 335)])
+def test_peac_odd_geometry(hvo, orc, synth, hh, ww):
+    """image sizes that are not multiples of the 10x10 block (pixels outside the block grid stay -1 unless the flood fill
+    reaches them) and of the flood / relabel tile sizes"""
+    d = np.ascontiguousarray(synth.make_depth(0x5EED1000)[:hh, :ww])
+    lo, po = orc.peac(d)
+    ctx = hvo.Context()
+    try:
+        lg, pg = ctx.compute_planes(d)
+    finally:
+        ctx.close()
+    assert len(po) >= 1
+    check(lg, pg, lo, po)
+
+
 def test_peac_1280(hvo, orc, synth):
     d = synth.make_depth(0x5EED0003, 1280, 960)
     K = synth.intrinsics(1280, 960)
