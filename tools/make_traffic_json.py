@@ -5,8 +5,8 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 GROUPS = {"peac_cluster": ["k_peac_cluster"], "lsd_grow": ["k_lsd_grow"], "peac_refine": ["k_peac_blkmap", "k_peac_flood", "k_peac_final", "k_peac_relabel"],
-          "orb_fast_cells": ["k_fast_cells"], "lsd_gradient": ["k_lsd_resize_grad"], "lbd_desc": ["k_lbd_desc"], "orb_pyramid": ["k_resize"],
-          "orb_blur": ["k_blur7"], "lsd_blur_scale": ["k_lsd_blur_h", "k_lsd_blur_v"], "lbd_sobel": ["k_lbd_blur5", "k_lbd_sobel"],
+          "orb_fast_cells": ["k_fast_cells"], "lsd_gradient": ["k_lsd_resize_grad"], "lbd_desc": ["k_lbd_desc"], "orb_pyramid": ["k_resize", "k_resize_dw"],
+          "orb_blur": ["k_blur7"], "lsd_blur_scale": ["k_lsd_blur"], "lbd_sobel": ["k_lbd_blur5", "k_lbd_sobel", "k_lbd_blur_sobel"],
           "orb_octree": ["k_octree"], "peac_blocks": ["k_peac_blocks"], "orb_orient": ["k_orient"], "orb_brief": ["k_brief"]}
 
 
@@ -27,7 +27,7 @@ def main():
     fe, wr = per_step(dfe, "FETCH_SIZE"), per_step(dwr, "WRITE_SIZE")
     j = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 1 --warmup 0`; KiB per step "
                  "summed over a group's kernels / frames per launch, x1024.  Calibration on kernels with a known byte count and the same access "
-                 "width: k_blur7 (dword loads/stores, 950532 B each way + halo/pitch) reads 1:1, k_lsd_blur_h writes 2400 KiB fp64 -> WRITE 2400 KiB; "
+                 "width: k_blur7 (dword loads/stores, 950532 B each way + halo/pitch) reads 1:1, k_lsd_blur writes 2400 KiB fp64 -> WRITE 2400 KiB; "
                  "the x2 FETCH_SIZE correction of MI355X_MICROARCH.md applies to 16 B/lane streaming reads only, these kernels use <= 8 B/lane.",
          "frames_per_launch": B, "bytes_per_frame": {}}
     for g, ks in GROUPS.items():
