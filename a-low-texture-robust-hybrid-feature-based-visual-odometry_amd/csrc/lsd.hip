@@ -19,7 +19,8 @@
 //                                 memory, one 32-byte record per candidate), the reference's sequential
 //                                 add-and-update walk is speculated, verified and committed in batches;
 //                                 emits segments, key-lines, the top-N selection and the line functions
-//   k_lbd_blur5 / k_lbd_sobel     GaussianBlur 5x5 sigma 1 (u8 fixed point) and Sobel dx, dy (s16)
+//   k_lbd_blur_sobel              GaussianBlur 5x5 sigma 1 (u8 fixed point) fused with Sobel dx, dy (s16);
+//                                 k_lbd_blur5 / k_lbd_sobel are the two-kernel formulation (HVO_LBD_SPLIT=1)
 //   k_lbd_desc                    one 64-thread workgroup per line: 63 row sums, 9 band sums,
 //                                 normalisation, 32-byte binary descriptor
 //

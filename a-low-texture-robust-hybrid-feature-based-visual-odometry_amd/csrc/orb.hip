@@ -2,7 +2,8 @@
 //
 // Replaces ORBextractor::operator() (reference src/ORBextractor.cc:1041-1103) for a batch of
 // independent frames.  Kernels (one launch covers every frame of the batch):
-//   k_resize        ComputePyramid                    ORBextractor.cc:1105-1130  (cv::resize u8 bilinear)
+//   k_resize_dw     ComputePyramid                    ORBextractor.cc:1105-1130  (cv::resize u8 bilinear; k_resize = byte-load
+//                   formulation for scale factors > 4/3 or HVO_RESIZE_BYTES=1)
 //   k_fast_cells    per-cell cv::FAST + fallback      ORBextractor.cc:787-827
 //   k_octree        DistributeOctTree / DivideNode    ORBextractor.cc:537-761, 479-535
 //   k_orient        IC_Angle + fastAtan2              ORBextractor.cc:75-102, 470-477
