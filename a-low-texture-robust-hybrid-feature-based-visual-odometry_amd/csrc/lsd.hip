@@ -828,6 +828,7 @@ __constant__ int c_lbd_comb[32][2] = {
     { 2, 3 }, { 2, 4 }, { 2, 5 }, { 2, 6 }, { 2, 7 }, { 2, 8 }, { 3, 4 }, { 3, 5 }, { 3, 6 }, { 3, 7 }, { 3, 8 },
     { 4, 5 }, { 4, 6 }, { 4, 7 }, { 4, 8 }, { 5, 6 }, { 5, 7 }, { 5, 8 }, { 6, 7 }, { 6, 8 }, { 7, 8 } };
 
+#define LBD_UNR 8
 __global__ __launch_bounds__(64) void k_lbd_desc(const short2 *__restrict__ dxyImg, int w, int h,
                                                  const hvo_keyline *__restrict__ kls, const int *__restrict__ nkl, int kl_cap,
                                                  const float *__restrict__ gL, const float *__restrict__ gG, uint8_t *__restrict__ desc)
@@ -854,20 +855,35 @@ __global__ __launch_bounds__(64) void k_lbd_desc(const short2 *__restrict__ dxyI
         for (int q = 0; q < t; q++) { sCorX0 = __fsub_rn(sCorX0, dL1); sCorY0 = __fadd_rn(sCorY0, dL0); }
         float sCorX = sCorX0, sCorY = sCorY0;
         float pL = 0, nL = 0, pO = 0, nO = 0;
-        for (short wID = 0; wID < lengthOfLSP; wID++) {
-            // (short)round((double)v) of the reference: a float's nearest integer (ties away from zero) is the
-            // same whether it is formed in float or in double
-            short tc = (short)roundf(sCorX);
-            const short xCor = (tc < 0) ? 0 : (tc > imageWidth) ? imageWidth : tc;
-            tc = (short)roundf(sCorY);
-            const short yCor = (tc < 0) ? 0 : (tc > imageHeight) ? imageHeight : tc;
-            const short2 g2 = DXY[(int)yCor * w + xCor];
-            const float ddx = (float)g2.x, ddy = (float)g2.y;
-            const float gDL = __fadd_rn(__fmul_rn(ddx, dL0), __fmul_rn(ddy, dL1));
-            const float gDO = __fadd_rn(__fmul_rn(ddx, dO0), __fmul_rn(ddy, dO1));
-            if (gDL > 0) pL = __fadd_rn(pL, gDL); else nL = __fsub_rn(nL, gDL);
-            if (gDO > 0) pO = __fadd_rn(pO, gDO); else nO = __fsub_rn(nO, gDO);
-            sCorX = __fadd_rn(sCorX, dL0); sCorY = __fadd_rn(sCorY, dL1);
+        // Samples are taken LBD_UNR at a time: the sample coordinates form a cheap sequential chain, the gathers that
+        // depend on them are all issued before the first one is consumed, and the signed sums are then accumulated in
+        // the reference's order.
+        for (int w0 = 0; w0 < lengthOfLSP; w0 += LBD_UNR) {
+            short2 g2[LBD_UNR];
+#pragma unroll
+            for (int u = 0; u < LBD_UNR; u++) {
+                g2[u] = make_short2(0, 0);
+                if (w0 + u < lengthOfLSP) {
+                    // (short)round((double)v) of the reference: a float's nearest integer (ties away from zero) is the
+                    // same whether it is formed in float or in double
+                    short tc = (short)roundf(sCorX);
+                    const short xCor = (tc < 0) ? 0 : (tc > imageWidth) ? imageWidth : tc;
+                    tc = (short)roundf(sCorY);
+                    const short yCor = (tc < 0) ? 0 : (tc > imageHeight) ? imageHeight : tc;
+                    g2[u] = DXY[(int)yCor * w + xCor];
+                    sCorX = __fadd_rn(sCorX, dL0); sCorY = __fadd_rn(sCorY, dL1);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < LBD_UNR; u++) {
+                if (w0 + u < lengthOfLSP) {
+                    const float ddx = (float)g2[u].x, ddy = (float)g2[u].y;
+                    const float gDL = __fadd_rn(__fmul_rn(ddx, dL0), __fmul_rn(ddy, dL1));
+                    const float gDO = __fadd_rn(__fmul_rn(ddx, dO0), __fmul_rn(ddy, dO1));
+                    if (gDL > 0) pL = __fadd_rn(pL, gDL); else nL = __fsub_rn(nL, gDL);
+                    if (gDO > 0) pO = __fadd_rn(pO, gDO); else nO = __fsub_rn(nO, gDO);
+                }
+            }
         }
         const float coef = gG[t];
         rows[t][0] = __fmul_rn(coef, pL); rows[t][1] = __fmul_rn(coef, nL); rows[t][2] = __fmul_rn(coef, pO); rows[t][3] = __fmul_rn(coef, nO);
