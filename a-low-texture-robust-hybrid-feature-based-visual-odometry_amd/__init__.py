@@ -346,20 +346,24 @@ class Context:
         kcap = self.params.orb_nfeatures + 8 * self.params.orb_nlevels + 64
         lcap = max(self.params.lsd_nfeatures, 1)
         fo = (FrameOut * B)()
-        res = []
-        for b in range(B):
-            r = {}
-            if stages & STAGE_ORB:
-                r["kp"] = np.zeros(kcap, KEYPOINT_DT); r["desc"] = np.zeros((kcap, 32), np.uint8)
-                fo[b].kp = r["kp"].ctypes.data; fo[b].desc = r["desc"].ctypes.data; fo[b].kp_cap = kcap
-            if stages & (STAGE_LSD | STAGE_LSD_CULL):
-                r["kl"] = np.zeros(lcap, KEYLINE_DT); r["ldesc"] = np.zeros((lcap, 32), np.uint8); r["linefn"] = np.zeros((lcap, 3))
-                fo[b].kl = r["kl"].ctypes.data; fo[b].ldesc = r["ldesc"].ctypes.data; fo[b].linefn = r["linefn"].ctypes.data
+        res = [dict() for _ in range(B)]
+        # one slab per output kind for the whole batch (per-frame results are views): 8 allocations, not 8 per frame
+        if stages & STAGE_ORB:
+            kp = np.zeros((B, kcap), KEYPOINT_DT); desc = np.zeros((B, kcap, 32), np.uint8)
+            for b in range(B):
+                res[b]["kp"] = kp[b]; res[b]["desc"] = desc[b]
+                fo[b].kp = kp[b].ctypes.data; fo[b].desc = desc[b].ctypes.data; fo[b].kp_cap = kcap
+        if stages & (STAGE_LSD | STAGE_LSD_CULL):
+            kl = np.zeros((B, lcap), KEYLINE_DT); ldesc = np.zeros((B, lcap, 32), np.uint8); linefn = np.zeros((B, lcap, 3))
+            for b in range(B):
+                res[b]["kl"] = kl[b]; res[b]["ldesc"] = ldesc[b]; res[b]["linefn"] = linefn[b]
+                fo[b].kl = kl[b].ctypes.data; fo[b].ldesc = ldesc[b].ctypes.data; fo[b].linefn = linefn[b].ctypes.data
                 fo[b].kl_cap = lcap
-            if stages & STAGE_PLANES:
-                r["labels"] = np.zeros((h, w), np.int32); r["planes"] = np.zeros(pl_cap, PLANE_DT)
-                fo[b].labels = r["labels"].ctypes.data; fo[b].planes = r["planes"].ctypes.data; fo[b].pl_cap = pl_cap
-            res.append(r)
+        if stages & STAGE_PLANES:
+            labels = np.empty((B, h, w), np.int32); planes = np.zeros((B, pl_cap), PLANE_DT)      # labels are always written in full
+            for b in range(B):
+                res[b]["labels"] = labels[b]; res[b]["planes"] = planes[b]
+                fo[b].labels = labels[b].ctypes.data; fo[b].planes = planes[b].ctypes.data; fo[b].pl_cap = pl_cap
         self._chk(lib().hvo_batch_download(self.h, B, fo), "batch_download")
         for b, r in enumerate(res):
             r["status"] = fo[b].status

@@ -88,6 +88,7 @@ void hvo_destroy(hvo_ctx *ctx)
     if (ctx->d_pattern) (void)hipFree(ctx->d_pattern);
     if (ctx->d_umax) (void)hipFree(ctx->d_umax);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    for (int i = 0; i < 2; i++) if (ctx->ev_stage[i]) (void)hipEventDestroy(ctx->ev_stage[i]);
     for (auto &r : ctx->prof) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->s_lsd) (void)hipStreamDestroy(ctx->s_lsd);
@@ -506,6 +507,42 @@ int hvo_prof_begin(hvo_ctx *ctx, const char *name, hipStream_t st)
 void hvo_prof_end(hvo_ctx *ctx, int id)
 {
     if (id >= 0) (void)hipEventRecord(ctx->prof[id].e1, ctx->prof[id].st);
+}
+
+// Batch download of one per-frame slab: frame f's record starts at dev_base + f * dev_stride and its first bytes[f]
+// bytes go to dst[f] (either may be null / 0).  The slab is moved in chunks of whole frames with one DMA each into
+// pinned memory (two buffers: the DMA of chunk c+1 runs while the host scatters chunk c), instead of one pageable
+// hipMemcpy per frame and field (each of those is staged synchronously by the runtime, ~2 GB/s).
+int hvo_staged_d2h(hvo_ctx *ctx, hipStream_t st, const void *dev_base, size_t dev_stride, int n, void *const *dst, const size_t *bytes)
+{
+    const size_t HALF = 64u << 20;
+    if (n <= 0) return HVO_OK;
+    if (dev_stride > HALF) {                                   // a frame larger than a buffer: plain copies
+        for (int f = 0; f < n; f++)
+            if (dst[f] && bytes[f]) HVO_HIP(hipMemcpyAsync(dst[f], (const char *)dev_base + (size_t)f * dev_stride, bytes[f], hipMemcpyDeviceToHost, st));
+        HVO_HIP(hipStreamSynchronize(st));
+        return HVO_OK;
+    }
+    char *stage = (char *)hvo_stage_host(ctx, 2 * HALF);
+    if (!stage) { ctx->last_error = "hipHostMalloc (download staging)"; return HVO_ERR_HIP; }
+    if (!ctx->ev_stage[0]) for (int i = 0; i < 2; i++) HVO_HIP(hipEventCreateWithFlags(&ctx->ev_stage[i], hipEventDisableTiming));
+    const int per = (int)std::max<size_t>(1, HALF / dev_stride);
+    const int nchunk = (n + per - 1) / per;
+    for (int c = 0; c <= nchunk; c++) {
+        if (c < nchunk) {
+            const int f0 = c * per, F = std::min(per, n - f0);
+            HVO_HIP(hipMemcpyAsync(stage + (size_t)(c & 1) * HALF, (const char *)dev_base + (size_t)f0 * dev_stride, (size_t)F * dev_stride, hipMemcpyDeviceToHost, st));
+            HVO_HIP(hipEventRecord(ctx->ev_stage[c & 1], st));
+        }
+        if (c > 0) {
+            const int pc = c - 1, f0 = pc * per, F = std::min(per, n - f0);
+            HVO_HIP(hipEventSynchronize(ctx->ev_stage[pc & 1]));
+            const char *src = stage + (size_t)(pc & 1) * HALF;
+            for (int f = 0; f < F; f++)
+                if (dst[f0 + f] && bytes[f0 + f]) memcpy(dst[f0 + f], src + (size_t)f * dev_stride, bytes[f0 + f]);
+        }
+    }
+    return HVO_OK;
 }
 
 void *hvo_stage_host(hvo_ctx *ctx, size_t bytes)

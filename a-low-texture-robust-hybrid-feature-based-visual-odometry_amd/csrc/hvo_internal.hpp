@@ -91,6 +91,7 @@ struct hvo_ctx {
     void *d_mout = nullptr; size_t mout_cap = 0;
     // host staging (pinned)
     void *h_stage = nullptr; size_t h_stage_cap = 0;
+    hipEvent_t ev_stage[2] = { nullptr, nullptr };     // download staging (hvo_staged_d2h)
     // profiling
     bool profile = false;
     bool serialize = false;                // profiling mode 2: all stages on one stream (clean per-kernel times)
@@ -123,6 +124,7 @@ static inline hipStream_t hvo_stream_peac(hvo_ctx *c);
 int  hvo_prof_begin(hvo_ctx *ctx, const char *name, hipStream_t st);
 void hvo_prof_end(hvo_ctx *ctx, int id);
 void *hvo_stage_host(hvo_ctx *ctx, size_t bytes);
+int hvo_staged_d2h(hvo_ctx *ctx, hipStream_t st, const void *dev_base, size_t dev_stride, int n, void *const *dst, const size_t *bytes);
 
 // orb.hip
 int orb_init_tables(hvo_ctx *ctx);

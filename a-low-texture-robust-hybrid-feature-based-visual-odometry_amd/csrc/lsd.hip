@@ -1258,19 +1258,24 @@ int lsd_download(hvo_ctx *ctx, int n, hvo_frame_out *out, bool culled)
     HVO_HIP(hipMemcpyAsync(nk.data(), d_nkl, n * sizeof(int), hipMemcpyDeviceToHost, ctx->s_lsd));
     HVO_HIP(hipMemcpyAsync(fl.data(), P->d_flags, n * sizeof(int), hipMemcpyDeviceToHost, ctx->s_lsd));
     HVO_HIP(hipStreamSynchronize(ctx->s_lsd));
+    std::vector<void *> d0(n, nullptr), d1(n, nullptr), d2(n, nullptr); std::vector<size_t> b0(n, 0), b1(n, 0), b2(n, 0);
     for (int f = 0; f < n; f++) {
         int m = nk[f];
         if (fl[f]) out[f].status = HVO_ERR_CAPACITY;
         if (out[f].kl) {
             if (m > out[f].kl_cap) { m = out[f].kl_cap; out[f].status = HVO_ERR_CAPACITY; }
             if (m > 0) {
-                HVO_HIP(hipMemcpyAsync(out[f].kl, d_kl + (size_t)f * P->nfeat, (size_t)m * sizeof(hvo_keyline), hipMemcpyDeviceToHost, ctx->s_lsd));
-                if (out[f].ldesc) HVO_HIP(hipMemcpyAsync(out[f].ldesc, d_desc + (size_t)f * P->nfeat * 32, (size_t)m * 32, hipMemcpyDeviceToHost, ctx->s_lsd));
-                if (out[f].linefn) HVO_HIP(hipMemcpyAsync(out[f].linefn, d_fn + (size_t)f * P->nfeat * 3, (size_t)m * 24, hipMemcpyDeviceToHost, ctx->s_lsd));
+                d0[f] = out[f].kl; b0[f] = (size_t)m * sizeof(hvo_keyline);
+                if (out[f].ldesc) { d1[f] = out[f].ldesc; b1[f] = (size_t)m * 32; }
+                if (out[f].linefn) { d2[f] = out[f].linefn; b2[f] = (size_t)m * 24; }
             }
         }
         out[f].n_kl = m;
     }
+    int rc = hvo_staged_d2h(ctx, ctx->s_lsd, d_kl, (size_t)P->nfeat * sizeof(hvo_keyline), n, d0.data(), b0.data());
+    if (rc) return rc;
+    if ((rc = hvo_staged_d2h(ctx, ctx->s_lsd, d_desc, (size_t)P->nfeat * 32, n, d1.data(), b1.data()))) return rc;
+    if ((rc = hvo_staged_d2h(ctx, ctx->s_lsd, d_fn, (size_t)P->nfeat * 24, n, d2.data(), b2.data()))) return rc;
     HVO_HIP(hipStreamSynchronize(ctx->s_lsd));
     return HVO_OK;
 }

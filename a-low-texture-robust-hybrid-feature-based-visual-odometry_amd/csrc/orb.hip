@@ -1102,19 +1102,22 @@ int orb_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
     HVO_HIP(hipMemcpyAsync(nk.data(), P.d_nkp, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HVO_HIP(hipMemcpyAsync(fl.data(), P.d_flags, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HVO_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<void *> dk(n, nullptr), dd(n, nullptr); std::vector<size_t> bk(n, 0), bd(n, 0);
     for (int f = 0; f < n; f++) {
         int m = nk[f];
         if (fl[f]) out[f].status = HVO_ERR_CAPACITY;
         if (out[f].kp) {
             if (m > out[f].kp_cap) { m = out[f].kp_cap; out[f].status = HVO_ERR_CAPACITY; }
             if (m > 0) {
-                HVO_HIP(hipMemcpyAsync(out[f].kp, P.d_kp + (size_t)f * P.kp_cap, (size_t)m * sizeof(hvo_keypoint), hipMemcpyDeviceToHost, ctx->stream));
-                if (out[f].desc)
-                    HVO_HIP(hipMemcpyAsync(out[f].desc, P.d_desc + (size_t)f * P.kp_cap * 32, (size_t)m * 32, hipMemcpyDeviceToHost, ctx->stream));
+                dk[f] = out[f].kp; bk[f] = (size_t)m * sizeof(hvo_keypoint);
+                if (out[f].desc) { dd[f] = out[f].desc; bd[f] = (size_t)m * 32; }
             }
         }
         out[f].n_kp = m;
     }
+    int rc = hvo_staged_d2h(ctx, ctx->stream, P.d_kp, (size_t)P.kp_cap * sizeof(hvo_keypoint), n, dk.data(), bk.data());
+    if (rc) return rc;
+    if ((rc = hvo_staged_d2h(ctx, ctx->stream, P.d_desc, (size_t)P.kp_cap * 32, n, dd.data(), bd.data()))) return rc;
     HVO_HIP(hipStreamSynchronize(ctx->stream));
     return HVO_OK;
 }

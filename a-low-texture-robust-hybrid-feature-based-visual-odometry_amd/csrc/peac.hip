@@ -1606,17 +1606,21 @@ int peac_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
     HVO_HIP(hipMemcpyAsync(meta.data(), P->d_meta, meta.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->s_peac));
     HVO_HIP(hipStreamSynchronize(ctx->s_peac));
     const size_t npix = (size_t)P->w * P->h;
+    std::vector<void *> dl(n, nullptr), dp(n, nullptr); std::vector<size_t> bl(n, 0), bp(n, 0);
     for (int f = 0; f < n; f++) {
         const int nfin = meta[(size_t)f * 16 + 4], flags = meta[(size_t)f * 16 + 3];
         if (flags) out[f].status = HVO_ERR_CAPACITY;
-        if (out[f].labels) HVO_HIP(hipMemcpyAsync(out[f].labels, P->d_labels + f * npix, npix * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->s_peac));
+        if (out[f].labels) { dl[f] = out[f].labels; bl[f] = npix * sizeof(int32_t); }
         int m = nfin;
         if (out[f].planes) {
             if (m > out[f].pl_cap) { m = out[f].pl_cap; out[f].status = HVO_ERR_CAPACITY; }
-            if (m > 0) HVO_HIP(hipMemcpyAsync(out[f].planes, P->d_planes + (size_t)f * MAX_PLANES, (size_t)m * sizeof(hvo_plane), hipMemcpyDeviceToHost, ctx->s_peac));
+            if (m > 0) { dp[f] = out[f].planes; bp[f] = (size_t)m * sizeof(hvo_plane); }
         }
         out[f].n_planes = m;
     }
+    int rc = hvo_staged_d2h(ctx, ctx->s_peac, P->d_labels, npix * sizeof(int32_t), n, dl.data(), bl.data());
+    if (rc) return rc;
+    if ((rc = hvo_staged_d2h(ctx, ctx->s_peac, P->d_planes, (size_t)MAX_PLANES * sizeof(hvo_plane), n, dp.data(), bp.data()))) return rc;
     HVO_HIP(hipStreamSynchronize(ctx->s_peac));
     return HVO_OK;
 }
