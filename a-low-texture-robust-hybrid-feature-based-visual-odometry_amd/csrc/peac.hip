@@ -133,23 +133,52 @@ __global__ __launch_bounds__(64) void k_peac_blocks(const uint16_t *__restrict__
     int N = 0;
     bool valid = true;
     const double dfx = (double)fx, dfy = (double)fy, dcx = (double)cx, dcy = (double)cy, df = (double)dfac;
+    // A block row is 10 depths + the right neighbour of the last one: six aligned dwords (20 * bj bytes into a 64-byte
+    // aligned row; the pair beyond the image edge is never used).  The row below is requested before this row is
+    // processed and only needed for its "down" jump test, so its latency hides behind the row's arithmetic; the
+    // reference's early exit at the first invalid pixel is a flag here (an invalid block keeps nothing of its sums).
+    const int i0 = bi * WIN;
+    const uint32_t *rp = reinterpret_cast<const uint32_t *>(D + (size_t)i0 * pitch + bj * WIN);
+    const int rstep = pitch >> 1;                               // dwords per row
+    uint32_t cur[6], nxt[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) cur[q] = rp[q];
     for (int ic = 0; ic < WIN && valid; ++ic) {
-        const int i = bi * WIN + ic;
-        const uint16_t *row = D + (size_t)i * pitch;
+        const int i = i0 + ic;
+        const bool has_down = i + 1 < h;
+#pragma unroll
+        for (int q = 0; q < 6; q++) nxt[q] = has_down ? rp[(size_t)(ic + 1) * rstep + q] : 0u;
+        const double yk = (double)i - dcy;
+        bool rowok = true;
+        double zrow[WIN];
+#pragma unroll
         for (int jc = 0; jc < WIN; ++jc) {
             const int j = bj * WIN + jc;
-            const int d = row[j];
-            if (d == 0) { valid = false; break; }               // ImagePointCloud::get: z == 0
+            const int d = (int)((cur[jc >> 1] >> (16 * (jc & 1))) & 0xFFFFu);
+            rowok = rowok && d != 0;                            // ImagePointCloud::get: z == 0
             const double z = (double)d * df;
-            if (j + 1 < w) { int dn = row[j + 1]; if (dn != 0) { double zn = (double)dn * df; if (fabs(z - zn) > 0.04 * fabs(z) + 0.02) { valid = false; break; } } }
-            if (i + 1 < h) { int dn = row[pitch + j]; if (dn != 0) { double zn = (double)dn * df; if (fabs(z - zn) > 0.04 * fabs(z) + 0.02) { valid = false; break; } } }
+            zrow[jc] = z;
+            if (j + 1 < w) {
+                const int dn = (int)((cur[(jc + 1) >> 1] >> (16 * ((jc + 1) & 1))) & 0xFFFFu);
+                if (dn != 0) { const double zn = (double)dn * df; if (fabs(z - zn) > 0.04 * fabs(z) + 0.02) rowok = false; }
+            }
             const double x = ((double)j - dcx) * z / dfx;
-            const double y = ((double)i - dcy) * z / dfy;
+            const double y = yk * z / dfy;
             st[0] += x; st[1] += y; st[2] += z;
             st[3] += x * x; st[4] += y * y; st[5] += z * z;
             st[6] += x * y; st[7] += y * z; st[8] += x * z;
             ++N;
         }
+        if (has_down) {
+#pragma unroll
+            for (int jc = 0; jc < WIN; ++jc) {
+                const int dn = (int)((nxt[jc >> 1] >> (16 * (jc & 1))) & 0xFFFFu);
+                if (dn != 0) { const double z = zrow[jc], zn = (double)dn * df; if (fabs(z - zn) > 0.04 * fabs(z) + 0.02) rowok = false; }
+            }
+        }
+        valid = rowok;
+#pragma unroll
+        for (int q = 0; q < 6; q++) cur[q] = nxt[q];
     }
     double *sd = segD + ((size_t)frame * segcap + blk) * SEG_D;
     int *si = segI + ((size_t)frame * segcap + blk) * SEG_I;
