@@ -101,6 +101,42 @@ struct hvo_ctx {
     void *lsd = nullptr;
 };
 
+// Image-border handling of the 12-byte row window {W0, W1, W2} = pixels x0-4 .. x0+7 of a 4-pixel strip without a byte
+// path: the three dwords are loaded from clamped in-row addresses and every window byte that lies outside the image is
+// replaced by its REFLECT_101 source, which is always inside the same window for the taps of the strip's valid pixels
+// (reach <= 3).  Three v_perm_b32 with per-thread selectors (identity for interior strips) and one operand select.
+struct EdgeSel { unsigned s0, s1, s2; bool lo2; };
+#ifdef __HIPCC__
+static __device__ __forceinline__ EdgeSel edge_sel(int x0, int w)
+{
+    EdgeSel e; e.s0 = 0x03020100u; e.s1 = 0x07060504u; e.s2 = 0x07060504u;
+    const int m = w - 1 - x0;                                  // last valid pixel relative to x0
+    e.lo2 = m <= 2;                                            // W2' comes from {W0, W1} instead of {W1, W2}
+    if (x0 >= 4 && m >= 7) return e;
+    unsigned s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+    for (int b = 0; b < 12; b++) {
+        const int px = x0 - 4 + b;
+        int r = px < 0 ? -px : (px >= w ? 2 * (w - 1) - px : px);
+        int sb = r - (x0 - 4);                                 // source byte in the window
+        if (b < 8) { if (sb < 0 || sb > 7) sb = b; }            // bytes no valid pixel's taps reach: anything
+        else if (e.lo2) { if (sb < 0 || sb > 7) sb = 7; }
+        else { sb -= 4; if (sb < 0 || sb > 7) sb = b - 4; }
+        if (b < 4) s0 |= (unsigned)sb << (8 * b);
+        else if (b < 8) s1 |= (unsigned)sb << (8 * (b - 4));
+        else s2 |= (unsigned)sb << (8 * (b - 8));
+    }
+    e.s0 = s0; e.s1 = s1; e.s2 = s2;
+    return e;
+}
+static __device__ __forceinline__ void edge_fix(const EdgeSel &e, unsigned &W0, unsigned &W1, unsigned &W2)
+{
+    const unsigned a = e.lo2 ? W1 : W2, b = e.lo2 ? W0 : W1;
+    const unsigned n0 = __builtin_amdgcn_perm(W1, W0, e.s0), n1 = __builtin_amdgcn_perm(W1, W0, e.s1);
+    W2 = __builtin_amdgcn_perm(a, b, e.s2); W0 = n0; W1 = n1;
+}
+#endif
+
 #define HVO_HIP(call)                                                                        \
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \

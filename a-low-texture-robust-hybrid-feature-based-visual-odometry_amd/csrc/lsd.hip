@@ -725,8 +725,8 @@ __global__ __launch_bounds__(256) void k_lbd_sobel(const uint8_t *__restrict__ b
 }
 
 // Blur and Sobel in one pass: a thread owns 4 adjacent columns and LBD_BLUR_ROWS output rows.  Per source row it
-// fetches three aligned dwords (pixels x0-4 .. x0+7; strips on the left / right image border assemble them byte by
-// byte with reflected indices) and forms the 5-tap row sums of the SIX columns x0-1 .. x0+4 with v_dot4 (the Sobel
+// fetches three aligned dwords (pixels x0-4 .. x0+7; strips on the left / right image border load from clamped
+// addresses and permute the reflected bytes into place, EdgeSel in hvo_internal.hpp) and forms the 5-tap row sums of the SIX columns x0-1 .. x0+4 with v_dot4 (the Sobel
 // needs the blurred neighbours of its own four); the last five row sums per column give one blurred row, the last
 // three blurred rows one Sobel row.  The u8 blurred image is never written.  Reflection of the blurred image at
 // the image border (refl(-1) = 1, refl(n) = n-2) is a substitution of the opposite neighbour.
@@ -738,7 +738,8 @@ __global__ __launch_bounds__(256) void k_lbd_blur_sobel(const uint8_t *__restric
     const int x0 = (item - rb * nstrip) * 4, yb = rb * LBD_BLUR_ROWS;
     if (yb >= h) return;
     const uint8_t *G = gray + (size_t)f * gframe;          // rows are 4-byte aligned (pitch % 64 == 0)
-    const bool interior = x0 >= 4 && x0 + 7 < gpitch && x0 + 6 < w;
+    const EdgeSel es = edge_sel(x0, w);
+    const int o0 = max(x0 - 4, 0), o2 = min(x0 + 4, gpitch - 4);     // window loads clamped into the row
     const unsigned kA = (unsigned)k0 | ((unsigned)k1 << 8) | ((unsigned)k2 << 16) | ((unsigned)k1 << 24);
     const int wv4 = w & ~3;
     const int v0 = max(yb - 1, 0), v1 = min(yb + LBD_BLUR_ROWS, h - 1);      // blurred rows formed here
@@ -755,18 +756,9 @@ __global__ __launch_bounds__(256) void k_lbd_blur_sobel(const uint8_t *__restric
     const bool vecst = (w & 3) == 0;                       // 16-byte stores need every row start aligned
     for (int sr = v0 - 2; sr <= v1 + 2; sr++) {
         const uint8_t *S = G + (size_t)refl(min(sr, h + 1), h) * gpitch;
-        unsigned W0, W1, W2;
-        if (interior) {
-            const uint32_t *p = reinterpret_cast<const uint32_t *>(S + x0 - 4);
-            W0 = p[0]; W1 = p[1]; W2 = p[2];
-        } else {
-            unsigned b[12];
-#pragma unroll
-            for (int i = 0; i < 12; i++) b[i] = S[refl(x0 - 4 + i, w)];
-            W0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-            W1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-            W2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
-        }
+        unsigned W0 = *reinterpret_cast<const uint32_t *>(S + o0), W1 = *reinterpret_cast<const uint32_t *>(S + x0),
+                 W2 = *reinterpret_cast<const uint32_t *>(S + o2);
+        edge_fix(es, W0, W1, W2);                          // REFLECT_101 at the left / right image border (identity elsewhere)
 #pragma unroll
         for (int q = 0; q < 4; q++)
 #pragma unroll

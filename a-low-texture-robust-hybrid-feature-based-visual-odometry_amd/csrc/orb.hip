@@ -683,25 +683,19 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
 // of BLUR_TH rows.  Per input row it loads the 12 bytes [x0-4, x0+8) as three aligned dwords, forms the
 // byte windows with v_alignbyte and evaluates the 7-tap row sum of each of its 4 pixels with two
 // v_dot4_u32_u8; the last 7 row sums per pixel stay in registers for the column pass.  Output is one
-// dword store per row.  Strips that touch the left/right image border assemble their window byte by
-// byte with REFLECT_101 indices (two threads per row).
+// dword store per row.  Strips that touch the left/right image border load from clamped addresses and permute
+// the reflected bytes into place (EdgeSel, hvo_internal.hpp): a byte-wise border path would be issued for every
+// wave that contains a border strip, two tile columns in three at 640 pixels.
 #define BLUR_TW 256            // pixels per workgroup row (64 threads x 4 px)
 #define BLUR_TH 32             // rows per wave; a workgroup (4 waves) covers 128 rows
 struct BlurWin { unsigned W0, W1, W2; };
-static __device__ __forceinline__ BlurWin blur_load(const uint8_t *__restrict__ row, int x0, int w, bool interior)
+static __device__ __forceinline__ BlurWin blur_load(const uint8_t *__restrict__ row, int o0, int x0, int o2, const EdgeSel &es)
 {
     BlurWin o;
-    if (interior) {
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(row + x0 - 4);
-        o.W0 = p[0]; o.W1 = p[1]; o.W2 = p[2];
-    } else {
-        unsigned b[12];
-#pragma unroll
-        for (int i = 0; i < 12; i++) b[i] = row[reflect101(x0 - 4 + i, w)];
-        o.W0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-        o.W1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-        o.W2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
-    }
+    o.W0 = *reinterpret_cast<const uint32_t *>(row + o0);      // x0 - 4, clamped into the row for the leftmost strip
+    o.W1 = *reinterpret_cast<const uint32_t *>(row + x0);
+    o.W2 = *reinterpret_cast<const uint32_t *>(row + o2);      // x0 + 4, clamped into the row's pitch
+    edge_fix(es, o.W0, o.W1, o.W2);                            // REFLECT_101 at the left / right image border (identity elsewhere)
     return o;
 }
 static __device__ __forceinline__ void blur_row_sums(const BlurWin &W, unsigned klo, unsigned khi, int hs[4])
@@ -731,7 +725,8 @@ __global__ __launch_bounds__(256) void k_blur7(const uint8_t *__restrict__ pyr, 
     const int x0 = t.y * BLUR_TW + lane * 4;
     const int y0 = (t.z * 4 + wv) * BLUR_TH;
     if (x0 >= L.w || y0 >= L.h) return;
-    const bool interior = x0 >= 4 && x0 + 7 < L.w;           // window [x0-4, x0+8) needs columns x0-3 .. x0+6
+    const EdgeSel es = edge_sel(x0, L.w);
+    const int o0 = max(x0 - 4, 0), o2 = min(x0 + 4, L.pitch - 4);
     const unsigned klo = (unsigned)k0 | ((unsigned)k1 << 8) | ((unsigned)k2 << 16) | ((unsigned)k3 << 24);
     const unsigned khi = (unsigned)k2 | ((unsigned)k1 << 8) | ((unsigned)k0 << 16);
     const int wv4 = L.w & ~3;
@@ -741,16 +736,16 @@ __global__ __launch_bounds__(256) void k_blur7(const uint8_t *__restrict__ pyr, 
     // requested while row r is being processed (two loads in flight per thread)
     BlurWin pw[6];
 #pragma unroll
-    for (int r = 0; r < 6; r++) pw[r] = blur_load(BLUR_ROW(r), x0, L.w, interior);
-    BlurWin n0 = blur_load(BLUR_ROW(6), x0, L.w, interior);
-    BlurWin n1 = blur_load(BLUR_ROW(7), x0, L.w, interior);
+    for (int r = 0; r < 6; r++) pw[r] = blur_load(BLUR_ROW(r), o0, x0, o2, es);
+    BlurWin n0 = blur_load(BLUR_ROW(6), o0, x0, o2, es);
+    BlurWin n1 = blur_load(BLUR_ROW(7), o0, x0, o2, es);
     int h[7][4];
 #pragma unroll
     for (int r = 0; r < 6; r++) blur_row_sums(pw[r], klo, khi, h[r]);
     for (int r = 0; r < rows; r++) {
         const BlurWin cur = n0;
         n0 = n1;
-        n1 = blur_load(BLUR_ROW(r + 8), x0, L.w, interior);       // rows past the band are loaded (reflected) but unused
+        n1 = blur_load(BLUR_ROW(r + 8), o0, x0, o2, es);       // rows past the band are loaded (reflected) but unused
         blur_row_sums(cur, klo, khi, h[6]);
         unsigned out = 0;
 #pragma unroll
