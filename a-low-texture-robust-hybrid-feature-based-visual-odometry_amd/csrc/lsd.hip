@@ -136,62 +136,83 @@ static __device__ __forceinline__ double scaled_at(const double *B, int w, int x
     return t0 * b0 + t1 * b1;
 }
 
-// One workgroup = 256 consecutive pixels of one scaled row.  A thread forms the two scaled values of its
-// column (rows y, y+1) and reads its right neighbour's from LDS, so a scaled value is interpolated ~1.25 times
-// instead of 4.  Only ~15 % of the pixels have a gradient above the threshold: they are compacted through LDS
-// and the expensive part (double cos / sin of the level-line angle) runs on dense lanes only.
+// One workgroup = 256 consecutive columns x GRAD_ROWS scaled rows.  A thread walks down its column: it forms the
+// scaled value of the next row (one bilinear interpolation of the blurred fp64 image), reads its right neighbour's
+// from LDS and has the 2x2 neighbourhood of the current pixel in registers, so a scaled value is interpolated
+// (GRAD_ROWS + 1) / GRAD_ROWS times instead of twice.  Only ~15 % of the pixels have a gradient above the threshold:
+// they are queued in LDS across rows and the expensive part (double cos / sin of the level-line angle) runs on
+// full workgroups of 256 queued pixels (the remainder at the end).
+#define GRAD_ROWS 8
 __global__ __launch_bounds__(256) void k_lsd_resize_grad(const double *__restrict__ blur, int w, int h, int sw, int sh,
                                                          const int *__restrict__ xofs, const float *__restrict__ xa,
                                                          const int *__restrict__ yofs, const float *__restrict__ yb,
                                                          double4 *__restrict__ px4,
                                                          unsigned *__restrict__ defined, int nwords, double rho)
 {
-    __shared__ double sv0[257], sv1[257];
-    __shared__ double la[256], lm[256]; __shared__ unsigned short lx[256];
+    __shared__ double sv[2][257];
+    __shared__ double la[512], lm[512]; __shared__ int lpos[512];
     __shared__ int wcnt[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int x0 = blockIdx.x * 256, x = x0 + tid, y = blockIdx.y, f = blockIdx.z;
+    const int x0 = blockIdx.x * 256, x = x0 + tid, y0 = blockIdx.y * GRAD_ROWS, f = blockIdx.z;
     const double *B = blur + (size_t)f * w * h;
-    const bool row1 = y + 1 < sh;
-    double v0 = 0, v1 = 0;
-    if (x < sw) { v0 = scaled_at(B, w, x, y, xofs, xa, yofs, yb, w); if (row1) v1 = scaled_at(B, w, x, y + 1, xofs, xa, yofs, yb, w); }
-    sv0[tid] = v0; sv1[tid] = v1;
-    if (tid == 0) {
-        const int xe = x0 + 256;
-        sv0[256] = xe < sw ? scaled_at(B, w, xe, y, xofs, xa, yofs, yb, w) : 0;
-        sv1[256] = xe < sw && row1 ? scaled_at(B, w, xe, y + 1, xofs, xa, yofs, yb, w) : 0;
-    }
+    double4 *PX = px4 + (size_t)f * sh * sw;
+    const bool incol = x < sw, edgecol = x0 + 256 < sw;
+    double vprev = incol ? scaled_at(B, w, x, y0, xofs, xa, yofs, yb, w) : 0;
+    sv[0][tid] = vprev;
+    if (tid == 0) sv[0][256] = edgecol ? scaled_at(B, w, x0 + 256, y0, xofs, xa, yofs, yb, w) : 0;
     __syncthreads();
-    bool def = false;
-    double a = LSD_NOTDEF, m = 0;
-    if (x < sw) {
+    double vprev_r = sv[0][tid + 1];
+    int npend = 0;
+    auto emit = [&](int i) {
+        // region_grow accumulates cos(float(angle)) / sin(float(angle)) evaluated in double
+        const double aa = la[i], af = (double)(float)aa;
+        PX[lpos[i]] = make_double4(aa, cos(af), sin(af), lm[i]);
+    };
+    for (int r = 0; r < GRAD_ROWS; r++) {
+        const int y = y0 + r;
+        if (y >= sh) break;
+        const bool row1 = y + 1 < sh;
+        const int buf = (r + 1) & 1;
+        const double vcur = incol && row1 ? scaled_at(B, w, x, y + 1, xofs, xa, yofs, yb, w) : 0;
+        sv[buf][tid] = vcur;
+        if (tid == 0) sv[buf][256] = edgecol && row1 ? scaled_at(B, w, x0 + 256, y + 1, xofs, xa, yofs, yb, w) : 0;
+        __syncthreads();
+        const double vcur_r = sv[buf][tid + 1];
+        bool def = false;
+        double a = LSD_NOTDEF, m = 0;
         if (x < sw - 1 && y < sh - 1) {
-            const double v00 = v0, v10 = sv0[tid + 1], v01 = v1, v11 = sv1[tid + 1];
-            const double DA = v11 - v00, BC = v10 - v01;
+            const double DA = vcur_r - vprev, BC = vprev_r - vcur;
             const double gx = DA + BC, gy = DA - BC;
             m = sqrt((gx * gx + gy * gy) / 4);
             if (!(m <= rho)) { a = (double)fatan2_deg((float)gx, (float)-gy) * (LSD_PI / 180); def = true; }
         }
         // records of pixels without a gradient angle are never read (the availability mask filters them): not written
+        // 256 threads = 8 words of 32 bits; rows are padded to a multiple of 32 bits in the mask
+        const unsigned long long bal = __ballot(def);
+        if (x < ((sw + 31) & ~31)) {
+            const int word = (y * ((sw + 31) / 32)) + (x >> 5);
+            if ((lane & 31) == 0) defined[(size_t)f * nwords + word] = (unsigned)(bal >> (lane & 32));
+        }
+        if (lane == 0) wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int base = 0, total = 0;
+        for (int i = 0; i < 4; i++) { const int c = wcnt[i]; if (i < wv) base += c; total += c; }
+        if (def) { const int p = npend + base + __popcll(bal & ((1ull << lane) - 1)); la[p] = a; lm[p] = m; lpos[p] = y * sw + x; }
+        npend += total;
+        __syncthreads();
+        if (npend >= 256) {                                   // a full workgroup of queued pixels
+            emit(tid);
+            const int rem = npend - 256;
+            double ta = 0, tm = 0; int tp = 0;
+            if (tid < rem) { ta = la[256 + tid]; tm = lm[256 + tid]; tp = lpos[256 + tid]; }
+            __syncthreads();
+            if (tid < rem) { la[tid] = ta; lm[tid] = tm; lpos[tid] = tp; }
+            npend = rem;
+            __syncthreads();
+        }
+        vprev = vcur; vprev_r = vcur_r;
     }
-    // 256 threads = 8 words of 32 bits; rows are padded to a multiple of 32 bits in the mask
-    const unsigned long long bal = __ballot(def);
-    if (x < ((sw + 31) & ~31)) {
-        const int word = (y * ((sw + 31) / 32)) + (x >> 5);
-        if ((lane & 31) == 0) defined[(size_t)f * nwords + word] = (unsigned)(bal >> (lane & 32));
-    }
-    // compaction of the defined pixels, then cos / sin on dense lanes
-    if (lane == 0) wcnt[wv] = __popcll(bal);
-    __syncthreads();
-    int base = 0, total = 0;
-    for (int i = 0; i < 4; i++) { const int c = wcnt[i]; if (i < wv) base += c; total += c; }
-    if (def) { const int p = base + __popcll(bal & ((1ull << lane) - 1)); la[p] = a; lm[p] = m; lx[p] = (unsigned short)tid; }
-    __syncthreads();
-    if (tid < total) {
-        // region_grow accumulates cos(float(angle)) / sin(float(angle)) evaluated in double
-        const double aa = la[tid], af = (double)(float)aa;
-        px4[((size_t)f * sh + y) * sw + x0 + lx[tid]] = make_double4(aa, cos(af), sin(af), lm[tid]);
-    }
+    if (tid < npend) emit(tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1202,7 +1223,7 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lsd_gradient", st);
     const int gx = (((sw + 31) & ~31) + 255) / 256;
-    hipLaunchKernelGGL(k_lsd_resize_grad, dim3(gx, sh, n), dim3(256), 0, st, P->d_blur, w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb,
+    hipLaunchKernelGGL(k_lsd_resize_grad, dim3(gx, (sh + GRAD_ROWS - 1) / GRAD_ROWS, n), dim3(256), 0, st, P->d_blur, w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb,
                        P->d_px, P->d_defined, P->nwords, P->rho);
     hvo_prof_end(ctx, id);
     if (ctx->ev_lsd_pre && !ctx->serialize) { HVO_HIP(hipEventRecord(ctx->ev_lsd_pre, st)); ctx->lsd_pre_recorded = true; }
