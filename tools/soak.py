@@ -15,6 +15,9 @@ def main():
     ap.add_argument("--kind", default="std")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0xC0FFEE00)
     ap.add_argument("--chunk", type=int, default=128)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--crop", default="", help="HxW: crop the generated frames to this size (odd geometries)")
     args = ap.parse_args()
     hvo = ge.package(); orc = ge.oracle()
     synth = importlib.import_module("hvo_amd.synth")
@@ -23,7 +26,10 @@ def main():
     bad, t0 = [], time.time()
     for c0 in range(0, args.frames, args.chunk):
         n = min(args.chunk, args.frames - c0)
-        gray, depth = synth.make_batch(args.kind, args.seed + c0, n)
+        gray, depth = synth.make_batch(args.kind, args.seed + c0, n, args.width, args.height)
+        if args.crop:
+            ch, cw = (int(v) for v in args.crop.lower().split("x"))
+            gray = np.ascontiguousarray(gray[:, :ch, :cw]); depth = np.ascontiguousarray(depth[:, :ch, :cw])
         ctx.batch_upload(gray, depth); ctx.batch_run(hvo.STAGE_ALL); res = ctx.batch_download(hvo.STAGE_ALL)
         for b in range(n):
             why = []
@@ -39,7 +45,7 @@ def main():
             if why: bad.append((c0 + b, why))
         print("frames %d..%d done, %d differ so far, %.0f s" % (c0, c0 + n - 1, len(bad), time.time() - t0), flush=True)
     ctx.close()
-    print("RESULT kind=%s seed=%#x frames=%d differing=%d %s" % (args.kind, args.seed, args.frames, len(bad), bad[:10]))
+    print("RESULT kind=%s seed=%#x %dx%d%s frames=%d differing=%d %s" % (args.kind, args.seed, args.width, args.height, (" crop " + args.crop) if args.crop else "", args.frames, len(bad), bad[:10]))
     return 1 if bad else 0
 
 
