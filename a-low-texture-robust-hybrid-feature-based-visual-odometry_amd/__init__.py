@@ -29,6 +29,7 @@ _LIB = None
 HVO_OK = 0
 STAGE_ORB, STAGE_LSD, STAGE_PLANES, STAGE_ALL = 1, 2, 4, 7
 STAGE_LSD_CULL = 8        # STAGE_LSD followed by Frame::cullingLine (merged lines replace the extractor's)
+LINE_MATCH_NNR, LINE_MATCH_BF, LINE_MATCH_DOUBLE = 0, 1, 2
 
 KEYPOINT_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                         ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
@@ -47,8 +48,11 @@ EXPORTS = [
     "hvo_hamming_matrix", "hvo_hamming_knn2", "hvo_match_nnr", "hvo_search_by_projection", "hvo_stereo_from_rgbd",
     "hvo_undistort_keypoints", "hvo_image_bounds", "hvo_assign_features_to_grid", "hvo_assign_lines_to_grid",
     "hvo_extract_lsd_culled", "hvo_set_line_culling", "hvo_search_by_projection_map", "hvo_frame_bf_match", "hvo_search_double",
-    "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch",
+    "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch", "hvo_batch_slab_layout", "hvo_batch_pack_results",
     "hvo_profile_last", "hvo_profile_enable",
+    "hvo_stream_create", "hvo_stream_destroy", "hvo_stream_last_error", "hvo_stream_capacity", "hvo_stream_image_bounds",
+    "hvo_stream_submit", "hvo_stream_poll", "hvo_stream_collect", "hvo_stream_stage_ms",
+    "hvo_stream_search_by_projection", "hvo_stream_match_lines",
 ]
 
 
@@ -77,6 +81,11 @@ class FrameOut(C.Structure):
                 ("kl", C.c_void_p), ("ldesc", C.c_void_p), ("linefn", C.c_void_p), ("kl_cap", C.c_int), ("n_kl", C.c_int),
                 ("labels", C.c_void_p), ("planes", C.c_void_p), ("pl_cap", C.c_int), ("n_planes", C.c_int),
                 ("status", C.c_int)]
+
+
+class StreamParams(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("depth", C.c_int32), ("stages", C.c_uint32),
+                ("dist5", C.c_float * 5), ("bf", C.c_float)]
 
 
 def build(force=False):
@@ -126,8 +135,21 @@ def lib():
         L.hvo_batch_run.argtypes = [C.c_void_p, C.c_uint]
         L.hvo_batch_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameOut)]
         L.hvo_extract_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameIn), C.POINTER(FrameOut), C.c_int, C.c_int, C.c_uint]
+        L.hvo_batch_slab_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+        L.hvo_batch_pack_results.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.hvo_profile_last.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
         L.hvo_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        L.hvo_stream_create.argtypes = [C.POINTER(Params), C.POINTER(StreamParams), C.POINTER(C.c_void_p)]
+        L.hvo_stream_destroy.argtypes = [C.c_void_p]; L.hvo_stream_destroy.restype = None
+        L.hvo_stream_last_error.argtypes = [C.c_void_p]; L.hvo_stream_last_error.restype = C.c_char_p
+        L.hvo_stream_capacity.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 3
+        L.hvo_stream_image_bounds.argtypes = [C.c_void_p, C.c_void_p]
+        L.hvo_stream_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+        L.hvo_stream_poll.argtypes = [C.c_void_p, C.c_int64]
+        L.hvo_stream_collect.argtypes = [C.c_void_p, C.c_int64, C.POINTER(FrameOut), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hvo_stream_stage_ms.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.hvo_stream_search_by_projection.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.hvo_stream_match_lines.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _LIB = L
     return _LIB
 
@@ -375,6 +397,16 @@ class Context:
                 r["planes"] = r["planes"][: fo[b].n_planes]
         return res
 
+    def slab_layout(self):
+        """(kp_cap, kl_cap, pl_cap, slab_bytes) of the resident batch's device result slabs"""
+        a, b, c, d = C.c_int(0), C.c_int(0), C.c_int(0), C.c_size_t(0)
+        self._chk(lib().hvo_batch_slab_layout(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "batch_slab_layout")
+        return a.value, b.value, c.value, d.value
+
+    def pack_results(self, n, device_ptr):
+        """write the first n frames' result slabs to device memory at `device_ptr` (n * slab_bytes bytes)"""
+        self._chk(lib().hvo_batch_pack_results(self.h, n, C.c_void_p(device_ptr)), "batch_pack_results")
+
     def profile_enable(self, mode=1):
         """0 off, 1 hipEvents around each kernel group, 2 events + stages serialised on one stream"""
         self._chk(lib().hvo_profile_enable(self.h, int(mode)), "profile_enable")
@@ -383,6 +415,111 @@ class Context:
         names = (C.c_char_p * 32)(); ms = (C.c_float * 32)()
         n = lib().hvo_profile_last(self.h, names, ms, 32)
         return {names[i].decode(): ms[i] for i in range(n)}
+
+
+class Stream:
+    """hvo_stream: the streamed-sequence mode (one Frame construction per camera image, src/Tracking.cc:262, with `depth`
+    frames in flight and the last `depth` frames' results resident in HBM for frame-to-frame matching)."""
+
+    def __init__(self, width=640, height=480, depth=4, stages=STAGE_ALL, dist5=(0, 0, 0, 0, 0), bf=40.0, params=None, **kw):
+        self.params = params if params is not None else default_params(**kw)
+        sp = StreamParams(); sp.width = width; sp.height = height; sp.depth = depth; sp.stages = stages; sp.bf = bf
+        for k in range(5):
+            sp.dist5[k] = dist5[k]
+        h = C.c_void_p()
+        rc = lib().hvo_stream_create(C.byref(self.params), C.byref(sp), C.byref(h))
+        if rc != HVO_OK:
+            raise HvoError(rc, "hvo_stream_create")
+        self.h = h; self.w = width; self.hgt = height; self.stages = stages; self.depth = depth
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        lib().hvo_stream_capacity(self.h, C.byref(a), C.byref(b), C.byref(c))
+        self.kp_cap, self.kl_cap, self.pl_cap = a.value, b.value, c.value
+        bb = np.zeros(4, np.float32); lib().hvo_stream_image_bounds(self.h, _p(bb)); self.bounds = bb      # mnMinX, mnMaxX, mnMinY, mnMaxY
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().hvo_stream_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc, what):
+        if rc != HVO_OK:
+            raise HvoError(rc, what + ": " + lib().hvo_stream_last_error(self.h).decode())
+
+    def submit(self, gray, depth=None):
+        assert gray.dtype == np.uint8 and gray.shape == (self.hgt, self.w) and gray.strides[1] == 1
+        t = C.c_int64(-1)
+        if depth is not None:
+            assert depth.dtype == np.uint16 and depth.shape == (self.hgt, self.w) and depth.strides[1] == 2
+            rc = lib().hvo_stream_submit(self.h, gray.ctypes.data, gray.strides[0], depth.ctypes.data, depth.strides[0], C.byref(t))
+        else:
+            rc = lib().hvo_stream_submit(self.h, gray.ctypes.data, gray.strides[0], None, 0, C.byref(t))
+        self._chk(rc, "stream_submit")
+        return t.value
+
+    def poll(self, ticket):
+        r = lib().hvo_stream_poll(self.h, ticket)
+        if r < 0:
+            raise HvoError(r, "stream_poll")
+        return r == 1
+
+    def collect(self, ticket, labels=True):
+        fo = FrameOut(); r = {}
+        if self.stages & STAGE_ORB:
+            kp = np.zeros(self.kp_cap, KEYPOINT_DT); desc = np.zeros((self.kp_cap, 32), np.uint8); kpu = np.zeros(self.kp_cap, KEYPOINT_DT)
+            ur = np.zeros(self.kp_cap, np.float32); zd = np.zeros(self.kp_cap, np.float32)
+            fo.kp = kp.ctypes.data; fo.desc = desc.ctypes.data; fo.kp_cap = self.kp_cap
+        if self.stages & (STAGE_LSD | STAGE_LSD_CULL):
+            kl = np.zeros(self.kl_cap, KEYLINE_DT); ldesc = np.zeros((self.kl_cap, 32), np.uint8); fn = np.zeros((self.kl_cap, 3))
+            fo.kl = kl.ctypes.data; fo.ldesc = ldesc.ctypes.data; fo.linefn = fn.ctypes.data; fo.kl_cap = self.kl_cap
+        if self.stages & STAGE_PLANES:
+            planes = np.zeros(self.pl_cap, PLANE_DT); fo.planes = planes.ctypes.data; fo.pl_cap = self.pl_cap
+            if labels:
+                lab = np.empty((self.hgt, self.w), np.int32); fo.labels = lab.ctypes.data
+        if self.stages & STAGE_ORB:
+            self._chk(lib().hvo_stream_collect(self.h, ticket, C.byref(fo), _p(kpu), _p(ur), _p(zd)), "stream_collect")
+            n = fo.n_kp
+            r.update(kp=kp[:n], desc=desc[:n], kp_un=kpu[:n], uright=ur[:n], zdepth=zd[:n])
+        else:
+            self._chk(lib().hvo_stream_collect(self.h, ticket, C.byref(fo), None, None, None), "stream_collect")
+        if self.stages & (STAGE_LSD | STAGE_LSD_CULL):
+            n = fo.n_kl
+            r.update(kl=kl[:n], ldesc=ldesc[:n], linefn=fn[:n])
+        if self.stages & STAGE_PLANES:
+            r["planes"] = planes[: fo.n_planes]
+            if labels:
+                r["labels"] = lab
+        r["status"] = fo.status
+        return r
+
+    def stage_ms(self, ticket):
+        ms = np.zeros(3, np.float32)
+        self._chk(lib().hvo_stream_stage_ms(self.h, ticket, _p(ms)), "stream_stage_ms")
+        return {"orb": float(ms[0]), "lsd": float(ms[1]), "planes": float(ms[2])}
+
+    def search_by_projection(self, cur, last, q_index, q_u, q_v, q_radius, q_min_level, q_max_level, q_ur, q_blocks,
+                             t_occupied=None, q_desc=None, th_high=100, check_orientation=True):
+        """ORBmatcher::SearchByProjection(Cur, Last) core between two resident frames -> (nmatches, idx, dist)"""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        q_index = np.ascontiguousarray(q_index, np.int32); nq = len(q_index)
+        q_u, q_v, q_radius = map(f32, (q_u, q_v, q_radius))
+        q_ur = f32(q_ur) if q_ur is not None else None
+        q_min_level = np.ascontiguousarray(q_min_level, np.int32); q_max_level = np.ascontiguousarray(q_max_level, np.int32)
+        q_blocks = np.ascontiguousarray(q_blocks, np.uint8)
+        t_occupied = np.ascontiguousarray(t_occupied, np.uint8) if t_occupied is not None else None
+        q_desc = np.ascontiguousarray(q_desc, np.uint8) if q_desc is not None else None
+        mi = np.zeros(max(nq, 1), np.int32); md = np.zeros(max(nq, 1), np.int32); n = C.c_int(0)
+        pp = lambda a: _p(a) if a is not None else None
+        self._chk(lib().hvo_stream_search_by_projection(self.h, cur, last, nq, _p(q_index), pp(q_desc), _p(q_u), _p(q_v), _p(q_radius), _p(q_min_level),
+                                                        _p(q_max_level), pp(q_ur), _p(q_blocks), pp(t_occupied), th_high, 1 if check_orientation else 0,
+                                                        _p(mi), _p(md), C.byref(n)), "stream_search_by_projection")
+        return n.value, mi[:nq], md[:nq]
+
+    def match_lines(self, frm, to, mode=LINE_MATCH_NNR, th=50.0, nnratio=0.95):
+        m = np.full(self.kl_cap, -1, np.int32); n1 = C.c_int(0); n = C.c_int(0)
+        self._chk(lib().hvo_stream_match_lines(self.h, frm, to, mode, th, nnratio, _p(m), C.byref(n1), C.byref(n)), "stream_match_lines")
+        return n.value, m[: n1.value]
 
 
 # ---------------------------------------------------------------------------------------

@@ -38,6 +38,7 @@ const char *hvo_strerror(int s)
     case HVO_ERR_UNSUPPORTED: return "unsupported configuration or image geometry";
     case HVO_ERR_CAPACITY: return "internal capacity exceeded, results truncated";
     case HVO_ERR_BAD_DTYPE: return "wrong image type";
+    case HVO_ERR_BUSY: return "stream slot still holds an uncollected frame";
     default: return "unknown status";
     }
 }
@@ -129,6 +130,7 @@ int hvo_batch_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h)
     for (int f = 0; f < n; f++) if (!in[f].depth) ctx->have_depth = false;
     if (ctx->have_depth) { rc = peac_upload(ctx, n, in, w, h); if (rc) return rc; }
     ctx->batch_n = n; ctx->batch_w = w; ctx->batch_h = h;
+    ctx->last_stages = 0;                                  // nothing has been computed for this batch yet
     return HVO_OK;
 }
 
@@ -168,6 +170,8 @@ int hvo_batch_run(hvo_ctx *ctx, unsigned stages)
     if (ctx->profile)
         for (int i = 0; i < ctx->nprof; i++)
             if (ctx->prof[i].used) HVO_HIP(hipEventElapsedTime(&ctx->prof[i].ms, ctx->prof[i].e0, ctx->prof[i].e1));
+    ctx->last_stages |= stages & (HVO_STAGE_ORB | HVO_STAGE_PLANES);
+    if (want_lsd) ctx->last_stages = (ctx->last_stages & ~(HVO_STAGE_LSD | HVO_STAGE_LSD_CULL)) | HVO_STAGE_LSD | (want_cull ? HVO_STAGE_LSD_CULL : 0u);
     return HVO_OK;
 }
 
@@ -176,12 +180,75 @@ int hvo_batch_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
     if (!ctx || !out || n < 1 || n > ctx->batch_n) return HVO_ERR_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
     for (int f = 0; f < n; f++) { out[f].status = HVO_OK; out[f].n_kp = out[f].n_kl = out[f].n_planes = 0; }
-    int rc = orb_download(ctx, n, out);
+    // only what hvo_batch_run computed for THIS resident batch is reported: a stage that did not run leaves its counts
+    // at 0 (its device slabs hold the results of some earlier batch or nothing at all)
+    int rc;
+    bool want_kp = false, want_pl = false, want_kl = false;
+    for (int f = 0; f < n; f++) { want_kp |= (out[f].kp != nullptr); want_pl |= (out[f].labels || out[f].planes); want_kl |= (out[f].kl != nullptr); }
+    if (want_kp && (ctx->last_stages & HVO_STAGE_ORB)) { rc = orb_download(ctx, n, out); if (rc) return rc; }
+    if (want_pl && (ctx->last_stages & HVO_STAGE_PLANES)) { rc = peac_download(ctx, n, out); if (rc) return rc; }
+    if (want_kl && (ctx->last_stages & HVO_STAGE_LSD)) { rc = lsd_download(ctx, n, out, ctx->last_cull); if (rc) return rc; }
+    return HVO_OK;
+}
+
+// ---- result slabs on the device (the multi-GPU gather of SURVEY.md 8e hands these to RCCL without a host round trip) ----
+static __global__ void k_pack_header(const int *__restrict__ nkp, const int *__restrict__ oflags, const int *__restrict__ nkl, const int *__restrict__ lflags,
+                                     const int *__restrict__ pmeta, int n, int kp_cap, int kl_cap, int pl_cap, char *__restrict__ slabs, size_t slab_bytes)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= n) return;
+    int a = nkp ? nkp[f] : 0, b = nkl ? nkl[f] : 0, c = pmeta ? pmeta[(size_t)f * 16 + 4] : 0, st = HVO_OK;
+    if ((oflags && oflags[f]) || (lflags && lflags[f]) || (pmeta && pmeta[(size_t)f * 16 + 3])) st = HVO_ERR_CAPACITY;
+    if (a > kp_cap) a = kp_cap;
+    if (b > kl_cap) b = kl_cap;
+    if (c > pl_cap) c = pl_cap;
+    int *h = reinterpret_cast<int *>(slabs + (size_t)f * slab_bytes);
+    h[0] = a; h[1] = b; h[2] = c; h[3] = st;
+}
+
+int hvo_batch_slab_layout(hvo_ctx *ctx, int *kp_cap, int *kl_cap, int *pl_cap, size_t *slab_bytes)
+{
+    if (!ctx || ctx->batch_n < 1 || ctx->orb.kp_cap <= 0) return HVO_ERR_INVALID_ARG;
+    const int kc = ctx->orb.kp_cap, lc = std::max(ctx->p.lsd_nfeatures, 1), pc = 64;
+    if (kp_cap) *kp_cap = kc;
+    if (kl_cap) *kl_cap = lc;
+    if (pl_cap) *pl_cap = pc;
+    if (slab_bytes) *slab_bytes = 16 + (size_t)kc * (sizeof(hvo_keypoint) + 32) + (size_t)lc * (sizeof(hvo_keyline) + 32 + 24) + (size_t)pc * sizeof(hvo_plane);
+    return HVO_OK;
+}
+
+int hvo_batch_pack_results(hvo_ctx *ctx, int n, void *d_slabs)
+{
+    if (!ctx || !d_slabs || n < 1 || n > ctx->batch_n) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    int kc, lc, pc; size_t sb;
+    int rc = hvo_batch_slab_layout(ctx, &kc, &lc, &pc, &sb);
     if (rc) return rc;
-    bool want_pl = false, want_kl = false;
-    for (int f = 0; f < n; f++) { want_pl |= (out[f].labels || out[f].planes); want_kl |= (out[f].kl != nullptr); }
-    if (want_pl) { rc = peac_download(ctx, n, out); if (rc) return rc; }
-    if (want_kl) { rc = lsd_download(ctx, n, out, ctx->last_cull); if (rc) return rc; }
+    const unsigned done = ctx->last_stages;
+    OrbPlan &O = ctx->orb;
+    LsdView lv; memset(&lv, 0, sizeof(lv));
+    PeacView pv; memset(&pv, 0, sizeof(pv));
+    if (done & HVO_STAGE_LSD) { if ((rc = lsd_prepare(ctx, ctx->batch_w, ctx->batch_h, ctx->batch_n, ctx->last_cull, &lv))) return rc; }
+    if (done & HVO_STAGE_PLANES) { if ((rc = peac_prepare(ctx, ctx->batch_w, ctx->batch_h, ctx->batch_n, &pv))) return rc; }
+    hipStream_t st = ctx->stream;
+    char *S = (char *)d_slabs;
+    HVO_HIP(hipMemsetAsync(S, 0, (size_t)n * sb, st));
+    hipLaunchKernelGGL(k_pack_header, dim3((n + 255) / 256), dim3(256), 0, st, (done & HVO_STAGE_ORB) ? O.d_nkp : nullptr, (done & HVO_STAGE_ORB) ? O.d_flags : nullptr,
+                       lv.d_nkl, lv.d_flags, pv.d_meta, n, kc, lc, pc, S, sb);
+    size_t off = 16;
+    auto field = [&](const void *src, size_t src_stride, size_t bytes, bool have) -> hipError_t {
+        hipError_t e = hipSuccess;
+        if (have) e = hipMemcpy2DAsync(S + off, sb, src, src_stride, bytes, (size_t)n, hipMemcpyDeviceToDevice, st);
+        off += bytes;
+        return e;
+    };
+    HVO_HIP(field(O.d_kp, (size_t)O.kp_cap * sizeof(hvo_keypoint), (size_t)kc * sizeof(hvo_keypoint), (done & HVO_STAGE_ORB) != 0));
+    HVO_HIP(field(O.d_desc, (size_t)O.kp_cap * 32, (size_t)kc * 32, (done & HVO_STAGE_ORB) != 0));
+    HVO_HIP(field(lv.d_kl, (size_t)lc * sizeof(hvo_keyline), (size_t)lc * sizeof(hvo_keyline), lv.d_kl != nullptr));
+    HVO_HIP(field(lv.d_desc, (size_t)lc * 32, (size_t)lc * 32, lv.d_kl != nullptr));
+    HVO_HIP(field(lv.d_fn, (size_t)lc * 24, (size_t)lc * 24, lv.d_kl != nullptr));
+    HVO_HIP(field(pv.d_planes, (size_t)pc * sizeof(hvo_plane), (size_t)pc * sizeof(hvo_plane), pv.d_planes != nullptr));
+    HVO_HIP(hipStreamSynchronize(st));
     return HVO_OK;
 }
 
@@ -205,6 +272,7 @@ int hvo_extract_orb(hvo_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
     in.gray = gray; in.gray_stride = stride;
     int rc = orb_upload(ctx, 1, &in, w, h);
     if (rc) return rc;
+    ctx->last_stages = 0;                                  // slot 0 of the resident batch has been overwritten
     for (int i = 0; i < ctx->nprof; i++) ctx->prof[i].used = false;
     if ((rc = orb_run(ctx, 1))) return rc;
     hvo_frame_out out; memset(&out, 0, sizeof(out));
@@ -279,44 +347,19 @@ int hvo_hamming_knn2(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, i
 int hvo_match_nnr(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float nnr,
                   int32_t *m12, int *n_matches)
 {
-    // LSDmatcher::matchNNR (LSDmatcher.cpp:803-826): the Hamming search runs on the GPU, the
-    // n1 ratio tests are the host-side epilogue (they read 2*n1 ints).
+    // LSDmatcher::matchNNR (LSDmatcher.cpp:803-826): knn-2 search and ratio test on the device (match.hip)
     if (!ctx || !m12 || !n_matches || n1 < 0 || n2 < 0) return HVO_ERR_INVALID_ARG;
     *n_matches = 0;
     if (n1 == 0) return HVO_OK;
-    int32_t *idx = (int32_t *)hvo_stage_host(ctx, (size_t)n1 * 4 * sizeof(int32_t));
-    if (!idx) return HVO_ERR_HIP;
-    int32_t *dist = idx + (size_t)n1 * 2;
-    int rc = hvo_hamming_knn2(ctx, d1, n1, d2, n2, idx, dist);
-    if (rc) return rc;
-    int m = 0;
-    for (int i = 0; i < n1; i++) {
-        m12[i] = -1;
-        if (n2 >= 2 && (float)dist[2 * i] < (float)dist[2 * i + 1] * nnr) { m12[i] = idx[2 * i]; m++; }
-    }
-    *n_matches = m;
-    return HVO_OK;
+    for (int i = 0; i < n1; i++) m12[i] = -1;
+    if (n2 < 2) return HVO_OK;
+    if (!d1 || !d2) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    return match_lines(ctx, d1, n1, d2, n2, 0.f, nnr, HVO_LINE_MATCH_NNR, m12, n_matches);
 }
 
-// LSDmatcher::FrameBFMatch (LSDmatcher.cpp:942-966) on a knn-2 table: lineDescriptorMAD's nn12 threshold
-// (1110-1135; medians are order statistics, the sorts' tie order cannot change them) and the three tests
-static void frame_bf_epilogue(const int32_t *idx2, const int32_t *dist2, int n1, float TH, float nnratio, int32_t *m12)
-{
-    std::vector<float> v(n1);
-    for (int i = 0; i < n1; i++) v[i] = (float)dist2[2 * i + 1] - (float)dist2[2 * i];
-    std::nth_element(v.begin(), v.begin() + n1 / 2, v.end(), [](float a, float b) { return a > b; });        // descending order
-    const double nn12_median = (double)v[n1 / 2];
-    for (int i = 0; i < n1; i++) v[i] = fabsf((float)((double)((float)dist2[2 * i + 1] - (float)dist2[2 * i]) - nn12_median));
-    std::nth_element(v.begin(), v.begin() + n1 / 2, v.end());
-    double nn12_th = 1.4826 * (double)v[n1 / 2];
-    nn12_th = nn12_th * 0.5;
-    for (int i = 0; i < n1; i++) {
-        const float d0 = (float)dist2[2 * i], d1 = (float)dist2[2 * i + 1];
-        const double dist_12 = (double)(d1 - d0);
-        m12[i] = (dist_12 > nn12_th && d0 < TH && d0 < nnratio * d1) ? idx2[2 * i] : -1;
-    }
-}
-
+// LSDmatcher::FrameBFMatch (LSDmatcher.cpp:942-966): knn-2, lineDescriptorMAD's threshold and the three tests all run on the
+// device (match.hip: k_hamming_knn2 + k_frame_bf_epilogue); the call stages the two descriptor sets and fetches n1 + 1 ints
 int hvo_frame_bf_match(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float th, float nnratio,
                        int32_t *m12, int *n_matches)
 {
@@ -324,15 +367,12 @@ int hvo_frame_bf_match(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d
     *n_matches = 0;
     for (int i = 0; i < n1; i++) m12[i] = -1;
     if (n1 == 0 || n2 < 2) return HVO_OK;                        // knnMatch(k = 2) needs two train descriptors
-    std::vector<int32_t> idx((size_t)n1 * 2), dist((size_t)n1 * 2);
-    int rc = hvo_hamming_knn2(ctx, d1, n1, d2, n2, idx.data(), dist.data());
-    if (rc) return rc;
-    frame_bf_epilogue(idx.data(), dist.data(), n1, th, nnratio, m12);
-    int m = 0; for (int i = 0; i < n1; i++) m += m12[i] >= 0;
-    *n_matches = m;
-    return HVO_OK;
+    if (!d1 || !d2) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    return match_lines(ctx, d1, n1, d2, n2, th, nnratio, HVO_LINE_MATCH_BF, m12, n_matches);
 }
 
+// LSDmatcher::SearchDouble / SearchByDescriptor core (LSDmatcher.cpp:902-939): FrameBFMatch in both directions + mutual check
 int hvo_search_double(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float th, float nnratio,
                       int32_t *m12, int *n_matches)
 {
@@ -340,17 +380,14 @@ int hvo_search_double(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2
     *n_matches = 0;
     for (int i = 0; i < n1; i++) m12[i] = -1;
     if (n1 == 0 || n2 == 0) return HVO_OK;                       // LSDmatcher.cpp:910-911
-    std::vector<int32_t> m21(n2);
-    int a = 0, b = 0;
-    int rc = hvo_frame_bf_match(ctx, d1, n1, d2, n2, th, nnratio, m12, &a);
-    if (rc) return rc;
-    if ((rc = hvo_frame_bf_match(ctx, d2, n2, d1, n1, th, nnratio, m21.data(), &b))) return rc;
-    int m = 0;
-    for (int i = 0; i < n1; i++) { const int j = m12[i]; if (j >= 0) { if (m21[j] != i) m12[i] = -1; else m++; } }
-    *n_matches = m;
-    return HVO_OK;
+    if (n1 < 2 || n2 < 2) return HVO_OK;                         // one of the two directions has no second neighbour: nothing survives
+    if (!d1 || !d2) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    return match_lines(ctx, d1, n1, d2, n2, th, nnratio, HVO_LINE_MATCH_DOUBLE, m12, n_matches);
 }
 
+// ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, mono) core: ranked window candidates per query, then the
+// reference's sequential pass (occupancy, TH_HIGH, rotation histogram) as a one-wave kernel (match.hip: k_sbp_epilogue)
 int hvo_search_by_projection(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
                              const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur, const float *q_angle,
                              const uint8_t *q_blocks, const hvo_keypoint *t_kp, const float *t_uright, const uint8_t *t_occupied,
@@ -365,66 +402,12 @@ int hvo_search_by_projection(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const 
     if (nt == 0) return HVO_OK;
     if (!t_kp || !t_desc || nt > 65535 || !(mnMaxX > mnMinX) || !(mnMaxY > mnMinY)) return HVO_ERR_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
-    std::vector<unsigned long long> keys((size_t)nq * HVO_SBP_K);
-    std::vector<int> cnt(nq);
-    // host epilogue: the reference's sequential pass (ORBmatcher.cc:1376-1470) over the ranked candidates.
-    // occ = features that already hold an observed map point + features claimed so far.  If a query finds
-    // all of its HVO_SBP_K ranked candidates claimed although more exist, the pass stops there and the
-    // remaining queries are ranked again against the occupancy reached so far (exact; rarely needed).
-    std::vector<uint8_t> occ(nt, 0);
-    if (t_occupied) for (int j = 0; j < nt; j++) occ[j] = t_occupied[j] ? 1 : 0;
-    std::vector<int> rot_bin(nq, -1);
-    int nm = 0;
-    const float factor = 1.0f / 30;
-    int start = 0;
-    while (start < nq) {
-        const int m = nq - start;
-        int rc = match_search_by_projection(ctx, q_desc + (size_t)start * 32, m, q_u + start, q_v + start, q_radius + start, q_min_level + start,
-                                            q_max_level + start, q_ur ? q_ur + start : nullptr, t_kp, t_uright, occ.data(), t_desc, nt,
-                                            mnMinX, mnMinY, mnMaxX, mnMaxY, keys.data(), cnt.data());
-        if (rc) return rc;
-        int i = start;
-        for (; i < nq; i++) {
-            const unsigned long long *kq = &keys[(size_t)(i - start) * HVO_SBP_K];
-            const int total = cnt[i - start], navail = total < HVO_SBP_K ? total : HVO_SBP_K;
-            int k = 0;
-            for (; k < navail; k++) if (!occ[(int)(kq[k] & 0xFFFF)]) break;
-            if (k == navail) { if (total > HVO_SBP_K) break; continue; }     // exhausted: re-rank from query i
-            const int j = (int)(kq[k] & 0xFFFF), d = (int)(kq[k] >> 32);
-            if (d <= th_high) {
-                match_idx[i] = j; match_dist[i] = d; nm++;
-                if (q_blocks[i]) occ[j] = 1;
-                if (check_orientation) {
-                    float rot = q_angle[i] - t_kp[j].angle;
-                    if (rot < 0.0) rot += 360.0f;
-                    int bin = (int)round(rot * factor);
-                    if (bin == 30) bin = 0;
-                    rot_bin[i] = bin;
-                }
-            }
-        }
-        start = i;
-    }
-    int status = HVO_OK;
-    if (check_orientation) {                                  // ComputeThreeMaxima (ORBmatcher.cc:1630-1673)
-        int hist[30] = { 0 };
-        for (int i = 0; i < nq; i++) if (rot_bin[i] >= 0) hist[rot_bin[i]]++;
-        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-        for (int b = 0; b < 30; b++) {
-            const int s = hist[b];
-            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = b; }
-            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = b; }
-            else if (s > max3) { max3 = s; ind3 = b; }
-        }
-        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-        else if (max3 < 0.1f * (float)max1) ind3 = -1;
-        for (int i = 0; i < nq; i++)
-            if (rot_bin[i] >= 0 && rot_bin[i] != ind1 && rot_bin[i] != ind2 && rot_bin[i] != ind3) { match_idx[i] = -1; nm--; }
-    }
-    *n_matches = nm;
-    return status;
+    return match_search_by_projection(ctx, q_desc, nq, q_u, q_v, q_radius, q_min_level, q_max_level, q_ur, q_angle, q_blocks, t_kp, t_uright, t_occupied,
+                                      t_desc, nt, mnMinX, mnMinY, mnMaxX, mnMaxY, th_high, check_orientation, 0, 0.f, match_idx, match_dist, n_matches);
 }
 
+// ORBmatcher::SearchByProjection(F, vpMapPoints, th) core (ORBmatcher.cc:45-132): same ranked candidates, best and second best
+// still-free candidate per query, same-octave ratio test
 int hvo_search_by_projection_map(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
                                  const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur, const uint8_t *q_blocks,
                                  const hvo_keypoint *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
@@ -439,39 +422,8 @@ int hvo_search_by_projection_map(hvo_ctx *ctx, const uint8_t *q_desc, int nq, co
     if (nt == 0) return HVO_OK;
     if (!t_kp || !t_desc || nt > 65535 || !(mnMaxX > mnMinX) || !(mnMaxY > mnMinY)) return HVO_ERR_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
-    std::vector<unsigned long long> keys((size_t)nq * HVO_SBP_K);
-    std::vector<int> cnt(nq);
-    // Same ranked candidates as hvo_search_by_projection; the sequential pass (ORBmatcher.cc:50-128) takes the best and
-    // the second best still-free candidate of every query (ranking order = the reference's first-minimum-wins order).
-    std::vector<uint8_t> occ(nt, 0);
-    if (t_occupied) for (int j = 0; j < nt; j++) occ[j] = t_occupied[j] ? 1 : 0;
-    int nm = 0, start = 0;
-    while (start < nq) {
-        const int m = nq - start;
-        int rc = match_search_by_projection(ctx, q_desc + (size_t)start * 32, m, q_u + start, q_v + start, q_radius + start, q_min_level + start,
-                                            q_max_level + start, q_ur ? q_ur + start : nullptr, t_kp, t_uright, occ.data(), t_desc, nt,
-                                            mnMinX, mnMinY, mnMaxX, mnMaxY, keys.data(), cnt.data());
-        if (rc) return rc;
-        int i = start;
-        for (; i < nq; i++) {
-            const unsigned long long *kq = &keys[(size_t)(i - start) * HVO_SBP_K];
-            const int total = cnt[i - start], navail = total < HVO_SBP_K ? total : HVO_SBP_K;
-            int k1 = -1, k2 = -1;
-            for (int k = 0; k < navail; k++) if (!occ[(int)(kq[k] & 0xFFFF)]) { if (k1 < 0) k1 = k; else { k2 = k; break; } }
-            if (k2 < 0 && total > HVO_SBP_K) break;                         // fewer than two free among the ranked ones: re-rank from query i
-            if (k1 < 0) continue;
-            const int j = (int)(kq[k1] & 0xFFFF), d = (int)(kq[k1] >> 32);
-            if (d >= 256 || d > th_high) continue;                         // bestDist starts at 256 and only strictly smaller distances enter
-            int d2 = 256, lvl2 = -1;
-            if (k2 >= 0 && (int)(kq[k2] >> 32) < 256) { d2 = (int)(kq[k2] >> 32); lvl2 = t_kp[(int)(kq[k2] & 0xFFFF)].octave; }
-            if (t_kp[j].octave == lvl2 && (float)d > nn_ratio * (float)d2) continue;
-            match_idx[i] = j; match_dist[i] = d; nm++;
-            if (q_blocks[i]) occ[j] = 1;
-        }
-        start = i;
-    }
-    *n_matches = nm;
-    return HVO_OK;
+    return match_search_by_projection(ctx, q_desc, nq, q_u, q_v, q_radius, q_min_level, q_max_level, q_ur, nullptr, q_blocks, t_kp, t_uright, t_occupied,
+                                      t_desc, nt, mnMinX, mnMinY, mnMaxX, mnMaxY, th_high, 0, 1, nn_ratio, match_idx, match_dist, n_matches);
 }
 
 int hvo_stereo_from_rgbd(hvo_ctx *ctx, const hvo_keypoint *kp, const hvo_keypoint *kp_un, int n, const uint16_t *depth, int w, int h, int stride,
@@ -513,11 +465,13 @@ void hvo_prof_end(hvo_ctx *ctx, int id)
 // bytes go to dst[f] (either may be null / 0).  The slab is moved in chunks of whole frames with one DMA each into
 // pinned memory (two buffers: the DMA of chunk c+1 runs while the host scatters chunk c), instead of one pageable
 // hipMemcpy per frame and field (each of those is staged synchronously by the runtime, ~2 GB/s).
-int hvo_staged_d2h(hvo_ctx *ctx, hipStream_t st, const void *dev_base, size_t dev_stride, int n, void *const *dst, const size_t *bytes)
+// widen8 != 0: the slab holds int8 values (the plane label image, -1 = none) that the caller's buffers receive as int32:
+// bytes[f] counts SOURCE bytes, dst[f] gets 4 * bytes[f].  The labels cross PCIe as 1 byte per pixel.
+int hvo_staged_d2h(hvo_ctx *ctx, hipStream_t st, const void *dev_base, size_t dev_stride, int n, void *const *dst, const size_t *bytes, int widen8)
 {
     const size_t HALF = 64u << 20;
     if (n <= 0) return HVO_OK;
-    if (dev_stride > HALF) {                                   // a frame larger than a buffer: plain copies
+    if (dev_stride > HALF && !widen8) {                        // a frame larger than a buffer: plain copies
         for (int f = 0; f < n; f++)
             if (dst[f] && bytes[f]) HVO_HIP(hipMemcpyAsync(dst[f], (const char *)dev_base + (size_t)f * dev_stride, bytes[f], hipMemcpyDeviceToHost, st));
         HVO_HIP(hipStreamSynchronize(st));
@@ -526,6 +480,7 @@ int hvo_staged_d2h(hvo_ctx *ctx, hipStream_t st, const void *dev_base, size_t de
     char *stage = (char *)hvo_stage_host(ctx, 2 * HALF);
     if (!stage) { ctx->last_error = "hipHostMalloc (download staging)"; return HVO_ERR_HIP; }
     if (!ctx->ev_stage[0]) for (int i = 0; i < 2; i++) HVO_HIP(hipEventCreateWithFlags(&ctx->ev_stage[i], hipEventDisableTiming));
+    if (dev_stride > HALF) { ctx->last_error = "label slab larger than the staging buffer"; return HVO_ERR_UNSUPPORTED; }
     const int per = (int)std::max<size_t>(1, HALF / dev_stride);
     const int nchunk = (n + per - 1) / per;
     for (int c = 0; c <= nchunk; c++) {
@@ -538,8 +493,14 @@ int hvo_staged_d2h(hvo_ctx *ctx, hipStream_t st, const void *dev_base, size_t de
             const int pc = c - 1, f0 = pc * per, F = std::min(per, n - f0);
             HVO_HIP(hipEventSynchronize(ctx->ev_stage[pc & 1]));
             const char *src = stage + (size_t)(pc & 1) * HALF;
-            for (int f = 0; f < F; f++)
-                if (dst[f0 + f] && bytes[f0 + f]) memcpy(dst[f0 + f], src + (size_t)f * dev_stride, bytes[f0 + f]);
+            for (int f = 0; f < F; f++) {
+                if (!dst[f0 + f] || !bytes[f0 + f]) continue;
+                if (!widen8) memcpy(dst[f0 + f], src + (size_t)f * dev_stride, bytes[f0 + f]);
+                else {
+                    const int8_t *s8 = (const int8_t *)(src + (size_t)f * dev_stride); int32_t *d32 = (int32_t *)dst[f0 + f];
+                    for (size_t k = 0; k < bytes[f0 + f]; k++) d32[k] = (int32_t)s8[k];
+                }
+            }
         }
     }
     return HVO_OK;

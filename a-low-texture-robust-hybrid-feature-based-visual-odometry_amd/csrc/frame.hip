@@ -16,10 +16,11 @@
 #define GRID_CELLS (GRID_COLS * GRID_ROWS)
 #define LINE_CELL_CAP 128          // cells one key line can visit: <= max(64, 48) + 2
 
-__global__ __launch_bounds__(256) void k_undistort(const hvo_keypoint *__restrict__ kp, int n, double fx, double fy, double cx, double cy,
+__global__ __launch_bounds__(256) void k_undistort(const hvo_keypoint *__restrict__ kp, int n_fixed, const int *__restrict__ n_ptr, double fx, double fy, double cx, double cy,
                                                    double k0, double k1, double p1, double p2, double k4, hvo_keypoint *__restrict__ out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = n_ptr ? *n_ptr : n_fixed;                   // the count may only exist on the device (streamed mode)
     if (i >= n) return;
     hvo_keypoint k = kp[i];
     const double ifx = 1. / fx, ify = 1. / fy;
@@ -135,7 +136,7 @@ int frame_undistort(hvo_ctx *ctx, const hvo_keypoint *kp, int n, const float *di
     if (hipMalloc((void **)&d_in, (size_t)n * sizeof(hvo_keypoint)) != hipSuccess || hipMalloc((void **)&d_out, (size_t)n * sizeof(hvo_keypoint)) != hipSuccess) rc = HVO_ERR_HIP;
     if (!rc) {
         (void)hipMemcpyAsync(d_in, kp, (size_t)n * sizeof(hvo_keypoint), hipMemcpyHostToDevice, ctx->stream);
-        hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_in, n, (double)ctx->p.fx, (double)ctx->p.fy, (double)ctx->p.cx, (double)ctx->p.cy,
+        hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_in, n, (const int *)nullptr, (double)ctx->p.fx, (double)ctx->p.fy, (double)ctx->p.cx, (double)ctx->p.cy,
                            (double)dist5[0], (double)dist5[1], (double)dist5[2], (double)dist5[3], (double)dist5[4], d_out);
         (void)hipMemcpyAsync(kp_un, d_out, (size_t)n * sizeof(hvo_keypoint), hipMemcpyDeviceToHost, ctx->stream);
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = HVO_ERR_HIP;
@@ -143,6 +144,27 @@ int frame_undistort(hvo_ctx *ctx, const hvo_keypoint *kp, int n, const float *di
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
     return rc;
+}
+
+// device-resident Frame::UndistortKeyPoints: d_kp -> d_out for the first *d_n (<= n_max) key points; k1 == 0 copies (Frame.cc:1703-1707)
+int frame_undistort_enqueue(hvo_ctx *ctx, hipStream_t st, const hvo_keypoint *d_kp, const int *d_n, int n_max, const float *dist5, hvo_keypoint *d_out)
+{
+    if (n_max < 1) return HVO_OK;
+    if (dist5[0] == 0.0f) { HVO_HIP(hipMemcpyAsync(d_out, d_kp, (size_t)n_max * sizeof(hvo_keypoint), hipMemcpyDeviceToDevice, st)); return HVO_OK; }
+    hipLaunchKernelGGL(k_undistort, dim3((n_max + 255) / 256), dim3(256), 0, st, d_kp, n_max, d_n, (double)ctx->p.fx, (double)ctx->p.fy, (double)ctx->p.cx, (double)ctx->p.cy,
+                       (double)dist5[0], (double)dist5[1], (double)dist5[2], (double)dist5[3], (double)dist5[4], d_out);
+    HVO_HIP(hipGetLastError());
+    return HVO_OK;
+}
+
+__global__ __launch_bounds__(256) void k_gather_angles(const hvo_keypoint *__restrict__ kp, const int *__restrict__ idx, int n, float *__restrict__ angle)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) angle[i] = kp[idx[i]].angle;
+}
+void frame_gather_angles_enqueue(hipStream_t st, const hvo_keypoint *d_kp, const int *d_idx, int n, float *d_angle)
+{
+    if (n > 0) hipLaunchKernelGGL(k_gather_angles, dim3((n + 255) / 256), dim3(256), 0, st, d_kp, d_idx, n, d_angle);
 }
 
 int frame_image_bounds(hvo_ctx *ctx, int w, int h, const float *dist5, float *bounds4)

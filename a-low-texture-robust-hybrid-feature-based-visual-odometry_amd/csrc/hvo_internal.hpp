@@ -76,6 +76,7 @@ struct hvo_ctx {
     int sched = 1;                         // overlap policy of hvo_batch_run, see api.hip
     double cull_dis = 5.0, cull_angle = 2.5, cull_endpoint = 15.0;   // Frame::cullingLine(im, 5, 2.5, 15, 30), Frame.cc:934
     bool last_cull = false;                // the resident batch was run with HVO_STAGE_LSD_CULL
+    unsigned last_stages = 0;              // stages hvo_batch_run has computed for the resident batch (hvo_batch_download reports only these)
     std::string last_error;
     OrbPlan orb;
     // ORB tables
@@ -86,9 +87,8 @@ struct hvo_ctx {
     // resident batch
     int batch_n = 0, batch_w = 0, batch_h = 0;
     bool have_depth = false;
-    // matcher scratch
-    uint8_t *d_mq = nullptr, *d_mt = nullptr; size_t mq_cap = 0, mt_cap = 0;
-    void *d_mout = nullptr; size_t mout_cap = 0;
+    // matcher staging arena (match.hip)
+    void *marena = nullptr;
     // host staging (pinned)
     void *h_stage = nullptr; size_t h_stage_cap = 0;
     hipEvent_t ev_stage[2] = { nullptr, nullptr };     // download staging (hvo_staged_d2h)
@@ -160,7 +160,7 @@ static inline hipStream_t hvo_stream_peac(hvo_ctx *c);
 int  hvo_prof_begin(hvo_ctx *ctx, const char *name, hipStream_t st);
 void hvo_prof_end(hvo_ctx *ctx, int id);
 void *hvo_stage_host(hvo_ctx *ctx, size_t bytes);
-int hvo_staged_d2h(hvo_ctx *ctx, hipStream_t st, const void *dev_base, size_t dev_stride, int n, void *const *dst, const size_t *bytes);
+int hvo_staged_d2h(hvo_ctx *ctx, hipStream_t st, const void *dev_base, size_t dev_stride, int n, void *const *dst, const size_t *bytes, int widen8 = 0);
 
 // orb.hip
 int orb_init_tables(hvo_ctx *ctx);
@@ -171,30 +171,56 @@ int orb_run(hvo_ctx *ctx, int n);
 int orb_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
 
 // match.hip
+#define HVO_SBP_K 16
+// device-resident arguments of the guided search (ORBmatcher::SearchByProjection cores)
+struct SbpDev {
+    const uint8_t *q_desc; const int *q_desc_index;            // query i's descriptor = q_desc + 32 * (q_desc_index ? q_desc_index[i] : i)
+    const float *q_u, *q_v, *q_radius; const int *q_min_level, *q_max_level; const float *q_ur, *q_angle; const uint8_t *q_blocks;
+    const hvo_keypoint *t_kp; const float *t_uright; const uint8_t *t_occ; const uint8_t *t_desc;
+    int nq, nt; float mnMinX, mnMinY, mnMaxX, mnMaxY;
+    int th_high, check_orientation, map_mode; float nn_ratio;
+    unsigned long long *keys; int *cnt;                        // scratch (match_sbp_enqueue carves them)
+    int32_t *match_idx, *match_dist; int *n_matches;          // results
+};
 int match_matrix(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *d);
 int match_knn2(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx2, int32_t *dist2);
+int match_knn2_enqueue(hipStream_t st, const uint8_t *dq, int nq, const uint8_t *dt, int nt, int32_t *d_idx2, int32_t *d_dist2);
 void match_free(hvo_ctx *ctx);
-#define HVO_SBP_K 16
+size_t match_sbp_scratch_bytes(int nq);
+int match_sbp_enqueue(hipStream_t st, SbpDev a, void *scratch);
 int match_search_by_projection(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
-                               const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur,
+                               const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur, const float *q_angle, const uint8_t *q_blocks,
                                const hvo_keypoint *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
-                               float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, unsigned long long *keys, int *cnt);
+                               float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, int th_high, int check_orientation, int map_mode, float nn_ratio,
+                               int32_t *match_idx, int32_t *match_dist, int *n_matches);
+size_t match_lines_scratch_bytes(int n1, int n2);
+int match_lines_enqueue(hipStream_t st, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float TH, float nnratio, int mode,
+                        void *scratch, int32_t *d_m12, int *d_nmatch);
+int match_lines(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float th, float nnratio, int mode, int32_t *m12, int *n_matches);
+int match_stereo_enqueue(hipStream_t st, const hvo_keypoint *d_kp, const hvo_keypoint *d_kpun, const int *d_n, int n_max, const uint16_t *d_depth, int pitch,
+                         int w, int h, float dfac, float bf, float *d_uright, float *d_zdepth);
 int match_stereo_from_rgbd(hvo_ctx *ctx, const hvo_keypoint *kp, const hvo_keypoint *kpun, int n, const uint16_t *depth, int w, int h, int stride,
                            float bf, float *uright, float *zdepth);
 
 // frame.hip
 int frame_undistort(hvo_ctx *ctx, const hvo_keypoint *kp, int n, const float *dist5, hvo_keypoint *kp_un);
 int frame_image_bounds(hvo_ctx *ctx, int w, int h, const float *dist5, float *bounds4);
+int frame_undistort_enqueue(hvo_ctx *ctx, hipStream_t st, const hvo_keypoint *d_kp, const int *d_n, int n_max, const float *dist5, hvo_keypoint *d_out);
+void frame_gather_angles_enqueue(hipStream_t st, const hvo_keypoint *d_kp, const int *d_idx, int n, float *d_angle);
 int frame_points_to_grid(hvo_ctx *ctx, const hvo_keypoint *kp_un, int n, const float *bounds4, int32_t *cell_start, int32_t *cell_items, int *n_out);
 int frame_lines_to_grid(hvo_ctx *ctx, const hvo_keyline *kl, int n, const float *bounds4, int32_t *cell_start, int32_t *cell_items, int cap, int *n_out);
 
 // peac.hip
+struct PeacView { uint16_t *d_depth; int pitch; size_t dframe; int8_t *d_labels8; hvo_plane *d_planes; int *d_meta; int npix, max_planes; };
+int peac_prepare(hvo_ctx *ctx, int w, int h, int batch, PeacView *v);      // plan for this geometry + where its inputs / results live
 int peac_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h);
 int peac_run(hvo_ctx *ctx, int n);
 int peac_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
 void peac_free(hvo_ctx *ctx);
 
 // lsd.hip (+ lbd)
+struct LsdView { hvo_keyline *d_kl; uint8_t *d_desc; double *d_fn; int *d_nkl; int *d_flags; int nfeat; };
+int lsd_prepare(hvo_ctx *ctx, int w, int h, int batch, bool culled, LsdView *v);
 int lsd_run(hvo_ctx *ctx, int n, bool cull = false);
 int lsd_download(hvo_ctx *ctx, int n, hvo_frame_out *out, bool culled = false);
 void lsd_free(hvo_ctx *ctx);

@@ -1131,12 +1131,21 @@ void lsd_free(hvo_ctx *ctx)
 
 static int cvfloor_f(float v) { int i = (int)v; return i - (i > v); }
 
+static int lsd_build_plan(hvo_ctx *ctx, int w, int h, int batch);
+// as orb_ensure_plan: a plan that fails half-way is freed, so its (w, h, batch) key never outlives its slabs
 static int lsd_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
 {
     LsdPlan *P = plan_of(ctx);
     if (P && P->w == w && P->h == h && P->batch >= batch) return HVO_OK;
     lsd_free(ctx);
-    P = new LsdPlan();
+    const int rc = lsd_build_plan(ctx, w, h, batch);
+    if (rc) lsd_free(ctx);
+    return rc;
+}
+
+static int lsd_build_plan(hvo_ctx *ctx, int w, int h, int batch)
+{
+    LsdPlan *P = new LsdPlan();
     ctx->lsd = P;
     P->w = w; P->h = h; P->batch = batch; P->nfeat = std::max(ctx->p.lsd_nfeatures, 1);
     P->sw = (int)lrint(w * 0.8); P->sh = (int)lrint(h * 0.8);
@@ -1201,7 +1210,20 @@ static int lsd_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
     HVO_HIP(hipMemcpy(P->d_gL, gLf.data(), 21 * 4, hipMemcpyHostToDevice));
     HVO_HIP(hipMemcpy(P->d_gG, gGf.data(), 63 * 4, hipMemcpyHostToDevice));
     HVO_HIP(hipMemsetAsync(P->d_defined, 0, B * P->nwords * 4, ctx->s_lsd));
+    HVO_HIP(hipMemsetAsync(P->d_nkl, 0, B * 4, ctx->s_lsd));
+    HVO_HIP(hipMemsetAsync(P->d_nkl2, 0, B * 4, ctx->s_lsd));
+    HVO_HIP(hipMemsetAsync(P->d_flags, 0, B * 4, ctx->s_lsd));
     HVO_HIP(hipDeviceSynchronize());
+    return HVO_OK;
+}
+
+int lsd_prepare(hvo_ctx *ctx, int w, int h, int batch, bool culled, LsdView *v)
+{
+    int rc = lsd_ensure_plan(ctx, w, h, batch);
+    if (rc) return rc;
+    LsdPlan *P = plan_of(ctx);
+    v->d_kl = culled ? P->d_kl2 : P->d_kl; v->d_desc = culled ? P->d_desc2 : P->d_desc; v->d_fn = culled ? P->d_fn2 : P->d_fn;
+    v->d_nkl = culled ? P->d_nkl2 : P->d_nkl; v->d_flags = P->d_flags; v->nfeat = P->nfeat;
     return HVO_OK;
 }
 
@@ -1305,6 +1327,7 @@ extern "C" int hvo_extract_lsd(hvo_ctx *ctx, const uint8_t *gray, int w, int h, 
     in.gray = gray; in.gray_stride = stride;
     int rc = orb_upload(ctx, 1, &in, w, h);
     if (rc) return rc;
+    ctx->last_stages = 0;                                  // slot 0 of the resident batch has been overwritten
     for (int i = 0; i < ctx->nprof; i++) ctx->prof[i].used = false;
     if ((rc = lsd_run(ctx, 1))) return rc;
     hvo_frame_out out; memset(&out, 0, sizeof(out));
@@ -1328,6 +1351,7 @@ extern "C" int hvo_extract_lsd_culled(hvo_ctx *ctx, const uint8_t *gray, int w, 
     in.gray = gray; in.gray_stride = stride;
     int rc = orb_upload(ctx, 1, &in, w, h);
     if (rc) return rc;
+    ctx->last_stages = 0;                                  // slot 0 of the resident batch has been overwritten
     for (int i = 0; i < ctx->nprof; i++) ctx->prof[i].used = false;
     if ((rc = lsd_run(ctx, 1, true))) return rc;
     hvo_frame_out out; memset(&out, 0, sizeof(out));

@@ -876,12 +876,24 @@ template <class T> static int dev_upload(hvo_ctx *ctx, T **p, const std::vector<
     return HVO_OK;
 }
 
+static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch);
+// The cache key (w, h, batch) stays valid only if every table and slab behind it exists: a geometry that is rejected
+// half-way (a level below 38 pixels, a cell larger than the LDS tile, an allocation failure) frees the partial plan,
+// which resets the key, so that the next call with the same geometry is rejected again instead of running on null slabs.
 int orb_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
 {
     OrbPlan &P = ctx->orb;
     if (P.w == w && P.h == h && P.batch >= batch) return HVO_OK;
     if (w < 64 || h < 64 || w > 4095 || h > 4095) return HVO_ERR_UNSUPPORTED;
     orb_free_plan(ctx);
+    const int rc = orb_build_plan(ctx, w, h, batch);
+    if (rc) orb_free_plan(ctx);
+    return rc;
+}
+
+static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch)
+{
+    OrbPlan &P = ctx->orb;
     const int nl = ctx->p.orb_nlevels;
     P.w = w; P.h = h; P.nlevels = nl; P.batch = batch;
     std::vector<CellDesc> cells;
@@ -1013,6 +1025,7 @@ int orb_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
     HVO_HIP(hipMemsetAsync(P.d_pyr, 0, B * P.pyr_bytes + 256, ctx->stream));
     HVO_HIP(hipMemsetAsync(P.d_blur, 0, B * P.pyr_bytes + 256, ctx->stream));
     HVO_HIP(hipMemsetAsync(P.d_flags, 0, B * sizeof(int), ctx->stream));
+    HVO_HIP(hipMemsetAsync(P.d_nkp, 0, B * sizeof(int), ctx->stream));
     HVO_HIP(hipDeviceSynchronize());     // also drains the null-stream table uploads above
     return HVO_OK;
 }

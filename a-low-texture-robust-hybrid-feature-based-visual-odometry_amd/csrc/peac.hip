@@ -40,12 +40,13 @@ struct PeacPlan {
     int *d_parent = nullptr, *d_dsize = nullptr, *d_eflag = nullptr;
     int *d_meta = nullptr;          // per frame 16 ints: [0]=nseg [1]=pooltop [2]=nextracted [3]=flags [4]=nfinal [5]=nq
     int *d_extracted = nullptr;     // per frame MAX_PLANES seg ids (coarse planes), then MAX_PLANES final
-    int *d_blkmap = nullptr; int32_t *d_labels = nullptr; uint2 *d_state = nullptr;
+    int *d_blkmap = nullptr; int8_t *d_labels = nullptr; uint2 *d_state = nullptr;     // labels: int8 on the device and on the wire (<= 64 planes), int32 at the ABI
     int *d_queue = nullptr; int *d_plidmap = nullptr; int *d_isvalid = nullptr;
     hvo_plane *d_planes = nullptr;
     unsigned long long *d_adj = nullptr;
     double *d_hkey = nullptr; int *d_hid = nullptr;
     double c15 = 0, c60 = 0, c30 = 0;   // cos thresholds evaluated on the host (glibc), like the oracle
+    double ang_factor = 0, ang_near = 0;
 };
 
 static PeacPlan *plan_of(hvo_ctx *ctx) { return (PeacPlan *)ctx->peac; }
@@ -203,7 +204,19 @@ struct ClArgs {
     double *hkey; int *hid;
     int segcap, poolcap, nblk, Nw, Nh;
     double c15, c60;
+    double ang_factor, ang_near;   // T_ang(P_INIT): (angle_far - angle_near) / (z_far - z_near), angle_near (AHCParamSet.hpp:113-121)
 };
+
+// ParamSet::T_ang(P_INIT, z) (AHCParamSet.hpp:113-121).  With metric depth z never exceeds z_near = 500 and the threshold is
+// the constant cos(15 deg) the host evaluated with its own libm (bit-identical to the oracle).  A depth_map_factor that
+// yields z > 500 (e.g. DepthMapFactor 1 with depth in millimetres) takes the general branch; device cos() and glibc cos()
+// may differ in the last bit there, which matters only for a block pair whose similarity equals the threshold to 1 ulp.
+static __device__ __forceinline__ double t_ang_init(const ClArgs &a, double z)
+{
+    if (!(z > 500.0)) return a.c15;
+    const double cz = z < 4000.0 ? z : 4000.0;
+    return cos(a.ang_factor * cz + a.ang_near - a.ang_factor * 500.0);
+}
 
 static __device__ __forceinline__ double nsim(const double *a, const double *b)
 {
@@ -899,7 +912,7 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
             if (!GOK(c - 1)) { --j; continue; }
             if (!GOK(c)) continue;
             if (j < Nw - 1 && !GOK(c + 1)) { ++j; continue; }
-            const double th = a.c15;                    // T_ang(P_INIT, z): z (metres) < z_near (500) always
+            const double th = t_ang_init(a, SD(c)[11]);   // T_ang(P_INIT, G[cidx]->center[2]), AHCPlaneFitter.hpp:903
             if ((j < Nw - 1 && nsim(SD(c - 1), SD(c + 1)) >= th) || (j == Nw - 1 && nsim(SD(c), SD(c - 1)) >= th)) {
                 eflag[c] |= 1; eflag[c - 1] |= 2;
                 if (j < Nw - 1) { eflag[c] |= 2; eflag[c + 1] |= 1; }
@@ -913,7 +926,7 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
             if (!GOK(c - Nw)) { --i; continue; }
             if (!GOK(c)) continue;
             if (i < Nh - 1 && !GOK(c + Nw)) { ++i; continue; }
-            const double th = a.c15;
+            const double th = t_ang_init(a, SD(c)[11]);   // AHCPlaneFitter.hpp:933
             if ((i < Nh - 1 && nsim(SD(c - Nw), SD(c + Nw)) >= th) || (i == Nh - 1 && nsim(SD(c), SD(c - Nw)) >= th)) {
                 eflag[c] |= 4; eflag[c - Nw] |= 8;
                 if (i < Nh - 1) { eflag[c] |= 8; eflag[c + Nw] |= 4; }
@@ -1492,15 +1505,25 @@ __global__ __launch_bounds__(64) void k_peac_final(RfArgs r, const unsigned long
     }
 }
 
-__global__ __launch_bounds__(256) void k_peac_relabel(const uint2 *__restrict__ state, int32_t *__restrict__ labels, const int *__restrict__ plidmap, int npix)
+// labels are written as int8 (plane ids < MAX_PLANES = 64, -1 = none), four pixels per thread and store; npix4 = ceil(npix / 4)
+// and the label slab of a frame is padded to a multiple of 4 bytes
+__global__ __launch_bounds__(256) void k_peac_relabel(const uint2 *__restrict__ state, int8_t *__restrict__ labels, const int *__restrict__ plidmap, int npix, size_t lframe)
 {
     const int frame = blockIdx.y;
     const uint2 *S = state + (size_t)frame * npix;
-    int32_t *L = labels + (size_t)frame * npix;
+    unsigned *L = reinterpret_cast<unsigned *>(labels + (size_t)frame * lframe);
     const int *pm = plidmap + (size_t)frame * MAX_PLANES;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
-        const int v = FS_LABEL(S[i].x);
-        L[i] = (v >= 0 && pm[v] >= 0) ? pm[v] : -1;
+    const int npix4 = (npix + 3) >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix4; i += gridDim.x * 256) {
+        unsigned out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int px = 4 * i + k;
+            int lab = -1;
+            if (px < npix) { const int v = FS_LABEL(S[px].x); lab = (v >= 0 && pm[v] >= 0) ? pm[v] : -1; }
+            out |= ((unsigned)lab & 0xFFu) << (8 * k);
+        }
+        L[i] = out;
     }
 }
 
@@ -1518,21 +1541,32 @@ void peac_free(hvo_ctx *ctx)
     ctx->peac = nullptr;
 }
 
+static int peac_build_plan(hvo_ctx *ctx, int w, int h, int batch);
+// as orb_ensure_plan: a plan that fails half-way is freed, so its (w, h, batch) key never outlives its slabs
 static int peac_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
 {
     PeacPlan *P = plan_of(ctx);
     if (P && P->w == w && P->h == h && P->batch >= batch) return HVO_OK;
     if (w < 2 * WIN || h < 2 * WIN || w > 4096 || h > 4096) return HVO_ERR_UNSUPPORTED;
     peac_free(ctx);
-    P = new PeacPlan();
+    const int rc = peac_build_plan(ctx, w, h, batch);
+    if (rc) peac_free(ctx);
+    return rc;
+}
+
+static int peac_build_plan(hvo_ctx *ctx, int w, int h, int batch)
+{
+    PeacPlan *P = new PeacPlan();
     ctx->peac = P;
     P->w = w; P->h = h; P->pitch = (w + 31) & ~31; P->Nw = w / WIN; P->Nh = h / WIN; P->nblk = P->Nw * P->Nh;
     P->segcap = 2 * P->nblk + 2 * MAX_PLANES; P->poolcap = 16 * P->nblk + 2 * MAX_PLANES * MAX_PLANES; P->qcap = 2 * w * h + 65536; P->batch = batch;
-    const double deg = 3.14159265358979323846 / 180.0;
+#define HVO_DEG2RAD(d) ((d) * 3.14159265358979323846 / 180.0)      /* MACRO_DEG2RAD, AHCParamSet.hpp:33: (d)*M_PI/180.0, in that order */
     // ParamSet: T_ang(P_INIT) clipped at z_near, similarityTh_merge, similarityTh_refine (AHCParamSet.hpp:68-76,113-134)
-    const double factor = (90.0 * deg - 15.0 * deg) / (4000.0 - 500.0);
-    P->c15 = cos(factor * 500.0 + 15.0 * deg - factor * 500.0);
-    P->c60 = cos(60.0 * deg); P->c30 = cos(30.0 * deg);
+    const double factor = (HVO_DEG2RAD(90.0) - HVO_DEG2RAD(15.0)) / (4000.0 - 500.0);
+    P->c15 = cos(factor * 500.0 + HVO_DEG2RAD(15.0) - factor * 500.0);
+    P->ang_factor = factor; P->ang_near = HVO_DEG2RAD(15.0);
+    P->c60 = cos(HVO_DEG2RAD(60.0)); P->c30 = cos(HVO_DEG2RAD(30.0));
+#undef HVO_DEG2RAD
     const size_t B = batch, npix = (size_t)w * h;
 #define PA(ptr, n) HVO_HIP(hipMalloc((void **)&(ptr), (n)))
     PA(P->d_depth, B * P->pitch * (h + 1) * sizeof(uint16_t));
@@ -1542,7 +1576,7 @@ static int peac_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_pool2, B * P->poolcap * sizeof(int));
     PA(P->d_parent, B * P->nblk * sizeof(int)); PA(P->d_dsize, B * P->nblk * sizeof(int)); PA(P->d_eflag, B * P->nblk * sizeof(int));
     PA(P->d_meta, B * 16 * sizeof(int)); PA(P->d_extracted, B * 2 * MAX_PLANES * sizeof(int));
-    PA(P->d_blkmap, B * P->nblk * sizeof(int)); PA(P->d_labels, B * npix * sizeof(int32_t)); PA(P->d_state, B * npix * sizeof(uint2));
+    PA(P->d_blkmap, B * P->nblk * sizeof(int)); PA(P->d_labels, B * ((npix + 3) & ~(size_t)3)); PA(P->d_state, B * npix * sizeof(uint2));
     PA(P->d_queue, B * P->qcap * sizeof(int));
     PA(P->d_plidmap, B * MAX_PLANES * sizeof(int)); PA(P->d_isvalid, B * MAX_PLANES * sizeof(int));
     PA(P->d_planes, B * MAX_PLANES * sizeof(hvo_plane));
@@ -1551,7 +1585,18 @@ static int peac_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
 #undef PA
     // stream-ordered fill: a null-stream hipMemset is not ordered against the non-blocking ctx stream
     HVO_HIP(hipMemsetAsync(P->d_depth, 0, B * P->pitch * (h + 1) * sizeof(uint16_t), ctx->s_peac));
+    HVO_HIP(hipMemsetAsync(P->d_meta, 0, B * 16 * sizeof(int), ctx->s_peac));
     HVO_HIP(hipDeviceSynchronize());
+    return HVO_OK;
+}
+
+int peac_prepare(hvo_ctx *ctx, int w, int h, int batch, PeacView *v)
+{
+    int rc = peac_ensure_plan(ctx, w, h, batch);
+    if (rc) return rc;
+    PeacPlan *P = plan_of(ctx);
+    v->d_depth = P->d_depth; v->pitch = P->pitch; v->dframe = (size_t)P->pitch * (h + 1); v->d_labels8 = P->d_labels; v->d_planes = P->d_planes;
+    v->d_meta = P->d_meta; v->npix = w * h; v->max_planes = MAX_PLANES;
     return HVO_OK;
 }
 
@@ -1586,6 +1631,7 @@ int peac_run(hvo_ctx *ctx, int n)
     a.segD = P->d_segD; a.segI = P->d_segI; a.pool = P->d_pool; a.pool2 = P->d_pool2; a.parent = P->d_parent; a.dsize = P->d_dsize; a.eflag = P->d_eflag;
     a.meta = P->d_meta; a.extracted = P->d_extracted; a.segcap = P->segcap; a.poolcap = P->poolcap; a.nblk = P->nblk; a.Nw = P->Nw; a.Nh = P->Nh;
     a.c15 = P->c15; a.c60 = P->c60; a.hkey = P->d_hkey; a.hid = P->d_hid;
+    a.ang_factor = P->ang_factor; a.ang_near = P->ang_near;
     id = hvo_prof_begin(ctx, "peac_cluster", st);
     {
         // 4 frames per wave pay off once the wave slots are saturated (measured: >= ~3000 resident frames);
@@ -1621,7 +1667,7 @@ int peac_run(hvo_ctx *ctx, int n)
         else hipLaunchKernelGGL((k_peac_flood<128, 1>), dim3(n), dim3(128), 0, st, r, P->d_adj);
     }
     hipLaunchKernelGGL(k_peac_final, dim3(n), dim3(64), 0, st, r, P->d_adj);
-    hipLaunchKernelGGL(k_peac_relabel, dim3(64, n), dim3(256), 0, st, P->d_state, P->d_labels, P->d_plidmap, P->w * P->h);
+    hipLaunchKernelGGL(k_peac_relabel, dim3(64, n), dim3(256), 0, st, P->d_state, P->d_labels, P->d_plidmap, P->w * P->h, ((size_t)P->w * P->h + 3) & ~(size_t)3);
     hvo_prof_end(ctx, id);
     HVO_HIP(hipGetLastError());
     return HVO_OK;
@@ -1639,7 +1685,7 @@ int peac_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
     for (int f = 0; f < n; f++) {
         const int nfin = meta[(size_t)f * 16 + 4], flags = meta[(size_t)f * 16 + 3];
         if (flags) out[f].status = HVO_ERR_CAPACITY;
-        if (out[f].labels) { dl[f] = out[f].labels; bl[f] = npix * sizeof(int32_t); }
+        if (out[f].labels) { dl[f] = out[f].labels; bl[f] = npix; }          // int8 on the wire, widened to int32 while scattering
         int m = nfin;
         if (out[f].planes) {
             if (m > out[f].pl_cap) { m = out[f].pl_cap; out[f].status = HVO_ERR_CAPACITY; }
@@ -1647,7 +1693,7 @@ int peac_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
         }
         out[f].n_planes = m;
     }
-    int rc = hvo_staged_d2h(ctx, ctx->s_peac, P->d_labels, npix * sizeof(int32_t), n, dl.data(), bl.data());
+    int rc = hvo_staged_d2h(ctx, ctx->s_peac, P->d_labels, (npix + 3) & ~(size_t)3, n, dl.data(), bl.data(), 1);
     if (rc) return rc;
     if ((rc = hvo_staged_d2h(ctx, ctx->s_peac, P->d_planes, (size_t)MAX_PLANES * sizeof(hvo_plane), n, dp.data(), bp.data()))) return rc;
     HVO_HIP(hipStreamSynchronize(ctx->s_peac));
@@ -1666,6 +1712,7 @@ extern "C" int hvo_compute_planes(hvo_ctx *ctx, const uint16_t *depth, int w, in
     in.depth = depth; in.depth_stride = stride;
     int rc = peac_upload(ctx, 1, &in, w, h);
     if (rc) return rc;
+    ctx->last_stages = 0;                                  // slot 0 of the resident batch has been overwritten
     for (int i = 0; i < ctx->nprof; i++) ctx->prof[i].used = false;
     if ((rc = peac_run(ctx, 1))) return rc;
     hvo_frame_out out; memset(&out, 0, sizeof(out));

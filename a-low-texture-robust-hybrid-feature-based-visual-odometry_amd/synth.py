@@ -157,3 +157,26 @@ def make_batch(kind, seed0, n, w=640, h=480):
     for k in range(n):
         g[k], d[k] = make_frame(kind, seed0 + k, w, h)
     return g, d
+
+
+def make_sequence(kind, seed, n, w=640, h=480, max_step=4, pad=(192, 144)):
+    """n frames of ONE scene seen through a window that drifts smoothly (<= max_step pixels per frame and axis): the
+    stand-in for a camera sequence (SURVEY.md 8d item 5, `stream-573`).  Gray and depth are cut out of a larger scene;
+    per-frame sensor noise is added to the gray image.  Returns (gray (n,h,w) u8, depth (n,h,w) u16, offsets (n,2) int)."""
+    W, H = w + pad[0], h + pad[1]
+    G = make_gray(kind, seed, W, H).astype(np.int32)
+    D = make_depth(seed, W, H)
+    r = _randint(seed, 20, 4, 0, 1 << 16).astype(np.float64) / 65536.0
+    ox = np.zeros(n, np.int64); oy = np.zeros(n, np.int64)
+    x = pad[0] / 2.0; y = pad[1] / 2.0
+    for k in range(n):
+        # a Lissajous-like drift whose per-frame step stays below max_step
+        vx = max_step * 0.9 * np.sin(2 * np.pi * (k / 97.0 + r[0])); vy = max_step * 0.9 * np.cos(2 * np.pi * (k / 61.0 + r[1]))
+        x = min(max(x + vx, 0.0), float(pad[0])); y = min(max(y + vy, 0.0), float(pad[1]))
+        ox[k] = int(round(x)); oy[k] = int(round(y))
+    g = np.empty((n, h, w), np.uint8); d = np.empty((n, h, w), np.uint16)
+    for k in range(n):
+        nz = _randint(seed + 7919 * (k + 1), 21, w * h, -2, 3).reshape(h, w)
+        g[k] = np.clip(G[oy[k]:oy[k] + h, ox[k]:ox[k] + w] + nz, 0, 255).astype(np.uint8)
+        d[k] = D[oy[k]:oy[k] + h, ox[k]:ox[k] + w]
+    return g, d, np.stack([ox, oy], axis=1)

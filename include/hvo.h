@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define HVO_ABI_VERSION 1
+#define HVO_ABI_VERSION 2      /* 2: streamed-sequence entry points (hvo_stream_*), HVO_ERR_BUSY */
 
 typedef enum {
     HVO_OK = 0,
@@ -48,8 +48,9 @@ typedef enum {
     HVO_ERR_HIP = -3,           /* a HIP runtime call failed (hvo_last_error has the text) */
     HVO_ERR_UNSUPPORTED = -4,   /* image geometry outside what the kernels were sized for */
     HVO_ERR_CAPACITY = -5,      /* an internal fixed-capacity slab overflowed; results truncated */
-    HVO_ERR_BAD_DTYPE = -6      /* mirrors the CV_8UC1 assert (ORBextractor.cc:1048) and the
+    HVO_ERR_BAD_DTYPE = -6,     /* mirrors the CV_8UC1 assert (ORBextractor.cc:1048) and the
                                    CV_16U check (PlaneExtractor.cpp:34-38) */
+    HVO_ERR_BUSY = -7           /* hvo_stream_submit: the ring slot still holds a frame that was not collected */
 } hvo_status;
 
 /* == cv::KeyPoint (28 bytes): what ORBextractor::operator() fills (ORBextractor.cc:1041-1103) */
@@ -233,9 +234,65 @@ int hvo_batch_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h);
 int hvo_batch_run(hvo_ctx *ctx, unsigned stages);
 /* HBM -> host copy of results (any pointer in hvo_frame_out may be NULL to skip it) */
 int hvo_batch_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
+/* Result slabs in device memory (the only multi-GPU exchange is a gather of these).  One record of *slab_bytes per
+ * frame: int32 {n_kp, n_kl, n_planes, status}, kp[kp_cap] (28 B), desc[kp_cap] (32 B), kl[kl_cap] (68 B), ldesc[kl_cap] (32 B),
+ * linefn[kl_cap] (3 doubles), planes[pl_cap] (64 B); entries beyond the counts are zero.  hvo_batch_pack_results writes the first
+ * n frames of the resident batch to d_slabs, a DEVICE pointer with room for n * slab_bytes (e.g. the tensor handed to
+ * ncclAllGather); stages that did not run report zero counts. */
+int hvo_batch_slab_layout(hvo_ctx *ctx, int *kp_cap, int *kl_cap, int *pl_cap, size_t *slab_bytes);
+int hvo_batch_pack_results(hvo_ctx *ctx, int n, void *d_slabs);
 /* upload + run + download */
 int hvo_extract_batch(hvo_ctx *ctx, int n, const hvo_frame_in *in, hvo_frame_out *out, int w, int h,
                       unsigned stages);
+
+/* ---- streamed sequence (BASELINE config 5) -----------------------------------------------------------------
+ * The reference constructs one Frame per camera image (src/Tracking.cc:262 -> Frame ctor src/Frame.cc:205-233: ExtractORB ||
+ * ExtractLSD || ComputePlanes on three threads, then UndistortKeyPoints / ComputeStereoFromRGBD) and matches it against the
+ * previous frame (TrackWithMotionModel: SearchByProjection(Cur, Last) src/Tracking.cc:2396, LSDmatcher::match(Last.mLdesc,
+ * Cur.mLdesc) src/Tracking.cc:2299 -> src/LSDmatcher.cpp:42).  A hvo_stream keeps `depth` frames in flight on the GPU (one
+ * frame's serial chains -- AHC, region growing -- leave most of the chip idle, the next frames run beside them) and the
+ * results of the last `depth` frames resident in HBM, so the frame-to-frame matching reads descriptors, undistorted key
+ * points and mvuRight where they were produced: only the tracker's per-query projections cross PCIe.
+ *   submit  : copies the images into pinned staging, enqueues uploads + every kernel + result downloads, returns at once
+ *   collect : waits for that frame and copies its results out (tickets may be collected in any order; a slot is reused
+ *             by ticket + depth, which is refused with HVO_ERR_BUSY until the slot's frame was collected)
+ * A frame stays matchable until `depth` newer frames have been submitted.  Not thread-safe. */
+typedef struct hvo_stream hvo_stream;
+typedef struct {
+    int32_t  width, height;
+    int32_t  depth;             /* frames in flight / resident (ring slots), 2..16 */
+    uint32_t stages;            /* HVO_STAGE_* mask */
+    float    dist5[5];          /* k1 k2 p1 p2 k3 for UndistortKeyPoints (k1 == 0: key points are copied, Frame.cc:1703-1707) */
+    float    bf;                /* ComputeStereoFromRGBD's mbf; <= 0: mvuRight / mvDepth are not computed */
+} hvo_stream_params;
+#define HVO_LINE_MATCH_NNR 0    /* LSDmatcher::match -> matchNNR (src/LSDmatcher.cpp:803-863): d0 < nnr * d1 */
+#define HVO_LINE_MATCH_BF 1     /* LSDmatcher::FrameBFMatch (942-966) */
+#define HVO_LINE_MATCH_DOUBLE 2 /* LSDmatcher::SearchDouble (902-939): both directions + mutual check */
+
+int  hvo_stream_create(const hvo_params *p, const hvo_stream_params *sp, hvo_stream **out);
+void hvo_stream_destroy(hvo_stream *s);
+const char *hvo_stream_last_error(const hvo_stream *s);
+/* capacities of the per-frame result arrays (key points / key lines / planes) */
+int  hvo_stream_capacity(const hvo_stream *s, int *kp_cap, int *kl_cap, int *pl_cap);
+/* Frame::ComputeImageBounds with the stream's distortion: {mnMinX, mnMaxX, mnMinY, mnMaxY} */
+int  hvo_stream_image_bounds(const hvo_stream *s, float bounds4[4]);
+/* depth may be NULL when planes are not requested (then mvuRight / mvDepth are not computed either) */
+int  hvo_stream_submit(hvo_stream *s, const uint8_t *gray, int gray_stride, const uint16_t *depth, int depth_stride, int64_t *ticket);
+int  hvo_stream_poll(hvo_stream *s, int64_t ticket);                 /* 1: complete, 0: still running */
+/* out as in hvo_batch_download (any pointer may be NULL); kp_un / uright / zdepth: kp_cap entries, may be NULL */
+int  hvo_stream_collect(hvo_stream *s, int64_t ticket, hvo_frame_out *out, hvo_keypoint *kp_un, float *uright, float *zdepth);
+/* device time from the start of the frame's upload to the end of its ORB / line / plane kernels (ms) */
+int  hvo_stream_stage_ms(hvo_stream *s, int64_t ticket, float ms3[3]);
+/* SearchByProjection(Cur, Last) core between two resident frames.  Query i = last-frame feature q_index[i] (its descriptor and
+ * key-point angle are read from the last frame's slot; pass q_desc (nq x 32) when pMP->GetDescriptor() differs from the frame's
+ * own descriptor); q_u .. q_blocks and t_occupied (n_kp(cur) entries, may be NULL) as in hvo_search_by_projection. */
+int  hvo_stream_search_by_projection(hvo_stream *s, int64_t cur, int64_t last, int nq, const int32_t *q_index, const uint8_t *q_desc,
+                                     const float *q_u, const float *q_v, const float *q_radius, const int32_t *q_min_level, const int32_t *q_max_level,
+                                     const float *q_ur, const uint8_t *q_blocks, const uint8_t *t_occupied, int th_high, int check_orientation,
+                                     int32_t *match_idx, int32_t *match_dist, int *n_matches);
+/* line matching between two resident frames: query = lines of `from`, train = lines of `to`; matches12 needs kl_cap entries,
+ * *n_from receives n_kl(from) */
+int  hvo_stream_match_lines(hvo_stream *s, int64_t from, int64_t to, int mode, float th, float nnratio, int32_t *matches12, int *n_from, int *n_matches);
 
 /* ---- measurement hooks (bench.py) ---- */
 /* Per-kernel-group device time of the last hvo_batch_run, measured with hipEvents on the ctx

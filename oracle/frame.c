@@ -105,6 +105,9 @@ static int line_cells(double x1, double y1, double x2, double y2, int *cx, int *
     return n;
 }
 
+/* test hook: the walk above for one segment (tests/test_ref_pins.py compares it with the reference's src/lineIterator.cpp) */
+int orc_grid_line_cells(double x1, double y1, double x2, double y2, int *cx, int *cy, int cap) { return line_cells(x1, y1, x2, y2, cx, cy, cap); }
+
 /* Frame::AssignFeaturesToGridForLine as CSR (same cell numbering); the end points are scaled by the grid
  * element inverses only (no mnMinX offset, as written at Frame.cc:862).  Returns the number of items, or
  * -1 if cap is too small (cell_start is valid either way). */

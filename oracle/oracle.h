@@ -100,6 +100,14 @@ void orc_eig33sym(const double K[3][3], double s[3], double V[3][3]);
 double orc_peac_T_mse_init(double z);
 double orc_peac_T_ang_init(double z);
 double orc_peac_T_dz(double z);
+double orc_peac_T_mse_merge(double z);
+/* test hooks (tests/test_ref_pins.py): the fitter's union-find, the grid walk of one segment */
+void *orc_ds_create(int n);
+int   orc_ds_union(void *d, int x, int y);
+int   orc_ds_find(void *d, int x);
+int   orc_ds_set_size(void *d, int x);
+void  orc_ds_free(void *d);
+int   orc_grid_line_cells(double x1, double y1, double x2, double y2, int *cx, int *cy, int cap);
 
 /* ---------------- lines (lsd.c, lbd.c) ---------------- */
 /* cv::LineSegmentDetector (LSD_REFINE_STD defaults) on a CV_8UC1 image: segs = n x 4 floats */

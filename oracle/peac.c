@@ -512,3 +512,19 @@ int orc_peac_run(const uint16_t *depth, int w, int h, int stride_bytes,
 double orc_peac_T_mse_init(double z) { return T_mse_init(z); }
 double orc_peac_T_ang_init(double z) { return T_ang_init(z); }
 double orc_peac_T_dz(double z) { return P_DEPTH_ALPHA * fabs(z) + P_DEPTH_CHANGE_TOL; }
+double orc_peac_T_mse_merge(double z) { return T_mse_merge(z); }
+
+/* The union-find the fitter uses, behind test hooks: tests/test_ref_pins.py runs random union sequences through
+ * these and through the reference's own include/peac/DisjointSet.hpp (compiled as it stands into oracle/_ref). */
+typedef struct { fitter_t f; } orc_ds;
+void *orc_ds_create(int n)
+{
+    orc_ds *d = (orc_ds *)calloc(1, sizeof(orc_ds));
+    d->f.parent = (int *)malloc(sizeof(int) * (n > 0 ? n : 1)); d->f.dsize = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) { d->f.parent[i] = i; d->f.dsize[i] = 1; }
+    return d;
+}
+int  orc_ds_union(void *d, int x, int y) { return ds_union(&((orc_ds *)d)->f, x, y); }
+int  orc_ds_find(void *d, int x) { return ds_find(&((orc_ds *)d)->f, x); }
+int  orc_ds_set_size(void *d, int x) { orc_ds *q = (orc_ds *)d; return q->f.dsize[ds_find(&q->f, x)]; }
+void orc_ds_free(void *d) { orc_ds *q = (orc_ds *)d; free(q->f.parent); free(q->f.dsize); free(q); }

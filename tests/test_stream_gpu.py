@@ -1,0 +1,123 @@
+"""Streamed-sequence mode (BASELINE.json config 5; reference call shape src/Tracking.cc:262, 2299, 2396): one frame at a time
+through hvo_stream_*, several frames in flight, frame-to-frame matching on the device-resident results of the previous frame.
+Every frame's extraction and every frame pair's matching is compared with the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BF = 40.0           # TUM3.yaml Camera.bf
+TH = 15             # TrackWithMotionModel's window for RGB-D (src/Tracking.cc:2390-2394)
+
+
+def queries_from_last(last, shift, scale_factors):
+    """what TrackWithMotionModel hands to SearchByProjection for the map points of the last frame (src/ORBmatcher.cc:1376-1420):
+    here the 'pose' is the known image-plane drift of the synthetic sequence"""
+    kp = last["kp_un"]; z = last["zdepth"]
+    sel = np.nonzero(z > 0)[0].astype(np.int32)                          # features that have a map point (depth available)
+    u = kp["x"][sel] - np.float32(shift[0]); v = kp["y"][sel] - np.float32(shift[1])
+    octv = kp["octave"][sel]
+    radius = (np.float32(TH) * scale_factors[octv]).astype(np.float32)
+    ur = (u - np.float32(BF) / z[sel]).astype(np.float32)
+    blocks = (sel % 3 != 0).astype(np.uint8)                             # map points with observations claim their feature
+    return sel, u.astype(np.float32), v.astype(np.float32), radius, (octv - 1).astype(np.int32), (octv + 1).astype(np.int32), ur, blocks
+
+
+def check_frame(r, g, d, orc, orb):
+    kpo, desco = orb.extract(g)
+    assert len(r["kp"]) == len(kpo) and np.array_equal(r["desc"], desco)
+    for f in ("x", "y", "octave", "response", "size", "angle"):
+        assert np.array_equal(r["kp"][f], kpo[f]), f
+    klo, ldo, fno = orc.line_extract(g)
+    assert len(r["kl"]) == len(klo) and np.array_equal(r["ldesc"], ldo)
+    assert np.array_equal(r["kl"]["sx"], klo["sx"]) and np.array_equal(r["kl"]["ey"], klo["ey"])
+    lo, po = orc.peac(d)
+    assert np.array_equal(r["labels"], lo) and len(r["planes"]) == len(po)
+    assert np.array_equal(r["planes"]["n_points"], po["n_points"])
+    # TUM3: no distortion -> UndistortKeyPoints copies (src/Frame.cc:1703-1707); ComputeStereoFromRGBD vs the oracle
+    assert np.array_equal(r["kp_un"], r["kp"])
+    uro, zo = orc.stereo_from_rgbd(kpo, kpo, d, float(np.float32(1.0) / np.float32(5000.0)), BF)
+    assert np.array_equal(r["uright"], uro) and np.array_equal(r["zdepth"], zo)
+
+
+def test_stream_64_frames_match_oracle(hvo, orc, synth):
+    n = 64
+    g, d, off = synth.make_sequence("std", 0x5EED2000, n)
+    st = hvo.Stream(depth=4, stages=hvo.STAGE_ALL, bf=BF)
+    orb = orc.Orb()
+    sf = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2), np.float32)])).astype(np.float32)     # mvScaleFactor (ORBextractor.cc:413-419)
+    try:
+        assert tuple(st.bounds) == (0.0, 640.0, 0.0, 480.0)
+        tick = [st.submit(g[0], d[0]), st.submit(g[1], d[1])]          # two frames in flight before the first collect
+        res = {}
+        total_pt = total_ln = 0
+        for i in range(n):
+            if i + 2 < n:
+                tick.append(st.submit(g[i + 2], d[i + 2]))
+            res[i] = st.collect(tick[i])
+            assert res[i]["status"] == 0
+            check_frame(res[i], g[i], d[i], orc, orb)
+            if i > 0:
+                cur, last = res[i], res[i - 1]
+                shift = off[i] - off[i - 1]
+                sel, u, v, rad, lmin, lmax, ur, blocks = queries_from_last(last, shift, sf)
+                nm, mi, md = st.search_by_projection(tick[i], tick[i - 1], sel, u, v, rad, lmin, lmax, ur, blocks)
+                mio, mdo = orc.search_by_projection(last["desc"][sel], u, v, rad, lmin, lmax, ur, last["kp_un"]["angle"][sel], blocks,
+                                                    cur["kp_un"], cur["uright"], np.zeros(len(cur["kp"]), np.uint8), cur["desc"],
+                                                    (0.0, 0.0, 640.0, 480.0))[1:]
+                assert np.array_equal(mi, mio) and np.array_equal(md[mi >= 0], mdo[mio >= 0])
+                assert nm == int((mio >= 0).sum())
+                total_pt += nm
+                # LSDmatcher::match(LastFrame.mLdesc, CurrentFrame.mLdesc, 0.95, matches_12) (src/LSDmatcher.cpp:42)
+                nl, ml = st.match_lines(tick[i - 1], tick[i], hvo.LINE_MATCH_NNR, nnratio=0.95)
+                no, mo = orc.match_nnr(last["ldesc"], cur["ldesc"], 0.95)
+                assert nl == no and np.array_equal(ml, mo)
+                total_ln += nl
+                del res[i - 1]
+        assert total_pt > 100 * (n - 1) and total_ln > 10 * (n - 1), (total_pt, total_ln)
+    finally:
+        st.close()
+
+
+def test_stream_slot_reuse_and_order(hvo, synth):
+    """a slot is refused until its frame was collected; tickets can be collected out of order; stale tickets are rejected"""
+    g, d, _ = synth.make_sequence("lowtex", 0x5EED2100, 4)
+    st = hvo.Stream(depth=2, stages=hvo.STAGE_ORB | hvo.STAGE_PLANES, bf=BF)
+    try:
+        t0 = st.submit(g[0], d[0]); t1 = st.submit(g[1], d[1])
+        with pytest.raises(hvo.HvoError) as e:
+            st.submit(g[2], d[2])
+        assert e.value.status == -7
+        r1 = st.collect(t1); r0 = st.collect(t0)
+        assert len(r0["planes"]) >= 3 and len(r1["planes"]) >= 3 and "kl" not in r0
+        t2 = st.submit(g[2], d[2])
+        with pytest.raises(hvo.HvoError):
+            st.collect(t0)                                           # its slot now belongs to t2
+        ms = None
+        r2 = st.collect(t2); ms = st.stage_ms(t2)
+        assert ms["planes"] > 0 and ms["orb"] > 0 and ms["lsd"] == 0
+        a = hvo.Context()
+        try:
+            lg, pg = a.compute_planes(d[2])
+        finally:
+            a.close()
+        assert np.array_equal(r2["labels"], lg) and np.array_equal(r2["planes"]["n_points"], pg["n_points"])
+    finally:
+        st.close()
+
+
+def test_stream_lines_bf_and_double(hvo, orc, synth):
+    g, d, _ = synth.make_sequence("std", 0x5EED2200, 3)
+    st = hvo.Stream(depth=3, stages=hvo.STAGE_LSD, bf=0.0)
+    try:
+        t = [st.submit(g[k]) for k in range(3)]
+        r = [st.collect(x) for x in t]
+        for a, b in ((0, 1), (1, 2), (2, 0)):
+            n1, m1 = st.match_lines(t[a], t[b], hvo.LINE_MATCH_BF, th=50.0, nnratio=0.9)
+            no, mo = orc.frame_bf_match(r[a]["ldesc"], r[b]["ldesc"], 50.0, 0.9)
+            assert n1 == no and np.array_equal(m1, mo)
+            n2, m2 = st.match_lines(t[a], t[b], hvo.LINE_MATCH_DOUBLE, th=50.0, nnratio=0.9)
+            no, mo = orc.frame_bf_match(r[a]["ldesc"], r[b]["ldesc"], 50.0, 0.9, mutual=True)
+            assert n2 == no and np.array_equal(m2, mo)
+    finally:
+        st.close()
