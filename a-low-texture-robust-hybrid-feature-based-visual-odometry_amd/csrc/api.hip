@@ -184,7 +184,7 @@ int hvo_batch_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
     // at 0 (its device slabs hold the results of some earlier batch or nothing at all)
     int rc;
     bool want_kp = false, want_pl = false, want_kl = false;
-    for (int f = 0; f < n; f++) { want_kp |= (out[f].kp != nullptr); want_pl |= (out[f].labels || out[f].planes); want_kl |= (out[f].kl != nullptr); }
+    for (int f = 0; f < n; f++) { want_kp |= (out[f].kp != nullptr); want_pl |= (out[f].labels || out[f].labels8 || out[f].planes); want_kl |= (out[f].kl != nullptr); }
     if (want_kp && (ctx->last_stages & HVO_STAGE_ORB)) { rc = orb_download(ctx, n, out); if (rc) return rc; }
     if (want_pl && (ctx->last_stages & HVO_STAGE_PLANES)) { rc = peac_download(ctx, n, out); if (rc) return rc; }
     if (want_kl && (ctx->last_stages & HVO_STAGE_LSD)) { rc = lsd_download(ctx, n, out, ctx->last_cull); if (rc) return rc; }

@@ -95,6 +95,7 @@ struct hvo_ctx {
     // profiling
     bool profile = false;
     bool serialize = false;                // profiling mode 2: all stages on one stream (clean per-kernel times)
+    bool lsd_on_orb_stream = false;        // streamed mode: ORB (0.6 ms) then the line chain on one stream, planes on the other (two HW queues per frame in flight)
     ProfileRec prof[HVO_MAX_PROFILE]; int nprof = 0;
     // opaque per-subsystem state (peac.hip / lsd.hip own these)
     void *peac = nullptr;
@@ -225,5 +226,5 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull = false);
 int lsd_download(hvo_ctx *ctx, int n, hvo_frame_out *out, bool culled = false);
 void lsd_free(hvo_ctx *ctx);
 
-static inline hipStream_t hvo_stream_lsd(hvo_ctx *c) { return c->serialize ? c->stream : c->s_lsd; }
+static inline hipStream_t hvo_stream_lsd(hvo_ctx *c) { return (c->serialize || c->lsd_on_orb_stream) ? c->stream : c->s_lsd; }
 static inline hipStream_t hvo_stream_peac(hvo_ctx *c) { return c->serialize ? c->stream : c->s_peac; }

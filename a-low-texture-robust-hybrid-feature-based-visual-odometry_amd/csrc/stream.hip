@@ -48,6 +48,7 @@ struct hvo_stream {
     float bounds[4];                       // mnMinX, mnMaxX, mnMinY, mnMaxY (Frame::ComputeImageBounds)
     // matching scratch (device + pinned), sized for kp_cap queries
     char *d_ms = nullptr, *h_ms = nullptr; size_t ms_bytes = 0;
+    hipStream_t s_match = nullptr;         // the matching calls run here, behind the two frames' events (not behind a frame's line chain)
     std::string last_error;
 };
 
@@ -76,6 +77,7 @@ void hvo_stream_destroy(hvo_stream *s)
     }
     if (s->d_ms) (void)hipFree(s->d_ms);
     if (s->h_ms) (void)hipHostFree(s->h_ms);
+    if (s->s_match) (void)hipStreamDestroy(s->s_match);
     delete s;
 }
 
@@ -98,6 +100,11 @@ int hvo_stream_create(const hvo_params *p, const hvo_stream_params *sp, hvo_stre
         StreamSlot &S = s->slot[i];
         if ((rc = hvo_create(&s->p, &S.ctx))) break;
         S.ctx->sched = 0;                                      // no cross-stream ordering inside a slot: the frames overlap instead
+        // Two HIP streams per frame in flight: [gray upload, ORB, undistort, stereo, ORB download, lines, line download] and
+        // [depth upload, planes, plane download].  The runtime maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues
+        // per priority level and streams that share a queue serialise, so every stream saved is a frame more that really
+        // runs beside the others (measured: 3 streams per frame stop scaling at 2 frames in flight, profiles/r02_stream_scaling.txt).
+        S.ctx->lsd_on_orb_stream = true;
         if ((rc = orb_ensure_plan(S.ctx, w, h, 1))) break;
         if ((rc = lsd_prepare(S.ctx, w, h, 1, s->culled, &S.lv))) break;
         if ((rc = peac_prepare(S.ctx, w, h, 1, &S.pv))) break;
@@ -139,7 +146,8 @@ int hvo_stream_create(const hvo_params *p, const hvo_stream_params *sp, hvo_stre
         const int nq = s->kp_cap;
         s->ms_bytes = al64((size_t)nq * 32) + 8 * al64((size_t)nq * 4) + 2 * al64((size_t)nq) + al64((size_t)s->kp_cap) + 3 * al64((size_t)nq * 4 + 64) +
                       match_sbp_scratch_bytes(nq) + match_lines_scratch_bytes(s->nfeat, s->nfeat) + al64((size_t)s->nfeat * 4 + 64) + 4096;
-        if (hipMalloc((void **)&s->d_ms, s->ms_bytes) != hipSuccess || hipHostMalloc((void **)&s->h_ms, s->ms_bytes, hipHostMallocDefault) != hipSuccess) rc = HVO_ERR_HIP;
+        if (hipMalloc((void **)&s->d_ms, s->ms_bytes) != hipSuccess || hipHostMalloc((void **)&s->h_ms, s->ms_bytes, hipHostMallocDefault) != hipSuccess ||
+            hipStreamCreateWithPriority(&s->s_match, hipStreamNonBlocking, -1) != hipSuccess) rc = HVO_ERR_HIP;
     }
     if (rc) { hvo_stream_destroy(s); return rc; }
     *out = s;
@@ -199,17 +207,6 @@ int hvo_stream_submit(hvo_stream *s, const uint8_t *gray, int gray_stride, const
         ST_HIP(hipMemcpyAsync(ho + L.labels, S.pv.d_labels8, (size_t)w * h, hipMemcpyDeviceToHost, c->s_peac));
     }
     ST_HIP(hipEventRecord(S.ev_peac, c->s_peac));
-    if (want_lsd) {
-        ST_HIP(hipStreamWaitEvent(c->s_lsd, S.ev_gray, 0));
-        if ((rc = lsd_run(c, 1, s->culled))) { s->last_error = c->last_error; return rc; }
-        ST_HIP(hipEventRecord(S.ev_kern[1], c->s_lsd));
-        ST_HIP(hipMemcpyAsync(hc + 4, S.lv.d_nkl, sizeof(int), hipMemcpyDeviceToHost, c->s_lsd));
-        ST_HIP(hipMemcpyAsync(hc + 5, S.lv.d_flags, sizeof(int), hipMemcpyDeviceToHost, c->s_lsd));
-        ST_HIP(hipMemcpyAsync(ho + L.kl, S.lv.d_kl, (size_t)s->nfeat * sizeof(hvo_keyline), hipMemcpyDeviceToHost, c->s_lsd));
-        ST_HIP(hipMemcpyAsync(ho + L.ldesc, S.lv.d_desc, (size_t)s->nfeat * 32, hipMemcpyDeviceToHost, c->s_lsd));
-        ST_HIP(hipMemcpyAsync(ho + L.fn, S.lv.d_fn, (size_t)s->nfeat * 24, hipMemcpyDeviceToHost, c->s_lsd));
-    }
-    ST_HIP(hipEventRecord(S.ev_lsd, c->s_lsd));
     if (want_orb) {
         if ((rc = orb_run(c, 1))) { s->last_error = c->last_error; return rc; }
         // Frame::UndistortKeyPoints (src/Frame.cc:1701-1731) and ComputeStereoFromRGBD (1940-1961) on the resident key points
@@ -231,6 +228,16 @@ int hvo_stream_submit(hvo_stream *s, const uint8_t *gray, int gray_stride, const
         }
     }
     ST_HIP(hipEventRecord(S.ev_orb, c->stream));
+    if (want_lsd) {
+        if ((rc = lsd_run(c, 1, s->culled))) { s->last_error = c->last_error; return rc; }
+        ST_HIP(hipEventRecord(S.ev_kern[1], c->stream));
+        ST_HIP(hipMemcpyAsync(hc + 4, S.lv.d_nkl, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        ST_HIP(hipMemcpyAsync(hc + 5, S.lv.d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        ST_HIP(hipMemcpyAsync(ho + L.kl, S.lv.d_kl, (size_t)s->nfeat * sizeof(hvo_keyline), hipMemcpyDeviceToHost, c->stream));
+        ST_HIP(hipMemcpyAsync(ho + L.ldesc, S.lv.d_desc, (size_t)s->nfeat * 32, hipMemcpyDeviceToHost, c->stream));
+        ST_HIP(hipMemcpyAsync(ho + L.fn, S.lv.d_fn, (size_t)s->nfeat * 24, hipMemcpyDeviceToHost, c->stream));
+    }
+    ST_HIP(hipEventRecord(S.ev_lsd, c->stream));
     S.ticket = s->next; S.busy = true;
     *ticket = s->next++;
     return HVO_OK;
@@ -302,6 +309,7 @@ int hvo_stream_collect(hvo_stream *s, int64_t ticket, hvo_frame_out *out, hvo_ke
                 const size_t npix = (size_t)s->w * s->h;
                 for (size_t k = 0; k < npix; k++) out->labels[k] = (int32_t)l8[k];
             }
+            if (out->labels8) memcpy(out->labels8, ho + L.labels, (size_t)s->w * s->h);
             if (out->planes) {
                 if (m > out->pl_cap) { m = out->pl_cap; out->status = HVO_ERR_CAPACITY; }
                 memcpy(out->planes, ho + L.planes, (size_t)m * sizeof(hvo_plane));
@@ -345,8 +353,9 @@ int hvo_stream_search_by_projection(hvo_stream *s, int64_t cur, int64_t last, in
     StreamSlot *C = slot_of(s, cur), *Lz = slot_of(s, last);
     if (!C || !Lz || C == Lz) return HVO_ERR_INVALID_ARG;
     if (hipSetDevice(s->p.device) != hipSuccess) return HVO_ERR_NO_DEVICE;
-    hipStream_t st = C->ctx->stream;
+    hipStream_t st = s->s_match;
     ST_HIP(hipStreamWaitEvent(st, Lz->ev_orb, 0));
+    ST_HIP(hipStreamWaitEvent(st, C->ev_orb, 0));
     // the current frame's key-point count is needed on the host for the launch geometry: it arrived with the frame's download
     ST_HIP(hipEventSynchronize(C->ev_orb));
     const int nt = ((const int *)(C->h_out + s->lay.counts))[0];
@@ -405,7 +414,9 @@ int hvo_stream_match_lines(hvo_stream *s, int64_t from, int64_t to, int mode, fl
     if (n_from) *n_from = n1;
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     if (n1 <= 0 || n2 < 2 || (mode == HVO_LINE_MATCH_DOUBLE && n1 < 2)) return HVO_OK;
-    hipStream_t st = B->ctx->s_lsd;
+    hipStream_t st = s->s_match;
+    ST_HIP(hipStreamWaitEvent(st, A->ev_lsd, 0));
+    ST_HIP(hipStreamWaitEvent(st, B->ev_lsd, 0));
     char *d = s->d_ms, *hh = s->h_ms; size_t off = 0;
     int32_t *dm = (int32_t *)(d + off); int32_t *hm = (int32_t *)(hh + off); off += al64(((size_t)n1 + 1) * 4);
     void *scratch = d + off; off += match_lines_scratch_bytes(n1, n2);

@@ -59,6 +59,38 @@ def unpack_results(pkg, slabs, kp_cap, kl_cap, pl_cap=64):
     return res
 
 
+def device_slabs(ctx, n):
+    """the first n frames' result slabs of ctx's resident batch as a CUDA uint8 tensor [n, slab_bytes]: packed on the device by
+    hvo_batch_pack_results (no host round trip); the layout is slab_layout(pkg, *ctx.slab_layout()[:3])"""
+    import torch
+    _, _, _, sb = ctx.slab_layout()
+    t = torch.empty((n, sb), dtype=torch.uint8, device="cuda")
+    ctx.pack_results(n, t.data_ptr())
+    return t
+
+
+def gather_device_slabs(ctx, n, reduce_device="cuda"):
+    """the path's one collective: all_gather of every rank's n result slabs.  With the nccl (= RCCL) backend the slabs go
+    from HBM to HBM over xGMI (all_gather_into_tensor on the packed tensor); with gloo (CPU rehearsal) they are staged
+    through the host.  Returns (ranks whose slabs arrived with results in them, slab bytes per frame, gathered tensor)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    t = device_slabs(ctx, n)
+    if reduce_device == "cuda":
+        out = torch.empty((world,) + tuple(t.shape), dtype=torch.uint8, device="cuda")
+        dist.all_gather_into_tensor(out, t)
+        torch.cuda.synchronize()
+    else:
+        tc = t.cpu()
+        outs = [torch.empty_like(tc) for _ in range(world)]
+        dist.all_gather(outs, tc)
+        out = torch.stack(outs)
+    hdr = out[:, 0, :HDR].cpu().numpy().view(np.int32).reshape(world, 4)
+    seen = int(((hdr[:, 0] > 0) | (hdr[:, 1] > 0) | (hdr[:, 2] > 0)).sum())
+    return seen, int(t.shape[1])
+
+
 def gather_results(pkg, local_results, n_frames, kp_cap, kl_cap, pl_cap=64, device="cpu"):
     """all_gather the per-rank slabs; returns the results of all frames in global frame order.
     Blocks may differ by one frame, so every rank pads to the largest block."""

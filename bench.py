@@ -1,48 +1,94 @@
 #!/usr/bin/env python3
 """bench.py -- RGB-D front-end throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--batch B] [--stages orb,lsd,planes]
+    python bench.py --gpus N --steps K --warmup W [--config std640|big1280|batch256] [--mode batch|stream]
 
-One "step" = one pass of the whole front-end (ORB 1000 features + LSD/LBD lines + PEAC planes)
-over one batch of B synthetic 640x480 RGB-D frames that is already resident in HBM
-(BASELINE.json configs[1]).  Independent frames shard across ranks with no data-path collective
-("weak" scaling: B frames per GPU); the only collectives are the timing barrier / max-reduce.
+mode batch (default): one "step" = one pass of the whole front-end (ORB 1000 features + LSD/LBD lines + PEAC planes)
+over one batch of B synthetic RGB-D frames that is already resident in HBM (BASELINE.json configs[1]; 256 distinct
+frames, 3/4 `std` + 1/4 `lowtex`, uploaded cyclically).  Independent frames shard across ranks with no data-path
+collective ("weak" scaling: B frames per GPU); at N > 1 the result slabs are all-gathered once after the timed region
+(device to device, reported as gather_ms).
+mode stream (BASELINE.json configs[4]): one frame at a time through hvo_stream_* (pinned staging, `--depth` frames in
+flight, SearchByProjection(Cur, Last) + line matching against the previous frame on the device); a "step" is a frame.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline":     HBM roofline of the dominant kernel group, from hipEvents recorded on the
-                  kernels' own stream inside the timed region (hvo_profile_last)
-  "cpu_baseline": the CPU oracle (kind "port") timed on this host on a bounded sample.
+  "roofline":       HBM roofline of the dominant kernel group, from hipEvents recorded on the kernels' own stream
+                    (hvo_profile_last); "kernel_roofline" has the same figure for every kernel group
+  "cpu_baseline":   the CPU oracle (kind "port") in the reference's own shape: one frame at a time, ORB || LSD || planes on
+                    three threads (src/Frame.cc:210-215); "cpu_baseline_all_cores": frames spread over every host core
+  "latency_ms", "pcie_inclusive_frames_per_s": single-frame / small-batch latency and the rate with upload and download.
+`--gpus N` without a torchrun environment starts the N ranks itself (before anything touches the GPU).
 """
 import argparse
 import importlib
-import importlib.util
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import __graft_entry__ as ge  # noqa: E402
+# The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues per priority level (default 4); streams that share a
+# queue serialise.  The streamed mode keeps two streams per frame in flight, so more than four frames in flight need more
+# queues (profiles/r02_stream_scaling.txt).  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+TRAFFIC_PROFILE = "profiles/r02_hbm_traffic.json"
+SQ_PROFILE = "profiles/r02_sq_utilisation.json"
+BYTES_PER_FRAME_640 = 25.2e6      # resident footprint of one 640x480 frame (profiles/r02_hbm_footprint.txt)
 
 
-def algorithmic_bytes(group, w, h, nkp, nlines):
-    """ALGORITHMIC bytes per FRAME for each kernel group (DESIGN.md section 'Kernels and rooflines').
-    S = sum of pyramid level areas."""
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 20 batches, or 573 frames in stream mode)")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="batch", choices=["batch", "stream"])
+    ap.add_argument("--config", default="std640", choices=["std640", "big1280", "batch256"],
+                    help="std640: BASELINE configs[1]; big1280: configs[2] (1280x960, 2000 ORB); batch256: configs[3] (256 frames over the ranks)")
+    ap.add_argument("--batch", type=int, default=0, help="frames resident per GPU per step; 0 = per config (std640: the largest of 8192/4096/... that fits)")
+    ap.add_argument("--stages", default="orb,lsd,planes")
+    ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic frames (3/4 std, 1/4 lowtex)")
+    ap.add_argument("--depth", type=int, default=4, help="stream mode: frames in flight")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the latency / PCIe-inclusive side measurements")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (rehearsal of the N>1 path on a 1-GPU box)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a child torchrun job (nothing has touched the GPU in
+    this process) and relay rank 0's JSON line."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout.splitlines():
+        if line.startswith("{"):
+            print(line)
+    sys.exit(p.returncode)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# algorithmic bytes (SURVEY.md 8d for the pyramid+BRIEF pass)
+# ---------------------------------------------------------------------------------------------------------------
+def algorithmic_bytes(w, h, nkp, nlines):
+    import numpy as np
     ws, hs = [], []
-    s = 1.0
     sc = np.float32(1.0)
-    for l in range(8):
+    for _ in range(8):
         inv = np.float32(1.0) / sc
         ws.append(int(np.rint(np.float32(w) * inv))); hs.append(int(np.rint(np.float32(h) * inv)))
         sc = sc * np.float32(1.2)
     areas = [a * b for a, b in zip(ws, hs)]
     S = sum(areas)
     sw, sh = int(round(w * 0.8)), int(round(h * 0.8))
+    nblk = (w // 10) * (h // 10)
     table = {
         "orb_pyramid": sum(areas[:-1]) + sum(areas[1:]),          # read levels 0..6, write 1..7
         "orb_fast_cells": S + 4 * 8 * nkp,                        # read every level once, emit candidates
@@ -50,101 +96,256 @@ def algorithmic_bytes(group, w, h, nkp, nlines):
         "orb_orient": 749 * nkp + 28 * nkp,
         "orb_blur": 2 * S,                                        # read level, write blurred level
         "orb_brief": 512 * nkp + 60 * nkp,                        # 512 gathers + keypoint + descriptor
-        "peac_blocks": 2 * w * h + 3072 * 160,                    # u16 depth in, block records out
-        "peac_cluster": 3072 * 160 * 2,
-        "peac_refine": 2 * w * h + 4 * w * h,                     # depth re-read + int32 labels out
+        "peac_blocks": 2 * w * h + nblk * 160,                    # u16 depth in, block records out
+        "peac_cluster": nblk * 160 * 2,
+        "peac_refine": 2 * w * h + 4 * w * h,                     # depth re-read + labels out (2WH + 4WH)
         "lsd_blur_scale": w * h + sw * sh,
         "lsd_gradient": sw * sh + 12 * sw * sh,
         "lsd_grow": 13 * sw * sh,
         "lbd_sobel": w * h + w * h + 4 * w * h,
         "lbd_desc": 63 * 4 * 60 * nlines + 100 * nlines,
+        "lsd_cull": 200 * nlines,
     }
-    return table.get(group, 0), 4 * S + 60 * nkp
+    return table, 4 * S + 60 * nkp
+
+
+def load_json(rel):
+    try:
+        with open(os.path.join(ROOT, rel)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def hbm_traffic(group, B, width):
-    """HBM bytes per launch of a kernel group from the PMC counters (FETCH_SIZE + WRITE_SIZE, collected in
-    separate rocprofv3 --pmc passes of this same command and committed as profiles/r01_hbm_traffic.json --
-    counters cannot be read from inside the process).  None when the committed measurement does not
-    cover this configuration."""
+    """HBM bytes per launch of a kernel group from the PMC counters (FETCH_SIZE + WRITE_SIZE, collected in separate
+    rocprofv3 --pmc passes of this same command; the counters cannot be read from inside the process, so the figure is
+    REPLAYED from the committed profile named in roofline.traffic_source).  None when that profile does not cover this
+    configuration."""
+    t = load_json(TRAFFIC_PROFILE)
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
-            t = json.load(f)
-        if t.get("frames_per_launch") != B or width != 640 or group not in t["bytes_per_frame"]:
+        if not t or t.get("frames_per_launch") != B or width != 640 or group not in t["bytes_per_frame"]:
             return None
         e = t["bytes_per_frame"][group]
         return int((e["fetch"] + e["write"]) * B)
-    except (OSError, ValueError, KeyError):
+    except (KeyError, TypeError):
         return None
 
 
 def sq_utilisation(frames_per_s):
-    """What the step spends on the SIMDs, from the committed SQ counters per frame (profiles/r01_sq_utilisation.json;
-    SQ_* count quad-cycles summed over waves): the VALU pipes' busy fraction at the measured rate (VALU instructions of
-    different waves of a SIMD cannot overlap, so this is a true pipe utilisation), the mean number of resident waves per
-    SIMD, and the share of a wave's life with an instruction in flight.  The step is NOT HBM bound; it is a set of
-    dependent-latency chains.  Extra keys of the roofline object; empty when the profile is absent."""
+    """VALU busy fraction / resident waves per SIMD at the measured rate, from the committed SQ counters per frame
+    (replayed, see roofline.counters_source)."""
+    t = load_json(SQ_PROFILE)
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_sq_utilisation.json")) as f:
-            t = json.load(f)
         tot = t["per_frame_total"]
         cap = t["simds"] * t["clock_hz"] / 4.0                     # SIMD quad-cycles per second
         return {"valu_busy_frac": round(tot["sq_active_inst_valu"] * frames_per_s / cap, 4),
                 "resident_waves_per_simd": round(tot["sq_wave_cycles"] * frames_per_s / cap, 3),
                 "wave_time_with_inst_active": round(tot["sq_active_inst_any"] / tot["sq_wave_cycles"], 4),
-                "valu_quad_cycles_per_frame": int(tot["sq_active_inst_valu"])}
-    except (OSError, ValueError, KeyError, ZeroDivisionError):
+                "counters_source": SQ_PROFILE + " (replayed: PMC counters cannot be read in-process)"}
+    except (KeyError, TypeError, ZeroDivisionError):
         return {}
 
 
-def cpu_baseline(stages, gray, depth, budget_s=12.0):
-    """time the CPU oracle (scalar port, 1 thread) on a bounded sample of the same workload"""
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baselines (the oracle, kind "port"): SURVEY.md 8d modes (i) and (ii)
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_reference_shaped(ge, stages, gray, depth, budget_s=8.0, max_frames=96):
+    """one frame at a time, ORB || LSD || planes on three threads, like the Frame constructor (src/Frame.cc:210-215)"""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    orc = ge.oracle(); orb = orc.Orb()
+    jobs = []
+    if "orb" in stages: jobs.append(lambda g, d: orb.extract(g))
+    if "lsd" in stages: jobs.append(lambda g, d: orc.line_extract(g))
+    if "planes" in stages: jobs.append(lambda g, d: orc.peac(d))
+    lat = []
+    with ThreadPoolExecutor(max(len(jobs), 1)) as pool:
+        t_all = time.perf_counter()
+        n = 0
+        while n < max_frames and (time.perf_counter() - t_all) < budget_s:
+            g, d = gray[n % len(gray)], depth[n % len(depth)]
+            t0 = time.perf_counter()
+            fs = [pool.submit(j, g, d) for j in jobs]
+            for f in fs: f.result()
+            lat.append(time.perf_counter() - t0)
+            n += 1
+        el = time.perf_counter() - t_all
+    lat = np.array(lat) * 1e3
+    return {"value": round(n / el, 3), "unit": "frames/s", "cores": len(jobs), "kind": "port",
+            "latency_ms_p50": round(float(np.percentile(lat, 50)), 3), "latency_ms_p99": round(float(np.percentile(lat, 99)), 3),
+            "sample": "%d frames of the same synthetic workload (%s), one frame at a time with ORB || LSD || planes on %d threads as in src/Frame.cc:210-215, "
+                      "oracle/liboracle.so; host has %d cores; the reference binary itself cannot run here (OpenCV 3.2 / PCL absent)"
+                      % (n, "+".join(stages), len(jobs), os.cpu_count())}
+
+
+def cpu_all_cores(ge, stages, gray, depth, per_thread=3):
+    """independent frames spread over every host core (one oracle instance per thread; the C calls release the GIL)"""
     orc = ge.oracle()
-    orb = orc.Orb()
-    n, t0 = 0, time.time()
-    while True:
-        g = gray[n % len(gray)]
-        if "orb" in stages:
-            orb.extract(g)
-        if "planes" in stages:
-            orc.peac(depth[n % len(depth)])
-        if "lsd" in stages:
-            orc.line_extract(g)
-        n += 1
-        el = time.time() - t0
-        if el > budget_s or n >= 64:
-            break
-    return {"value": round(n / el, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same synthetic 640x480 workload (%s), oracle/liboracle.so, 1 thread, host has %d cores"
-                      % (n, "+".join(stages), os.cpu_count())}
+    nthr = os.cpu_count() or 1
+    done = [0] * nthr
+    def work(t):
+        orb = orc.Orb()
+        for k in range(per_thread):
+            i = (t * per_thread + k)
+            g, d = gray[i % len(gray)], depth[i % len(depth)]
+            if "orb" in stages: orb.extract(g)
+            if "planes" in stages: orc.peac(d)
+            if "lsd" in stages: orc.line_extract(g)
+            done[t] += 1
+    thr = [threading.Thread(target=work, args=(t,)) for t in range(nthr)]
+    t0 = time.perf_counter()
+    for t in thr: t.start()
+    for t in thr: t.join()
+    el = time.perf_counter() - t0
+    n = sum(done)
+    return {"value": round(n / el, 2), "unit": "frames/s", "cores": nthr, "kind": "port",
+            "sample": "%d frames, %d per thread on %d threads (every host core), oracle/liboracle.so" % (n, per_thread, nthr)}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# synthetic workload
+# ---------------------------------------------------------------------------------------------------------------
+def make_frames(synth, n, w, h, seed0):
+    """n distinct frames, every fourth one `lowtex` (the paper's target regime), the rest `std`"""
+    import numpy as np
+    g = np.empty((n, h, w), np.uint8); d = np.empty((n, h, w), np.uint16)
+    kinds = []
+    for k in range(n):
+        kind = "lowtex" if k % 4 == 3 else "std"
+        g[k], d[k] = synth.make_frame(kind, seed0 + k, w, h)
+        kinds.append(kind)
+    return g, d, kinds
+
+
+def geometry(cfg):
+    return (1280, 960, 2000) if cfg == "big1280" else (640, 480, 1000)
+
+
+def new_context(hvo, cfg, B, device):
+    w, h, nfeat = geometry(cfg)
+    s = w / 640.0
+    return hvo.Context(max_batch=B, device=device, orb_nfeatures=nfeat, fx=535.4 * s, fy=539.2 * s, cx=320.1 * s, cy=247.6 * s)
+
+
+def latency_probe(hvo, cfg, g, d, mask, device, sizes=(1, 32)):
+    """ms per hvo_batch_run of small resident batches (the three subsystems overlapped), best of 5"""
+    out = {}
+    for B in sizes:
+        ctx = new_context(hvo, cfg, B, device)
+        try:
+            reps = (B + len(g) - 1) // len(g)
+            ctx.batch_upload(g[:B] if B <= len(g) else g, d[:B] if B <= len(d) else d, repeat=1 if B <= len(g) else reps)
+            for _ in range(2): ctx.batch_run(mask)
+            best = 1e9
+            for _ in range(5):
+                t0 = time.perf_counter(); ctx.batch_run(mask); best = min(best, time.perf_counter() - t0)
+            out["B%d" % B] = round(best * 1e3, 3)
+        finally:
+            ctx.close()
+    return out
+
+
+def pcie_inclusive(hvo, cfg, g, d, mask, device, B=1024, rounds=3):
+    """upload + run + download of consecutive batches, overlapped: two contexts on two host threads, each doing its own
+    upload -> run -> download loop (different contexts may run concurrently, include/hvo.h), so one context's PCIe traffic
+    runs under the other's kernels.  Pageable numpy buffers on the host side; the label image crosses PCIe and is
+    handed over as int8 (hvo_frame_out.labels8); the result arrays are reused from batch to batch."""
+    ctxs = [new_context(hvo, cfg, B, device) for _ in range(2)]
+    reps = max(1, B // len(g))
+    n = reps * len(g)
+    def loop(c, k):
+        for _ in range(k):
+            c.batch_upload(g, d, repeat=reps); c.batch_run(mask); c.batch_download(mask, reuse=True, labels8=True)
+    try:
+        for c in ctxs: loop(c, 1)                                    # warm-up: plans, pinned staging
+        thr = [threading.Thread(target=loop, args=(c, rounds)) for c in ctxs]
+        t0 = time.perf_counter()
+        for t in thr: t.start()
+        for t in thr: t.join()
+        el = time.perf_counter() - t0
+    finally:
+        for c in ctxs: c.close()
+    return round(2 * rounds * n / el, 1), n
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# stream mode
+# ---------------------------------------------------------------------------------------------------------------
+def stream_queries(np, last, shift, sf, bf, th=15):
+    kp = last["kp_un"]; z = last["zdepth"]
+    sel = np.nonzero(z > 0)[0].astype(np.int32)
+    u = (kp["x"][sel] - np.float32(shift[0])).astype(np.float32); v = (kp["y"][sel] - np.float32(shift[1])).astype(np.float32)
+    octv = kp["octave"][sel]
+    rad = (np.float32(th) * sf[octv]).astype(np.float32)
+    ur = (u - np.float32(bf) / z[sel]).astype(np.float32)
+    return sel, u, v, rad, (octv - 1).astype(np.int32), (octv + 1).astype(np.int32), ur, np.ones(len(sel), np.uint8)
+
+
+def run_stream(hvo, np, g, d, off, mask, depth, device, nframes, paced_hz=0.0):
+    """frames through hvo_stream_* with `depth` in flight; every frame is collected and matched against its predecessor
+    (SearchByProjection(Cur, Last) + LSDmatcher::match) before the next collect.  Returns (seconds, per-frame latency ms,
+    matches per frame)."""
+    bf = 40.0
+    st = hvo.Stream(width=g.shape[2], height=g.shape[1], depth=depth, stages=mask, bf=bf, device=device)
+    sf = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2), np.float32)])).astype(np.float32)
+    lat = []; nm_pts = 0; nm_lines = 0
+    try:
+        tick = {}; tsub = {}
+        inflight = max(1, depth - 1)              # one slot keeps the previous frame resident for the matching
+        nxt = 0
+        t_start = time.perf_counter()
+        def submit(k):
+            if paced_hz > 0:
+                due = t_start + k / paced_hz
+                while time.perf_counter() < due: time.sleep(0.0002)
+            tsub[k] = time.perf_counter()
+            tick[k] = st.submit(g[k % len(g)], d[k % len(d)])
+        while nxt < min(inflight, nframes):
+            submit(nxt); nxt += 1
+        last = None
+        for i in range(nframes):
+            cur = st.collect(tick[i], labels=True)
+            if last is not None and (mask & 1):
+                shift = off[i % len(off)] - off[(i - 1) % len(off)] if i % len(off) else (0, 0)
+                sel, u, v, rad, lmin, lmax, ur, blocks = stream_queries(np, last, shift, sf, bf)
+                n, _, _ = st.search_by_projection(tick[i], tick[i - 1], sel, u, v, rad, lmin, lmax, ur, blocks)
+                nm_pts += n
+            if last is not None and (mask & 2):
+                n, _ = st.match_lines(tick[i - 1], tick[i], hvo.LINE_MATCH_NNR, nnratio=0.95)
+                nm_lines += n
+            lat.append((time.perf_counter() - tsub[i]) * 1e3)
+            last = cur
+            if nxt < nframes:
+                submit(nxt); nxt += 1
+        el = time.perf_counter() - t_start
+    finally:
+        st.close()
+    return el, np.array(lat), nm_pts / max(nframes - 1, 1), nm_lines / max(nframes - 1, 1)
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=0,
-                    help="frames resident per GPU per step (multiple of 16); 0 = the largest of 8192/4096/2048/1024 that fits in 85 %% of the free HBM")
-    ap.add_argument("--stages", default="orb,lsd,planes")
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (rehearsal of the N>1 path on a 1-GPU box)")
-    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
-    args = ap.parse_args()
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        spawn_ranks(args)                                            # does not return
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s\n" % (args.gpus, env_world))
+        sys.exit(2)
 
+    import numpy as np
     import torch
+    import __graft_entry__ as ge
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"     # where the two scalar reductions live
+    red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"     # where the scalar reductions live
     if world > 1:
         import torch.distributed as dist
         if args.dist_backend == "nccl":
@@ -152,33 +353,16 @@ def main():
         else:
             dist.init_process_group(backend=args.dist_backend)
 
-    ge.build() if not os.path.exists(os.path.join(ge.PKG_DIR, "csrc", "libhvo.so")) else None
+    if not os.path.exists(os.path.join(ge.PKG_DIR, "csrc", "libhvo.so")):
+        ge.build()
     hvo = ge.package()
     synth = importlib.import_module("hvo_amd.synth")
+    hdist = importlib.import_module("hvo_amd.dist")
     stages = [s for s in args.stages.split(",") if s]
     mask = 0
     for s in stages:
         mask |= {"orb": hvo.STAGE_ORB, "lsd": hvo.STAGE_LSD, "planes": hvo.STAGE_PLANES}[s]
-
-    B = args.batch
-    if B <= 0:
-        # 28.5 MB per resident 640x480 frame (profiles/r01_hbm_footprint.txt); more frames in flight = more latency hiding
-        free_b, _ = torch.cuda.mem_get_info()
-        per_frame = 28.5e6 * (args.width * args.height) / (640.0 * 480.0)
-        B = next((c for c in (8192, 4096, 2048, 1024) if c * per_frame <= 0.85 * free_b), 512)
-        if dist is not None:                 # every rank must run the same workload
-            t = torch.tensor([B], dtype=torch.int64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            B = int(t.item())
-    ndistinct = min(B, 16)
-    g0, d0 = synth.make_batch("std", 0x5EED1000 + 1000 * rank, ndistinct, args.width, args.height)
-    reps = max(1, B // ndistinct)
-    B = reps * ndistinct                    # the 16 distinct frames are uploaded cyclically, by pointer
-
-    s = args.width / 640.0
-    ctx = hvo.Context(max_batch=B, device=local_rank, orb_nfeatures=1000 if args.width <= 640 else 2000,
-                      fx=535.4 * s, fy=539.2 * s, cx=320.1 * s, cy=247.6 * s)
-    ctx.batch_upload(g0, d0, repeat=reps)   # inputs resident in HBM before the timed region
+    w, h, nfeat = geometry(args.config)
 
     def barrier():
         torch.cuda.synchronize()
@@ -186,11 +370,80 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ======================================================= stream mode ==========================================
+    if args.mode == "stream":
+        nframes = args.steps if args.steps > 0 else 573          # length of Examples/RGB-D/associations/fr1_desk.txt
+        ndist = min(nframes + args.warmup, 573)
+        g, d, off = synth.make_sequence("std", 0x5EED3000 + 1000 * rank, ndist, w, h)
+        run_stream(hvo, np, g, d, off, mask, args.depth, local_rank, max(args.warmup, 2))          # warm-up: plans, pinned buffers
+        barrier()
+        el, lat, mpts, mlines = run_stream(hvo, np, g, d, off, mask, args.depth, local_rank, nframes)
+        barrier()
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        if rank == 0:
+            out = {
+                "metric": "RGB-D frames/sec (640×480, 1k ORB + LSD + PEAC) at 1/2/4/8 GPUs", "value": round(world * nframes / el, 2), "unit": "frames/s",
+                "n_gpus": world, "steps": nframes, "warmup": args.warmup, "ms_per_step": round(el / nframes * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16 integer + f32/f64", "data": "synthetic",
+                "config": {"workload": "stream-%d: %dx%d synthetic RGB-D sequence (smooth <= 4 px/frame drift), one frame at a time through hvo_stream_* "
+                                       "(upload + %d ORB + LSD + PEAC + download + SearchByProjection(Cur,Last) + line match per frame), %d frames in flight"
+                                       % (nframes, w, h, nfeat, args.depth),
+                           "mode": "stream", "stages": stages, "depth": args.depth, "pcie_inclusive": True,
+                           "mean_point_matches": round(mpts, 1), "mean_line_matches": round(mlines, 1)},
+                "latency_ms": {"pipelined_p50": round(float(np.percentile(lat, 50)), 3), "pipelined_p99": round(float(np.percentile(lat, 99)), 3)},
+                "roofline": None,
+            }
+            if not args.no_extras:
+                # single-frame latency: nothing else in flight (submit, collect, match, then the next frame)
+                _, lat1, _, _ = run_stream(hvo, np, g, d, off, mask, 2, local_rank, min(nframes, 64))
+                out["latency_ms"].update(single_frame_p50=round(float(np.percentile(lat1, 50)), 3), single_frame_p99=round(float(np.percentile(lat1, 99)), 3))
+                # which pipeline depth keeps up with a 30 fps camera (frames submitted on a 33.3 ms clock)
+                sustain = {}
+                for dep in (2, 3, 4):
+                    e2, l2, _, _ = run_stream(hvo, np, g, d, off, mask, dep, local_rank, min(nframes, 90), paced_hz=30.0)
+                    sustain["depth%d" % dep] = {"fps": round(min(nframes, 90) / e2, 2), "latency_ms_p50": round(float(np.percentile(l2, 50)), 3),
+                                               "latency_ms_p99": round(float(np.percentile(l2, 99)), 3)}
+                out["paced_30fps"] = sustain
+                ok = [int(k[5:]) for k, v in sustain.items() if v["fps"] >= 29.5 and v["latency_ms_p99"] < 1000.0 / 30.0 * (int(k[5:]) - 1) + 5.0]
+                out["pipeline_depth_sustaining_30fps"] = min(ok) if ok else None
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_reference_shaped(ge, stages, g, d)
+                out["latency_ms"]["cpu_reference_shaped_3_threads_p50"] = out["cpu_baseline"]["latency_ms_p50"]
+            print(json.dumps(out))
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
+
+    # ======================================================= batch mode ===========================================
+    B = args.batch
+    per_frame = BYTES_PER_FRAME_640 * (w * h) / (640.0 * 480.0) * (nfeat / 1000.0 * 0.15 + 0.85)
+    if B <= 0:
+        if args.config == "batch256":
+            B = max(1, 256 // world)                                 # BASELINE configs[3]: 256 frames over the ranks
+        else:
+            free_b, _ = torch.cuda.mem_get_info()
+            B = next((c for c in (8192, 4096, 2048, 1024, 512, 256) if c * per_frame <= 0.85 * free_b), 128)
+        if dist is not None:                 # every rank must run the same workload
+            t = torch.tensor([B], dtype=torch.int64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            B = int(t.item())
+    ndistinct = max(1, min(B, args.distinct))
+    g0, d0, kinds = make_frames(synth, ndistinct, w, h, 0x5EED1000 + 100000 * rank)
+    reps = max(1, B // ndistinct)
+    B = reps * ndistinct                    # the distinct frames are uploaded cyclically, by pointer
+    steps = args.steps if args.steps > 0 else 20
+
+    ctx = new_context(hvo, args.config, B, local_rank)
+    ctx.batch_upload(g0, d0, repeat=reps)   # inputs resident in HBM before the timed region
+
     for _ in range(args.warmup):
         ctx.batch_run(mask)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         ctx.batch_run(mask)                 # enqueues every kernel (ORB || LSD || PEAC streams) and waits
     barrier()
     dt = time.perf_counter() - t0
@@ -203,7 +456,7 @@ def main():
     # and the three subsystems serialised, so that a group's time is its own (with the streams
     # overlapped a group's event interval mostly measures waiting for CU slots held by the others).
     prof = {}
-    psteps = max(1, min(args.steps, 3))
+    psteps = max(1, min(steps, 3))
     ctx.profile_enable(2)
     for _ in range(psteps):
         ctx.batch_run(mask)
@@ -211,45 +464,74 @@ def main():
             prof[k] = prof.get(k, 0.0) + v
     ctx.profile_enable(0)
 
-    res = ctx.batch_download(mask, n=64)     # a sample is enough for the workload statistics
+    # N > 1: the one collective of the path -- all_gather of the device-resident result slabs (RCCL over xGMI)
+    gather = None
+    if dist is not None:
+        barrier()
+        tg = time.perf_counter()
+        ranks_seen, slab_bytes = hdist.gather_device_slabs(ctx, B, red_dev)
+        barrier()
+        gather = {"gather_ms": round((time.perf_counter() - tg) * 1e3, 3), "ranks_seen": ranks_seen, "slab_bytes_per_frame": slab_bytes,
+                  "frames_gathered": world * B}
+
+    res = ctx.batch_download(mask, n=min(B, 256))     # a sample is enough for the workload statistics
     nkp = float(np.mean([len(r["kp"]) for r in res])) if "orb" in stages else 0.0
     nlines = float(np.mean([len(r["kl"]) for r in res])) if "lsd" in stages else 0.0
     nplanes = float(np.mean([len(r["planes"]) for r in res])) if "planes" in stages else 0.0
     bad = sum(1 for r in res if r["status"] != 0)
+    ctx.close()
 
     if rank == 0:
-        frames = world * B * args.steps
+        frames = world * B * steps
         value = frames / dt
         groups = {k: v / psteps for k, v in prof.items()}           # ms per launch group per step (serialised pass)
+        table, pass_bytes = algorithmic_bytes(w, h, nkp, nlines)
+        kroof = {}
+        for k, ms in groups.items():
+            pf = table.get(k, 0)
+            gbps = pf * B / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            kroof[k] = {"ms": round(ms, 4), "alg_bytes_per_frame": int(pf), "GBps": round(gbps, 2), "frac": round(gbps / HBM_PEAK_GBS, 5)}
         dom = max(groups, key=groups.get) if groups else None
         roof = None
         if dom:
-            per_frame, pass_bytes = algorithmic_bytes(dom, args.width, args.height, nkp, nlines)
-            ach = per_frame * B / (groups[dom] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": hbm_traffic(dom, B, args.width),
-                    "bytes_per_launch": int(per_frame * B), "ms_per_launch": round(groups[dom], 4)}
+            tr = hbm_traffic(dom, B, w)
+            roof = {"bound": "hbm", "kernel": dom, "achieved": kroof[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": kroof[dom]["frac"], "traffic": tr,
+                    "traffic_source": (TRAFFIC_PROFILE + " (replayed: separate rocprofv3 --pmc passes of this command)") if tr is not None else None,
+                    "bytes_per_launch": int(table.get(dom, 0) * B), "ms_per_launch": round(groups[dom], 4),
+                    "limiter": "dependent-latency chain (serial semantics), not HBM bandwidth: see valu_busy_frac / DESIGN.md section 4"}
             roof.update(sq_utilisation(value))
             orb_ms = sum(v for k, v in groups.items() if k in ("orb_pyramid", "orb_fast_cells", "orb_blur", "orb_brief", "orb_orient"))
             if orb_ms > 0:
                 roof["orb_pyramid_brief_pass_GBps"] = round(pass_bytes * B / (orb_ms * 1e-3) / 1e9, 2)
+                roof["orb_pyramid_brief_pass_frac"] = round(pass_bytes * B / (orb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         out = {
-            "metric": "RGB-D frames/sec (640\u00d7480, 1k ORB + LSD + PEAC) at 1/2/4/8 GPUs", "value": round(value, 2), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "metric": "RGB-D frames/sec (640×480, 1k ORB + LSD + PEAC) at 1/2/4/8 GPUs", "value": round(value, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16 integer + f32/f64",
             "data": "synthetic",
-            "config": {"workload": "%dx%d synthetic RGB-D, %d ORB + LSD lines + PEAC planes, %d frames per GPU per step"
-                                   % (args.width, args.height, ctx.params.orb_nfeatures, B),
+            "config": {"workload": "%dx%d synthetic RGB-D, %d ORB + LSD lines + PEAC planes, %d frames per GPU per step (%s)"
+                                   % (w, h, nfeat, B, args.config),
                        "stages": stages, "frames_per_gpu": B, "parallelism": "frames sharded, %d rank(s), no data-path collective" % world,
+                       "distinct_frames": ndistinct, "scene_mix": {k: kinds.count(k) for k in sorted(set(kinds))},
                        "mean_keypoints": round(nkp, 1), "mean_lines": round(nlines, 1), "mean_planes": round(nplanes, 2),
-                       "frames_with_capacity_flags": bad},
+                       "frames_with_capacity_flags": bad, "resident_bytes_per_frame_estimate": int(per_frame)},
             "kernel_ms_per_step_serialised": {k: round(v, 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1])},
+            "kernel_roofline": kroof,
             "roofline": roof,
         }
+        if gather:
+            out["gather"] = gather
+        if world == 1 and not args.no_extras:
+            out["latency_ms"] = latency_probe(hvo, args.config, g0, d0, mask, local_rank)
+            if args.config != "big1280":
+                rate, nb = pcie_inclusive(hvo, args.config, g0, d0, mask, local_rank)
+                out["pcie_inclusive_frames_per_s"] = rate
+                out["pcie_inclusive_note"] = "2 contexts x %d frames on 2 host threads, upload + run + download overlapped, pageable host buffers, int8 labels on the wire" % nb
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(stages, g0, d0)
+            out["cpu_baseline"] = cpu_reference_shaped(ge, stages, g0, d0)
+            out["cpu_baseline_all_cores"] = cpu_all_cores(ge, stages, g0, d0)
         print(json.dumps(out))
-    ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

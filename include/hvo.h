@@ -226,6 +226,8 @@ typedef struct {
     hvo_keyline *kl; uint8_t *ldesc; double *linefn; int kl_cap; int n_kl;
     int32_t *labels; hvo_plane *planes; int pl_cap; int n_planes;
     int status;                                  /* per-frame hvo_status */
+    int8_t *labels8;                             /* optional: the label image as int8 (w*h bytes, -1 = none; plane ids < 64), i.e. as it
+                                                    crosses PCIe, without the widening to CV_32S that `labels` gets (ABI version 2) */
 } hvo_frame_out;
 
 /* host -> HBM copy of n (<= max_batch) frames of one geometry */

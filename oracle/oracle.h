@@ -96,7 +96,8 @@ int         orc_orb_level_count(const orc_orb *o, int level);            /* kps 
 int  orc_peac_run(const uint16_t *depth, int w, int h, int stride_bytes,
                   float fx, float fy, float cx, float cy, float depth_factor,
                   int32_t *labels, orc_plane *planes, int cap, int *nplanes);
-void orc_eig33sym(const double K[3][3], double s[3], double V[3][3]);
+void orc_eig33sym(const double K[3][3], double s[3], double V[3][3]);        /* cyclic Jacobi: cross-check only */
+void orc_eig33_smallest(const double K[3][3], double *lambda0, double v[3]);  /* what Stats::compute uses */
 double orc_peac_T_mse_init(double z);
 double orc_peac_T_ang_init(double z);
 double orc_peac_T_dz(double z);

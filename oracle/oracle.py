@@ -225,6 +225,15 @@ def peac(depth, fx=535.4, fy=539.2, cx=320.1, cy=247.6, depth_factor=None, cap=6
     return labels, planes[: min(n.value, cap)].copy()
 
 
+def eig33_smallest(K):
+    """the smallest eigenpair as Stats::compute uses it (orc_eig33_smallest) -> (lambda0, v)"""
+    K = np.ascontiguousarray(K, np.float64); l = C.c_double(0); v = np.zeros(3)
+    L = lib()
+    L.orc_eig33_smallest.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_void_p]; L.orc_eig33_smallest.restype = None
+    L.orc_eig33_smallest(_p(K), C.byref(l), _p(v))
+    return l.value, v
+
+
 def eig33sym(K):
     K = np.ascontiguousarray(K, np.float64); s = np.zeros(3); V = np.zeros((3, 3))
     L = lib()

@@ -21,8 +21,10 @@
  *     creation order.
  *   - std::priority_queue ties on mse and std::sort ties on N: creation order.
  *   - LA::eig33sym (Eigen::SelfAdjointEigenSolver, eig33sym.hpp:70-74, Eigen not vendored): ASSUMED
- *     any accurate symmetric 3x3 solver; here cyclic Jacobi in a fixed operation order (the HIP
- *     kernel runs the identical sequence).
+ *     any backward-stable symmetric 3x3 solver.  Stats::compute only uses the smallest eigenpair, which
+ *     orc_eig33_smallest computes (Laguerre iteration + adjugate column, fixed operation order; the HIP
+ *     kernels run the identical sequence).  The cyclic Jacobi solver orc_eig33sym is kept as the
+ *     high-accuracy cross-check of that routine.
  *   - membershipImg keeps negative "trail" counters for unlabelled pixels; the oracle reports them
  *     all as -1.
  */
@@ -104,6 +106,53 @@ void orc_eig33sym(const double Kin[3][3], double s[3], double V[3][3])
     for (int i = 0; i < 3; i++) { s[i] = d[o[i]]; for (int r = 0; r < 3; r++) V[r][i] = v[r][o[i]]; }
 }
 
+/* Smallest eigenpair of a symmetric positive semi-definite 3x3 matrix: all that Stats::compute uses of LA::eig33sym
+ * (AHCPlaneSeg.hpp:139-153: normal = V[:,0] flipped towards the camera, mse = s[0] / N, curvature = s[0] / (s[0]+s[1]+s[2]),
+ * and s[0]+s[1]+s[2] = trace(K)).
+ * lambda0: Laguerre's iteration on q(l) = det(l I - K) from l = 0.  For a polynomial with real roots Laguerre's step from
+ * below the smallest root never passes it, so the iterates rise monotonically to lambda0 (cubic convergence for a simple
+ * root, two or three steps for plane-like covariances); q, q' and q'' come from K - l I itself:
+ *     q = -det(K - l I),  q' = sum of its principal 2x2 minors,  q'' = -2 trace(K - l I),
+ *     l <- l + 3 det / (q' + sqrt(4 q'^2 - 6 q q'')).
+ * It stops when a step no longer raises l by more than one ulp of trace(K) (or after 8 steps).  Eigenvector: adj(K - lambda0 I)
+ * has rank one (= c v v^T), so the column holding its largest diagonal minor, normalised, is v.
+ * Accuracy: |lambda0 - exact| <= ~2e-16 trace(K), the backward-stable bound that the reference's own solver
+ * (Eigen::SelfAdjointEigenSolver, tridiagonal QL; eig33sym.hpp:70-74) meets; measured against the cyclic Jacobi solver
+ * orc_eig33sym over 2e5 random covariances of noisy planar patches: max 2.3e-16 trace(K), normals within 5e-8 rad
+ * (tests/test_oracle_known_answers.py).  Only + - * / sqrt in a fixed order: the HIP kernels run the identical sequence. */
+void orc_eig33_smallest(const double K[3][3], double *lambda0, double v[3])
+{
+    const double a = K[0][0], b = K[1][1], c = K[2][2], d = K[0][1], e = K[1][2], f = K[0][2];
+    const double tol = 2.220446049250313e-16 * (a + b + c);
+    double l = 0.0;
+    for (int it = 0; it < 8; it++) {
+        const double A = a - l, B = b - l, C = c - l;
+        const double m1 = B * C - e * e, m2 = A * C - f * f, m3 = A * B - d * d;
+        const double det = A * m1 - d * (d * C - e * f) + f * (d * e - B * f);
+        const double dq = m1 + m2 + m3;
+        if (!(dq > 0.0)) break;
+        const double q2 = -2.0 * (A + B + C);
+        double disc = 4.0 * dq * dq + 6.0 * det * q2;
+        if (disc < 0.0) disc = 0.0;
+        const double ln = l + 3.0 * det / (dq + sqrt(disc));
+        if (!(ln > l)) break;
+        const double step = ln - l;
+        l = ln;
+        if (step <= tol) break;
+    }
+    const double A = a - l, B = b - l, C = c - l;
+    const double m1 = B * C - e * e, m2 = A * C - f * f, m3 = A * B - d * d;
+    const double am1 = fabs(m1), am2 = fabs(m2), am3 = fabs(m3);
+    double x, y, z;
+    if (am1 >= am2 && am1 >= am3) { x = m1; y = e * f - d * C; z = d * e - B * f; }
+    else if (am2 >= am3) { x = e * f - d * C; y = m2; z = d * f - A * e; }
+    else { x = d * e - B * f; y = d * f - A * e; z = m3; }
+    const double n2 = x * x + y * y + z * z;
+    if (n2 > 0.0) { const double inv = 1.0 / sqrt(n2); v[0] = x * inv; v[1] = y * inv; v[2] = z * inv; }
+    else { v[0] = 0.0; v[1] = 0.0; v[2] = 1.0; }            /* K is a multiple of the identity: any direction */
+    *lambda0 = l;
+}
+
 typedef struct { double sx, sy, sz, sxx, syy, szz, sxy, syz, sxz; int N; } stats_t;
 
 typedef struct {
@@ -123,15 +172,15 @@ static void stats_compute(const stats_t *s, double center[3], double normal[3], 
         { 0, s->syy - s->sy * s->sy * sc, s->syz - s->sy * s->sz * sc },
         { 0, 0, s->szz - s->sz * s->sz * sc } };
     K[1][0] = K[0][1]; K[2][0] = K[0][2]; K[2][1] = K[1][2];
-    double sv[3], V[3][3];
-    orc_eig33sym(K, sv, V);
-    if (V[0][0] * center[0] + V[1][0] * center[1] + V[2][0] * center[2] <= 0) {
-        normal[0] = V[0][0]; normal[1] = V[1][0]; normal[2] = V[2][0];
+    double l0, v[3];
+    orc_eig33_smallest(K, &l0, v);
+    if (v[0] * center[0] + v[1] * center[1] + v[2] * center[2] <= 0) {
+        normal[0] = v[0]; normal[1] = v[1]; normal[2] = v[2];
     } else {
-        normal[0] = -V[0][0]; normal[1] = -V[1][0]; normal[2] = -V[2][0];
+        normal[0] = -v[0]; normal[1] = -v[1]; normal[2] = -v[2];
     }
-    *mse = sv[0] * sc;
-    *curv = sv[0] / (sv[0] + sv[1] + sv[2]);
+    *mse = l0 * sc;
+    *curv = l0 / (K[0][0] + K[1][1] + K[2][2]);
 }
 
 typedef struct {
@@ -387,7 +436,11 @@ int orc_peac_run(const uint16_t *depth, int w, int h, int stride_bytes,
             } else --i;
         }
 
+#ifdef ORC_PEAC_CLUSTER_HOOK                /* tools/ahc_spec_sim.c: the same loop with instrumentation (this file is #included there) */
+    ORC_PEAC_CLUSTER_HOOK(f);
+#else
     ah_cluster(f);
+#endif
 
     /* ---- refineDetails ---- */
     const int nold = f->nextracted;

@@ -38,4 +38,28 @@ def test_bench_prints_the_contract_line():
         assert k in d["roofline"], k
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 3          # ORB || LSD || planes, src/Frame.cc:210-215
+    assert d["cpu_baseline_all_cores"]["cores"] == os.cpu_count()
+    assert set(d["latency_ms"]) == {"B1", "B32"} and d["pcie_inclusive_frames_per_s"] > 0
+    assert len(d["kernel_roofline"]) >= 14 and all("frac" in v for v in d["kernel_roofline"].values())
+    assert d["config"]["distinct_frames"] == 64 and d["config"]["scene_mix"] == {"lowtex": 16, "std": 48}
+
+
+@pytest.mark.gpu
+def test_bench_stream_mode_line():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "stream", "--steps", "24", "--warmup", "2", "--no-extras"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["unit"] == "frames/s" and d["value"] > 0 and d["steps"] == 24 and d["config"]["mode"] == "stream"
+    assert d["latency_ms"]["pipelined_p50"] > 0 and d["cpu_baseline"]["cores"] == 3
+    assert d["config"]["mean_point_matches"] > 100
+
+
+def test_gpus_flag_must_match_world_size():
+    """--gpus N inside a torchrun environment of another size is an error (before anything touches the GPU)"""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 2 and "WORLD_SIZE" in p.stderr

@@ -150,6 +150,35 @@ def test_eig33sym_against_numpy(orc):
         assert np.allclose(K @ V, V * s, atol=1e-9 * np.abs(K).max())
 
 
+def test_eig33_smallest_against_jacobi_and_numpy(orc):
+    """Stats::compute's solver (Laguerre + adjugate column) on covariances of noisy planar patches, from nearly exact planes
+    to blobs: the eigenvalue is within 4 ulp of trace(K) of the Jacobi / LAPACK value (the backward-stable bound the
+    reference's Eigen solver has) and the eigenvector satisfies K v = lambda v to the same tolerance"""
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for t in range(400):
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        ext = rng.uniform(0.02, 2.0); sig = ext * 10.0 ** rng.uniform(-6, -0.3)
+        P = rng.uniform(-ext, ext, size=(int(rng.integers(100, 3000)), 3))
+        P -= np.outer(P @ n, n); P += np.outer(rng.normal(scale=sig, size=len(P)), n); P += rng.uniform(-3, 3, size=3)
+        s = P.sum(0); K = P.T @ P - np.outer(s, s) / len(P)
+        l0, v = orc.eig33_smallest(K)
+        sj, Vj = orc.eig33sym(K)
+        tr = np.trace(K)
+        assert abs(l0 - sj[0]) <= 9e-16 * tr and abs(l0 - np.linalg.eigvalsh(K)[0]) <= 2e-15 * tr
+        assert abs(np.linalg.norm(v) - 1) < 1e-14
+        assert np.linalg.norm(K @ v - l0 * v) <= 1e-14 * tr
+        gap = sj[1] - sj[0]
+        ang = np.linalg.norm(np.cross(v, Vj[:, 0]))
+        assert ang <= 1e-13 * tr / max(gap, 1e-300) + 1e-12, (ang, gap / tr)
+        worst = max(worst, abs(l0 - sj[0]) / tr)
+    # exact plane: lambda0 = 0 up to rounding of K, and a multiple of the identity returns a unit vector
+    l0, v = orc.eig33_smallest(np.diag([2.0, 3.0, 0.0]))
+    assert l0 == 0.0 and np.allclose(np.abs(v), [0, 0, 1])
+    l0, v = orc.eig33_smallest(np.eye(3) * 0.5)
+    assert abs(l0 - 0.5) < 1e-15 and abs(np.linalg.norm(v) - 1) < 1e-15
+
+
 def test_peac_synthetic_scene_finds_the_walls(orc, synth):
     lab, pl = orc.peac(synth.make_depth(0x5EED0002))
     assert len(pl) == 4 and np.all(np.diff(pl["n_points"]) <= 0)

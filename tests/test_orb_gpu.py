@@ -101,3 +101,39 @@ def test_orb_properties_full_size(gpu_ctx, synth):
     s = 1.2 ** kp1["octave"]
     assert np.all(kp1["x"] / s >= 15.9) and np.all(kp1["y"] / s >= 15.9)
     assert np.all((kp1["angle"] >= 0) & (kp1["angle"] < 360))
+
+
+SLAB_SCRIPT = r"""
+import importlib, sys
+import numpy as np
+import torch
+torch.cuda.init()                      # torch's HIP runtime first: a process that loads libhvo.so before torch cannot initialise torch.cuda
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+hvo = ge.package(); synth = importlib.import_module("hvo_amd.synth"); hd = importlib.import_module("hvo_amd.dist")
+g, d = synth.make_batch("std", 0x5EED1000, 3)
+ctx = hvo.Context(max_batch=3)
+ctx.batch_upload(g, d); ctx.batch_run(hvo.STAGE_ALL)
+res = ctx.batch_download(hvo.STAGE_ALL)
+kc, lc, pc, sb = ctx.slab_layout()
+assert sb == hd.slab_layout(hvo, kc, lc, pc)["size"]
+slabs = hd.device_slabs(ctx, 3)
+assert slabs.is_cuda and tuple(slabs.shape) == (3, sb)
+back = hd.unpack_results(hvo, slabs.cpu().numpy(), kc, lc, pc)
+for a, b in zip(back, res):
+    assert a["status"] == b["status"]
+    for k in ("kp", "desc", "kl", "ldesc", "linefn", "planes"):
+        assert np.array_equal(a[k], b[k]), k
+    assert len(a["kp"]) > 500 and len(a["kl"]) > 20 and len(a["planes"]) >= 3
+ctx.close()
+print("slabs ok")
+"""
+
+
+def test_device_result_slabs_match_download():
+    """hvo_batch_pack_results: the device-resident slabs (what the multi-GPU gather ships, written into a torch CUDA tensor)
+    hold exactly what hvo_batch_download returns.  Own process: torch.cuda has to be initialised before libhvo.so is loaded."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", SLAB_SCRIPT % root], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "slabs ok" in p.stdout, p.stderr[-3000:]
