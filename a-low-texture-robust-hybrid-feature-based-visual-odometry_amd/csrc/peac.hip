@@ -32,6 +32,10 @@
 #define SEG_D 16          // doubles per seg: st[9], center[3], normal[3], mse
 #define SEG_I 8           // ints per seg: N, rid, nouse, nb_off, nb_cnt, nb_cap, valid, pad
 #define LCAP 1024         // neighbour-list length staged in LDS
+#define LAT_MAX_BATCH 2048     // plans up to this many frames also allocate k_peac_cluster_lat's node records (1.6 MB per 640x480 frame)
+#ifndef LAT_DEFAULT_BATCH
+#define LAT_DEFAULT_BATCH 0    // k_peac_cluster_lat is opt-in (HVO_PEAC_LAT=1): 28.7 ms per frame against 27.0 ms for k_peac_cluster<64>
+#endif
 
 struct PeacPlan {
     int w = 0, h = 0, pitch = 0, Nw = 0, Nh = 0, nblk = 0, segcap = 0, poolcap = 0, qcap = 0, batch = 0;
@@ -45,6 +49,7 @@ struct PeacPlan {
     hvo_plane *d_planes = nullptr;
     unsigned long long *d_adj = nullptr;
     double *d_hkey = nullptr; int *d_hid = nullptr;
+    void *d_nodes = nullptr; int lat_batch = 0;     // k_peac_cluster_lat's 256-byte node records (plans of fewer than LAT_MAX_BATCH frames)
     double c15 = 0, c60 = 0, c30 = 0;   // cos thresholds evaluated on the host (glibc), like the oracle
     double ang_factor = 0, ang_near = 0;
 };
@@ -187,7 +192,8 @@ __global__ __launch_bounds__(64) void k_peac_blocks(const uint16_t *__restrict__
     for (int k = 0; k < 9; k++) sd[k] = st[k];
     sd[9] = center[0]; sd[10] = center[1]; sd[11] = center[2];
     sd[12] = normal[0]; sd[13] = normal[1]; sd[14] = normal[2]; sd[15] = mse;
-    si[0] = N; si[1] = blk; si[2] = ok ? 0 : 1; si[3] = blk * 4; si[4] = 0; si[5] = 4; si[6] = ok; si[7] = 0;
+    // [5], [7]: size and root of the node's disjoint set (a live node IS one set: DisjointSet::Union then needs no Find chain)
+    si[0] = N; si[1] = blk; si[2] = ok ? 0 : 1; si[3] = blk * 4; si[4] = 0; si[5] = 1; si[6] = ok; si[7] = blk;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -296,7 +302,7 @@ static __device__ void pool_gc(int *segI, int nseg, int *&pool, int *&pool2, int
         for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
         const int dst = top + incl - sz;
         for (int k = 0; k < sz; k++) pool2[dst + k] = pool[off + k];
-        if (id < nseg) { int *si = segI + (size_t)id * SEG_I; if (!si[2]) { si[3] = dst; si[5] = sz; } }
+        if (id < nseg) { int *si = segI + (size_t)id * SEG_I; if (!si[2]) { si[3] = dst; } }
         top += __shfl(incl, 63);
     }
     int *t = pool; pool = pool2; pool2 = t;
@@ -583,7 +589,7 @@ static __device__ void gpool_gc(int *segI, int nseg, int *&pool, int *&pool2, in
         for (int o = 1; o < GL; o <<= 1) { const int t = __shfl_up(incl, o, GL); if (gl >= o) incl += t; }
         const int dst = top + incl - sz;
         for (int k = 0; k < sz; k++) pool2[dst + k] = pool[off + k];
-        if (in) { int *si = segI + (size_t)id * SEG_I; if (!si[2]) { si[3] = dst; si[5] = sz; } }
+        if (in) { int *si = segI + (size_t)id * SEG_I; if (!si[2]) { si[3] = dst; } }
         top += Grp<GL>::shfl(incl, GL - 1);
     }
     if (need) { int *t = pool; pool = pool2; pool2 = t; pooltop = top; }
@@ -614,12 +620,12 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
     __syncthreads();
     int ptop = hn > 0 ? H.id(0) : -1;
     // the popped node's record (sums, normal, list) is fetched one iteration ahead, underneath the sift-down
-    double nps[9], npn[3]; int n_nouse = 1, n_cnt = 0, n_off = 0, n_N = 0, n_rid = 0, a0n = -1;
+    double nps[9], npn[3]; int n_nouse = 1, n_cnt = 0, n_off = 0, n_N = 0, n_rid = 0, n_dsr = 0, n_dss = 0, a0n = -1;
     auto fetch_next = [&](int r) {
         const int q = r < 0 ? 0 : r;
         const int *qi = segI + (size_t)q * SEG_I;
         const double *qd = segD + (size_t)q * SEG_D;
-        n_nouse = qi[2]; n_cnt = qi[4]; n_off = qi[3]; n_N = qi[0]; n_rid = qi[1];
+        n_nouse = qi[2]; n_cnt = qi[4]; n_off = qi[3]; n_N = qi[0]; n_rid = qi[1]; n_dsr = qi[7]; n_dss = qi[5];
 #pragma unroll
         for (int q2 = 0; q2 < 9; q2++) nps[q2] = qd[q2];
         npn[0] = qd[12]; npn[1] = qd[13]; npn[2] = qd[14];
@@ -640,7 +646,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
         PT(1)
         int *pi = segI + (size_t)(p < 0 ? 0 : p) * SEG_I;
         const bool live = act && n_nouse == 0;                 // skip nouse nodes (lazy deletion)
-        const int pcnt = live ? n_cnt : 0, poff = n_off, pN = n_N, prid = n_rid;
+        const int pcnt = live ? n_cnt : 0, poff = n_off, pN = n_N, prid = n_rid, pdsr = n_dsr, pdss = n_dss;
         double ps[9], pn[3];                                   // popped node: sums and normal (uniform per group)
 #pragma unroll
         for (int q = 0; q < 9; q++) ps[q] = nps[q];
@@ -648,7 +654,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
         const int a0 = gl < pcnt ? a0n : -1;                   // first chunk of p's list, reused by the merge
         // ---- evaluate the merge with every neighbour, one candidate per lane; each lane keeps its best ----
         bool bhas = false; double bm = 0; int bid = 0x7FFFFFFF, bN = 0, gid = 0x7FFFFFFF, xid = -1;
-        int brid = 0, bnoff = 0, bncnt = 0;                    // the candidate's rid and list, fetched with its sums
+        int brid = 0, bnoff = 0, bncnt = 0, bdsr = 0, bdss = 0; // the candidate's rid, set and list, fetched with its sums
         double bc[3] = { 0, 0, 0 }, bn[3] = { 0, 0, 0 };        // (the merged sums are re-formed when the record is written)
         PT(2)
         int id_cur = a0;                                        // ids of the next chunk are fetched one pass ahead
@@ -656,14 +662,14 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
             PT_CNT(9, 1)
             const int k = base + gl;
             const int id_nxt = k + GL < pcnt ? pool[poff + k + GL] : -1;
-            double lst[9]; int lN = 4, nb = 0, nrid = 0, noff_ = 0, ncnt_ = 0; bool has = false;
+            double lst[9]; int lN = 4, nb = 0, nrid = 0, noff_ = 0, ncnt_ = 0, ndsr = 0, ndss = 0; bool has = false;
 #pragma unroll
             for (int q = 0; q < 9; q++) lst[q] = 0;
             if (k < pcnt) {
                 nb = id_cur;
                 const double *nd = segD + (size_t)nb * SEG_D;
                 const int *nI = segI + (size_t)nb * SEG_I;
-                const int nN = nI[0]; nrid = nI[1]; noff_ = nI[3]; ncnt_ = nI[4];
+                const int nN = nI[0]; nrid = nI[1]; noff_ = nI[3]; ncnt_ = nI[4]; ndsr = nI[7]; ndss = nI[5];
                 if (!(fabs(pn[0] * nd[12] + pn[1] * nd[13] + pn[2] * nd[14]) < a.c60)) {      // T_ang(P_MERGING)
 #pragma unroll
                     for (int q = 0; q < 9; q++) lst[q] = ps[q] + nd[q];
@@ -682,7 +688,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
                     if (better) { gid = good ? nb : 0x7FFFFFFF; xid = nb; }
                     else if (equal) { if (good && nb < gid) gid = nb; if (nb > xid) xid = nb; }
                     if (better || (equal && nb < bid)) {                   // payload follows (mse, id)
-                        bid = nb; bN = lN; brid = nrid; bnoff = noff_; bncnt = ncnt_;
+                        bid = nb; bN = lN; brid = nrid; bnoff = noff_; bncnt = ncnt_; bdsr = ndsr; bdss = ndss;
 #pragma unroll
                         for (int q = 0; q < 3; q++) { bc[q] = tc[q]; bn[q] = tn[q]; }
                     }
@@ -718,7 +724,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
             // (uniformly over the group; lane 0 of the group then owns it)
             const bool refit = any_cand && wm == 0;
             if (__any(refit)) {
-                double lst[9]; int lN = 4, rrid = 0, roff = 0, rcnt = 0;
+                double lst[9]; int lN = 4, rrid = 0, roff = 0, rcnt = 0, rdsr = 0, rdss = 0;
 #pragma unroll
                 for (int q = 0; q < 9; q++) lst[q] = 0;
                 if (refit) {
@@ -726,14 +732,14 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
                     const int *nI = segI + (size_t)win * SEG_I;
 #pragma unroll
                     for (int q = 0; q < 9; q++) lst[q] = ps[q] + nd[q];
-                    lN = pN + nI[0]; rrid = nI[1]; roff = nI[3]; rcnt = nI[4];
+                    lN = pN + nI[0]; rrid = nI[1]; roff = nI[3]; rcnt = nI[4]; rdsr = nI[7]; rdss = nI[5];
                 }
                 double tc[3], tn[3], tm;
                 stats_compute_dev(lst, lN, tc, tn, tm);
                 if (refit) {
 #pragma unroll
                     for (int q = 0; q < 3; q++) { bc[q] = tc[q]; bn[q] = tn[q]; }
-                    bm = tm; bN = lN; brid = rrid; bid = win; m = tm; c2 = tc[2]; noff = roff; ncnt = rcnt;
+                    bm = tm; bN = lN; brid = rrid; bdsr = rdsr; bdss = rdss; bid = win; m = tm; c2 = tc[2]; noff = roff; ncnt = rcnt;
                     is_w = gl == 0;
                 }
             }
@@ -809,12 +815,12 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
                 for (int q = 0; q < 9; q++) md[q] = ps[q] + wd[q];
                 md[9] = bc[0]; md[10] = bc[1]; md[11] = bc[2]; md[12] = bn[0]; md[13] = bn[1]; md[14] = bn[2]; md[15] = bm;
                 int *mi = segI + (size_t)id * SEG_I;
-                mi[0] = bN; mi[1] = pN >= bN - pN ? prid : brid; mi[2] = 0; mi[3] = moff; mi[4] = mcnt; mi[5] = pcnt + ncnt; mi[6] = 1; mi[7] = 0;
-                int xr = ds_find_ro(parent, prid), yr = ds_find_ro(parent, brid);          // ds.Union(pa.rid, pb.rid)
-                if (xr != yr) {
-                    if (dsize[xr] < dsize[yr]) { parent[xr] = yr; dsize[yr] += dsize[xr]; }
-                    else { parent[yr] = xr; dsize[xr] += dsize[yr]; }
-                }
+                // ds.Union(pa.rid, pb.rid) (DisjointSet.hpp:63-83): the two nodes carry their sets' roots and sizes -- two stores, no Find
+                int root = pdsr, size = pdss + bdss;
+                if (pdsr == bdsr) size = pdss;
+                else if (pdss < bdss) { parent[pdsr] = bdsr; dsize[bdsr] = size; root = bdsr; }
+                else { parent[bdsr] = pdsr; dsize[pdsr] = size; }
+                mi[0] = bN; mi[1] = pN >= bN - pN ? prid : brid; mi[2] = 0; mi[3] = moff; mi[4] = mcnt; mi[5] = size; mi[6] = 1; mi[7] = root;
                 int *ni = segI + (size_t)nb * SEG_I;
                 pi[2] = 1; ni[2] = 1; pi[4] = 0; ni[4] = 0;
             }
@@ -979,6 +985,8 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
 #undef GOK
 #undef SD
 }
+
+#include "peac_lat.inc"
 
 // ------------------------------------------------------------------------------------------------
 // k_peac_blkmap: findBlockMembership (block erosion) + coarse membership image
@@ -1529,7 +1537,7 @@ void peac_free(hvo_ctx *ctx)
     PeacPlan *P = plan_of(ctx);
     if (!P) return;
     void *ptrs[] = { P->d_depth, P->d_segD, P->d_segI, P->d_pool, P->d_pool2, P->d_parent, P->d_dsize, P->d_eflag, P->d_meta, P->d_extracted,
-                     P->d_blkmap, P->d_labels, P->d_state, P->d_queue, P->d_plidmap, P->d_isvalid, P->d_planes, P->d_adj, P->d_hkey, P->d_hid };
+                     P->d_blkmap, P->d_labels, P->d_state, P->d_queue, P->d_plidmap, P->d_isvalid, P->d_planes, P->d_adj, P->d_hkey, P->d_hid, P->d_nodes };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
     ctx->peac = nullptr;
@@ -1576,6 +1584,8 @@ static int peac_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_planes, B * MAX_PLANES * sizeof(hvo_plane));
     PA(P->d_adj, B * MAX_PLANES * sizeof(unsigned long long));
     PA(P->d_hkey, B * P->nblk * sizeof(double)); PA(P->d_hid, B * P->nblk * sizeof(int));
+    // the low-latency kernel keeps the whole heap (10 bytes per block) and one bit per node in LDS: up to ~14 k blocks (1280x960 has 12 288)
+    if (batch <= LAT_MAX_BATCH && P->segcap <= 65535 && (size_t)P->nblk * 10 + (size_t)P->segcap * 2 + 64 <= 150 * 1024) { PA(P->d_nodes, B * P->segcap * sizeof(Node2)); P->lat_batch = batch; }
 #undef PA
     // stream-ordered fill: a null-stream hipMemset is not ordered against the non-blocking ctx stream
     HVO_HIP(hipMemsetAsync(P->d_depth, 0, B * P->pitch * (h + 1) * sizeof(uint16_t), ctx->s_peac));
@@ -1627,7 +1637,23 @@ int peac_run(hvo_ctx *ctx, int n)
     a.c15 = P->c15; a.c60 = P->c60; a.hkey = P->d_hkey; a.hid = P->d_hid;
     a.ang_factor = P->ang_factor; a.ang_near = P->ang_near;
     id = hvo_prof_begin(ctx, "peac_cluster", st);
-    {
+    // k_peac_cluster_lat (one frame per workgroup, queue in LDS, adjacency inline in 256-byte node records): an experiment in
+    // trading memory round trips for instructions that did not pay (a lone wave issues one instruction every 5-8 cycles,
+    // whatever it waits for); kept behind HVO_PEAC_LAT=1 with its parity tests, see DESIGN.md section 4
+    bool lat = P->d_nodes != nullptr && n <= P->lat_batch && n <= LAT_DEFAULT_BATCH;
+    { const char *e = getenv("HVO_PEAC_LAT"); if (e) lat = atoi(e) != 0 && P->d_nodes != nullptr && n <= P->lat_batch; }
+    if (lat) {
+        Cl2Args A2; A2.a = a; A2.nodes = (Node2 *)P->d_nodes; A2.ovf = (unsigned short *)P->d_pool2; A2.ovfcap = P->poolcap;
+        { const char *e = getenv("HVO_PEAC_OVFCAP"); if (e && atoi(e) > 0 && atoi(e) < P->poolcap) A2.ovfcap = atoi(e); }     // tests: force the pool compaction
+        A2.heap_lds = P->nblk;
+        const size_t lds = ((((size_t)A2.heap_lds * 10 + (size_t)P->segcap * 2) + 15) & ~(size_t)15) + 16;
+        static size_t lds_set = 0;
+        if (lds > 48 * 1024 && lds > lds_set) {
+            HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_lat), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_set = lds;
+        }
+        hipLaunchKernelGGL(k_peac_cluster_lat, dim3(n), dim3(64), lds, st, A2, n);
+    } else {
         // 4 frames per wave pay off once the wave slots are saturated (measured: >= ~3000 resident frames);
         // HVO_PEAC_GL forces a group width (tests run the 16-lane path on small batches with it)
         const char *e = getenv("HVO_PEAC_GL");

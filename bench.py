@@ -283,45 +283,50 @@ def stream_queries(np, last, shift, sf, bf, th=15):
 
 
 def run_stream(hvo, np, g, d, off, mask, depth, device, nframes, paced_hz=0.0):
-    """frames through hvo_stream_* with `depth` in flight; every frame is collected and matched against its predecessor
-    (SearchByProjection(Cur, Last) + LSDmatcher::match) before the next collect.  Returns (seconds, per-frame latency ms,
-    matches per frame)."""
+    """frames through hvo_stream_* with up to depth - 1 in flight (one slot keeps the previous frame resident for the
+    matching); every frame is collected and matched against its predecessor (SearchByProjection(Cur, Last) +
+    LSDmatcher::match).  paced_hz = 0: the next frame is submitted as soon as a slot is free (sustained rate); paced_hz > 0:
+    frames arrive on a camera clock and a frame is collected as soon as it is complete (latency under a 30 fps feed).
+    Returns (seconds, per-frame latency ms from submit to results + matches in hand, matches per frame)."""
     bf = 40.0
     st = hvo.Stream(width=g.shape[2], height=g.shape[1], depth=depth, stages=mask, bf=bf, device=device)
     sf = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2), np.float32)])).astype(np.float32)
-    lat = []; nm_pts = 0; nm_lines = 0
+    lat = []; nm = [0, 0]
     try:
-        tick = {}; tsub = {}
-        inflight = max(1, depth - 1)              # one slot keeps the previous frame resident for the matching
-        nxt = 0
+        tick = {}; tsub = {}; state = {"last": None, "done": 0}
+        inflight = max(1, depth - 1)
         t_start = time.perf_counter()
-        def submit(k):
-            if paced_hz > 0:
-                due = t_start + k / paced_hz
-                while time.perf_counter() < due: time.sleep(0.0002)
-            tsub[k] = time.perf_counter()
-            tick[k] = st.submit(g[k % len(g)], d[k % len(d)])
-        while nxt < min(inflight, nframes):
-            submit(nxt); nxt += 1
-        last = None
-        for i in range(nframes):
+
+        def finish(i):                                    # collect frame i, match it against frame i - 1
             cur = st.collect(tick[i], labels=True)
+            last = state["last"]
             if last is not None and (mask & 1):
                 shift = off[i % len(off)] - off[(i - 1) % len(off)] if i % len(off) else (0, 0)
                 sel, u, v, rad, lmin, lmax, ur, blocks = stream_queries(np, last, shift, sf, bf)
                 n, _, _ = st.search_by_projection(tick[i], tick[i - 1], sel, u, v, rad, lmin, lmax, ur, blocks)
-                nm_pts += n
+                nm[0] += n
             if last is not None and (mask & 2):
                 n, _ = st.match_lines(tick[i - 1], tick[i], hvo.LINE_MATCH_NNR, nnratio=0.95)
-                nm_lines += n
+                nm[1] += n
             lat.append((time.perf_counter() - tsub[i]) * 1e3)
-            last = cur
-            if nxt < nframes:
-                submit(nxt); nxt += 1
+            state["last"] = cur; state["done"] = i + 1
+
+        for k in range(nframes):
+            if paced_hz > 0:
+                due = t_start + k / paced_hz
+                while time.perf_counter() < due:
+                    if state["done"] < k and st.poll(tick[state["done"]]): finish(state["done"])
+                    else: time.sleep(0.0002)
+            while k - state["done"] >= inflight:          # every slot busy: the oldest frame has to leave first
+                finish(state["done"])
+            tsub[k] = time.perf_counter()
+            tick[k] = st.submit(g[k % len(g)], d[k % len(d)])
+        while state["done"] < nframes:
+            finish(state["done"])
         el = time.perf_counter() - t_start
     finally:
         st.close()
-    return el, np.array(lat), nm_pts / max(nframes - 1, 1), nm_lines / max(nframes - 1, 1)
+    return el, np.array(lat), nm[0] / max(nframes - 1, 1), nm[1] / max(nframes - 1, 1)
 
 
 def main():
