@@ -40,14 +40,16 @@ KEYLINE_DT = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"),
                        ("length", "<f4"), ("num_pixels", "<i4")])
 PLANE_DT = np.dtype([("normal", "<f8", 3), ("center", "<f8", 3), ("mse", "<f8"),
                      ("n_points", "<i4"), ("rid", "<i4")])
-assert KEYPOINT_DT.itemsize == 28 and KEYLINE_DT.itemsize == 68 and PLANE_DT.itemsize == 64
+LINE3D_DT = np.dtype([("A", "<f8", 3), ("B", "<f8", 3), ("line_nor", "<f8", 3), ("line_eq", "<f4", 3), ("good", "<i4"),
+                      ("n_samples", "<i4"), ("n_inliers", "<i4"), ("inlier_mask", "<u4"), ("pad", "<i4")])
+assert KEYPOINT_DT.itemsize == 28 and KEYLINE_DT.itemsize == 68 and PLANE_DT.itemsize == 64 and LINE3D_DT.itemsize == 104
 
 EXPORTS = [
     "hvo_abi_version", "hvo_default_params", "hvo_create", "hvo_destroy", "hvo_strerror", "hvo_last_error",
     "hvo_extract_orb", "hvo_extract_lsd", "hvo_compute_planes",
     "hvo_hamming_matrix", "hvo_hamming_knn2", "hvo_match_nnr", "hvo_search_by_projection", "hvo_stereo_from_rgbd",
     "hvo_undistort_keypoints", "hvo_image_bounds", "hvo_assign_features_to_grid", "hvo_assign_lines_to_grid",
-    "hvo_extract_lsd_culled", "hvo_set_line_culling", "hvo_search_by_projection_map", "hvo_frame_bf_match", "hvo_search_double",
+    "hvo_extract_lsd_culled", "hvo_set_line_culling", "hvo_lines_3d", "hvo_search_by_projection_map", "hvo_frame_bf_match", "hvo_search_double",
     "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch", "hvo_batch_slab_layout", "hvo_batch_pack_results",
     "hvo_profile_last", "hvo_profile_enable",
     "hvo_stream_create", "hvo_stream_destroy", "hvo_stream_last_error", "hvo_stream_capacity", "hvo_stream_image_bounds",
@@ -127,6 +129,7 @@ def lib():
         L.hvo_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         L.hvo_extract_lsd_culled.argtypes = L.hvo_extract_lsd.argtypes
         L.hvo_set_line_culling.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        L.hvo_lines_3d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p]
         L.hvo_undistort_keypoints.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.hvo_image_bounds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.hvo_assign_features_to_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
@@ -222,6 +225,14 @@ class Context:
     def set_line_culling(self, dis=5.0, angle_deg=2.5, endpoint_dis=15.0):
         """parameters of Frame::cullingLine (Frame.cc:934)"""
         self._chk(lib().hvo_set_line_culling(self.h, dis, angle_deg, endpoint_dis), "set_line_culling")
+
+    def lines_3d(self, kl, depth, seed=1):
+        """Frame::isLineGood (src/Frame.cc:1205-1322): mvLines3D / mvLineEq / mvLineNor of every key line -> LINE3D_DT array"""
+        kl = np.ascontiguousarray(kl); depth = np.ascontiguousarray(depth, np.uint16)
+        h, w = depth.shape
+        out = np.zeros(len(kl), LINE3D_DT)
+        self._chk(lib().hvo_lines_3d(self.h, _p(kl), len(kl), _p(depth), w, h, depth.strides[0], seed, _p(out)), "lines_3d")
+        return out
 
     def compute_planes(self, depth, cap=64):
         if depth.dtype != np.uint16 or depth.ndim != 2:

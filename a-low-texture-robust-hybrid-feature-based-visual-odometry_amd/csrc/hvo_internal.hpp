@@ -211,6 +211,10 @@ void frame_gather_angles_enqueue(hipStream_t st, const hvo_keypoint *d_kp, const
 int frame_points_to_grid(hvo_ctx *ctx, const hvo_keypoint *kp_un, int n, const float *bounds4, int32_t *cell_start, int32_t *cell_items, int *n_out);
 int frame_lines_to_grid(hvo_ctx *ctx, const hvo_keyline *kl, int n, const float *bounds4, int32_t *cell_start, int32_t *cell_items, int cap, int *n_out);
 
+// line3d.hip
+int lines3d_enqueue(hvo_ctx *ctx, hipStream_t st, const hvo_keyline *d_kl, const int *d_n, int n_max, const uint16_t *d_depth, int pitch, int w, int h,
+                    unsigned seed, hvo_line3d *d_out);
+
 // peac.hip
 struct PeacView { uint16_t *d_depth; int pitch; size_t dframe; int8_t *d_labels8; hvo_plane *d_planes; int *d_meta; int npix, max_planes; };
 int peac_prepare(hvo_ctx *ctx, int w, int h, int batch, PeacView *v);      // plan for this geometry + where its inputs / results live

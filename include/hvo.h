@@ -174,6 +174,23 @@ int hvo_extract_lsd_culled(hvo_ctx *ctx, const uint8_t *gray, int w, int h, int 
                            hvo_keyline *kl, uint8_t *desc32, double *linefn3, int cap, int *n);
 int hvo_set_line_culling(hvo_ctx *ctx, double dis, double angle_deg, double endpoint_dis);
 
+/* Frame::isLineGood (reference src/Frame.cc:1205-1322): the 3-D line of every key line from the depth image --
+ * <= 21 samples along the segment with nearest-pixel depth, LINEextractor::compPt3dCov (src/LineExtractor.cpp:44-97) and the RANSAC
+ * on Mahalanobis point-line distances of LINEextractor::extract3dline_mahdist (220-327).  The reference draws from a time-seeded
+ * rand(); here the caller passes a seed and every line draws from its own xorshift32 stream (seed, line index), so results are
+ * reproducible and independent of the order of the lines.  depth / intrinsics as in hvo_stereo_from_rgbd. */
+typedef struct {
+    double A[3], B[3];          /* mvLines3D[i] (camera frame); zeros when no line was fitted */
+    double line_nor[3];         /* mvLineNor[i] = A x B; (-1,-1,-1) when none */
+    float  line_eq[3];          /* mvLineEq[i] = (B - A) / |B - A| (float); (-1,-1,-1) when none */
+    int32_t good;               /* 1: |A - B| > 0.02: the line enters mVF3DLines */
+    int32_t n_samples;          /* samples with a valid depth (<= 21) */
+    int32_t n_inliers;          /* RandomLine3d::pts.size() */
+    uint32_t inlier_mask;       /* bit j: valid sample j is an inlier */
+    int32_t pad;
+} hvo_line3d;
+int hvo_lines_3d(hvo_ctx *ctx, const hvo_keyline *kl, int n, const uint16_t *depth, int w, int h, int stride, uint32_t seed, hvo_line3d *out);
+
 /* ---- Frame post-processing of the outputs above ----------------------------------------
  * dist5 = {k1, k2, p1, p2, k3} (Camera.k1.. of the settings file; k3 = 0 when absent); the intrinsics are the
  * context's (hvo_params fx, fy, cx, cy).  The 64 x 48 grids (FRAME_GRID_COLS x FRAME_GRID_ROWS) are returned as

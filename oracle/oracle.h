@@ -169,6 +169,20 @@ int  orc_line_iterator_count_clipped(int w, int h, float x1, float y1, float x2,
 int  orc_cull_lines(const uint8_t *gray, int w, int h, int stride, const orc_keyline *kl, const double *fn, int n,
                     double dis, double angle_deg, double endpoint_dis, orc_keyline *kl_out, uint8_t *desc32, double *fn_out);
 
+/* Frame::isLineGood (src/Frame.cc:1205-1322): the 3-D line of every key line (line3d.c).  Layout == hvo_line3d. */
+typedef struct {
+    double A[3], B[3];          /* mvLines3D[i] (camera frame); zeros when no line was fitted */
+    double line_nor[3];         /* mvLineNor[i] = A x B; (-1,-1,-1) when none */
+    float  line_eq[3];          /* mvLineEq[i] = (B - A) / |B - A| in float; (-1,-1,-1) when none */
+    int32_t good;               /* 1: |A - B| > 0.02, the line was pushed to mVF3DLines */
+    int32_t n_samples;          /* samples with valid depth (<= 21) */
+    int32_t n_inliers;          /* rl.pts.size() */
+    uint32_t inlier_mask;       /* bit j: valid sample j is an inlier */
+    int32_t pad;
+} orc_line3d;
+int  orc_lines_3d(const orc_keyline *kl, int n, const uint16_t *depth, int w, int h, int stride_bytes,
+                  float fx, float fy, float cx, float cy, float depth_factor, uint32_t seed, orc_line3d *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -225,6 +225,22 @@ def peac(depth, fx=535.4, fy=539.2, cx=320.1, cy=247.6, depth_factor=None, cap=6
     return labels, planes[: min(n.value, cap)].copy()
 
 
+LINE3D_DT = np.dtype([("A", "<f8", 3), ("B", "<f8", 3), ("line_nor", "<f8", 3), ("line_eq", "<f4", 3), ("good", "<i4"),
+                      ("n_samples", "<i4"), ("n_inliers", "<i4"), ("inlier_mask", "<u4"), ("pad", "<i4")])
+
+
+def lines_3d(kl, depth, seed=1, fx=535.4, fy=539.2, cx=320.1, cy=247.6, depth_factor=None):
+    """Frame::isLineGood (src/Frame.cc:1205-1322) -> LINE3D_DT array"""
+    kl = np.ascontiguousarray(kl); depth = np.ascontiguousarray(depth, np.uint16); h, w = depth.shape
+    if depth_factor is None:
+        depth_factor = float(np.float32(1.0) / np.float32(5000.0))
+    out = np.zeros(len(kl), LINE3D_DT)
+    L = lib()
+    L.orc_lines_3d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_float] * 5 + [C.c_uint32, C.c_void_p]
+    L.orc_lines_3d(_p(kl), len(kl), _p(depth), w, h, depth.strides[0], fx, fy, cx, cy, depth_factor, seed, _p(out))
+    return out
+
+
 def eig33_smallest(K):
     """the smallest eigenpair as Stats::compute uses it (orc_eig33_smallest) -> (lambda0, v)"""
     K = np.ascontiguousarray(K, np.float64); l = C.c_double(0); v = np.zeros(3)
