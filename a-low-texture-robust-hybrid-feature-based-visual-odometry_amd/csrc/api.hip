@@ -471,6 +471,22 @@ int hvo_staged_d2h(hvo_ctx *ctx, hipStream_t st, const void *dev_base, size_t de
 {
     const size_t HALF = 64u << 20;
     if (n <= 0) return HVO_OK;
+    // Direct path: equally sized, equally spaced destinations in page-locked memory (a caller's pinned result slab, see
+    // hvo_pin_host) take ONE strided DMA from the device slab; no staging copy, no host memcpy.
+    if (!widen8 && n >= 2 && dst[0] && bytes[0]) {
+        bool regular = true;
+        const ptrdiff_t D = (const char *)dst[1] - (const char *)dst[0];
+        for (int f = 0; f < n && regular; f++) regular = dst[f] == (void *)((char *)dst[0] + (ptrdiff_t)f * D) && bytes[f] == bytes[0];
+        if (regular && D >= (ptrdiff_t)bytes[0]) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, dst[0]) == hipSuccess && at.type == hipMemoryTypeHost) {
+                HVO_HIP(hipMemcpy2DAsync(dst[0], (size_t)D, dev_base, dev_stride, bytes[0], (size_t)n, hipMemcpyDeviceToHost, st));
+                HVO_HIP(hipStreamSynchronize(st));
+                return HVO_OK;
+            }
+            (void)hipGetLastError();                               // "not a registered pointer" is not an error here
+        }
+    }
     if (dev_stride > HALF && !widen8) {                        // a frame larger than a buffer: plain copies
         for (int f = 0; f < n; f++)
             if (dst[f] && bytes[f]) HVO_HIP(hipMemcpyAsync(dst[f], (const char *)dev_base + (size_t)f * dev_stride, bytes[f], hipMemcpyDeviceToHost, st));
@@ -504,6 +520,19 @@ int hvo_staged_d2h(hvo_ctx *ctx, hipStream_t st, const void *dev_base, size_t de
         }
     }
     return HVO_OK;
+}
+
+// Page-lock / unlock a caller's buffer (hipHostRegister): images and result slabs in pinned memory move by DMA at the link
+// rate without the runtime's staging copy.  For callers that do not link HIP themselves.
+extern "C" int hvo_pin_host(void *p, size_t bytes)
+{
+    if (!p || !bytes) return HVO_ERR_INVALID_ARG;
+    return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? HVO_OK : HVO_ERR_HIP;
+}
+extern "C" int hvo_unpin_host(void *p)
+{
+    if (!p) return HVO_ERR_INVALID_ARG;
+    return hipHostUnregister(p) == hipSuccess ? HVO_OK : HVO_ERR_HIP;
 }
 
 void *hvo_stage_host(hvo_ctx *ctx, size_t bytes)

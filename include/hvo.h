@@ -313,6 +313,12 @@ int  hvo_stream_search_by_projection(hvo_stream *s, int64_t cur, int64_t last, i
  * *n_from receives n_kl(from) */
 int  hvo_stream_match_lines(hvo_stream *s, int64_t from, int64_t to, int mode, float th, float nnratio, int32_t *matches12, int *n_from, int *n_matches);
 
+/* Page-lock (hipHostRegister) / unlock a caller's host buffer.  Images handed to hvo_batch_upload / hvo_stream_submit and result
+ * slabs handed to hvo_batch_download move by DMA at the link rate when they are pinned (no staging copy on either side); equally
+ * sized, equally spaced pinned destinations (e.g. labels8 of consecutive frames in one slab) take a single strided DMA. */
+int hvo_pin_host(void *p, size_t bytes);
+int hvo_unpin_host(void *p);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* Per-kernel-group device time of the last hvo_batch_run, measured with hipEvents on the ctx
  * stream.  names[i] points at static strings.  Returns the number of groups written (<= cap). */
