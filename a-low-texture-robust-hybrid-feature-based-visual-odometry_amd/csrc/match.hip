@@ -617,3 +617,34 @@ int match_stereo_from_rgbd(hvo_ctx *ctx, const hvo_keypoint *kp, const hvo_keypo
     memcpy(uright, hur, (size_t)n * 4); memcpy(zdepth, hz, (size_t)n * 4);
     return HVO_OK;
 }
+
+// diagnostics (tools/match_rate.py; not part of include/hvo.h): device time of `iters` back-to-back launches of the knn-2 (kind 0) or
+// distance-matrix (kind 1) kernel on descriptors resident in HBM -> ms per launch
+extern "C" int hvo_debug_match_rate(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int kind, int iters, float *ms)
+{
+    if (!ctx || !q || !t || !ms || nq < 1 || nt < 1 || iters < 1 || nt > 65535) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    const size_t ob = kind == 0 ? (size_t)nq * 4 * sizeof(int32_t) : (size_t)nq * nt * sizeof(uint16_t);
+    int rc = arena_begin(ctx, AL(nq * 32, char) + AL(nt * 32, char) + AL(ob, char), AL(nq * 32, char) + AL(nt * 32, char));
+    if (rc) return rc;
+    const uint8_t *dq = arena_up(ctx, q, (size_t)nq * 32), *dt = arena_up(ctx, t, (size_t)nt * 32);
+    char *dout = arena_dev<char>(ctx, ob);
+    hipEvent_t e0, e1;
+    HVO_HIP(hipEventCreate(&e0)); HVO_HIP(hipEventCreate(&e1));
+    for (int pass = 0; pass < 2; pass++) {                          // pass 0 warms up
+        HVO_HIP(hipEventRecord(e0, ctx->stream));
+        for (int i = 0; i < iters; i++) {
+            if (kind == 0) hipLaunchKernelGGL(k_hamming_knn2, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, (const ulonglong4 *)dq, nq, (const ulonglong4 *)dt, nt,
+                                              (int32_t *)dout, (int32_t *)dout + (size_t)nq * 2);
+            else hipLaunchKernelGGL(k_hamming_matrix, dim3(std::min((nt + 63) / 64, 64), (nq + 3) / 4), dim3(256), 0, ctx->stream, (const ulonglong4 *)dq, nq,
+                                    (const ulonglong4 *)dt, nt, (uint16_t *)dout);
+        }
+        HVO_HIP(hipEventRecord(e1, ctx->stream));
+        HVO_HIP(hipEventSynchronize(e1));
+    }
+    float tot = 0;
+    HVO_HIP(hipEventElapsedTime(&tot, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms = tot / iters;
+    return HVO_OK;
+}

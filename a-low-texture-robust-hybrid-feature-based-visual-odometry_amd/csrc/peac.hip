@@ -1585,7 +1585,8 @@ static int peac_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_adj, B * MAX_PLANES * sizeof(unsigned long long));
     PA(P->d_hkey, B * P->nblk * sizeof(double)); PA(P->d_hid, B * P->nblk * sizeof(int));
     // the low-latency kernel keeps the whole heap (10 bytes per block) and one bit per node in LDS: up to ~14 k blocks (1280x960 has 12 288)
-    if (batch <= LAT_MAX_BATCH && P->segcap <= 65535 && (size_t)P->nblk * 10 + (size_t)P->segcap * 2 + 64 <= 150 * 1024) { PA(P->d_nodes, B * P->segcap * sizeof(Node2)); P->lat_batch = batch; }
+    const bool want_lat = LAT_DEFAULT_BATCH > 0 || (getenv("HVO_PEAC_LAT") && atoi(getenv("HVO_PEAC_LAT")) != 0);    // opt-in: its node records cost 1.6 MB per frame
+    if (want_lat && batch <= LAT_MAX_BATCH && P->segcap <= 65535 && (size_t)P->nblk * 10 + (size_t)P->segcap * 2 + 64 <= 150 * 1024) { PA(P->d_nodes, B * P->segcap * sizeof(Node2)); P->lat_batch = batch; }
 #undef PA
     // stream-ordered fill: a null-stream hipMemset is not ordered against the non-blocking ctx stream
     HVO_HIP(hipMemsetAsync(P->d_depth, 0, B * P->pitch * (h + 1) * sizeof(uint16_t), ctx->s_peac));
