@@ -42,14 +42,17 @@ PLANE_DT = np.dtype([("normal", "<f8", 3), ("center", "<f8", 3), ("mse", "<f8"),
                      ("n_points", "<i4"), ("rid", "<i4")])
 LINE3D_DT = np.dtype([("A", "<f8", 3), ("B", "<f8", 3), ("line_nor", "<f8", 3), ("line_eq", "<f4", 3), ("good", "<i4"),
                       ("n_samples", "<i4"), ("n_inliers", "<i4"), ("inlier_mask", "<u4"), ("pad", "<i4")])
+PLANE_CLOUD_DT = np.dtype([("coef", "<f4", 4), ("valid", "<i4"), ("gate_ok", "<i4"), ("first", "<i4"), ("n_points", "<i4"), ("n_pixels", "<i4"), ("n_inliers", "<i4")])
+SURFACE_NORMAL_DT = np.dtype([("normal", "<f4", 3), ("position", "<f4", 3), ("frame_x", "<i4"), ("frame_y", "<i4")])
 assert KEYPOINT_DT.itemsize == 28 and KEYLINE_DT.itemsize == 68 and PLANE_DT.itemsize == 64 and LINE3D_DT.itemsize == 104
+assert PLANE_CLOUD_DT.itemsize == 40 and SURFACE_NORMAL_DT.itemsize == 32
 
 EXPORTS = [
     "hvo_abi_version", "hvo_default_params", "hvo_create", "hvo_destroy", "hvo_strerror", "hvo_last_error",
     "hvo_extract_orb", "hvo_extract_lsd", "hvo_compute_planes",
     "hvo_hamming_matrix", "hvo_hamming_knn2", "hvo_match_nnr", "hvo_search_by_projection", "hvo_stereo_from_rgbd",
     "hvo_undistort_keypoints", "hvo_image_bounds", "hvo_assign_features_to_grid", "hvo_assign_lines_to_grid",
-    "hvo_extract_lsd_culled", "hvo_set_line_culling", "hvo_lines_3d", "hvo_search_by_projection_map", "hvo_frame_bf_match", "hvo_search_double",
+    "hvo_extract_lsd_culled", "hvo_set_line_culling", "hvo_lines_3d", "hvo_plane_clouds", "hvo_surface_normals", "hvo_search_by_projection_map", "hvo_frame_bf_match", "hvo_search_double",
     "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch", "hvo_batch_slab_layout", "hvo_batch_pack_results",
     "hvo_profile_last", "hvo_profile_enable", "hvo_pin_host", "hvo_unpin_host",
     "hvo_stream_create", "hvo_stream_destroy", "hvo_stream_last_error", "hvo_stream_capacity", "hvo_stream_image_bounds",
@@ -130,6 +133,8 @@ def lib():
         L.hvo_extract_lsd_culled.argtypes = L.hvo_extract_lsd.argtypes
         L.hvo_set_line_culling.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
         L.hvo_lines_3d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p]
+        L.hvo_plane_clouds.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.hvo_surface_normals.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.hvo_undistort_keypoints.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.hvo_image_bounds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.hvo_assign_features_to_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
@@ -259,6 +264,22 @@ class Context:
         n = C.c_int(0)
         self._chk(lib().hvo_compute_planes(self.h, _p(depth), w, h, depth.strides[0], _p(labels), _p(planes), cap, C.byref(n)), "compute_planes")
         return labels, planes[: n.value].copy()
+
+    def plane_clouds(self, depth, labels, planes, dist_th=0.05, cap=200000):
+        """the per-plane tail of Frame::ComputePlanes (src/Frame.cc:2110-2154, 2214-2274) -> (PLANE_CLOUD_DT array, cloud (n, 3) f32)"""
+        depth = np.ascontiguousarray(depth, np.uint16); labels = np.ascontiguousarray(labels, np.int32); planes = np.ascontiguousarray(planes)
+        h, w = depth.shape
+        out = np.zeros(len(planes), PLANE_CLOUD_DT); cloud = np.zeros((cap, 3), np.float32); n = C.c_int(0)
+        self._chk(lib().hvo_plane_clouds(self.h, _p(depth), w, h, depth.strides[0], _p(labels), _p(planes), len(planes), dist_th, _p(cloud), cap, _p(out), C.byref(n)), "plane_clouds")
+        return out, cloud[: n.value].copy()
+
+    def surface_normals(self, depth):
+        """vSurfaceNormal of Frame::ComputePlanes (src/Frame.cc:2157-2212) -> SURFACE_NORMAL_DT array"""
+        depth = np.ascontiguousarray(depth, np.uint16); h, w = depth.shape
+        cap = (((h + 2) // 3) // 2) * (((w + 2) // 3) // 2)
+        out = np.zeros(max(cap, 1), SURFACE_NORMAL_DT); n = C.c_int(0)
+        self._chk(lib().hvo_surface_normals(self.h, _p(depth), w, h, depth.strides[0], _p(out), cap, C.byref(n)), "surface_normals")
+        return out[: n.value].copy()
 
     def peac_stats(self, frame=0):
         """diagnostics (not part of the reference interface): bookkeeping words of the last plane run of `frame`"""

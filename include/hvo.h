@@ -191,6 +191,27 @@ typedef struct {
 } hvo_line3d;
 int hvo_lines_3d(hvo_ctx *ctx, const hvo_keyline *kl, int n, const uint16_t *depth, int w, int h, int stride, uint32_t seed, hvo_line3d *out);
 
+/* The tail of Frame::ComputePlanes after the plane detector (reference src/Frame.cc:2110-2212) and Frame::MaxPointDistanceFromPlane
+ * (2214-2274), SURVEY.md 8f.3.  labels / planes are the outputs of hvo_compute_planes for the same depth image.
+ * hvo_plane_clouds: per plane the points of its pixels (float), pcl::VoxelGrid(0.1 m), the gate |n.p + d| <= dist_th
+ * (Plane.DistanceThreshold of the settings file) and the pcl::SACSegmentation refit with the sign rule; valid planes are the
+ * entries of mvPlanePoints / mvPlaneCoefficients, in order.  cloud_xyz (cap x 3 floats) receives every plane's voxel cloud,
+ * plane i at [first, first + n_points).  PCL's semantics are restated (it is not vendored by the reference): oracle/planes_tail.c.
+ * hvo_surface_normals: the 1/3-resolution cloud and pcl::IntegralImageNormalEstimation(AVERAGE_3D_GRADIENT, 0.05, 10) at the odd
+ * grid positions = vSurfaceNormal (normal NaN where PCL leaves it undefined); needs (h/3/2) * (w/3/2) entries (80 x 107 for 640x480). */
+typedef struct {
+    float coef[4];              /* mvPlaneCoefficients entry when valid (refit, sign rule applied), else (n, -n.c) of the extracted plane */
+    int32_t valid;              /* 1: passed the gate and the refit: the plane enters mvPlanePoints / mvPlaneCoefficients */
+    int32_t gate_ok;            /* 1: no voxel point farther than dist_th from the extracted plane */
+    int32_t first, n_points;    /* its voxel-grid cloud in cloud_xyz */
+    int32_t n_pixels;           /* plane_vertices_[i].size() */
+    int32_t n_inliers;          /* inliers of the refined model */
+} hvo_plane_cloud;
+typedef struct { float normal[3]; float position[3]; int32_t frame_x, frame_y; } hvo_surface_normal;   /* SurfaceNormal: normal, cameraPosition, FramePosition */
+int hvo_plane_clouds(hvo_ctx *ctx, const uint16_t *depth, int w, int h, int stride, const int32_t *labels, const hvo_plane *planes, int n_planes,
+                     double dist_th, float *cloud_xyz, int cap, hvo_plane_cloud *out, int *n_total);
+int hvo_surface_normals(hvo_ctx *ctx, const uint16_t *depth, int w, int h, int stride, hvo_surface_normal *out, int cap, int *n);
+
 /* ---- Frame post-processing of the outputs above ----------------------------------------
  * dist5 = {k1, k2, p1, p2, k3} (Camera.k1.. of the settings file; k3 = 0 when absent); the intrinsics are the
  * context's (hvo_params fx, fy, cx, cy).  The 64 x 48 grids (FRAME_GRID_COLS x FRAME_GRID_ROWS) are returned as

@@ -183,6 +183,23 @@ typedef struct {
 int  orc_lines_3d(const orc_keyline *kl, int n, const uint16_t *depth, int w, int h, int stride_bytes,
                   float fx, float fy, float cx, float cy, float depth_factor, uint32_t seed, orc_line3d *out);
 
+/* The tail of Frame::ComputePlanes (src/Frame.cc:2110-2212, 2214-2274; planes_tail.c).  Layouts == hvo_plane_cloud / hvo_surface_normal. */
+typedef struct {
+    float coef[4];              /* mvPlaneCoefficients entry: the refit (sign rule applied) when valid, else (n, -n.c) of the extracted plane */
+    int32_t valid;              /* 1: the plane passed the distance gate and the refit -> pushed to mvPlanePoints / mvPlaneCoefficients */
+    int32_t gate_ok;            /* 1: no voxel point farther than Plane.DistanceThreshold */
+    int32_t first, n_points;    /* its voxel-grid cloud = cloud_xyz[first .. first + n_points) */
+    int32_t n_pixels;           /* plane_vertices_[i].size() */
+    int32_t n_inliers;          /* inliers of the refined model */
+} orc_plane_cloud;
+typedef struct { float normal[3]; float position[3]; int32_t frame_x, frame_y; } orc_surface_normal;
+int  orc_sac_plane(const float *xyz, int n, double threshold, float coef[4]);
+int  orc_plane_clouds(const uint16_t *depth, int w, int h, int stride_bytes, float fx, float fy, float cx, float cy, float depth_factor,
+                      const int32_t *labels, const orc_plane *planes, int nplanes, double dist_th,
+                      float *cloud_xyz, int cap, orc_plane_cloud *out);
+int  orc_surface_normals(const uint16_t *depth, int w, int h, int stride_bytes, float fx, float fy, float cx, float cy, float depth_factor,
+                         orc_surface_normal *out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

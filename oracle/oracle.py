@@ -241,6 +241,44 @@ def lines_3d(kl, depth, seed=1, fx=535.4, fy=539.2, cx=320.1, cy=247.6, depth_fa
     return out
 
 
+PLANE_CLOUD_DT = np.dtype([("coef", "<f4", 4), ("valid", "<i4"), ("gate_ok", "<i4"), ("first", "<i4"), ("n_points", "<i4"), ("n_pixels", "<i4"), ("n_inliers", "<i4")])
+SURFACE_NORMAL_DT = np.dtype([("normal", "<f4", 3), ("position", "<f4", 3), ("frame_x", "<i4"), ("frame_y", "<i4")])
+
+
+def plane_clouds(depth, labels, planes, dist_th=0.05, fx=535.4, fy=539.2, cx=320.1, cy=247.6, depth_factor=None, cap=200000):
+    """the per-plane part of Frame::ComputePlanes' tail (src/Frame.cc:2110-2154, 2214-2274) -> (PLANE_CLOUD_DT array, cloud (n,3) f32)"""
+    depth = np.ascontiguousarray(depth, np.uint16); h, w = depth.shape
+    labels = np.ascontiguousarray(labels, np.int32); planes = np.ascontiguousarray(planes)
+    if depth_factor is None:
+        depth_factor = float(np.float32(1.0) / np.float32(5000.0))
+    out = np.zeros(len(planes), PLANE_CLOUD_DT); cloud = np.zeros((cap, 3), np.float32)
+    L = lib()
+    L.orc_plane_clouds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_float] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p]
+    n = L.orc_plane_clouds(_p(depth), w, h, depth.strides[0], fx, fy, cx, cy, depth_factor, _p(labels), _p(planes), len(planes), dist_th, _p(cloud), cap, _p(out))
+    return out, cloud[: min(n, cap)].copy()
+
+
+def sac_plane(xyz, threshold):
+    xyz = np.ascontiguousarray(xyz, np.float32); coef = np.zeros(4, np.float32)
+    L = lib()
+    L.orc_sac_plane.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+    n = L.orc_sac_plane(_p(xyz), len(xyz), threshold, _p(coef))
+    return n, coef
+
+
+def surface_normals(depth, fx=535.4, fy=539.2, cx=320.1, cy=247.6, depth_factor=None):
+    """the 1/3-resolution cloud + integral-image normals of Frame::ComputePlanes (src/Frame.cc:2157-2212) -> SURFACE_NORMAL_DT array"""
+    depth = np.ascontiguousarray(depth, np.uint16); h, w = depth.shape
+    if depth_factor is None:
+        depth_factor = float(np.float32(1.0) / np.float32(5000.0))
+    cap = ((h + 2) // 3) * ((w + 2) // 3)
+    out = np.zeros(cap, SURFACE_NORMAL_DT)
+    L = lib()
+    L.orc_surface_normals.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_float] * 5 + [C.c_void_p, C.c_int]
+    n = L.orc_surface_normals(_p(depth), w, h, depth.strides[0], fx, fy, cx, cy, depth_factor, _p(out), cap)
+    return out[:n].copy()
+
+
 def eig33_smallest(K):
     """the smallest eigenpair as Stats::compute uses it (orc_eig33_smallest) -> (lambda0, v)"""
     K = np.ascontiguousarray(K, np.float64); l = C.c_double(0); v = np.zeros(3)

@@ -1,0 +1,110 @@
+"""The tail of Frame::ComputePlanes (reference src/Frame.cc:2110-2212, 2214-2274): per-plane voxel clouds, distance
+gate, plane refit, and the integral-image surface normals.  PCL is not vendored: the oracle restates PCL 1.8 (ASSUMED).
+CPU: known answers of the oracle.  GPU (-m gpu): hvo_plane_clouds / hvo_surface_normals vs the oracle through the C ABI."""
+import numpy as np
+import pytest
+
+FX, FY, CX, CY = 535.4, 539.2, 320.1, 247.6
+
+
+def plane_depth(nx, ny, nz, d, w=640, h=480):
+    j = np.arange(w)[None, :]; i = np.arange(h)[:, None]
+    z = d / (nx * (j - CX) / FX + ny * (i - CY) / FY + nz)
+    return np.rint(z * 5000).astype(np.uint16)
+
+
+def test_mt19937_and_sac_plane_known_answers(orc):
+    """orc_sac_plane on an exact plane with outliers: the refit recovers the plane (unit normal, offset) and counts the inliers"""
+    rng = np.random.default_rng(3)
+    n = np.array([0.3, -0.2, 0.9]); n /= np.linalg.norm(n)
+    P = rng.uniform(-1, 1, (800, 3)); P -= np.outer(P @ n, n); P += n * 2.0                 # points with n.p = 2
+    P[:50] += rng.uniform(0.2, 0.5, (50, 1)) * n                                           # outliers off the plane
+    P += rng.normal(scale=2e-3, size=P.shape)
+    ninl, coef = orc.sac_plane(P.astype(np.float32), 0.05)
+    assert 745 <= ninl <= 760
+    s = np.sign(coef[:3] @ n)
+    assert np.allclose(s * coef[:3], n, atol=2e-3) and abs(s * coef[3] + 2.0) < 5e-3 and abs(np.linalg.norm(coef[:3]) - 1) < 1e-5
+    assert orc.sac_plane(P[:2].astype(np.float32), 0.05)[0] == 0                            # fewer than three points: no model
+
+
+def test_plane_clouds_known_answers(orc):
+    """one exact plane: every pixel belongs to it; the voxel cloud's points lie on the plane, one point per 0.1 m voxel, gate and
+    refit pass; a second 'plane' whose pixels are far from its stated parameters fails the gate"""
+    d = plane_depth(0.1, 0.2, 1.0, 2.0)
+    lab, pl = orc.peac(d)
+    assert len(pl) == 1
+    pc, cloud = orc.plane_clouds(d, lab, pl, dist_th=0.05)
+    assert pc["n_pixels"][0] == 640 * 480 and pc["valid"][0] == 1 and pc["gate_ok"][0] == 1 and pc["first"][0] == 0
+    assert pc["n_points"][0] == len(cloud) and 300 < len(cloud) < 4000 and pc["n_inliers"][0] == len(cloud)
+    nrm = np.array([0.1, 0.2, 1.0]) / np.linalg.norm([0.1, 0.2, 1.0])
+    assert np.abs(cloud @ nrm - 2.0 / np.linalg.norm([0.1, 0.2, 1.0])).max() < 2e-3
+    vox = np.floor(cloud * np.float32(10.0)).astype(np.int64)
+    assert len(np.unique(vox, axis=0)) == len(cloud)                                       # one centroid per voxel
+    c = pc["coef"][0]
+    assert abs(np.linalg.norm(c[:3]) - 1) < 1e-5 and np.allclose(np.abs(c[:3]), nrm, atol=2e-3)
+    assert np.sign(c[3]) == np.sign(-(pl["normal"][0] @ pl["center"][0]))                  # the sign rule keeps d's sign
+    bad = pl.copy(); bad["center"][0][2] += 0.3                                            # a plane 0.3 m away from its points
+    pc2, _ = orc.plane_clouds(d, lab, bad, dist_th=0.05)
+    assert pc2["gate_ok"][0] == 0 and pc2["valid"][0] == 0 and pc2["n_points"][0] == pc["n_points"][0]
+
+
+def test_surface_normals_known_answers(orc):
+    """a slanted plane: 80 x 107 samples at the odd positions of the 160 x 214 grid, normals NaN in PCL's 10-cell border and equal to
+    the plane normal (towards the camera) inside; FramePosition = 3 * grid position"""
+    d = plane_depth(0.1, 0.2, 1.0, 2.0)
+    sn = orc.surface_normals(d)
+    assert len(sn) == 80 * 107
+    assert tuple(sn["frame_x"][:3]) == (3, 9, 15) and sn["frame_y"][0] == 3 and sn["frame_y"][107] == 9
+    ok = np.isfinite(sn["normal"][:, 0])
+    gx = sn["frame_x"] // 3; gy = sn["frame_y"] // 3
+    inside = (gx >= 10) & (gx < 214 - 10) & (gy >= 10) & (gy < 160 - 10)
+    assert np.array_equal(ok, inside)
+    nrm = -np.array([0.1, 0.2, 1.0]) / np.linalg.norm([0.1, 0.2, 1.0])
+    assert np.abs(sn["normal"][ok] - nrm).max() < 0.03
+    # a depth step: no normals within PCL's smoothing distance of the discontinuity
+    d2 = d.copy(); d2[:, 320:] = plane_depth(0.1, 0.2, 1.0, 3.0)[:, 320:]
+    sn2 = orc.surface_normals(d2)
+    near = np.abs(sn2["frame_x"] - 320) <= 6
+    assert not np.isfinite(sn2["normal"][near, 0]).any() and np.isfinite(sn2["normal"][~near & inside, 0]).sum() > 3000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0x5EED0002, 0x5EED1003, 0x5EED1007])
+def test_plane_clouds_parity(gpu_ctx, orc, synth, seed):
+    d = synth.make_depth(seed)
+    lab, pl = orc.peac(d)
+    po, co = orc.plane_clouds(d, lab, pl, dist_th=0.05)
+    pg, cg = gpu_ctx.plane_clouds(d, lab, pl, dist_th=0.05)
+    for f in ("valid", "gate_ok", "first", "n_points", "n_pixels"):
+        assert np.array_equal(pg[f], po[f]), f
+    assert np.array_equal(cg, co)                                                        # voxel centroids: bit-exact
+    # the refit runs float atan2 / cos / sin (pcl::eigen33) in the host's and the device's libm: coefficients to 1e-5
+    assert np.allclose(pg["coef"], po["coef"], rtol=0, atol=1e-5)
+    assert np.all(np.abs(pg["n_inliers"] - po["n_inliers"]) <= 2)
+    assert po["valid"].sum() >= 2
+    # a looser gate: more planes pass
+    po2, _ = orc.plane_clouds(d, lab, pl, dist_th=0.2); pg2, _ = gpu_ctx.plane_clouds(d, lab, pl, dist_th=0.2)
+    assert np.array_equal(pg2["valid"], po2["valid"]) and po2["valid"].sum() >= po["valid"].sum()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0x5EED0002, 0x5EED1003])
+def test_surface_normals_parity(gpu_ctx, orc, synth, seed):
+    d = synth.make_depth(seed)
+    so = orc.surface_normals(d); sg = gpu_ctx.surface_normals(d)
+    assert len(sg) == len(so) == 80 * 107
+    assert sg.tobytes() == so.tobytes(), [f for f in so.dtype.names if not np.array_equal(sg[f], so[f], equal_nan=True)]
+    assert np.isfinite(so["normal"][:, 0]).sum() > 4000
+
+
+@pytest.mark.gpu
+def test_planes_tail_edge_cases(gpu_ctx, orc):
+    d = np.zeros((480, 640), np.uint16)                                                   # no depth: no planes, all normals undefined
+    sg = gpu_ctx.surface_normals(d); so = orc.surface_normals(d)
+    assert sg.tobytes() == so.tobytes()
+    lab = np.full((480, 640), -1, np.int32)
+    pg, cg = gpu_ctx.plane_clouds(d, lab, np.zeros(0, orc.PLANE_DT))
+    assert len(pg) == 0 and len(cg) == 0
+    d = plane_depth(0.0, 0.0, 1.0, 1.5); lab, pl = orc.peac(d)                             # fronto-parallel plane: one voxel layer
+    po, co = orc.plane_clouds(d, lab, pl); pg, cg = gpu_ctx.plane_clouds(d, lab, pl)
+    assert np.array_equal(cg, co) and np.array_equal(pg["valid"], po["valid"]) and np.allclose(pg["coef"], po["coef"], atol=1e-5)
