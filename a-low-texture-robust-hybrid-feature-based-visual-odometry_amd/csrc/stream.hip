@@ -100,11 +100,12 @@ int hvo_stream_create(const hvo_params *p, const hvo_stream_params *sp, hvo_stre
         StreamSlot &S = s->slot[i];
         if ((rc = hvo_create(&s->p, &S.ctx))) break;
         S.ctx->sched = 0;                                      // no cross-stream ordering inside a slot: the frames overlap instead
-        // Two HIP streams per frame in flight: [gray upload, ORB, undistort, stereo, ORB download, lines, line download] and
-        // [depth upload, planes, plane download].  The runtime maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues
-        // per priority level and streams that share a queue serialise, so every stream saved is a frame more that really
-        // runs beside the others (measured: 3 streams per frame stop scaling at 2 frames in flight, profiles/r02_stream_scaling.txt).
-        S.ctx->lsd_on_orb_stream = true;
+        // Three HIP streams per frame in flight (points, lines, planes; priorities 0 / -1 / +1), as in the batch mode.  The runtime
+        // maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues per priority level and streams that share a queue
+        // serialise: measured (profiles/r02_stream_scaling.txt) 32.8 / 64.6 / 64.9 / 93.9 frames/s at 1 / 2 / 3 / 5 frames in
+        // flight.  Putting the line chain behind ORB on one stream (HVO_STREAM_LSD_OWN=0) serialises it with the plane chain on
+        // the ROCm 7.2 runtime (20.8 frames/s at one frame in flight); GPU_MAX_HW_QUEUES=8 collapses to < 10 frames/s at five.
+        S.ctx->lsd_on_orb_stream = getenv("HVO_STREAM_LSD_OWN") && atoi(getenv("HVO_STREAM_LSD_OWN")) == 0;
         if ((rc = orb_ensure_plan(S.ctx, w, h, 1))) break;
         if ((rc = lsd_prepare(S.ctx, w, h, 1, s->culled, &S.lv))) break;
         if ((rc = peac_prepare(S.ctx, w, h, 1, &S.pv))) break;
@@ -228,16 +229,18 @@ int hvo_stream_submit(hvo_stream *s, const uint8_t *gray, int gray_stride, const
         }
     }
     ST_HIP(hipEventRecord(S.ev_orb, c->stream));
+    hipStream_t LS = hvo_stream_lsd(c);
     if (want_lsd) {
+        if (!c->lsd_on_orb_stream) ST_HIP(hipStreamWaitEvent(c->s_lsd, S.ev_gray, 0));
         if ((rc = lsd_run(c, 1, s->culled))) { s->last_error = c->last_error; return rc; }
-        ST_HIP(hipEventRecord(S.ev_kern[1], c->stream));
-        ST_HIP(hipMemcpyAsync(hc + 4, S.lv.d_nkl, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        ST_HIP(hipMemcpyAsync(hc + 5, S.lv.d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        ST_HIP(hipMemcpyAsync(ho + L.kl, S.lv.d_kl, (size_t)s->nfeat * sizeof(hvo_keyline), hipMemcpyDeviceToHost, c->stream));
-        ST_HIP(hipMemcpyAsync(ho + L.ldesc, S.lv.d_desc, (size_t)s->nfeat * 32, hipMemcpyDeviceToHost, c->stream));
-        ST_HIP(hipMemcpyAsync(ho + L.fn, S.lv.d_fn, (size_t)s->nfeat * 24, hipMemcpyDeviceToHost, c->stream));
+        ST_HIP(hipEventRecord(S.ev_kern[1], LS));
+        ST_HIP(hipMemcpyAsync(hc + 4, S.lv.d_nkl, sizeof(int), hipMemcpyDeviceToHost, LS));
+        ST_HIP(hipMemcpyAsync(hc + 5, S.lv.d_flags, sizeof(int), hipMemcpyDeviceToHost, LS));
+        ST_HIP(hipMemcpyAsync(ho + L.kl, S.lv.d_kl, (size_t)s->nfeat * sizeof(hvo_keyline), hipMemcpyDeviceToHost, LS));
+        ST_HIP(hipMemcpyAsync(ho + L.ldesc, S.lv.d_desc, (size_t)s->nfeat * 32, hipMemcpyDeviceToHost, LS));
+        ST_HIP(hipMemcpyAsync(ho + L.fn, S.lv.d_fn, (size_t)s->nfeat * 24, hipMemcpyDeviceToHost, LS));
     }
-    ST_HIP(hipEventRecord(S.ev_lsd, c->stream));
+    ST_HIP(hipEventRecord(S.ev_lsd, LS));
     S.ticket = s->next; S.busy = true;
     *ticket = s->next++;
     return HVO_OK;

@@ -30,10 +30,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues per priority level (default 4); streams that share a
-# queue serialise.  The streamed mode keeps two streams per frame in flight, so more than four frames in flight need more
-# queues (profiles/r02_stream_scaling.txt).  Must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 TRAFFIC_PROFILE = "profiles/r02_hbm_traffic.json"

@@ -55,6 +55,27 @@ with open(os.path.join(P, tag + "_pmc_hbm_summary.txt"), "w") as f:
 subprocess.check_call([py, os.path.join(ROOT, "tools", "make_traffic_json.py"), os.path.join(src, "pmc_fetch"), os.path.join(src, "pmc_write"), str(B),
                        os.path.join(P, tag + "_hbm_traffic.json")])
 subprocess.check_call([py, os.path.join(ROOT, "tools", "make_sq_json.py"), os.path.join(src, "pmc_sq"), str(B), os.path.join(P, tag + "_sq_utilisation.json")])
-shutil.copy(os.path.join(src, "pcie_note.txt"), os.path.join(P, tag + "_pcie_note.txt"))
+with open(os.path.join(P, tag + "_pcie_note.txt"), "w") as f:
+    f.write("# tools/pcie_overlap.py BATCH CONTEXTS ROUNDS: upload + run + download of consecutive batches, C contexts on C host threads, one lock per\n"
+            "# stage (last line: LOCKS=0, threads not coordinated); pinned host images and label slabs, int8 labels; leg_ms = upload / run / download\n")
+    f.write(open(os.path.join(src, "pcie_note.txt")).read())
 shutil.copy(os.path.join(src, "hbm_footprint.txt"), os.path.join(P, tag + "_hbm_footprint.txt"))
+for name in ("bench_stream", "bench_big1280", "bench_batch256"):
+    d2 = last_json_line(os.path.join(src, name + ".json"))
+    json.dump(d2, open(os.path.join(P, tag + "_" + name + ".json"), "w")); open(os.path.join(P, tag + "_" + name + ".json"), "a").write("\n")
+with open(os.path.join(P, tag + "_latency_small_batches.json"), "w") as f:
+    json.dump({k: json.load(open(os.path.join(src, "latency_%s.json" % k))) for k in ("std", "lowtex")}, f, indent=1)
+with open(os.path.join(P, tag + "_stream_scaling.txt"), "w") as f:
+    f.write("# tools/stream_scaling.py: sustained frames/s of hvo_stream_* (no matching, labels not copied out) against the ring depth (depth - 1 frames in flight)\n")
+    for k in ("q4", "torch_runtime", "q16"):
+        pth = os.path.join(src, "stream_scaling_%s.json" % k)
+        if os.path.exists(pth):
+            j = json.load(open(pth))
+            f.write("%-14s GPU_MAX_HW_QUEUES=%s torch_runtime=%s : %s\n" % (k, j.get("GPU_MAX_HW_QUEUES"), j.get("torch_runtime"), {a: b["fps"] for a, b in j.items() if a.startswith("depth")}))
+    f.write("# 3 streams per frame (points / lines / planes).  Variants measured once (gpurun_out, 100 frames): lines behind ORB on one stream (2 streams per frame)\n"
+            "# on the ROCm 7.2 runtime: 20.8 / 41.0 / 41.2 / 60.9 frames/s at depth 2 / 3 / 4 / 6 (the two streams serialise); GPU_MAX_HW_QUEUES=8: 95 frames/s at depth 4\n"
+            "# but 3.6-7.6 frames/s at depth 6 (hardware queues oversubscribed).\n")
+shutil.copy(os.path.join(src, "match_rate.txt"), os.path.join(P, tag + "_match_rate.txt"))
+shutil.copy(os.path.join(src, "peac_timing_batch.txt"), os.path.join(P, tag + "_peac_cluster_phases_batch8192.txt"))
+shutil.copy(os.path.join(src, "peac_lat_timing.txt"), os.path.join(P, tag + "_peac_cluster_lat_phases_1frame.txt"))
 print("value", d["value"], "frames/s; under rocprof", u["value"])

@@ -2,6 +2,7 @@
 """Diagnostics: where k_peac_cluster_lat spends its cycles (s_memtime ticks per phase, HVO_PEAC_TIMING build in a temp dir)."""
 import ctypes, importlib, os, shutil, subprocess, sys, tempfile
 import numpy as np
+os.environ["HVO_PEAC_LAT"] = "1"      # the kernel is opt-in
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge

@@ -4,6 +4,8 @@ GPU_MAX_HW_QUEUES: the HIP runtime maps streams onto that many hardware queues p
     GPU_MAX_HW_QUEUES=16 python tools/stream_scaling.py [frames]"""
 import importlib, json, os, sys, time
 import numpy as np
+if os.environ.get("IMPORT_TORCH"):
+    import torch; torch.cuda.init()         # torch's bundled HIP runtime instead of /opt/rocm's (whichever loads first serves both)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
@@ -12,8 +14,9 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     hvo = ge.package(); synth = importlib.import_module("hvo_amd.synth")
     g, d, off = synth.make_sequence("std", 0x5EED3000, 64)
-    out = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "default")}
-    for depth in (2, 3, 4, 6, 8, 12, 16):
+    out = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "default"), "torch_runtime": bool(os.environ.get("IMPORT_TORCH")),
+           "lsd_own_stream": os.environ.get("HVO_STREAM_LSD_OWN", "0")}
+    for depth in [int(x) for x in os.environ.get("DEPTHS", "2,3,4,6,8,12,16").split(",")]:
         st = hvo.Stream(depth=depth, stages=hvo.STAGE_ALL, bf=40.0)
         inflight = depth - 1
         tick = [st.submit(g[k % 64], d[k % 64]) for k in range(inflight)]
