@@ -996,6 +996,12 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
 // survived the erosion: never touched) | depth << 16,  y = distMap entry (float bits).
 #define FS_VALID 0x100u
 #define FS_LABEL(x) ((int)(signed char)((x) & 0xFFu))
+// Flood-state layout: 4x4-pixel tiles, one 128-byte line each (a pixel's four neighbours mostly share its tile, and a front
+// that advances through a tile finds it in L2 for four rings instead of one row-major line per ring): FS_TW tiles per row.
+#define FS_TW(w) (((w) + 3) >> 2)
+#define FS_TH(h) (((h) + 3) >> 2)
+#define FS_IDX(x, y, tw) (((((y) >> 2) * (tw) + ((x) >> 2)) << 4) | (((y) & 3) << 2) | ((x) & 3))
+#define FS_FRAME(w, h) ((size_t)FS_TW(w) * FS_TH(h) * 16)
 #define FS_MAKE(lab, valid, d) (((unsigned)(lab) & 0xFFu) | ((valid) ? FS_VALID : 0u) | ((unsigned)(d) << 16))
 __global__ __launch_bounds__(256) void k_peac_blkmap(const int *__restrict__ parent_, const int *__restrict__ dsize_,
                                                      const int *__restrict__ segI_, const int *__restrict__ ext_, const int *__restrict__ meta_,
@@ -1009,7 +1015,7 @@ __global__ __launch_bounds__(256) void k_peac_blkmap(const int *__restrict__ par
     const int *ext = ext_ + (size_t)frame * 2 * MAX_PLANES;
     const int next = meta_[(size_t)frame * 16 + 2];
     int *blkmap = blkmap_ + (size_t)frame * nblk, *isvalid = isvalid_ + (size_t)frame * MAX_PLANES;
-    uint2 *state = state_ + (size_t)frame * w * h;
+    uint2 *state = state_ + (size_t)frame * FS_FRAME(w, h);
     const uint16_t *D = depth_ + (size_t)frame * dframe;
     // phase 1: one thread per block
     for (int b = tid; b < nblk; b += 256) {
@@ -1031,14 +1037,16 @@ __global__ __launch_bounds__(256) void k_peac_blkmap(const int *__restrict__ par
         blkmap[b] = plid;
     }
     __syncthreads();
-    // phase 2: the frame's pixels, row by row (coalesced); pixels outside the block grid get -1
-    for (int y = 0; y < h; y++) {
-        const int by = y / WIN;
-        for (int x = tid; x < w; x += 256) {
-            const int bx = x / WIN;
-            const int lab = (by < Nh && bx < Nw) ? blkmap[by * Nw + bx] : -1;
-            state[(size_t)y * w + x] = make_uint2(FS_MAKE(lab, lab >= 0, D[(size_t)y * pitch + x]), 0x7F7FFFFFu);   // FLT_MAX
-        }
+    // phase 2: the frame's pixels in state order (tile by tile: coalesced stores, depth read in 8-byte row pieces);
+    // pixels outside the block grid get -1, tile padding outside the image is never read
+    const int tw = FS_TW(w), nst = tw * FS_TH(h) * 16;
+    for (int i = tid; i < nst; i += 256) {
+        const int t = i >> 4, ty = t / tw, tx = t - ty * tw;
+        const int x = tx * 4 + (i & 3), y = ty * 4 + ((i >> 2) & 3);
+        if (x >= w || y >= h) continue;
+        const int by = y / WIN, bx = x / WIN;
+        const int lab = (by < Nh && bx < Nw) ? blkmap[by * Nw + bx] : -1;
+        state[i] = make_uint2(FS_MAKE(lab, lab >= 0, D[(size_t)y * pitch + x]), 0x7F7FFFFFu);   // FLT_MAX
     }
 }
 
@@ -1111,7 +1119,8 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
     const int *ext = a.extracted + (size_t)frame * 2 * MAX_PLANES;
     const double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
     const int *blkmap = r.blkmap + (size_t)frame * nblk;
-    uint2 *state = r.state + (size_t)frame * w * h;
+    uint2 *state = r.state + (size_t)frame * FS_FRAME(w, h);
+    const int stw = FS_TW(w);
     int *queue = r.queue + (size_t)frame * r.qcap;
     int flags = 0;
     if (tid < MAX_PLANES) {
@@ -1218,7 +1227,7 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                 const bool ex[4] = { own[e] && sx > 0, own[e] && sx < w - 1, own[e] && sy > 0, own[e] && sy < h - 1 };
                 const int px[4] = { sx - 1, sx + 1, sx, sx }, py[4] = { sy, sy, sy - 1, sy + 1 };
 #pragma unroll
-                for (int j = 0; j < 4; j++) { st[e][j] = make_uint2(FS_VALID, 0); if (ex[j]) st[e][j] = state[py[j] * w + px[j]]; }   // the only scattered reads
+                for (int j = 0; j < 4; j++) { st[e][j] = make_uint2(FS_VALID, 0); if (ex[j]) st[e][j] = state[FS_IDX(px[j], py[j], stw)]; }   // the only scattered reads
             }
             unsigned actm = 0;
 #pragma unroll
@@ -1275,7 +1284,7 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                     const uint4 R = rec[c];
                     eq[p] = R.x; es[p] = R.y; ed[p] = __uint_as_float(R.z);
                     const int ep = (int)(R.x >> 26), ex_ = (int)(R.x & 8191u), ey = (int)((R.x >> 13) & 8191u);
-                    eix[p] = ey * w + ex_;
+                    eix[p] = FS_IDX(ex_, ey, stw);
                     geom(pl[ep], ex_, ey, (int)(R.y >> 16), ecd[p], eok[p]);
                     int s = (int)(((unsigned)eix[p] * 2654435761u) >> 19) & (FLOOD_HS - 1);
                     for (;;) {
@@ -1410,7 +1419,7 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                     for (int j = 0; j < 4; j++) {
                         const int x = x0 + (j == 0 ? -1 : j == 1 ? 1 : 0), y = y0 + (j == 2 ? -1 : j == 3 ? 1 : 0);
                         if (x < 0 || x >= w || y < 0 || y >= h) continue;
-                        const int ix = y * w + x;
+                        const int ix = FS_IDX(x, y, stw);
                         const uint2 s = state[ix];
                         int trail = FS_LABEL(s.x); float dist = __uint_as_float(s.y);
                         if ((s.x & FS_VALID) || trail <= -6 || trail == ep) continue;
@@ -1507,25 +1516,31 @@ __global__ __launch_bounds__(64) void k_peac_final(RfArgs r, const unsigned long
     }
 }
 
-// labels are written as int8 (plane ids < MAX_PLANES = 64, -1 = none), four pixels per thread and store; npix4 = ceil(npix / 4)
-// and the label slab of a frame is padded to a multiple of 4 bytes
-__global__ __launch_bounds__(256) void k_peac_relabel(const uint2 *__restrict__ state, int8_t *__restrict__ labels, const int *__restrict__ plidmap, int npix, size_t lframe)
+// labels are written as int8 (plane ids < MAX_PLANES = 64, -1 = none); a thread takes one row of a state tile (32 contiguous
+// bytes) and stores its four labels as one word when the width allows; the label slab of a frame is padded to a multiple of 4 bytes
+__global__ __launch_bounds__(256) void k_peac_relabel(const uint2 *__restrict__ state, int8_t *__restrict__ labels, const int *__restrict__ plidmap, int w, int h, size_t lframe)
 {
     const int frame = blockIdx.y;
-    const uint2 *S = state + (size_t)frame * npix;
-    unsigned *L = reinterpret_cast<unsigned *>(labels + (size_t)frame * lframe);
+    const int tw = FS_TW(w), nrow = tw * FS_TH(h) * 4;
+    const uint2 *S = state + (size_t)frame * FS_FRAME(w, h);
+    int8_t *L = labels + (size_t)frame * lframe;
     const int *pm = plidmap + (size_t)frame * MAX_PLANES;
-    const int npix4 = (npix + 3) >> 2;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix4; i += gridDim.x * 256) {
-        unsigned out = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nrow; i += gridDim.x * 256) {
+        const int t = i >> 2, ty = t / tw, tx = t - ty * tw;
+        const int x0 = tx * 4, y = ty * 4 + (i & 3);
+        if (y >= h) continue;
+        const uint4 a = reinterpret_cast<const uint4 *>(S + (size_t)i * 4)[0], b = reinterpret_cast<const uint4 *>(S + (size_t)i * 4)[1];
+        const unsigned sx[4] = { a.x, a.z, b.x, b.z };
+        int lab[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int px = 4 * i + k;
-            int lab = -1;
-            if (px < npix) { const int v = FS_LABEL(S[px].x); lab = (v >= 0 && pm[v] >= 0) ? pm[v] : -1; }
-            out |= ((unsigned)lab & 0xFFu) << (8 * k);
+        for (int k = 0; k < 4; k++) { const int v = FS_LABEL(sx[k]); lab[k] = (v >= 0 && pm[v] >= 0) ? pm[v] : -1; }
+        int8_t *dst = L + (size_t)y * w + x0;
+        if ((w & 3) == 0) {
+            *reinterpret_cast<unsigned *>(dst) = ((unsigned)lab[0] & 0xFFu) | (((unsigned)lab[1] & 0xFFu) << 8) | (((unsigned)lab[2] & 0xFFu) << 16) | (((unsigned)lab[3] & 0xFFu) << 24);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (x0 + k < w) dst[k] = (int8_t)lab[k];
         }
-        L[i] = out;
     }
 }
 
@@ -1578,7 +1593,7 @@ static int peac_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_pool2, B * P->poolcap * sizeof(int));
     PA(P->d_parent, B * P->nblk * sizeof(int)); PA(P->d_dsize, B * P->nblk * sizeof(int)); PA(P->d_eflag, B * P->nblk * sizeof(int));
     PA(P->d_meta, B * 16 * sizeof(int)); PA(P->d_extracted, B * 2 * MAX_PLANES * sizeof(int));
-    PA(P->d_blkmap, B * P->nblk * sizeof(int)); PA(P->d_labels, B * ((npix + 3) & ~(size_t)3)); PA(P->d_state, B * npix * sizeof(uint2));
+    PA(P->d_blkmap, B * P->nblk * sizeof(int)); PA(P->d_labels, B * ((npix + 3) & ~(size_t)3)); PA(P->d_state, B * FS_FRAME(w, h) * sizeof(uint2));
     PA(P->d_queue, B * P->qcap * sizeof(int));
     PA(P->d_plidmap, B * MAX_PLANES * sizeof(int)); PA(P->d_isvalid, B * MAX_PLANES * sizeof(int));
     PA(P->d_planes, B * MAX_PLANES * sizeof(hvo_plane));
@@ -1688,7 +1703,7 @@ int peac_run(hvo_ctx *ctx, int n)
         else hipLaunchKernelGGL((k_peac_flood<128, 1>), dim3(n), dim3(128), 0, st, r, P->d_adj);
     }
     hipLaunchKernelGGL(k_peac_final, dim3(n), dim3(64), 0, st, r, P->d_adj);
-    hipLaunchKernelGGL(k_peac_relabel, dim3(64, n), dim3(256), 0, st, P->d_state, P->d_labels, P->d_plidmap, P->w * P->h, ((size_t)P->w * P->h + 3) & ~(size_t)3);
+    hipLaunchKernelGGL(k_peac_relabel, dim3(64, n), dim3(256), 0, st, P->d_state, P->d_labels, P->d_plidmap, P->w, P->h, ((size_t)P->w * P->h + 3) & ~(size_t)3);
     hvo_prof_end(ctx, id);
     HVO_HIP(hipGetLastError());
     return HVO_OK;
