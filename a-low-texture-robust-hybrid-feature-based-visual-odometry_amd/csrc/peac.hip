@@ -480,6 +480,33 @@ static __device__ __forceinline__ void list_find2(const int *pool, int off, int 
     }
 }
 
+// list_find2 in two halves, so that the first eight entries of several lists travel in one round trip
+struct ListFind {
+    int u[8], off, cnt;
+    __device__ __forceinline__ void issue(const int *pool, int off_, int cnt_)
+    {
+        off = off_; cnt = cnt_;
+#pragma unroll
+        for (int j = 0; j < 8; j++) u[j] = j < cnt ? pool[off + j] : -1;
+    }
+    __device__ __forceinline__ void finish(const int *pool, int a, int b, bool want2, int &i1, int &i2) const
+    {
+        i1 = -1; i2 = -1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (u[j] >= 0 && (u[j] == a || u[j] == b)) { if (i1 < 0) i1 = j; else i2 = j; }
+        if (cnt > 8 && !(i1 >= 0 && (!want2 || i2 >= 0))) {
+            for (int x0 = 8; x0 < cnt; x0 += 8) {
+                int w[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) w[j] = x0 + j < cnt ? pool[off + x0 + j] : -1;
+#pragma unroll
+                for (int j = 0; j < 8; j++) if (w[j] >= 0 && (w[j] == a || w[j] == b)) { if (i1 < 0) i1 = x0 + j; else i2 = x0 + j; }
+                if (i1 >= 0 && (!want2 || i2 >= 0)) break;
+            }
+        }
+    }
+};
+
 template <int GL> struct Grp {
     static_assert(GL == 8 || GL == 16 || GL == 32 || GL == 64, "group width");
     static __device__ __forceinline__ int gl() { return threadIdx.x & (GL - 1); }
@@ -643,7 +670,8 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
         }
         PT(0)
         const int p = act ? ptop : -1;
-        PT(1)
+        double lk_last = 0; int li_last = 0;                     // the heap's last entry, in case the root is not replaced by a merged node
+        if (act) { lk_last = H.key(hn - 1); li_last = H.id(hn - 1); }
         int *pi = segI + (size_t)(p < 0 ? 0 : p) * SEG_I;
         const bool live = act && n_nouse == 0;                 // skip nouse nodes (lazy deletion)
         const int pcnt = live ? n_cnt : 0, poff = n_off, pN = n_N, prid = n_rid, pdsr = n_dsr, pdss = n_dss;
@@ -757,104 +785,169 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
         }
         if (!do_merge) ncnt = 0;
         const int id = nseg;
+        const bool no_merge = live && !do_merge;
+        if (do_merge) { PT_CNT(10, 1) nseg++; }
+        if (no_merge) { PT_CNT(11, 1) }
         PT(4)
-        if (__any(do_merge)) {
-            PT_CNT(10, 1)
-            if (do_merge) nseg++;
-            const int moff = pooltop;
-            // new.nbs = (p.nbs U nb.nbs) \ {p, nb}, and every member's own list gets p / nb replaced by the
-            // new id.  Pass B walks nb's list: a member that also holds p is left to pass A (read only here);
-            // the others are copied and get nb -> id.  Pass A walks p's list: copy, p -> id, nb dropped.
-            // B only writes lists of nodes that are not p's neighbours and reads the others before A writes
-            // them, so no ordering beyond program order is needed.
-            int qa_off = 0, qa_cnt = 0;                         // pass A's first round trip, started early
-            if (do_merge && a0 >= 0 && a0 != nb) { const int *qi = segI + (size_t)a0 * SEG_I; qa_off = qi[3]; qa_cnt = qi[4]; }
-            int mcnt = 0;
-            for (int base = 0; __any(base < ncnt); base += GL) {
-                const int k = base + gl;
-                int v = -1; bool keep = false;
-                if (k < ncnt) {
-                    v = pool[noff + k];
-                    if (v != p) {
-                        const int *qi = segI + (size_t)v * SEG_I;
-                        const int off = qi[3], cnt = qi[4];
-                        int i1, i2;
-                        list_find2(pool, off, cnt, nb, p, true, i1, i2);
-                        if (i2 < 0) { keep = true; if (i1 >= 0) pool[off + i1] = id; }
-                    }
+        // From here on an iteration is three independent chains of dependent loads: pass B (the partner's list -> its members'
+        // list headers -> their lists), pass A (p's members' list headers -> their lists) and the heap (one level of children
+        // after the other).  They are issued together, stage by stage, so that a stage costs ONE memory round trip for all
+        // three (loads of a wave return in order): 3-4 round trips instead of the 8-9 of running them one after the other.
+        //   * new.nbs = (p.nbs U nb.nbs) \ {p, nb}, and every member's own list gets p / nb replaced by the new id.  Pass B walks
+        //     nb's list: a member that also holds p is left to pass A (read only here); the others are copied and get nb -> id.
+        //     Pass A walks p's list: copy, p -> id, nb dropped.  B only writes lists of nodes that are not p's neighbours and
+        //     reads the others before A writes them (all of B, its tail included, precedes A's stores);
+        //   * no merge: disconnectAllNbs = pass A with "drop p";
+        //   * the heap is touched once per iteration: the popped root is replaced by the merged node (merge) or by the last
+        //     entry (otherwise), with one sift-down whose first level yields the next top; that node's record is fetched
+        //     underneath the remaining stages (everything in it but its list, which this iteration may still edit).
+        const int moff = pooltop;
+        double s_k = m; int s_idv = id; bool sift = do_merge;
+        if (act && !do_merge) { hn--; s_k = lk_last; s_idv = li_last; sift = hn > 0; }
+        int s_i = 0, s_root = sift ? s_idv : -1, s_cid = 0x7FFFFFFF, s_ci = -1; bool s_go = sift, s_cont = false; double s_ck = 1.0e308;
+        auto sift_issue = [&]() {
+            const int c0 = GH_ARY * s_i + 1;
+            s_cont = s_go && c0 < hn;
+            s_ck = 1.0e308; s_cid = 0x7FFFFFFF; s_ci = -1;
+            if (s_cont && gl < GH_ARY && c0 + gl < hn) { s_ci = c0 + gl; s_ck = H.key(s_ci); s_cid = H.id(s_ci); }
+        };
+        auto sift_take = [&]() {
+#define GH_STEP(o) { const double ok = row_partner<o>(s_ck); const int oid = row_partner<o>(s_cid), oi = row_partner<o>(s_ci); \
+                     if (oi >= 0 && (s_ci < 0 || hless(ok, oid, s_ck, s_cid))) { s_ck = ok; s_cid = oid; s_ci = oi; } }
+            GH_STEP(1) GH_STEP(2) GH_STEP(4) if (GH_ARY > 8) GH_STEP(8)
+#undef GH_STEP
+            if (GL > 16) { s_ck = Grp<GL>::shfl(s_ck, 0); s_cid = Grp<GL>::shfl(s_cid, 0); s_ci = Grp<GL>::shfl(s_ci, 0); }
+            const bool mv = s_cont && s_ci >= 0 && hless(s_ck, s_cid, s_k, s_idv);
+            if (mv) { if (gl == 0) H.set(s_i, s_ck, s_cid); if (s_i == 0) s_root = s_cid; s_i = s_ci; }
+            s_go = mv;
+        };
+        // stage 0: the partner's first chunk, my member's list header, the heap's first level
+        const bool editA = a0 >= 0 && ((do_merge && a0 != nb) || no_merge);
+        int qa_off = 0, qa_cnt = 0;
+        if (editA) { const int *qi = segI + (size_t)a0 * SEG_I; qa_off = qi[3]; qa_cnt = qi[4]; }
+        const int vB = gl < ncnt ? pool[noff + gl] : -1;        // ncnt == 0 unless this group merges
+        sift_issue();
+        // stage 1: B's members' list headers, A's lists, the heap's second level + the next top's record
+        const bool inB = vB >= 0 && vB != p;
+        int qb_off = 0, qb_cnt = 0;
+        if (inB) { const int *qi = segI + (size_t)vB * SEG_I; qb_off = qi[3]; qb_cnt = qi[4]; }
+        ListFind fa; fa.issue(pool, qa_off, editA ? qa_cnt : 0);
+        sift_take();
+        ptop = sift ? s_root : -1;
+        fetch_next(ptop);
+        sift_issue();
+        // stage 2: B's lists, the heap's third level
+        ListFind fb; fb.issue(pool, qb_off, inB ? qb_cnt : 0);
+        int a_i1, a_i2;
+        fa.finish(pool, p, do_merge ? nb : p, do_merge, a_i1, a_i2);
+        sift_take();
+        sift_issue();
+        // stage 3: the edits.  All of B first ...
+        int mcnt = 0;
+        {
+            int b_i1, b_i2;
+            fb.finish(pool, nb, p, true, b_i1, b_i2);
+            const bool keep = inB && b_i2 < 0;
+            if (keep && b_i1 >= 0) pool[qb_off + b_i1] = id;
+            const unsigned long long km = Grp<GL>::ballot(keep);
+            if (keep) pool[moff + mcnt + __popcll(km & lt_mask)] = vB;
+            mcnt += __popcll(km);
+        }
+        for (int base = GL; __any(base < ncnt); base += GL) {    // partner lists longer than a chunk (rare)
+            const int k = base + gl;
+            int v = -1; bool keep = false;
+            if (k < ncnt) {
+                v = pool[noff + k];
+                if (v != p) {
+                    const int *qi = segI + (size_t)v * SEG_I;
+                    const int off = qi[3], cnt = qi[4];
+                    int i1, i2;
+                    list_find2(pool, off, cnt, nb, p, true, i1, i2);
+                    if (i2 < 0) { keep = true; if (i1 >= 0) pool[off + i1] = id; }
                 }
-                const unsigned long long km = Grp<GL>::ballot(keep);
-                if (keep) pool[moff + mcnt + __popcll(km & lt_mask)] = v;
-                mcnt += __popcll(km);
             }
-            for (int base = 0; __any(do_merge && base < pcnt); base += GL) {
-                const int k = base + gl;
-                int v = -1; bool keep = false;
-                if (do_merge && k < pcnt) {
-                    v = base == 0 ? a0 : pool[poff + k];
-                    if (v != nb) {
+            const unsigned long long km = Grp<GL>::ballot(keep);
+            if (keep) pool[moff + mcnt + __popcll(km & lt_mask)] = v;
+            mcnt += __popcll(km);
+        }
+        // ... then A: the first of {p, nb} found becomes the new id, the second is dropped (merge); p is dropped (no merge)
+        {
+            if (editA) {
+                int *qi = segI + (size_t)a0 * SEG_I;
+                if (do_merge) {
+                    if (a_i1 >= 0) pool[qa_off + a_i1] = id;
+                    if (a_i2 >= 0) { if (a_i2 != qa_cnt - 1) pool[qa_off + a_i2] = pool[qa_off + qa_cnt - 1]; qi[4] = qa_cnt - 1; }
+                } else if (a_i1 >= 0) { if (a_i1 != qa_cnt - 1) pool[qa_off + a_i1] = pool[qa_off + qa_cnt - 1]; qi[4] = qa_cnt - 1; }
+            }
+            const bool keep = editA && do_merge;
+            const unsigned long long km = Grp<GL>::ballot(keep);
+            if (keep) pool[moff + mcnt + __popcll(km & lt_mask)] = a0;
+            mcnt += __popcll(km);
+        }
+        for (int base = GL; __any(live && base < pcnt); base += GL) {         // p's list beyond the first chunk (rare)
+            const int k = base + gl;
+            int v = -1; bool keep = false;
+            if (live && k < pcnt) {
+                v = pool[poff + k];
+                if (!do_merge || v != nb) {
+                    int *qi = segI + (size_t)v * SEG_I;
+                    const int off = qi[3], cnt = qi[4];
+                    int i1, i2;
+                    if (do_merge) {
                         keep = true;
-                        int *qi = segI + (size_t)v * SEG_I;
-                        int off = qa_off, cnt = qa_cnt;
-                        if (base != 0) { off = qi[3]; cnt = qi[4]; }
-                        int i1, i2;
                         list_find2(pool, off, cnt, p, nb, true, i1, i2);
                         if (i1 >= 0) pool[off + i1] = id;
                         if (i2 >= 0) { if (i2 != cnt - 1) pool[off + i2] = pool[off + cnt - 1]; qi[4] = cnt - 1; }
-                    }
-                }
-                const unsigned long long km = Grp<GL>::ballot(keep);
-                if (keep) pool[moff + mcnt + __popcll(km & lt_mask)] = v;
-                mcnt += __popcll(km);
-            }
-            PT(5)
-            if (do_merge && is_w) {
-                double *md = segD + (size_t)id * SEG_D;
-                const double *wd = segD + (size_t)bid * SEG_D;                                // sums of the merge = p's + the partner's
-#pragma unroll
-                for (int q = 0; q < 9; q++) md[q] = ps[q] + wd[q];
-                md[9] = bc[0]; md[10] = bc[1]; md[11] = bc[2]; md[12] = bn[0]; md[13] = bn[1]; md[14] = bn[2]; md[15] = bm;
-                int *mi = segI + (size_t)id * SEG_I;
-                // ds.Union(pa.rid, pb.rid) (DisjointSet.hpp:63-83): the two nodes carry their sets' roots and sizes -- two stores, no Find
-                int root = pdsr, size = pdss + bdss;
-                if (pdsr == bdsr) size = pdss;
-                else if (pdss < bdss) { parent[pdsr] = bdsr; dsize[bdsr] = size; root = bdsr; }
-                else { parent[bdsr] = pdsr; dsize[pdsr] = size; }
-                mi[0] = bN; mi[1] = pN >= bN - pN ? prid : brid; mi[2] = 0; mi[3] = moff; mi[4] = mcnt; mi[5] = size; mi[6] = 1; mi[7] = root;
-                int *ni = segI + (size_t)nb * SEG_I;
-                pi[2] = 1; ni[2] = 1; pi[4] = 0; ni[4] = 0;
-            }
-            if (do_merge) pooltop += pcnt + ncnt;
-            PT(7)
-        }
-        const bool no_merge = live && !do_merge;
-        if (__any(no_merge)) {
-            PT_CNT(11, 1)
-            if (no_merge) {
-                if (pN >= MIN_SUPPORT) { if (next < MAX_PLANES) { if (gl == 0) ext[next] = p; next++; } else flags |= 16; }
-                for (int base = 0; base < pcnt; base += GL) {                              // disconnectAllNbs
-                    const int k = base + gl;
-                    if (k < pcnt) {
-                        int *qi = segI + (size_t)(base == 0 ? a0 : pool[poff + k]) * SEG_I;
-                        const int off = qi[3], cnt = qi[4];
-                        int i1, i2;
+                    } else {
                         list_find2(pool, off, cnt, p, p, false, i1, i2);
                         if (i1 >= 0) { if (i1 != cnt - 1) pool[off + i1] = pool[off + cnt - 1]; qi[4] = cnt - 1; }
                     }
                 }
-                if (gl == 0) pi[4] = 0;
             }
+            const unsigned long long km = Grp<GL>::ballot(keep);
+            if (keep) pool[moff + mcnt + __popcll(km & lt_mask)] = v;
+            mcnt += __popcll(km);
         }
-        // ---- the heap: the merged node, or the last entry, replaces the popped root ----
-        __syncthreads();                                       // this iteration's records / lists and the previous sift's heap stores
+        PT(5)
+        // the heap's third level and whatever is left of the sift (frames with more than 4 k blocks)
+        sift_take();
+        while (__any(s_go)) { sift_issue(); sift_take(); }
+        if (sift && gl == 0) H.set(s_i, s_k, s_idv);
+        PT(6)
+        if (do_merge && is_w) {
+            double *md = segD + (size_t)id * SEG_D;
+            const double *wd = segD + (size_t)bid * SEG_D;                                // sums of the merge = p's + the partner's
+#pragma unroll
+            for (int q = 0; q < 9; q++) md[q] = ps[q] + wd[q];
+            md[9] = bc[0]; md[10] = bc[1]; md[11] = bc[2]; md[12] = bn[0]; md[13] = bn[1]; md[14] = bn[2]; md[15] = bm;
+            int *mi = segI + (size_t)id * SEG_I;
+            // ds.Union(pa.rid, pb.rid) (DisjointSet.hpp:63-83): the two nodes carry their sets' roots and sizes -- two stores, no Find
+            int root = pdsr, size = pdss + bdss;
+            if (pdsr == bdsr) size = pdss;
+            else if (pdss < bdss) { parent[pdsr] = bdsr; dsize[bdsr] = size; root = bdsr; }
+            else { parent[bdsr] = pdsr; dsize[pdsr] = size; }
+            mi[0] = bN; mi[1] = pN >= bN - pN ? prid : brid; mi[2] = 0; mi[3] = moff; mi[4] = mcnt; mi[5] = size; mi[6] = 1; mi[7] = root;
+            int *ni = segI + (size_t)nb * SEG_I;
+            pi[2] = 1; ni[2] = 1; pi[4] = 0; ni[4] = 0;
+        }
+        if (do_merge) pooltop += pcnt + ncnt;
+        if (no_merge) {
+            if (pN >= MIN_SUPPORT) { if (next < MAX_PLANES) { if (gl == 0) ext[next] = p; next++; } else flags |= 16; }
+            if (gl == 0) pi[4] = 0;
+        }
+        PT(7)
+        __syncthreads();                                       // this iteration's records, lists and heap stores
+        // the next top's list (and all of its record when it is the node this iteration created; the partner stays in the
+        // heap, lazily deleted: its record said "in use" when it was fetched)
         {
-            double k = m; int idv = id; bool sift = do_merge;
-            if (act && !do_merge) { hn--; k = H.key(hn); idv = H.id(hn); sift = hn > 0; }
-            ptop = gheap_sift_root<GL>(H, hn, k, idv, sift, fetch_next);
-            if (!sift) ptop = -1;
+            const bool fresh = do_merge && ptop == id;
+            if (__any(fresh)) { if (fresh) fetch_next(ptop); }
+            if (do_merge && ptop == nb) n_nouse = 1;
+            n_cnt = segI[(size_t)(ptop < 0 ? 0 : ptop) * SEG_I + 4];
+            if (fresh) { n_cnt = mcnt; n_off = moff; }
             a0n = gl < n_cnt ? pool[n_off + gl] : -1;
         }
-        PT(6)
+        PT(0)
     }
     // std::sort by N descending, ties -> extraction order (stable insertion sort)
     __syncthreads();
