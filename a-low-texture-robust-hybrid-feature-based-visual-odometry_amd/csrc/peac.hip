@@ -48,7 +48,7 @@ struct PeacPlan {
     int *d_queue = nullptr; int *d_plidmap = nullptr; int *d_isvalid = nullptr;
     hvo_plane *d_planes = nullptr;
     unsigned long long *d_adj = nullptr;
-    double *d_hkey = nullptr; int *d_hid = nullptr;
+    double *d_hkey = nullptr, *d_m1k = nullptr; int *d_hid = nullptr;      // TQueue: keys, bucket minima, their ids
     void *d_nodes = nullptr; int lat_batch = 0;     // k_peac_cluster_lat's 256-byte node records (plans of fewer than LAT_MAX_BATCH frames)
     double c15 = 0, c60 = 0, c30 = 0;   // cos thresholds evaluated on the host (glibc), like the oracle
     double ang_factor = 0, ang_near = 0;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) void k_peac_blocks(const uint16_t *__restrict__
 // ------------------------------------------------------------------------------------------------
 struct ClArgs {
     double *segD; int *segI; int *pool; int *pool2; int *parent; int *dsize; int *eflag; int *meta; int *extracted;
-    double *hkey; int *hid;
+    double *tqK, *tqM1k; int *tqM1i; int tq_n0;      // the grouped kernel's min-MSE queue (TQueue): n0 * 256 keys, n0 * 16 bucket minima per frame
     int segcap, poolcap, nblk, Nw, Nh;
     double c15, c60;
     double ang_factor, ang_near;   // T_ang(P_INIT): (angle_far - angle_near) / (z_far - z_near), angle_near (AHCParamSet.hpp:113-121)
@@ -508,7 +508,7 @@ struct ListFind {
 };
 
 template <int GL> struct Grp {
-    static_assert(GL == 8 || GL == 16 || GL == 32 || GL == 64, "group width");
+    static_assert(GL == 16 || GL == 32 || GL == 64, "group width (a DPP row or more: TQueue reduces over 16-lane rows)");
     static __device__ __forceinline__ int gl() { return threadIdx.x & (GL - 1); }
     static __device__ __forceinline__ int gb() { return threadIdx.x & 63 & ~(GL - 1); }
     static __device__ __forceinline__ unsigned long long ballot(bool p)
@@ -533,72 +533,86 @@ template <int STEP> static __device__ __forceinline__ double row_partner(double 
     return __hiloint2double(row_partner<STEP>(__double2hiint(v)), row_partner<STEP>(__double2loint(v)));
 }
 
-// arity of the grouped heap: one child per lane, at most a DPP row
-#define GH_ARY (GL < 16 ? GL : 16)
-template <int GL>
-static __device__ void gheap_sift_down(double *key, int *id, int n, int i, double k, int idv, bool act)
+// ------------------------------------------------------------------------------------------------
+// TQueue: the min-MSE queue of ahCluster for the grouped kernel, as a 16-ary TOURNAMENT over node ids.
+//   K[id]            key of node id, +inf when it is not queued                       (global, 16 keys = one 128-byte line)
+//   M1k/M1i[b]       smallest (key, id) of bucket b = ids 16 b .. 16 b + 15            (global)
+//   M0k/M0i[s]       smallest (key, id) of the 16 buckets 16 s .. 16 s + 15             (LDS, n0 = ceil(segcap / 256) entries)
+// The top is the minimum of M0 (n0 / 16 LDS reads per lane and one row reduction).  Changing the keys of up to three ids
+// (a merge: p and its partner leave, the new node enters) re-reduces their buckets and super-buckets: nine independent line
+// loads = ONE memory round trip, against one per level for a heap's sift; ids that share a bucket are patched in registers.
+// Above all nothing is deleted lazily: with a heap the partner stayed queued until it was popped, and those dead pops
+// were HALF of all iterations -- at four frames per wave in lockstep almost every one of them cost a full iteration.
+// Ties: (key, id) lexicographic, as everywhere else (hless).
+// ------------------------------------------------------------------------------------------------
+#define TQ_INF 1.7976931348623157e308
+struct TQueue { double *K, *M1k; int *M1i; double *M0k; int *M0i; int n0; };
+// all-reduce of (k, i) under hless over the 16-lane DPP row (every lane ends up with the minimum)
+static __device__ __forceinline__ void row_min16(double &k, int &i)
 {
-    const int gl = Grp<GL>::gl();
-    bool go = act;
-    while (__any(go)) {
-        const int c0 = GH_ARY * i + 1;
-        const bool cont = go && c0 < n;
-        double ck = 1.0e308; int cid = 0x7FFFFFFF, ci = -1;
-        if (cont && gl < GH_ARY && c0 + gl < n) { ci = c0 + gl; ck = key[ci]; cid = id[ci]; }
+#define RM_STEP(o) { const double ok = row_partner<o>(k); const int oi = row_partner<o>(i); if (hless(ok, oi, k, i)) { k = ok; i = oi; } }
+    RM_STEP(1) RM_STEP(2) RM_STEP(4) RM_STEP(8)
+#undef RM_STEP
+}
+static __device__ __forceinline__ int tq_top(const TQueue &Q, int rl)
+{
+    double k = TQ_INF; int i = 0x7FFFFFFF;
+    for (int j = rl; j < Q.n0; j += 16) { const double a = Q.M0k[j]; const int b = Q.M0i[j]; if (hless(a, b, k, i)) { k = a; i = b; } }
+    row_min16(k, i);
+    return k < TQ_INF ? i : -1;
+}
+// an update of nx (0, 1 or 3; uniform per group) keys, in two halves: issue() starts the loads, take() finishes and returns
+// the new top.  rl = lane within the 16-lane row (wider groups compute every row redundantly), writer = the group's lane 0.
+struct TQUpdate {
+    double kk[3], mk[3], kn[3]; int mi[3], x[3], nx;
+    __device__ __forceinline__ void issue(const TQueue &Q, int rl, int nx_, int x0, double k0, int x1, double k1, int x2, double k2)
+    {
+        nx = nx_; x[0] = x0; x[1] = x1; x[2] = x2; kn[0] = k0; kn[1] = k1; kn[2] = k2;
 #pragma unroll
-        for (int o = 1; o < GH_ARY; o <<= 1) {
-            const double ok = __shfl_xor(ck, o); const int oid = __shfl_xor(cid, o), oi = __shfl_xor(ci, o);
-            if (oi >= 0 && (ci < 0 || hless(ok, oid, ck, cid))) { ck = ok; cid = oid; ci = oi; }
+        for (int t = 0; t < 3; t++) {
+            kk[t] = TQ_INF; mk[t] = TQ_INF; mi[t] = 0x7FFFFFFF;
+            if (t < nx) { kk[t] = Q.K[(x[t] & ~15) + rl]; const int j = ((x[t] >> 8) << 4) + rl; mk[t] = Q.M1k[j]; mi[t] = Q.M1i[j]; }
         }
-        ck = Grp<GL>::shfl(ck, 0); cid = Grp<GL>::shfl(cid, 0); ci = Grp<GL>::shfl(ci, 0);
-        const bool mv = cont && ci >= 0 && hless(ck, cid, k, idv);
-        if (mv) { if (gl == 0) { key[i] = ck; id[i] = cid; } i = ci; }
-        go = mv;
     }
-    if (act && gl == 0) { key[i] = k; id[i] = idv; }
-}
-
-// Optionally the top three levels of the 16-ary heap (1 + 16 + 256 entries) live in LDS.  Measured: no
-// gain for the kernel alone (the sift is bound by the cross-lane reduction, not by the loads) and a loss
-// for the whole front-end, because LDS is the resource k_lsd_grow exhausts while both kernels run.
-#ifndef GH_TOP
-#define GH_TOP 0            // 273 = cache three levels; 0 = heap entirely in global memory (see note)
-#endif
-struct GHeap {
-    double *gk; int *gi;       // global arrays (entries >= GH_TOP are authoritative there)
-    double *lk; int *li;       // LDS copy of entries < GH_TOP (authoritative)
-    __device__ __forceinline__ double key(int i) const { return i < GH_TOP ? lk[i] : gk[i]; }
-    __device__ __forceinline__ int id(int i) const { return i < GH_TOP ? li[i] : gi[i]; }
-    __device__ __forceinline__ void set(int i, double k, int v) const { if (i < GH_TOP) { lk[i] = k; li[i] = v; } else { gk[i] = k; gi[i] = v; } }
+    __device__ __forceinline__ int take(const TQueue &Q, int rl, bool writer)
+    {
+#pragma unroll
+        for (int t = 0; t < 3; t++) if (writer && t < nx) Q.K[x[t]] = kn[t];
+        double bk[3]; int bi[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            double k = kk[t]; int i = (x[t] & ~15) + rl;
+#pragma unroll
+            for (int u = 0; u < 3; u++) if (u < nx && ((x[u] ^ x[t]) >> 4) == 0 && (x[u] & 15) == rl) k = kn[u];
+            if (t >= nx) { k = TQ_INF; i = 0x7FFFFFFF; }
+            row_min16(k, i);
+            bk[t] = k; bi[t] = i;
+        }
+#pragma unroll
+        for (int t = 0; t < 3; t++) if (writer && t < nx) { Q.M1k[x[t] >> 4] = bk[t]; Q.M1i[x[t] >> 4] = bi[t]; }
+        double sk[3]; int si[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            double k = mk[t]; int i = mi[t];
+#pragma unroll
+            for (int u = 0; u < 3; u++) if (u < nx && ((x[u] ^ x[t]) >> 8) == 0 && ((x[u] >> 4) & 15) == rl) { k = bk[u]; i = bi[u]; }
+            if (t >= nx) { k = TQ_INF; i = 0x7FFFFFFF; }
+            row_min16(k, i);
+            sk[t] = k; si[t] = i;
+        }
+        double k = TQ_INF; int i = 0x7FFFFFFF;
+        for (int j = rl; j < Q.n0; j += 16) {
+            double a = Q.M0k[j]; int b = Q.M0i[j];
+#pragma unroll
+            for (int u = 0; u < 3; u++) if (u < nx && (x[u] >> 8) == j) { a = sk[u]; b = si[u]; }
+            if (hless(a, b, k, i)) { k = a; i = b; }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; t++) if (writer && t < nx) { Q.M0k[x[t] >> 8] = sk[t]; Q.M0i[x[t] >> 8] = si[t]; }
+        row_min16(k, i);
+        return k < TQ_INF ? i : -1;
+    }
 };
-// sift (k, idv) down from the root; returns the id that ends up AT the root, i.e. the next top.  The root is
-// known after the first level: on_root(root) is called there, so that the caller's loads for the next
-// iteration travel underneath the remaining levels.
-template <int GL, class F>
-static __device__ int gheap_sift_root(const GHeap &H, int n, double k, int idv, bool act, F on_root)
-{
-    const int gl = Grp<GL>::gl();
-    int i = 0, root = act ? idv : -1;
-    bool go = act, first = true;
-    do {
-        const int c0 = GH_ARY * i + 1;
-        const bool cont = go && c0 < n;
-        double ck = 1.0e308; int cid = 0x7FFFFFFF, ci = -1;
-        if (cont && gl < GH_ARY && c0 + gl < n) { ci = c0 + gl; ck = H.key(ci); cid = H.id(ci); }
-#define GH_STEP(o) { const double ok = row_partner<o>(ck); const int oid = row_partner<o>(cid), oi = row_partner<o>(ci); \
-                     if (oi >= 0 && (ci < 0 || hless(ok, oid, ck, cid))) { ck = ok; cid = oid; ci = oi; } }
-        GH_STEP(1) GH_STEP(2) GH_STEP(4) if (GH_ARY > 8) GH_STEP(8)
-#undef GH_STEP
-        // every lane of the first GH_ARY lanes now holds the minimum; wider groups broadcast it
-        if (GL > 16) { ck = Grp<GL>::shfl(ck, 0); cid = Grp<GL>::shfl(cid, 0); ci = Grp<GL>::shfl(ci, 0); }
-        const bool mv = cont && ci >= 0 && hless(ck, cid, k, idv);
-        if (mv) { if (gl == 0) H.set(i, ck, cid); if (i == 0) root = cid; i = ci; }
-        go = mv;
-        if (first) { on_root(root); first = false; }
-    } while (__any(go));
-    if (act && gl == 0) H.set(i, k, idv);
-    return root;
-}
 
 template <int GL>
 static __device__ void gpool_gc(int *segI, int nseg, int *&pool, int *&pool2, int &pooltop, bool need)
@@ -633,7 +647,7 @@ static __device__ void gpool_gc(int *segI, int nseg, int *&pool, int *&pool2, in
 // That is three reductions (min mse; min id with N >= mse; max id), so lists need no order, merging
 // two lists is mark / test / compact in parallel, and removing an id is replace-or-swap-with-last.
 template <int GL>
-static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHeap &H, int &hn, int &nseg, int &pooltop,
+static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQueue &Q, int &hn, int &nseg, int &pooltop,
                                           int *&pool, int *&pool2, int *ext, int &next, int &flags)
 {
     const int gl = Grp<GL>::gl(), gb = Grp<GL>::gb();
@@ -642,17 +656,16 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
     int *parent = a.parent + (size_t)frame * a.nblk, *dsize = a.dsize + (size_t)frame * a.nblk;
     const unsigned long long lt_mask = (1ull << gl) - 1;       // lanes of my group below me
     PT_DECL
-    // The heap is touched once per iteration: the popped root is only replaced at the end, by the merged
-    // node (merge) or by the last entry (no merge), with one sift-down that also yields the next top.
+    const int rl = gl & 15;
     __syncthreads();
-    int ptop = hn > 0 ? H.id(0) : -1;
-    // the popped node's record (sums, normal, list) is fetched one iteration ahead, underneath the sift-down
-    double nps[9], npn[3]; int n_nouse = 1, n_cnt = 0, n_off = 0, n_N = 0, n_rid = 0, n_dsr = 0, n_dss = 0, a0n = -1;
+    int ptop = hn > 0 ? tq_top(Q, rl) : -1;                     // hn = queued (= live) nodes
+    // the popped node's record (sums, normal) is fetched one iteration ahead, underneath the list edits
+    double nps[9], npn[3]; int n_cnt = 0, n_off = 0, n_N = 0, n_rid = 0, n_dsr = 0, n_dss = 0, a0n = -1;
     auto fetch_next = [&](int r) {
         const int q = r < 0 ? 0 : r;
         const int *qi = segI + (size_t)q * SEG_I;
         const double *qd = segD + (size_t)q * SEG_D;
-        n_nouse = qi[2]; n_cnt = qi[4]; n_off = qi[3]; n_N = qi[0]; n_rid = qi[1]; n_dsr = qi[7]; n_dss = qi[5];
+        n_cnt = qi[4]; n_off = qi[3]; n_N = qi[0]; n_rid = qi[1]; n_dsr = qi[7]; n_dss = qi[5];
 #pragma unroll
         for (int q2 = 0; q2 < 9; q2++) nps[q2] = qd[q2];
         npn[0] = qd[12]; npn[1] = qd[13]; npn[2] = qd[14];
@@ -670,10 +683,8 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
         }
         PT(0)
         const int p = act ? ptop : -1;
-        double lk_last = 0; int li_last = 0;                     // the heap's last entry, in case the root is not replaced by a merged node
-        if (act) { lk_last = H.key(hn - 1); li_last = H.id(hn - 1); }
         int *pi = segI + (size_t)(p < 0 ? 0 : p) * SEG_I;
-        const bool live = act && n_nouse == 0;                 // skip nouse nodes (lazy deletion)
+        const bool live = act;                                 // every queued node is in use (nothing is deleted lazily)
         const int pcnt = live ? n_cnt : 0, poff = n_off, pN = n_N, prid = n_rid, pdsr = n_dsr, pdss = n_dss;
         double ps[9], pn[3];                                   // popped node: sums and normal (uniform per group)
 #pragma unroll
@@ -798,50 +809,30 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
         //     Pass A walks p's list: copy, p -> id, nb dropped.  B only writes lists of nodes that are not p's neighbours and
         //     reads the others before A writes them (all of B, its tail included, precedes A's stores);
         //   * no merge: disconnectAllNbs = pass A with "drop p";
-        //   * the heap is touched once per iteration: the popped root is replaced by the merged node (merge) or by the last
-        //     entry (otherwise), with one sift-down whose first level yields the next top; that node's record is fetched
-        //     underneath the remaining stages (everything in it but its list, which this iteration may still edit).
+        //   * the queue (TQueue): p leaves; on a merge the partner leaves and the new node enters.  One round trip yields the
+        //     next top, whose record is fetched underneath the remaining stages (everything in it but its list, which this
+        //     iteration may still edit).
         const int moff = pooltop;
-        double s_k = m; int s_idv = id; bool sift = do_merge;
-        if (act && !do_merge) { hn--; s_k = lk_last; s_idv = li_last; sift = hn > 0; }
-        int s_i = 0, s_root = sift ? s_idv : -1, s_cid = 0x7FFFFFFF, s_ci = -1; bool s_go = sift, s_cont = false; double s_ck = 1.0e308;
-        auto sift_issue = [&]() {
-            const int c0 = GH_ARY * s_i + 1;
-            s_cont = s_go && c0 < hn;
-            s_ck = 1.0e308; s_cid = 0x7FFFFFFF; s_ci = -1;
-            if (s_cont && gl < GH_ARY && c0 + gl < hn) { s_ci = c0 + gl; s_ck = H.key(s_ci); s_cid = H.id(s_ci); }
-        };
-        auto sift_take = [&]() {
-#define GH_STEP(o) { const double ok = row_partner<o>(s_ck); const int oid = row_partner<o>(s_cid), oi = row_partner<o>(s_ci); \
-                     if (oi >= 0 && (s_ci < 0 || hless(ok, oid, s_ck, s_cid))) { s_ck = ok; s_cid = oid; s_ci = oi; } }
-            GH_STEP(1) GH_STEP(2) GH_STEP(4) if (GH_ARY > 8) GH_STEP(8)
-#undef GH_STEP
-            if (GL > 16) { s_ck = Grp<GL>::shfl(s_ck, 0); s_cid = Grp<GL>::shfl(s_cid, 0); s_ci = Grp<GL>::shfl(s_ci, 0); }
-            const bool mv = s_cont && s_ci >= 0 && hless(s_ck, s_cid, s_k, s_idv);
-            if (mv) { if (gl == 0) H.set(s_i, s_ck, s_cid); if (s_i == 0) s_root = s_cid; s_i = s_ci; }
-            s_go = mv;
-        };
-        // stage 0: the partner's first chunk, my member's list header, the heap's first level
+        if (act) hn -= 1;                                       // merge: -2 + 1
+        TQUpdate qu;
+        // stage 0: the partner's first chunk, my member's list header, the queue's lines
         const bool editA = a0 >= 0 && ((do_merge && a0 != nb) || no_merge);
         int qa_off = 0, qa_cnt = 0;
         if (editA) { const int *qi = segI + (size_t)a0 * SEG_I; qa_off = qi[3]; qa_cnt = qi[4]; }
         const int vB = gl < ncnt ? pool[noff + gl] : -1;        // ncnt == 0 unless this group merges
-        sift_issue();
-        // stage 1: B's members' list headers, A's lists, the heap's second level + the next top's record
+        qu.issue(Q, rl, act ? (do_merge ? 3 : 1) : 0, p, TQ_INF, nb, TQ_INF, id, m);
+        // stage 1: B's members' list headers, A's lists, the next top's record
         const bool inB = vB >= 0 && vB != p;
         int qb_off = 0, qb_cnt = 0;
         if (inB) { const int *qi = segI + (size_t)vB * SEG_I; qb_off = qi[3]; qb_cnt = qi[4]; }
         ListFind fa; fa.issue(pool, qa_off, editA ? qa_cnt : 0);
-        sift_take();
-        ptop = sift ? s_root : -1;
+        ptop = qu.take(Q, rl, gl == 0);
+        if (hn <= 0) ptop = -1;
         fetch_next(ptop);
-        sift_issue();
-        // stage 2: B's lists, the heap's third level
+        // stage 2: B's lists
         ListFind fb; fb.issue(pool, qb_off, inB ? qb_cnt : 0);
         int a_i1, a_i2;
         fa.finish(pool, p, do_merge ? nb : p, do_merge, a_i1, a_i2);
-        sift_take();
-        sift_issue();
         // stage 3: the edits.  All of B first ...
         int mcnt = 0;
         {
@@ -909,11 +900,6 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
             mcnt += __popcll(km);
         }
         PT(5)
-        // the heap's third level and whatever is left of the sift (frames with more than 4 k blocks)
-        sift_take();
-        while (__any(s_go)) { sift_issue(); sift_take(); }
-        if (sift && gl == 0) H.set(s_i, s_k, s_idv);
-        PT(6)
         if (do_merge && is_w) {
             double *md = segD + (size_t)id * SEG_D;
             const double *wd = segD + (size_t)bid * SEG_D;                                // sums of the merge = p's + the partner's
@@ -937,12 +923,10 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const GHea
         }
         PT(7)
         __syncthreads();                                       // this iteration's records, lists and heap stores
-        // the next top's list (and all of its record when it is the node this iteration created; the partner stays in the
-        // heap, lazily deleted: its record said "in use" when it was fetched)
+        // the next top's list (and all of its record when it is the node this iteration created)
         {
             const bool fresh = do_merge && ptop == id;
             if (__any(fresh)) { if (fresh) fetch_next(ptop); }
-            if (do_merge && ptop == nb) n_nouse = 1;
             n_cnt = segI[(size_t)(ptop < 0 ? 0 : ptop) * SEG_I + 4];
             if (fresh) { n_cnt = mcnt; n_off = moff; }
             a0n = gl < n_cnt ? pool[n_off + gl] : -1;
@@ -977,15 +961,16 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
 #ifdef HVO_CLUSTER_INFLATE      // experiment: allocate more registers without using them (tools/build_variant.sh)
     asm volatile("v_mov_b32 v231, 0" ::: "v231");
 #endif
-    __shared__ double lks[NG][GH_TOP + 1];
-    __shared__ int lis[NG][GH_TOP + 1];
+    extern __shared__ __attribute__((aligned(16))) unsigned char tq_lds[];          // NG groups x n0 x (double + int)
     const int lane = threadIdx.x, gl = Grp<GL>::gl(), gid = lane / GL;
     int frame = blockIdx.x * NG + gid;
     const bool galive = frame < nframes;
     if (!galive) frame = nframes - 1;                          // idle group: aliases a frame read-only, writes nothing
     const int nblk = a.nblk, Nw = a.Nw, Nh = a.Nh;
-    double *hkey = a.hkey + (size_t)frame * nblk;              // heap arrays in global memory (L2)
-    int *hid = a.hid + (size_t)frame * nblk;
+    TQueue Q; Q.n0 = a.tq_n0;
+    Q.K = a.tqK + (size_t)frame * Q.n0 * 256; Q.M1k = a.tqM1k + (size_t)frame * Q.n0 * 16; Q.M1i = a.tqM1i + (size_t)frame * Q.n0 * 16;
+    Q.M0k = reinterpret_cast<double *>(tq_lds) + (size_t)gid * Q.n0;
+    Q.M0i = reinterpret_cast<int *>(tq_lds + (size_t)NG * Q.n0 * sizeof(double)) + (size_t)gid * Q.n0;
     double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
     int *segI = a.segI + (size_t)frame * a.segcap * SEG_I;
     int *pool = a.pool + (size_t)frame * a.poolcap, *pool2 = a.pool2 + (size_t)frame * a.poolcap;
@@ -1027,9 +1012,9 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
         }
     }
     __syncthreads();
-    // adjacency lists in ascending id order (up, left, right, down) and the heap's initial content
+    // adjacency lists in ascending id order (up, left, right, down); the queue's keys: a block's mse when it holds a node
     int hn = 0;
-    for (int base = 0; base < nblk; base += GL) {
+    for (int base = 0; base < Q.n0 * 256; base += GL) {
         const int b = base + gl;
         bool ok = false;
         if (galive && b < nblk) {
@@ -1043,33 +1028,32 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
             si[4] = n;
             ok = si[6] != 0;
         }
-        const unsigned long long m = Grp<GL>::ballot(ok);
-        if (ok) { const int pos = hn + __popcll(m & ((1ull << gl) - 1)); hkey[pos] = segD[(size_t)b * SEG_D + 15]; hid[pos] = b; }
-        hn += __popcll(m);
+        if (galive) Q.K[b] = ok ? segD[(size_t)b * SEG_D + 15] : TQ_INF;
+        hn += __popcll(Grp<GL>::ballot(ok));
     }
     __syncthreads();
 #ifdef HVO_PEAC_TIMING
     const unsigned long long t_in1 = clock64();
 #endif
-    // Floyd heapify from the last parent down (each sift is group-cooperative)
-    for (int i = (nblk - 2) / GH_ARY; i >= 0; i--) {
-        const bool act = hn > 1 && i <= (hn - 2) / GH_ARY;
-        if (!__any(act)) continue;
-        double k = 0; int id = 0;
-        if (act) { k = hkey[i]; id = hid[i]; }
-        __syncthreads();
-        gheap_sift_down<GL>(hkey, hid, hn, i, k, id, act);
-        __syncthreads();
+    // the tournament above the keys: a lane reduces a whole bucket (16 contiguous keys), then a whole super-bucket
+    if (galive) for (int j = gl; j < Q.n0 * 16; j += GL) {
+        double k = TQ_INF; int i = 0x7FFFFFFF;
+        for (int q = 0; q < 16; q++) { const double kq = Q.K[j * 16 + q]; if (hless(kq, j * 16 + q, k, i)) { k = kq; i = j * 16 + q; } }
+        Q.M1k[j] = k; Q.M1i[j] = i;
+    }
+    __syncthreads();
+    for (int j = gl; j < Q.n0; j += GL) {
+        double k = TQ_INF; int i = 0x7FFFFFFF;
+        if (galive) for (int q = 0; q < 16; q++) { const double kq = Q.M1k[j * 16 + q]; const int iq = Q.M1i[j * 16 + q]; if (hless(kq, iq, k, i)) { k = kq; i = iq; } }
+        Q.M0k[j] = k; Q.M0i[j] = i;
     }
 #ifdef HVO_PEAC_TIMING
     if (lane == 0) { const unsigned long long t_in2 = clock64(); atomicAdd(&g_peac_t[12], t_in1 - t_in0); atomicAdd(&g_peac_t[13], t_in2 - t_in1); atomicAdd(&g_peac_t[14], 1ull); }
 #endif
     int nseg = nblk, pooltop = nblk * 4, next = 0, flags = 0;
     int *ext = a.extracted + (size_t)frame * 2 * MAX_PLANES;
-    GHeap H; H.gk = hkey; H.gi = hid; H.lk = lks[gid]; H.li = lis[gid];
     __syncthreads();
-    for (int i = gl; i < min(hn, GH_TOP); i += GL) { H.lk[i] = hkey[i]; H.li[i] = hid[i]; }
-    ah_cluster_grouped<GL>(a, frame, H, hn, nseg, pooltop, pool, pool2, ext, next, flags);
+    ah_cluster_grouped<GL>(a, frame, Q, hn, nseg, pooltop, pool, pool2, ext, next, flags);
     if (galive && gl == 0) {
         int *meta = a.meta + (size_t)frame * 16;
         meta[0] = nseg; meta[1] = pooltop; meta[2] = next; meta[3] = flags;
@@ -1645,7 +1629,7 @@ void peac_free(hvo_ctx *ctx)
     PeacPlan *P = plan_of(ctx);
     if (!P) return;
     void *ptrs[] = { P->d_depth, P->d_segD, P->d_segI, P->d_pool, P->d_pool2, P->d_parent, P->d_dsize, P->d_eflag, P->d_meta, P->d_extracted,
-                     P->d_blkmap, P->d_labels, P->d_state, P->d_queue, P->d_plidmap, P->d_isvalid, P->d_planes, P->d_adj, P->d_hkey, P->d_hid, P->d_nodes };
+                     P->d_blkmap, P->d_labels, P->d_state, P->d_queue, P->d_plidmap, P->d_isvalid, P->d_planes, P->d_adj, P->d_hkey, P->d_m1k, P->d_hid, P->d_nodes };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
     ctx->peac = nullptr;
@@ -1691,7 +1675,7 @@ static int peac_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_plidmap, B * MAX_PLANES * sizeof(int)); PA(P->d_isvalid, B * MAX_PLANES * sizeof(int));
     PA(P->d_planes, B * MAX_PLANES * sizeof(hvo_plane));
     PA(P->d_adj, B * MAX_PLANES * sizeof(unsigned long long));
-    PA(P->d_hkey, B * P->nblk * sizeof(double)); PA(P->d_hid, B * P->nblk * sizeof(int));
+    { const size_t n0 = (P->segcap + 255) / 256; PA(P->d_hkey, B * n0 * 256 * sizeof(double)); PA(P->d_m1k, B * n0 * 16 * sizeof(double)); PA(P->d_hid, B * n0 * 16 * sizeof(int)); }   // TQueue
     // the low-latency kernel keeps the whole heap (10 bytes per block) and one bit per node in LDS: up to ~14 k blocks (1280x960 has 12 288)
     const bool want_lat = LAT_DEFAULT_BATCH > 0 || (getenv("HVO_PEAC_LAT") && atoi(getenv("HVO_PEAC_LAT")) != 0);    // opt-in: its node records cost 1.6 MB per frame
     if (want_lat && batch <= LAT_MAX_BATCH && P->segcap <= 65535 && (size_t)P->nblk * 10 + (size_t)P->segcap * 2 + 64 <= 150 * 1024) { PA(P->d_nodes, B * P->segcap * sizeof(Node2)); P->lat_batch = batch; }
@@ -1743,7 +1727,7 @@ int peac_run(hvo_ctx *ctx, int n)
     ClArgs a;
     a.segD = P->d_segD; a.segI = P->d_segI; a.pool = P->d_pool; a.pool2 = P->d_pool2; a.parent = P->d_parent; a.dsize = P->d_dsize; a.eflag = P->d_eflag;
     a.meta = P->d_meta; a.extracted = P->d_extracted; a.segcap = P->segcap; a.poolcap = P->poolcap; a.nblk = P->nblk; a.Nw = P->Nw; a.Nh = P->Nh;
-    a.c15 = P->c15; a.c60 = P->c60; a.hkey = P->d_hkey; a.hid = P->d_hid;
+    a.c15 = P->c15; a.c60 = P->c60; a.tqK = P->d_hkey; a.tqM1k = P->d_m1k; a.tqM1i = P->d_hid; a.tq_n0 = (P->segcap + 255) / 256;
     a.ang_factor = P->ang_factor; a.ang_near = P->ang_near;
     id = hvo_prof_begin(ctx, "peac_cluster", st);
     // k_peac_cluster_lat (one frame per workgroup, queue in LDS, adjacency inline in 256-byte node records): an experiment in
@@ -1768,10 +1752,10 @@ int peac_run(hvo_ctx *ctx, int n)
         const char *e = getenv("HVO_PEAC_GL");
         const int gl = e ? atoi(e) : -1;
         const int use = gl > 0 ? gl : (n >= 3072 ? 16 : 64);
-        if (use == 64) hipLaunchKernelGGL(k_peac_cluster<64>, dim3(n), dim3(64), 0, st, a, n);
-        else if (use == 32) hipLaunchKernelGGL(k_peac_cluster<32>, dim3((n + 1) / 2), dim3(64), 0, st, a, n);
-        else if (use == 8) hipLaunchKernelGGL(k_peac_cluster<8>, dim3((n + 7) / 8), dim3(64), 0, st, a, n);
-        else hipLaunchKernelGGL(k_peac_cluster<16>, dim3((n + 3) / 4), dim3(64), 0, st, a, n);
+        const size_t lq = (size_t)a.tq_n0 * 12;                  // LDS per group: the queue's top level
+        if (use == 64) hipLaunchKernelGGL(k_peac_cluster<64>, dim3(n), dim3(64), lq, st, a, n);
+        else if (use == 32) hipLaunchKernelGGL(k_peac_cluster<32>, dim3((n + 1) / 2), dim3(64), 2 * lq, st, a, n);
+        else hipLaunchKernelGGL(k_peac_cluster<16>, dim3((n + 3) / 4), dim3(64), 4 * lq, st, a, n);
     }
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "peac_refine", st);
