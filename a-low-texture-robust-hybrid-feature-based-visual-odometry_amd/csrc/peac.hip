@@ -48,6 +48,7 @@ struct PeacPlan {
     int *d_queue = nullptr; int *d_plidmap = nullptr; int *d_isvalid = nullptr;
     hvo_plane *d_planes = nullptr;
     unsigned long long *d_adj = nullptr;
+    void *d_hot = nullptr;                                                 // HotNode records of the grouped AHC kernel
     double *d_hkey = nullptr, *d_m1k = nullptr; int *d_hid = nullptr;      // TQueue: keys, bucket minima, their ids
     void *d_nodes = nullptr; int lat_batch = 0;     // k_peac_cluster_lat's 256-byte node records (plans of fewer than LAT_MAX_BATCH frames)
     double c15 = 0, c60 = 0, c30 = 0;   // cos thresholds evaluated on the host (glibc), like the oracle
@@ -117,13 +118,18 @@ static __device__ void stats_compute_dev(const double *st, int N, double center[
 // ------------------------------------------------------------------------------------------------
 // k_peac_blocks: one thread per 10x10 block
 // ------------------------------------------------------------------------------------------------
+// Node record of the grouped AHC kernel: everything an iteration reads of a node -- the sums and the normal (candidate
+// evaluation), the header of its neighbour list, its disjoint set -- in ONE 128-byte line (segD + segI keep the blocks'
+// fits, which the kernel reads once, and receive the extracted planes' records at the end).  A dead node has cnt == 0.
+struct __attribute__((aligned(128))) HotNode { double st[9], nrm[3], mse; int N, rid, off, cnt, dss, dsr; };
+static_assert(sizeof(HotNode) == 128, "HotNode is one cache line");
 #ifdef HVO_WPE_BLOCKS
 __attribute__((amdgpu_waves_per_eu(HVO_WPE_BLOCKS)))
 #endif
 __global__ __launch_bounds__(64) void k_peac_blocks(const uint16_t *__restrict__ depth, size_t dframe, int pitch,
                                                     int w, int h, int Nw, int nblk,
                                                     float fx, float fy, float cx, float cy, float dfac,
-                                                    double *__restrict__ segD, int *__restrict__ segI, int segcap)
+                                                    double *__restrict__ segD, int *__restrict__ segI, int segcap, HotNode *__restrict__ hot)
 {
     const int blk = blockIdx.x * 64 + threadIdx.x, frame = blockIdx.y;
     if (blk >= nblk) return;
@@ -194,6 +200,11 @@ __global__ __launch_bounds__(64) void k_peac_blocks(const uint16_t *__restrict__
     sd[12] = normal[0]; sd[13] = normal[1]; sd[14] = normal[2]; sd[15] = mse;
     // [5], [7]: size and root of the node's disjoint set (a live node IS one set: DisjointSet::Union then needs no Find chain)
     si[0] = N; si[1] = blk; si[2] = ok ? 0 : 1; si[3] = blk * 4; si[4] = 0; si[5] = 1; si[6] = ok; si[7] = blk;
+    // the grouped AHC kernel's record of the block (its list length is set there, with the edges)
+    HotNode *hb = hot + (size_t)frame * segcap + blk;
+    for (int k = 0; k < 9; k++) hb->st[k] = st[k];
+    hb->nrm[0] = normal[0]; hb->nrm[1] = normal[1]; hb->nrm[2] = normal[2]; hb->mse = mse;
+    hb->N = N; hb->rid = blk; hb->off = blk * 4; hb->cnt = 0; hb->dss = 1; hb->dsr = blk;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -201,6 +212,7 @@ __global__ __launch_bounds__(64) void k_peac_blocks(const uint16_t *__restrict__
 // ------------------------------------------------------------------------------------------------
 struct ClArgs {
     double *segD; int *segI; int *pool; int *pool2; int *parent; int *dsize; int *eflag; int *meta; int *extracted;
+    struct HotNode *hot;                            // the grouped kernel's node records (one 128-byte line each)
     double *tqK, *tqM1k; int *tqM1i; int tq_n0;      // the grouped kernel's min-MSE queue (TQueue): n0 * 256 keys, n0 * 16 bucket minima per frame
     int segcap, poolcap, nblk, Nw, Nh;
     double c15, c60;
@@ -489,6 +501,14 @@ struct ListFind {
 #pragma unroll
         for (int j = 0; j < 8; j++) u[j] = j < cnt ? pool[off + j] : -1;
     }
+    // the entries in registers only; true when the search is complete
+    __device__ __forceinline__ bool scan(int a, int b, bool want2, int &i1, int &i2) const
+    {
+        i1 = -1; i2 = -1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (u[j] >= 0 && (u[j] == a || u[j] == b)) { if (i1 < 0) i1 = j; else i2 = j; }
+        return cnt <= 8 || (i1 >= 0 && (!want2 || i2 >= 0));
+    }
     __device__ __forceinline__ void finish(const int *pool, int a, int b, bool want2, int &i1, int &i2) const
     {
         i1 = -1; i2 = -1;
@@ -615,7 +635,7 @@ struct TQUpdate {
 };
 
 template <int GL>
-static __device__ void gpool_gc(int *segI, int nseg, int *&pool, int *&pool2, int &pooltop, bool need)
+static __device__ void gpool_gc(HotNode *hot, int nseg, int *&pool, int *&pool2, int &pooltop, bool need)
 {
     const int gl = Grp<GL>::gl();
     __syncthreads();
@@ -624,13 +644,13 @@ static __device__ void gpool_gc(int *segI, int nseg, int *&pool, int *&pool2, in
         const int id = base + gl;
         int sz = 0, off = 0;
         const bool in = need && id < nseg;
-        if (in) { const int *si = segI + (size_t)id * SEG_I; if (!si[2]) { sz = si[4]; off = si[3]; } }
+        if (in) { sz = hot[id].cnt; off = hot[id].off; }                     // dead nodes: cnt == 0
         int incl = sz;
 #pragma unroll
         for (int o = 1; o < GL; o <<= 1) { const int t = __shfl_up(incl, o, GL); if (gl >= o) incl += t; }
         const int dst = top + incl - sz;
         for (int k = 0; k < sz; k++) pool2[dst + k] = pool[off + k];
-        if (in) { int *si = segI + (size_t)id * SEG_I; if (!si[2]) { si[3] = dst; } }
+        if (in && sz) hot[id].off = dst;
         top += Grp<GL>::shfl(incl, GL - 1);
     }
     if (need) { int *t = pool; pool = pool2; pool2 = t; pooltop = top; }
@@ -646,13 +666,13 @@ static __device__ void gpool_gc(int *segI, int nseg, int *&pool, int *&pool2, in
 // is the smallest-id tied candidate with N >= mse, or the largest-id tied candidate if there is none.
 // That is three reductions (min mse; min id with N >= mse; max id), so lists need no order, merging
 // two lists is mark / test / compact in parallel, and removing an id is replace-or-swap-with-last.
+#define ACH 3                // chunks (of GL neighbours) of the popped node whose list edits travel in one round trip
 template <int GL>
 static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQueue &Q, int &hn, int &nseg, int &pooltop,
                                           int *&pool, int *&pool2, int *ext, int &next, int &flags)
 {
     const int gl = Grp<GL>::gl(), gb = Grp<GL>::gb();
-    double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
-    int *segI = a.segI + (size_t)frame * a.segcap * SEG_I;
+    HotNode *hot = a.hot + (size_t)frame * a.segcap;
     int *parent = a.parent + (size_t)frame * a.nblk, *dsize = a.dsize + (size_t)frame * a.nblk;
     const unsigned long long lt_mask = (1ull << gl) - 1;       // lanes of my group below me
     PT_DECL
@@ -663,12 +683,11 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
     double nps[9], npn[3]; int n_cnt = 0, n_off = 0, n_N = 0, n_rid = 0, n_dsr = 0, n_dss = 0, a0n = -1;
     auto fetch_next = [&](int r) {
         const int q = r < 0 ? 0 : r;
-        const int *qi = segI + (size_t)q * SEG_I;
-        const double *qd = segD + (size_t)q * SEG_D;
-        n_cnt = qi[4]; n_off = qi[3]; n_N = qi[0]; n_rid = qi[1]; n_dsr = qi[7]; n_dss = qi[5];
+        const HotNode *h = hot + q;
+        n_cnt = h->cnt; n_off = h->off; n_N = h->N; n_rid = h->rid; n_dsr = h->dsr; n_dss = h->dss;
 #pragma unroll
-        for (int q2 = 0; q2 < 9; q2++) nps[q2] = qd[q2];
-        npn[0] = qd[12]; npn[1] = qd[13]; npn[2] = qd[14];
+        for (int q2 = 0; q2 < 9; q2++) nps[q2] = h->st[q2];
+        npn[0] = h->nrm[0]; npn[1] = h->nrm[1]; npn[2] = h->nrm[2];
     };
     fetch_next(ptop);
     a0n = gl < n_cnt ? pool[n_off + gl] : -1;
@@ -677,13 +696,13 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
         PT_CNT(8, 1)
         const bool need_gc = act && pooltop > a.poolcap - 2 * a.nblk;
         if (__any(need_gc)) {
-            gpool_gc<GL>(segI, nseg, pool, pool2, pooltop, need_gc);       // relocates the lists: fetch the list again
-            n_off = segI[(size_t)(ptop < 0 ? 0 : ptop) * SEG_I + 3];
+            gpool_gc<GL>(hot, nseg, pool, pool2, pooltop, need_gc);        // relocates the lists: fetch the list again
+            n_off = hot[ptop < 0 ? 0 : ptop].off;
             a0n = gl < n_cnt ? pool[n_off + gl] : -1;
         }
         PT(0)
         const int p = act ? ptop : -1;
-        int *pi = segI + (size_t)(p < 0 ? 0 : p) * SEG_I;
+        HotNode *hp = hot + (p < 0 ? 0 : p);
         const bool live = act;                                 // every queued node is in use (nothing is deleted lazily)
         const int pcnt = live ? n_cnt : 0, poff = n_off, pN = n_N, prid = n_rid, pdsr = n_dsr, pdss = n_dss;
         double ps[9], pn[3];                                   // popped node: sums and normal (uniform per group)
@@ -697,6 +716,9 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
         double bc[3] = { 0, 0, 0 }, bn[3] = { 0, 0, 0 };        // (the merged sums are re-formed when the record is written)
         PT(2)
         int id_cur = a0;                                        // ids of the next chunk are fetched one pass ahead
+        int aid[ACH], aoff[ACH], acnt[ACH];                     // my neighbour of chunk u and its list header: pass A edits these lists
+#pragma unroll
+        for (int u = 0; u < ACH; u++) { aid[u] = -1; aoff[u] = 0; acnt[u] = 0; }
         for (int base = 0; __any(base < pcnt); base += GL) {
             PT_CNT(9, 1)
             const int k = base + gl;
@@ -706,15 +728,16 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
             for (int q = 0; q < 9; q++) lst[q] = 0;
             if (k < pcnt) {
                 nb = id_cur;
-                const double *nd = segD + (size_t)nb * SEG_D;
-                const int *nI = segI + (size_t)nb * SEG_I;
-                const int nN = nI[0]; nrid = nI[1]; noff_ = nI[3]; ncnt_ = nI[4]; ndsr = nI[7]; ndss = nI[5];
-                if (!(fabs(pn[0] * nd[12] + pn[1] * nd[13] + pn[2] * nd[14]) < a.c60)) {      // T_ang(P_MERGING)
+                const HotNode *nd = hot + nb;
+                const int nN = nd->N; nrid = nd->rid; noff_ = nd->off; ncnt_ = nd->cnt; ndsr = nd->dsr; ndss = nd->dss;
+                if (!(fabs(pn[0] * nd->nrm[0] + pn[1] * nd->nrm[1] + pn[2] * nd->nrm[2]) < a.c60)) {      // T_ang(P_MERGING)
 #pragma unroll
-                    for (int q = 0; q < 9; q++) lst[q] = ps[q] + nd[q];
+                    for (int q = 0; q < 9; q++) lst[q] = ps[q] + nd->st[q];
                     lN = pN + nN;
                     has = true;
                 }
+#pragma unroll
+                for (int u = 0; u < ACH; u++) if (base == u * GL) { aid[u] = nb; aoff[u] = noff_; acnt[u] = ncnt_; }
             }
             // one 3x3 eigen-solve pass serves every group (uniform call: no divergence inside)
             if (__any(has)) {
@@ -767,11 +790,10 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
 #pragma unroll
                 for (int q = 0; q < 9; q++) lst[q] = 0;
                 if (refit) {
-                    const double *nd = segD + (size_t)win * SEG_D;
-                    const int *nI = segI + (size_t)win * SEG_I;
+                    const HotNode *nd = hot + win;
 #pragma unroll
-                    for (int q = 0; q < 9; q++) lst[q] = ps[q] + nd[q];
-                    lN = pN + nI[0]; rrid = nI[1]; roff = nI[3]; rcnt = nI[4]; rdsr = nI[7]; rdss = nI[5];
+                    for (int q = 0; q < 9; q++) lst[q] = ps[q] + nd->st[q];
+                    lN = pN + nd->N; rrid = nd->rid; roff = nd->off; rcnt = nd->cnt; rdsr = nd->dsr; rdss = nd->dss;
                 }
                 double tc[3], tn[3], tm;
                 stats_compute_dev(lst, lN, tc, tn, tm);
@@ -816,23 +838,44 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
         if (act) hn -= 1;                                       // merge: -2 + 1
         TQUpdate qu;
         // stage 0: the partner's first chunk, my member's list header, the queue's lines
-        const bool editA = a0 >= 0 && ((do_merge && a0 != nb) || no_merge);
-        int qa_off = 0, qa_cnt = 0;
-        if (editA) { const int *qi = segI + (size_t)a0 * SEG_I; qa_off = qi[3]; qa_cnt = qi[4]; }
+        bool editA[ACH]; ListFind fa[ACH];                     // (the headers of p's members came with the evaluation's loads)
+#pragma unroll
+        for (int u = 0; u < ACH; u++) { editA[u] = aid[u] >= 0 && ((do_merge && aid[u] != nb) || no_merge); fa[u].issue(pool, aoff[u], editA[u] ? acnt[u] : 0); }
         const int vB = gl < ncnt ? pool[noff + gl] : -1;        // ncnt == 0 unless this group merges
         qu.issue(Q, rl, act ? (do_merge ? 3 : 1) : 0, p, TQ_INF, nb, TQ_INF, id, m);
         // stage 1: B's members' list headers, A's lists, the next top's record
         const bool inB = vB >= 0 && vB != p;
         int qb_off = 0, qb_cnt = 0;
-        if (inB) { const int *qi = segI + (size_t)vB * SEG_I; qb_off = qi[3]; qb_cnt = qi[4]; }
-        ListFind fa; fa.issue(pool, qa_off, editA ? qa_cnt : 0);
+        if (inB) { qb_off = hot[vB].off; qb_cnt = hot[vB].cnt; }
         ptop = qu.take(Q, rl, gl == 0);
         if (hn <= 0) ptop = -1;
+        PT(1)
         fetch_next(ptop);
         // stage 2: B's lists
         ListFind fb; fb.issue(pool, qb_off, inB ? qb_cnt : 0);
-        int a_i1, a_i2;
-        fa.finish(pool, p, do_merge ? nb : p, do_merge, a_i1, a_i2);
+        int a_i1[ACH], a_i2[ACH];
+        {
+            // lists longer than the eight entries in registers: the chunks continue TOGETHER, eight more entries each per round trip
+            bool more[ACH]; bool anymore = false;
+#pragma unroll
+            for (int u = 0; u < ACH; u++) { more[u] = !fa[u].scan(p, do_merge ? nb : p, do_merge, a_i1[u], a_i2[u]); anymore |= more[u]; }
+            for (int x0 = 8; __any(anymore); x0 += 8) {
+                int w[ACH][8];
+#pragma unroll
+                for (int u = 0; u < ACH; u++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) w[u][j] = (more[u] && x0 + j < fa[u].cnt) ? pool[fa[u].off + x0 + j] : -1;
+                anymore = false;
+#pragma unroll
+                for (int u = 0; u < ACH; u++) {
+                    const int fa_a = p, fa_b = do_merge ? nb : p;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) if (w[u][j] >= 0 && (w[u][j] == fa_a || w[u][j] == fa_b)) { if (a_i1[u] < 0) a_i1[u] = x0 + j; else a_i2[u] = x0 + j; }
+                    more[u] = more[u] && x0 + 8 < fa[u].cnt && !(a_i1[u] >= 0 && (!do_merge || a_i2[u] >= 0));
+                    anymore |= more[u];
+                }
+            }
+        }
         // stage 3: the edits.  All of B first ...
         int mcnt = 0;
         {
@@ -850,8 +893,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
             if (k < ncnt) {
                 v = pool[noff + k];
                 if (v != p) {
-                    const int *qi = segI + (size_t)v * SEG_I;
-                    const int off = qi[3], cnt = qi[4];
+                    const int off = hot[v].off, cnt = hot[v].cnt;
                     int i1, i2;
                     list_find2(pool, off, cnt, nb, p, true, i1, i2);
                     if (i2 < 0) { keep = true; if (i1 >= 0) pool[off + i1] = id; }
@@ -862,36 +904,40 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
             mcnt += __popcll(km);
         }
         // ... then A: the first of {p, nb} found becomes the new id, the second is dropped (merge); p is dropped (no merge)
-        {
-            if (editA) {
-                int *qi = segI + (size_t)a0 * SEG_I;
-                if (do_merge) {
-                    if (a_i1 >= 0) pool[qa_off + a_i1] = id;
-                    if (a_i2 >= 0) { if (a_i2 != qa_cnt - 1) pool[qa_off + a_i2] = pool[qa_off + qa_cnt - 1]; qi[4] = qa_cnt - 1; }
-                } else if (a_i1 >= 0) { if (a_i1 != qa_cnt - 1) pool[qa_off + a_i1] = pool[qa_off + qa_cnt - 1]; qi[4] = qa_cnt - 1; }
+#pragma unroll
+        for (int u = 0; u < ACH; u++) {
+            if (__any(aid[u] >= 0)) {
+                if (editA[u]) {
+                    HotNode *hv = hot + aid[u];
+                    const int off = aoff[u], cnt = acnt[u], i1 = a_i1[u], i2 = a_i2[u];
+                    if (do_merge) {
+                        if (i1 >= 0) pool[off + i1] = id;
+                        if (i2 >= 0) { if (i2 != cnt - 1) pool[off + i2] = pool[off + cnt - 1]; hv->cnt = cnt - 1; }
+                    } else if (i1 >= 0) { if (i1 != cnt - 1) pool[off + i1] = pool[off + cnt - 1]; hv->cnt = cnt - 1; }
+                }
+                const bool keep = editA[u] && do_merge;
+                const unsigned long long km = Grp<GL>::ballot(keep);
+                if (keep) pool[moff + mcnt + __popcll(km & lt_mask)] = aid[u];
+                mcnt += __popcll(km);
             }
-            const bool keep = editA && do_merge;
-            const unsigned long long km = Grp<GL>::ballot(keep);
-            if (keep) pool[moff + mcnt + __popcll(km & lt_mask)] = a0;
-            mcnt += __popcll(km);
         }
-        for (int base = GL; __any(live && base < pcnt); base += GL) {         // p's list beyond the first chunk (rare)
+        for (int base = ACH * GL; __any(live && base < pcnt); base += GL) {   // p's list beyond ACH chunks (rare)
             const int k = base + gl;
             int v = -1; bool keep = false;
             if (live && k < pcnt) {
                 v = pool[poff + k];
                 if (!do_merge || v != nb) {
-                    int *qi = segI + (size_t)v * SEG_I;
-                    const int off = qi[3], cnt = qi[4];
+                    HotNode *hv = hot + v;
+                    const int off = hv->off, cnt = hv->cnt;
                     int i1, i2;
                     if (do_merge) {
                         keep = true;
                         list_find2(pool, off, cnt, p, nb, true, i1, i2);
                         if (i1 >= 0) pool[off + i1] = id;
-                        if (i2 >= 0) { if (i2 != cnt - 1) pool[off + i2] = pool[off + cnt - 1]; qi[4] = cnt - 1; }
+                        if (i2 >= 0) { if (i2 != cnt - 1) pool[off + i2] = pool[off + cnt - 1]; hv->cnt = cnt - 1; }
                     } else {
                         list_find2(pool, off, cnt, p, p, false, i1, i2);
-                        if (i1 >= 0) { if (i1 != cnt - 1) pool[off + i1] = pool[off + cnt - 1]; qi[4] = cnt - 1; }
+                        if (i1 >= 0) { if (i1 != cnt - 1) pool[off + i1] = pool[off + cnt - 1]; hv->cnt = cnt - 1; }
                     }
                 }
             }
@@ -901,25 +947,23 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
         }
         PT(5)
         if (do_merge && is_w) {
-            double *md = segD + (size_t)id * SEG_D;
-            const double *wd = segD + (size_t)bid * SEG_D;                                // sums of the merge = p's + the partner's
+            HotNode *M = hot + id;
+            const HotNode *W = hot + bid;                                                 // sums of the merge = p's + the partner's
 #pragma unroll
-            for (int q = 0; q < 9; q++) md[q] = ps[q] + wd[q];
-            md[9] = bc[0]; md[10] = bc[1]; md[11] = bc[2]; md[12] = bn[0]; md[13] = bn[1]; md[14] = bn[2]; md[15] = bm;
-            int *mi = segI + (size_t)id * SEG_I;
+            for (int q = 0; q < 9; q++) M->st[q] = ps[q] + W->st[q];
+            M->nrm[0] = bn[0]; M->nrm[1] = bn[1]; M->nrm[2] = bn[2]; M->mse = bm;
             // ds.Union(pa.rid, pb.rid) (DisjointSet.hpp:63-83): the two nodes carry their sets' roots and sizes -- two stores, no Find
             int root = pdsr, size = pdss + bdss;
             if (pdsr == bdsr) size = pdss;
             else if (pdss < bdss) { parent[pdsr] = bdsr; dsize[bdsr] = size; root = bdsr; }
             else { parent[bdsr] = pdsr; dsize[pdsr] = size; }
-            mi[0] = bN; mi[1] = pN >= bN - pN ? prid : brid; mi[2] = 0; mi[3] = moff; mi[4] = mcnt; mi[5] = size; mi[6] = 1; mi[7] = root;
-            int *ni = segI + (size_t)nb * SEG_I;
-            pi[2] = 1; ni[2] = 1; pi[4] = 0; ni[4] = 0;
+            M->N = bN; M->rid = pN >= bN - pN ? prid : brid; M->off = moff; M->cnt = mcnt; M->dss = size; M->dsr = root;
+            hp->cnt = 0; hot[nb].cnt = 0;
         }
         if (do_merge) pooltop += pcnt + ncnt;
         if (no_merge) {
             if (pN >= MIN_SUPPORT) { if (next < MAX_PLANES) { if (gl == 0) ext[next] = p; next++; } else flags |= 16; }
-            if (gl == 0) pi[4] = 0;
+            if (gl == 0) hp->cnt = 0;
         }
         PT(7)
         __syncthreads();                                       // this iteration's records, lists and heap stores
@@ -927,7 +971,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
         {
             const bool fresh = do_merge && ptop == id;
             if (__any(fresh)) { if (fresh) fetch_next(ptop); }
-            n_cnt = segI[(size_t)(ptop < 0 ? 0 : ptop) * SEG_I + 4];
+            n_cnt = hot[ptop < 0 ? 0 : ptop].cnt;
             if (fresh) { n_cnt = mcnt; n_off = moff; }
             a0n = gl < n_cnt ? pool[n_off + gl] : -1;
         }
@@ -938,9 +982,28 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
     if (gl == 0) {
         for (int i = 1; i < next; i++) {
             int v = ext[i], j = i - 1;
-            int vN = segI[(size_t)v * SEG_I];
-            while (j >= 0 && segI[(size_t)ext[j] * SEG_I] < vN) { ext[j + 1] = ext[j]; j--; }
+            int vN = hot[v].N;
+            while (j >= 0 && hot[ext[j]].N < vN) { ext[j + 1] = ext[j]; j--; }
             ext[j + 1] = v;
+        }
+    }
+    __syncthreads();
+    // what the refinement kernels read: segI of every node this kernel created says "dead, no list" (k_peac_final's pool
+    // compaction walks them), and the extracted planes get their records (sums, centre, normal, mse; N, rid) in segD / segI
+    {
+        double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
+        int *segI = a.segI + (size_t)frame * a.segcap * SEG_I;
+        for (int v = a.nblk + gl; v < nseg; v += GL) { int *si = segI + (size_t)v * SEG_I; si[2] = 1; si[3] = 0; si[4] = 0; }
+        __syncthreads();
+        for (int e = gl; e < next; e += GL) {
+            const int v = ext[e]; const HotNode *nv = hot + v;
+            double *sd = segD + (size_t)v * SEG_D; int *si = segI + (size_t)v * SEG_I;
+            const double sc = 1.0 / nv->N;
+#pragma unroll
+            for (int q = 0; q < 9; q++) sd[q] = nv->st[q];
+            sd[9] = nv->st[0] * sc; sd[10] = nv->st[1] * sc; sd[11] = nv->st[2] * sc;
+            sd[12] = nv->nrm[0]; sd[13] = nv->nrm[1]; sd[14] = nv->nrm[2]; sd[15] = nv->mse;
+            si[0] = nv->N; si[1] = nv->rid; si[2] = 0; si[3] = 0; si[4] = 0; si[5] = 0; si[6] = 1; si[7] = 0;
         }
     }
     __syncthreads();
@@ -976,6 +1039,7 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
     int *pool = a.pool + (size_t)frame * a.poolcap, *pool2 = a.pool2 + (size_t)frame * a.poolcap;
     int *parent = a.parent + (size_t)frame * nblk, *dsize = a.dsize + (size_t)frame * nblk;
     int *eflag = a.eflag + (size_t)frame * nblk;
+    HotNode *hot = a.hot + (size_t)frame * a.segcap;
 #ifdef HVO_PEAC_TIMING
     const unsigned long long t_in0 = clock64();
 #endif
@@ -1016,19 +1080,20 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
     int hn = 0;
     for (int base = 0; base < Q.n0 * 256; base += GL) {
         const int b = base + gl;
-        bool ok = false;
+        bool ok = false; double mse_b = 0;
         if (galive && b < nblk) {
-            int *si = segI + (size_t)b * SEG_I;
+            const int *si = segI + (size_t)b * SEG_I;
             const int e = eflag[b];
             int n = 0;
             if (e & 4) pool[b * 4 + n++] = b - Nw;
             if (e & 1) pool[b * 4 + n++] = b - 1;
             if (e & 2) pool[b * 4 + n++] = b + 1;
             if (e & 8) pool[b * 4 + n++] = b + Nw;
-            si[4] = n;
             ok = si[6] != 0;
+            hot[b].cnt = n;                                      // (the rest of the record: k_peac_blocks)
+            mse_b = hot[b].mse;
         }
-        if (galive) Q.K[b] = ok ? segD[(size_t)b * SEG_D + 15] : TQ_INF;
+        if (galive) Q.K[b] = ok ? mse_b : TQ_INF;
         hn += __popcll(Grp<GL>::ballot(ok));
     }
     __syncthreads();
@@ -1056,8 +1121,7 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
     ah_cluster_grouped<GL>(a, frame, Q, hn, nseg, pooltop, pool, pool2, ext, next, flags);
     if (galive && gl == 0) {
         int *meta = a.meta + (size_t)frame * 16;
-        meta[0] = nseg; meta[1] = pooltop; meta[2] = next; meta[3] = flags;
-        meta[6] = (pool == a.pool + (size_t)frame * a.poolcap) ? 0 : 1;      // which pool buffer is live
+        meta[0] = nseg; meta[1] = 0; meta[2] = next; meta[3] = flags; meta[6] = 0;      // the lists are dead: k_peac_final starts an empty pool
     }
 #undef GOK
 #undef SD
@@ -1629,7 +1693,7 @@ void peac_free(hvo_ctx *ctx)
     PeacPlan *P = plan_of(ctx);
     if (!P) return;
     void *ptrs[] = { P->d_depth, P->d_segD, P->d_segI, P->d_pool, P->d_pool2, P->d_parent, P->d_dsize, P->d_eflag, P->d_meta, P->d_extracted,
-                     P->d_blkmap, P->d_labels, P->d_state, P->d_queue, P->d_plidmap, P->d_isvalid, P->d_planes, P->d_adj, P->d_hkey, P->d_m1k, P->d_hid, P->d_nodes };
+                     P->d_blkmap, P->d_labels, P->d_state, P->d_queue, P->d_plidmap, P->d_isvalid, P->d_planes, P->d_adj, P->d_hkey, P->d_m1k, P->d_hid, P->d_nodes, P->d_hot };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
     ctx->peac = nullptr;
@@ -1675,6 +1739,7 @@ static int peac_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_plidmap, B * MAX_PLANES * sizeof(int)); PA(P->d_isvalid, B * MAX_PLANES * sizeof(int));
     PA(P->d_planes, B * MAX_PLANES * sizeof(hvo_plane));
     PA(P->d_adj, B * MAX_PLANES * sizeof(unsigned long long));
+    PA(P->d_hot, B * P->segcap * 128);
     { const size_t n0 = (P->segcap + 255) / 256; PA(P->d_hkey, B * n0 * 256 * sizeof(double)); PA(P->d_m1k, B * n0 * 16 * sizeof(double)); PA(P->d_hid, B * n0 * 16 * sizeof(int)); }   // TQueue
     // the low-latency kernel keeps the whole heap (10 bytes per block) and one bit per node in LDS: up to ~14 k blocks (1280x960 has 12 288)
     const bool want_lat = LAT_DEFAULT_BATCH > 0 || (getenv("HVO_PEAC_LAT") && atoi(getenv("HVO_PEAC_LAT")) != 0);    // opt-in: its node records cost 1.6 MB per frame
@@ -1722,12 +1787,12 @@ int peac_run(hvo_ctx *ctx, int n)
     HVO_HIP(hipMemsetAsync(P->d_isvalid, 0, (size_t)n * MAX_PLANES * sizeof(int), st));
     int id = hvo_prof_begin(ctx, "peac_blocks", st);
     hipLaunchKernelGGL(k_peac_blocks, dim3((P->nblk + 63) / 64, n), dim3(64), 0, st, P->d_depth, dframe, P->pitch, P->w, P->h, P->Nw, P->nblk,
-                       p.fx, p.fy, p.cx, p.cy, p.depth_map_factor, P->d_segD, P->d_segI, P->segcap);
+                       p.fx, p.fy, p.cx, p.cy, p.depth_map_factor, P->d_segD, P->d_segI, P->segcap, (HotNode *)P->d_hot);
     hvo_prof_end(ctx, id);
     ClArgs a;
     a.segD = P->d_segD; a.segI = P->d_segI; a.pool = P->d_pool; a.pool2 = P->d_pool2; a.parent = P->d_parent; a.dsize = P->d_dsize; a.eflag = P->d_eflag;
     a.meta = P->d_meta; a.extracted = P->d_extracted; a.segcap = P->segcap; a.poolcap = P->poolcap; a.nblk = P->nblk; a.Nw = P->Nw; a.Nh = P->Nh;
-    a.c15 = P->c15; a.c60 = P->c60; a.tqK = P->d_hkey; a.tqM1k = P->d_m1k; a.tqM1i = P->d_hid; a.tq_n0 = (P->segcap + 255) / 256;
+    a.c15 = P->c15; a.c60 = P->c60; a.hot = (HotNode *)P->d_hot; a.tqK = P->d_hkey; a.tqM1k = P->d_m1k; a.tqM1i = P->d_hid; a.tq_n0 = (P->segcap + 255) / 256;
     a.ang_factor = P->ang_factor; a.ang_near = P->ang_near;
     id = hvo_prof_begin(ctx, "peac_cluster", st);
     // k_peac_cluster_lat (one frame per workgroup, queue in LDS, adjacency inline in 256-byte node records): an experiment in

@@ -207,11 +207,10 @@ def test_peac_batch(hvo, orc, synth):
         check(res[b]["labels"], res[b]["planes"], lo, po)
 
 
-@pytest.mark.parametrize("gl,flood_t", [(8, 64), (16, 64), (32, 128), (64, 256)])
+@pytest.mark.parametrize("gl,flood_t", [(16, 64), (16, 128), (32, 128), (64, 256)])
 def test_peac_batch_grouped_paths(hvo, orc, synth, monkeypatch, gl, flood_t):
     """the configurations large batches select (several frames per wave in lockstep, smaller flood
-    blocks), forced on a small ragged batch: 6 frames = one full and one half-empty wave at 16 lanes, one
-    partly filled wave at 8 lanes"""
+    blocks), forced on a small ragged batch: 6 frames = one full and one half-empty wave at 16 lanes"""
     monkeypatch.setenv("HVO_PEAC_GL", str(gl))
     monkeypatch.setenv("HVO_FLOOD_T", str(flood_t))
     depth = np.stack([synth.make_depth(s) for s in (0x5EED0002, 0x5EED1000, 0x5EED1003, 77, 0x5EED1001, 0x5EED1002)])
