@@ -118,6 +118,10 @@ void orc_resize_linear_u8_factor(const uint8_t *src, int sw, int sh, int sstride
     resize_linear_u8_impl(src, sw, sh, sstride, dst, dw, dh, dstride, fx, fy);
 }
 
+static int g_reading[ORC_READING_COUNT];
+void orc_set_reading(int which, int on) { if (which >= 0 && which < ORC_READING_COUNT) g_reading[which] = on != 0; }
+int orc_get_reading(int which) { return which >= 0 && which < ORC_READING_COUNT ? g_reading[which] : 0; }
+
 /* cv::getGaussianKernel(ksize, sigma, CV_32F) followed by the CV_8U fixed-point conversion of
  * createSeparableLinearFilter (kernel.convertTo(CV_32S, 256)).  sigma>0 only. */
 int orc_gaussian_kernel_q8(int ksize, double sigma, int *k)
@@ -147,6 +151,35 @@ int orc_gaussian_kernel_q8(int ksize, double sigma, int *k)
 void orc_gaussian_blur_u8(const uint8_t *src, int w, int h, int sstride,
                           uint8_t *dst, int dstride, int ksize, double sigma)
 {
+    if (g_reading[ORC_READING_BLUR_FLOAT]) {
+        /* ASSUMED alternative (IPP-style): the float kernel of getGaussianKernel(ksize, sigma, CV_32F), rows then columns
+         * accumulated in float in tap order, one round-half-to-even and saturation at the end */
+        float kf[33];
+        {
+            double scale2x = -0.5 / (sigma * sigma), sum = 0;
+            for (int i = 0; i < ksize; i++) { double x = i - (ksize - 1) * 0.5; kf[i] = (float)exp(scale2x * x * x); sum += kf[i]; }
+            sum = 1. / sum;
+            for (int i = 0; i < ksize; i++) kf[i] = (float)(kf[i] * sum);
+        }
+        const int r = ksize / 2;
+        float *tf = (float *)malloc(sizeof(float) * (size_t)w * h);
+        for (int y = 0; y < h; y++) {
+            const uint8_t *S = src + (size_t)y * sstride;
+            for (int x = 0; x < w; x++) {
+                float s = 0;
+                for (int i = 0; i < ksize; i++) s += kf[i] * (float)S[reflect101(x + i - r, w)];
+                tf[(size_t)y * w + x] = s;
+            }
+        }
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                float s = 0;
+                for (int j = 0; j < ksize; j++) s += kf[j] * tf[(size_t)reflect101(y + j - r, h) * w + x];
+                dst[(size_t)y * dstride + x] = sat_u8(orc_cvround_f(s));
+            }
+        free(tf);
+        return;
+    }
     int k[33];
     orc_gaussian_kernel_q8(ksize, sigma, k);
     int r = ksize / 2;

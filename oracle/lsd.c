@@ -19,8 +19,9 @@
  *     i.e. raster order (a known quirk of these versions), so no sort enters the result;
  *   - region growing visits the 8-neighbourhood with x as the outer loop;
  *   - cos / sin of float arguments evaluate in double (global ::cos), sqrt follows its argument type.
- * Alternative readings (CV_8U pipeline + std::sort of seeds) exist in later OpenCV versions; the
- * oracle documents its choice here and is itself the parity target of the HIP path.
+ * Alternative readings exist in later OpenCV versions: the CV_8U pipeline is a switch here
+ * (orc_set_reading(ORC_READING_LSD_8U, 1), oracle.h), the std::sort of seeds is not implemented.  The default (all
+ * switches 0) is the parity target of the HIP path.
  *
  * Determinism rule: std::sort by response (unstable) is replaced by a stable sort -- ties keep
  * detection order.
@@ -277,14 +278,24 @@ int orc_lsd_detect(const uint8_t *gray, int w, int h, int stride, float *segs, i
     const double sigma = SIGMA_SCALE / SCALE, sprec = 3;
     const unsigned hk = (unsigned)ceil(sigma * sqrt(2 * sprec * log(10.0)));
     const int ksize = 1 + 2 * hk;
-    double *blur = (double *)malloc(sizeof(double) * (size_t)w * h);
-    gaussian_blur_f64(gray, w, h, stride, blur, ksize, sigma);
     lsd_t L;
     L.w = orc_cvround_d(w * SCALE); L.h = orc_cvround_d(h * SCALE);
     const size_t np = (size_t)L.w * L.h;
     L.scaled = (double *)malloc(sizeof(double) * np);
-    resize_linear_f64(blur, w, h, L.scaled, L.w, L.h, SCALE, SCALE);
-    free(blur);
+    if (orc_get_reading(ORC_READING_LSD_8U)) {
+        /* ASSUMED alternative: the detector keeps the image CV_8U -- GaussianBlur and resize(Size(), 0.8, 0.8, INTER_LINEAR)
+         * take their u8 fixed-point paths (cvsem.c) and the gradient reads the rounded bytes */
+        uint8_t *b8 = (uint8_t *)malloc((size_t)w * h), *s8 = (uint8_t *)malloc(np);
+        orc_gaussian_blur_u8(gray, w, h, stride, b8, w, ksize, sigma);
+        orc_resize_linear_u8_factor(b8, w, h, w, s8, L.w, L.h, L.w, SCALE, SCALE);
+        for (size_t i = 0; i < np; i++) L.scaled[i] = (double)s8[i];
+        free(b8); free(s8);
+    } else {
+        double *blur = (double *)malloc(sizeof(double) * (size_t)w * h);
+        gaussian_blur_f64(gray, w, h, stride, blur, ksize, sigma);
+        resize_linear_f64(blur, w, h, L.scaled, L.w, L.h, SCALE, SCALE);
+        free(blur);
+    }
     L.angles = (double *)malloc(sizeof(double) * np);
     L.modgrad = (double *)calloc(np, sizeof(double));
     L.used = (uint8_t *)calloc(np, 1);

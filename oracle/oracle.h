@@ -36,6 +36,19 @@ typedef struct {
 
 typedef struct { double normal[3], center[3], mse; int32_t n_points, rid; } orc_plane;
 
+/* ---------------- alternative readings of un-vendored dependencies ----------------
+ * Two places where the author's OpenCV build may have behaved differently from the oracle's default reading (SURVEY.md
+ * Appendix A marks them "(?)").  Each is a switch, so that a box with OpenCV 3.2 settles it by flipping a flag; the
+ * defaults (all 0) are what the golden vectors and the HIP path implement.
+ *   ORC_READING_BLUR_FLOAT  cv::GaussianBlur on CV_8U served by IPP (ippiFilterGaussianBorder): float kernel, float
+ *                           accumulation, one rounding at the end -- differs from the fixed-point path by at most 1.
+ *                           Affects the 7x7 blur of ORB (ORBextractor.cc:1084) and the 5x5 blur of LBD.
+ *   ORC_READING_LSD_8U      cv::LineSegmentDetector working on CV_8U (blur and 0.8x resize in the u8 fixed-point paths,
+ *                           as OpenCV >= 3.2-ish asserts 8UC1) instead of on the image converted to CV_64F.            */
+enum { ORC_READING_BLUR_FLOAT = 0, ORC_READING_LSD_8U = 1, ORC_READING_COUNT = 2 };
+void  orc_set_reading(int which, int on);
+int   orc_get_reading(int which);
+
 /* ---------------- assumed OpenCV 3.2.0 primitives (cvsem.c) ---------------- */
 int   orc_cvround_f(float v);
 int   orc_cvround_d(double v);

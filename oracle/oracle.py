@@ -96,6 +96,18 @@ def _bind_optional(L):
         L.orc_lbd_combinations.restype = C.POINTER(C.c_int)
 
 
+READINGS = {"blur_float": 0, "lsd_8u": 1}
+
+
+def set_reading(name, on):
+    """alternative reading of an un-vendored dependency (oracle.h: ORC_READING_*); process-global, default off"""
+    lib().orc_set_reading(READINGS[name], int(bool(on)))
+
+
+def get_reading(name):
+    return bool(lib().orc_get_reading(READINGS[name]))
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
