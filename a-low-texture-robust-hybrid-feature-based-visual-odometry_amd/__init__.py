@@ -40,6 +40,10 @@ KEYLINE_DT = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"),
                        ("length", "<f4"), ("num_pixels", "<i4")])
 PLANE_DT = np.dtype([("normal", "<f8", 3), ("center", "<f8", 3), ("mse", "<f8"),
                      ("n_points", "<i4"), ("rid", "<i4")])
+class VpResult(C.Structure):
+    _fields_ = [("vps", (C.c_double * 3) * 3), ("score", C.c_double), ("best", C.c_int32), ("n_hypotheses", C.c_int32)]
+
+
 LINE3D_DT = np.dtype([("A", "<f8", 3), ("B", "<f8", 3), ("line_nor", "<f8", 3), ("line_eq", "<f4", 3), ("good", "<i4"),
                       ("n_samples", "<i4"), ("n_inliers", "<i4"), ("inlier_mask", "<u4"), ("pad", "<i4")])
 PLANE_CLOUD_DT = np.dtype([("coef", "<f4", 4), ("valid", "<i4"), ("gate_ok", "<i4"), ("first", "<i4"), ("n_points", "<i4"), ("n_pixels", "<i4"), ("n_inliers", "<i4")])
@@ -52,7 +56,7 @@ EXPORTS = [
     "hvo_extract_orb", "hvo_extract_lsd", "hvo_compute_planes",
     "hvo_hamming_matrix", "hvo_hamming_knn2", "hvo_match_nnr", "hvo_search_by_projection", "hvo_stereo_from_rgbd",
     "hvo_undistort_keypoints", "hvo_image_bounds", "hvo_assign_features_to_grid", "hvo_assign_lines_to_grid",
-    "hvo_extract_lsd_culled", "hvo_set_line_culling", "hvo_lines_3d", "hvo_plane_clouds", "hvo_surface_normals", "hvo_search_by_projection_map", "hvo_frame_bf_match", "hvo_search_double",
+    "hvo_extract_lsd_culled", "hvo_set_line_culling", "hvo_lines_3d", "hvo_vanishing_points", "hvo_plane_clouds", "hvo_surface_normals", "hvo_search_by_projection_map", "hvo_frame_bf_match", "hvo_search_double",
     "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch", "hvo_batch_slab_layout", "hvo_batch_pack_results",
     "hvo_profile_last", "hvo_profile_enable", "hvo_pin_host", "hvo_unpin_host",
     "hvo_stream_create", "hvo_stream_destroy", "hvo_stream_last_error", "hvo_stream_capacity", "hvo_stream_image_bounds",
@@ -132,6 +136,7 @@ def lib():
         L.hvo_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         L.hvo_extract_lsd_culled.argtypes = L.hvo_extract_lsd.argtypes
         L.hvo_set_line_culling.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        L.hvo_vanishing_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hvo_lines_3d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p]
         L.hvo_plane_clouds.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
         L.hvo_surface_normals.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
@@ -253,6 +258,18 @@ class Context:
         h, w = depth.shape
         out = np.zeros(len(kl), LINE3D_DT)
         self._chk(lib().hvo_lines_3d(self.h, _p(kl), len(kl), _p(depth), w, h, depth.strides[0], seed, _p(out)), "lines_3d")
+        return out
+
+    def vanishing_points(self, kl, seed=1, th_angle=None, want_grid=False):
+        """Frame::getVPHypVia2Lines .. line2Vps (src/Frame.cc:442-778) -> dict(vps (3,3), best, score, n_hypotheses, vp_idx (n)[, grid (90,360)])"""
+        kl = np.ascontiguousarray(kl); n = len(kl)
+        if th_angle is None:
+            th_angle = 1.0 / 180.0 * 3.1415926535897932384626433832795          # Frame.h:365
+        res = VpResult(); idx = np.full(n, 3, np.int32); grid = np.zeros((90, 360)) if want_grid else None
+        self._chk(lib().hvo_vanishing_points(self.h, _p(kl), n, seed, th_angle, C.byref(res), _p(idx), _p(grid) if want_grid else None), "vanishing_points")
+        out = dict(vps=np.array([[res.vps[i][j] for j in range(3)] for i in range(3)]), best=res.best, score=res.score, n_hypotheses=res.n_hypotheses, vp_idx=idx)
+        if want_grid:
+            out["grid"] = grid
         return out
 
     def compute_planes(self, depth, cap=64):

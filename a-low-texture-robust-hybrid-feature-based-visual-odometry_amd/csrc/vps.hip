@@ -1,0 +1,253 @@
+// vps.hip -- vanishing-point clustering of a frame's key lines, reference src/Frame.cc:330-337:
+//   Frame::getVPHypVia2Lines   src/Frame.cc:442-545   k_vp_lines (line functions, lengths, orientations), k_vp_hyp (105 x 360 hypotheses)
+//   Frame::getSphereGrids      src/Frame.cc:546-650   k_vp_pairs + k_vp_grid (90 x 360 sphere grid), k_vp_smooth
+//   Frame::getBestVpsHyp       src/Frame.cc:651-707   k_vp_hyp (scores), k_vp_best (first maximum)
+//   Frame::line2Vps            src/Frame.cc:708-778   k_vp_best (cluster of every line)
+// Determinism: the reference draws its line pairs from a time-seeded rand(); here the caller passes a seed and hypothesis
+// group i draws from its own xorshift32 stream (seed, i) -- the rule of oracle/vps.c, which this file follows step by step.
+// The sphere grid is accumulated in the reference's order (pairs (i, j), i-major): a cell's owner thread walks the pair list
+// in that order, so the sums are the sequential ones whatever the launch shape (fp64 addition is not associative, and the
+// best hypothesis is an argmax over sums of grid cells).  sin / cos / atan / acos / atan2 are the device's.
+#include "hvo_internal.hpp"
+#include <cstring>
+#include <cmath>
+#include <hip/hip_runtime.h>
+
+#define VP_PI 3.1415926535897932384626433832795
+#define VP_NUM2 360
+#define VP_LA 90
+#define VP_LO 360
+#define VP_CELLS (VP_LA * VP_LO)
+#define VP_MAX_LINES 1024
+
+static __device__ __forceinline__ void vcross(const double *a, const double *b, double *c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+}
+static __device__ __forceinline__ unsigned vxs32(unsigned &s) { unsigned x = s; x ^= x << 13; x ^= x >> 17; x ^= x << 5; s = x; return x; }
+
+// src/Frame.cc:454-473
+__global__ __launch_bounds__(256) void k_vp_lines(const hvo_keyline *__restrict__ kl, int n, double *__restrict__ para, double *__restrict__ len, double *__restrict__ ori)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double p1[3] = { (double)kl[i].sx, (double)kl[i].sy, 1.0 }, p2[3] = { (double)kl[i].ex, (double)kl[i].ey, 1.0 };
+    double c[3];
+    vcross(p1, p2, c);
+    para[3 * i] = c[0]; para[3 * i + 1] = c[1]; para[3 * i + 2] = c[2];
+    const double dx = (double)(kl[i].ex - kl[i].sx), dy = (double)(kl[i].ey - kl[i].sy);
+    len[i] = sqrt(dx * dx + dy * dy);
+    double o = atan2(dy, dx);
+    if (o < 0) o += VP_PI;
+    ori[i] = o;
+}
+
+// one thread per pair (i < j), written at the pair's rank in the reference's loop order: cell (-1: contributes nothing), value
+__global__ __launch_bounds__(256) void k_vp_pairs(const double *__restrict__ para, const double *__restrict__ len, const double *__restrict__ ori, int n,
+                                                  double fx, double cx, double cy, int *__restrict__ cell, double *__restrict__ val)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j <= i || j >= n) return;
+    const size_t p = (size_t)i * (2 * (size_t)n - i - 1) / 2 + (j - i - 1);
+    const double acc = 1.0 / 180.0 * VP_PI, tol = 60.0 / 180.0 * VP_PI;
+    double pt[3];
+    vcross(para + 3 * i, para + 3 * j, pt);
+    int c = -1; double v = 0;
+    if (pt[2] != 0) {
+        const double x = pt[0] / pt[2], y = pt[1] / pt[2];
+        const double X = x - cx, Y = y - cy, Z = fx, N = sqrt(X * X + Y * Y + Z * Z);
+        const double latitude = acos(Z / N), longitude = atan2(X, Y) + VP_PI;
+        int LA = (int)(latitude / acc); if (LA >= VP_LA) LA = VP_LA - 1;
+        int LO = (int)(longitude / acc); if (LO >= VP_LO) LO = VP_LO - 1;
+        double dev = fabs(ori[i] - ori[j]);
+        dev = fmin(VP_PI - dev, dev);
+        if (!(dev > tol)) { c = LA * VP_LO + LO; v = sqrt(len[i] * len[j]) * (sin(2.0 * dev) + 0.2); }
+    }
+    cell[p] = c; val[p] = v;
+}
+
+// a thread owns a cell and adds the values of its pairs in pair order; the pair list is staged through LDS, 2048 at a time
+__global__ __launch_bounds__(256) void k_vp_grid(const int *__restrict__ cell, const double *__restrict__ val, size_t npairs, double *__restrict__ raw)
+{
+    __shared__ int sc[2048]; __shared__ double sv[2048];
+    const int me = blockIdx.x * 256 + threadIdx.x;
+    const int lo = blockIdx.x * 256, hi = lo + 256;
+    double acc = 0.0;
+    for (size_t base = 0; base < npairs; base += 2048) {
+        const int m = (int)(npairs - base < 2048 ? npairs - base : 2048);
+        __syncthreads();
+        for (int t = threadIdx.x; t < m; t += 256) { const int c = cell[base + t]; sc[t] = (c >= lo && c < hi) ? c : -1; sv[t] = val[base + t]; }
+        __syncthreads();
+        for (int t = 0; t < m; t++) if (sc[t] == me) acc += sv[t];
+    }
+    if (me < VP_CELLS) raw[me] = acc;
+}
+
+// src/Frame.cc:629-649: new = old + (3x3 sum) / 9 in the interior, 0 on the border rows / columns
+__global__ __launch_bounds__(256) void k_vp_smooth(const double *__restrict__ raw, double *__restrict__ grid)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= VP_CELLS) return;
+    const int i = c / VP_LO, j = c - i * VP_LO;
+    double out = 0.0;
+    if (i >= 1 && i < VP_LA - 1 && j >= 1 && j < VP_LO - 1) {
+        double tot = 0.0;
+        for (int m = 0; m < 3; m++) for (int q = 0; q < 3; q++) tot += raw[(i - 1 + m) * VP_LO + (j - 1 + q)];
+        out = raw[c] + tot / 9;
+    }
+    grid[c] = out;
+}
+
+static __device__ __forceinline__ double vp_cell_of(const double *grid, const double *v)
+{
+    const double oneDegree = 1.0 / 180.0 * VP_PI;
+    if (v[2] == 0.0) return 0.0;
+    const double latitude = acos(v[2]), longitude = atan2(v[0], v[1]) + VP_PI;
+    int LA = (int)(latitude / oneDegree); if (LA == 90) LA = 89;
+    int LO = (int)(longitude / oneDegree); if (LO == 360) LO = 359;
+    if (LA < 0 || LA > 89 || LO < 0 || LO > 359) return 0.0;     // cannot happen for unit vectors with z >= 0; keeps a NaN hypothesis from reading outside
+    return grid[LA * VP_LO + LO];
+}
+
+// block = hypothesis group i (one pair of lines), thread = j of its 360 hypotheses: vp1, vp2, vp3 and the score
+__global__ __launch_bounds__(384) void k_vp_hyp(const double *__restrict__ para, int n, double fx, double cx, double cy, unsigned seed,
+                                                const double *__restrict__ grid, double *__restrict__ hyp, double *__restrict__ score)
+{
+    const int i = blockIdx.x, j = threadIdx.x;
+    unsigned rs = seed ^ (0x9E3779B9u * (unsigned)(i + 1)); if (rs == 0) rs = 0x6D2B79F5u;
+    double vp1[3];
+    for (;;) {                                       // uniform over the block: every thread draws the same pair
+        const int idx1 = (int)((vxs32(rs) & 0x7fffffffu) % (unsigned)n);
+        int idx2 = (int)((vxs32(rs) & 0x7fffffffu) % (unsigned)n);
+        while (idx2 == idx1) idx2 = (int)((vxs32(rs) & 0x7fffffffu) % (unsigned)n);
+        double v[3];
+        vcross(para + 3 * idx1, para + 3 * idx2, v);
+        if (v[2] == 0) continue;
+        vp1[0] = v[0] / v[2] - cx; vp1[1] = v[1] / v[2] - cy; vp1[2] = fx;
+        break;
+    }
+    if (j >= VP_NUM2) return;
+    if (vp1[2] == 0) vp1[2] = 0.0011;
+    double N = sqrt(vp1[0] * vp1[0] + vp1[1] * vp1[1] + vp1[2] * vp1[2]);
+    { const double s = 1.0 / N; vp1[0] *= s; vp1[1] *= s; vp1[2] *= s; }
+    const double stepVp2 = 2.0 * VP_PI / VP_NUM2;
+    const double lambda = j * stepVp2;
+    const double k1 = vp1[0] * sin(lambda) + vp1[1] * cos(lambda), k2 = vp1[2];
+    const double phi = atan(-k2 / k1);
+    double vp2[3] = { sin(phi) * sin(lambda), sin(phi) * cos(lambda), cos(phi) }, vp3[3];
+    if (vp2[2] == 0.0) vp2[2] = 0.0011;
+    N = sqrt(vp2[0] * vp2[0] + vp2[1] * vp2[1] + vp2[2] * vp2[2]);
+    { const double s = 1.0 / N; vp2[0] *= s; vp2[1] *= s; vp2[2] *= s; }
+    if (vp2[2] < 0) { vp2[0] *= -1.0; vp2[1] *= -1.0; vp2[2] *= -1.0; }
+    vcross(vp1, vp2, vp3);
+    if (vp3[2] == 0.0) vp3[2] = 0.0011;
+    N = sqrt(vp3[0] * vp3[0] + vp3[1] * vp3[1] + vp3[2] * vp3[2]);
+    { const double s = 1.0 / N; vp3[0] *= s; vp3[1] *= s; vp3[2] *= s; }
+    if (vp3[2] < 0) { vp3[0] *= -1.0; vp3[1] *= -1.0; vp3[2] *= -1.0; }
+    const size_t h = (size_t)i * VP_NUM2 + j;
+    double *o = hyp + h * 9;
+    o[0] = vp1[0]; o[1] = vp1[1]; o[2] = vp1[2]; o[3] = vp2[0]; o[4] = vp2[1]; o[5] = vp2[2]; o[6] = vp3[0]; o[7] = vp3[1]; o[8] = vp3[2];
+    double s = 0.0;
+    s += vp_cell_of(grid, vp1); s += vp_cell_of(grid, vp2); s += vp_cell_of(grid, vp3);
+    score[h] = s;
+}
+
+// first maximum above 0 (index 0 when there is none), then line2Vps: one workgroup
+__global__ __launch_bounds__(1024) void k_vp_best(const double *__restrict__ score, int nh, const double *__restrict__ hyp,
+                                                  const hvo_keyline *__restrict__ kl, int n, double fx, double fy, double cx, double cy, double th_angle,
+                                                  hvo_vp_result *__restrict__ res, int32_t *__restrict__ vp_idx)
+{
+    __shared__ double bs[1024]; __shared__ int bi[1024];
+    const int tid = threadIdx.x;
+    double s = 0.0; int b = 0x7FFFFFFF;
+    for (int h = tid; h < nh; h += 1024) { const double v = score[h]; if (v > s) { s = v; b = h; } }     // ascending h: the first of this thread's maxima
+    bs[tid] = s; bi[tid] = b;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) {
+            const double s2 = bs[tid + o]; const int b2 = bi[tid + o];
+            if (s2 > bs[tid] || (s2 == bs[tid] && b2 < bi[tid])) { bs[tid] = s2; bi[tid] = b2; }
+        }
+        __syncthreads();
+    }
+    const int best = bi[0] == 0x7FFFFFFF ? 0 : bi[0];
+    const double *v = hyp + (size_t)best * 9;
+    if (tid == 0) {
+        for (int q = 0; q < 9; q++) res->vps[q / 3][q % 3] = v[q];
+        res->score = bs[0]; res->best = best; res->n_hypotheses = nh;
+    }
+    double vx[3], vy[3];
+    for (int j = 0; j < 3; j++) { vx[j] = v[3 * j] * fx / v[3 * j + 2] + cx; vy[j] = v[3 * j + 1] * fy / v[3 * j + 2] + cy; }
+    for (int i = tid; i < n; i += 1024) {
+        const double x1 = kl[i].sx, y1 = kl[i].sy, x2 = kl[i].ex, y2 = kl[i].ey;
+        const double xm = (x1 + x2) / 2.0, ym = (y1 + y2) / 2.0;
+        double v1x = x1 - x2, v1y = y1 - y2;
+        const double N1 = sqrt(v1x * v1x + v1y * v1y);
+        v1x /= N1; v1y /= N1;
+        double minAngle = 1000.0; int bj = 0;
+        for (int j = 0; j < 3; j++) {
+            double v2x = vx[j] - xm, v2y = vy[j] - ym;
+            const double N2 = sqrt(v2x * v2x + v2y * v2y);
+            v2x /= N2; v2y /= N2;
+            double c = v1x * v2x + v1y * v2y;
+            if (c > 1.0) c = 1.0;
+            if (c < -1.0) c = -1.0;
+            double angle = acos(c);
+            angle = fmin(VP_PI - angle, angle);
+            if (angle < minAngle) { minAngle = angle; bj = j; }
+        }
+        vp_idx[i] = minAngle < th_angle ? bj : 3;
+    }
+}
+
+static int vp_iterations()
+{
+    const double noiseRatio = 0.5, p = 1.0 / 3.0 * pow(1.0 - noiseRatio, 2), confEfficience = 0.9999;
+    return (int)(log(1 - confEfficience) / log(1.0 - p));
+}
+
+extern "C" int hvo_vanishing_points(hvo_ctx *ctx, const hvo_keyline *kl, int n, uint32_t seed, double th_angle,
+                                    hvo_vp_result *res, int32_t *vp_idx, double *grid_out)
+{
+    if (!ctx || !res || n < 0 || n > VP_MAX_LINES) return HVO_ERR_INVALID_ARG;
+    if (n < 2) {                                       // the reference skips the path (src/Frame.cc:328): nothing is a structure line
+        std::memset(res, 0, sizeof(*res));
+        if (vp_idx) for (int i = 0; i < n; i++) vp_idx[i] = 3;
+        return HVO_OK;
+    }
+    if (!kl || !vp_idx) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    const hvo_params &P = ctx->p;
+    const int it = vp_iterations(), nh = it * VP_NUM2;
+    const size_t npairs = (size_t)n * (n - 1) / 2;
+    hipStream_t st = ctx->stream;
+    hvo_keyline *dk = nullptr; double *dd = nullptr; int *dcell = nullptr; hvo_vp_result *dres = nullptr; int32_t *didx = nullptr;
+    // doubles: para 3n, len n, ori n, val npairs, raw CELLS, grid CELLS, hyp 9 nh, score nh
+    const size_t nd = 5 * (size_t)n + npairs + 2 * VP_CELLS + 10 * (size_t)nh;
+    int rc = HVO_OK;
+    if (hipMalloc((void **)&dk, (size_t)n * sizeof(hvo_keyline)) != hipSuccess || hipMalloc((void **)&dd, nd * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&dcell, npairs * sizeof(int)) != hipSuccess || hipMalloc((void **)&dres, sizeof(hvo_vp_result)) != hipSuccess ||
+        hipMalloc((void **)&didx, (size_t)n * sizeof(int32_t)) != hipSuccess) rc = HVO_ERR_HIP;
+    if (!rc) {
+        double *para = dd, *len = para + 3 * (size_t)n, *ori = len + n, *val = ori + n, *raw = val + npairs, *grid = raw + VP_CELLS,
+               *hyp = grid + VP_CELLS, *score = hyp + 9 * (size_t)nh;
+        const double fx = P.fx, fy = P.fy, cx = P.cx, cy = P.cy;
+        (void)hipMemcpyAsync(dk, kl, (size_t)n * sizeof(hvo_keyline), hipMemcpyHostToDevice, st);
+        hipLaunchKernelGGL(k_vp_lines, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, para, len, ori);
+        hipLaunchKernelGGL(k_vp_pairs, dim3((n + 255) / 256, n - 1), dim3(256), 0, st, para, len, ori, n, fx, cx, cy, dcell, val);
+        hipLaunchKernelGGL(k_vp_grid, dim3((VP_CELLS + 255) / 256), dim3(256), 0, st, dcell, val, npairs, raw);
+        hipLaunchKernelGGL(k_vp_smooth, dim3((VP_CELLS + 255) / 256), dim3(256), 0, st, raw, grid);
+        hipLaunchKernelGGL(k_vp_hyp, dim3(it), dim3(384), 0, st, para, n, fx, cx, cy, seed, grid, hyp, score);
+        hipLaunchKernelGGL(k_vp_best, dim3(1), dim3(1024), 0, st, score, nh, hyp, dk, n, fx, fy, cx, cy, th_angle, dres, didx);
+        (void)hipMemcpyAsync(res, dres, sizeof(hvo_vp_result), hipMemcpyDeviceToHost, st);
+        (void)hipMemcpyAsync(vp_idx, didx, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (grid_out) (void)hipMemcpyAsync(grid_out, grid, VP_CELLS * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) rc = HVO_ERR_HIP;
+    }
+    if (dk) (void)hipFree(dk);
+    if (dd) (void)hipFree(dd);
+    if (dcell) (void)hipFree(dcell);
+    if (dres) (void)hipFree(dres);
+    if (didx) (void)hipFree(didx);
+    return rc;
+}

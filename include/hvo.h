@@ -191,6 +191,23 @@ typedef struct {
 } hvo_line3d;
 int hvo_lines_3d(hvo_ctx *ctx, const hvo_keyline *kl, int n, const uint16_t *depth, int w, int h, int stride, uint32_t seed, hvo_line3d *out);
 
+/* The vanishing-point clustering of the key lines that the Frame constructor runs on every frame (reference src/Frame.cc:330-337,
+ * SURVEY.md 8f.4): Frame::getVPHypVia2Lines (442-545: 105 random pairs of lines x 360 rotations = 37 800 hypotheses of three
+ * orthogonal vanishing directions), getSphereGrids (546-650: the 90 x 360 grid of pairwise line intersections, weighted, 3x3
+ * smoothed), getBestVpsHyp (651-707: the first hypothesis with the largest sum of its three cells) and line2Vps (708-778: the
+ * cluster of every line, thAngle = 1 degree in Frame.h:365).  kl are the (undistorted) key lines (mvKeylinesUn), intrinsics
+ * the context's.  The reference draws from a time-seeded rand(); the caller passes a seed, group i of 360 hypotheses draws its
+ * pair of lines from its own xorshift32 stream (seed, i).  vp_idx[i] = 0..2 (isStructLine[i] = true) or 3 (none);
+ * grid (optional) receives the 90 x 360 smoothed sphere grid.  n < 2: nothing is computed (as the reference), all vp_idx = 3. */
+typedef struct {
+    double vps[3][3];           /* tmp_vps: the best hypothesis, three unit vectors (camera frame) */
+    double score;               /* its summed grid length (0 when no hypothesis scored) */
+    int32_t best;               /* its index, group * 360 + rotation */
+    int32_t n_hypotheses;       /* 37 800 */
+} hvo_vp_result;
+int hvo_vanishing_points(hvo_ctx *ctx, const hvo_keyline *kl, int n, uint32_t seed, double th_angle,
+                         hvo_vp_result *res, int32_t *vp_idx, double *grid);
+
 /* The tail of Frame::ComputePlanes after the plane detector (reference src/Frame.cc:2110-2212) and Frame::MaxPointDistanceFromPlane
  * (2214-2274), SURVEY.md 8f.3.  labels / planes are the outputs of hvo_compute_planes for the same depth image.
  * hvo_plane_clouds: per plane the points of its pixels (float), pcl::VoxelGrid(0.1 m), the gate |n.p + d| <= dist_th

@@ -213,6 +213,15 @@ int  orc_plane_clouds(const uint16_t *depth, int w, int h, int stride_bytes, flo
 int  orc_surface_normals(const uint16_t *depth, int w, int h, int stride_bytes, float fx, float fy, float cx, float cy, float depth_factor,
                          orc_surface_normal *out, int cap);
 
+/* ---------------- vanishing-point clustering of the key lines (vps.c; reference src/Frame.cc:442-778) ---------------- */
+int  orc_vp_iterations(void);                                                                     /* 105 */
+void orc_vp_line_params(const orc_keyline *kl, int n, double *para, double *length, double *ori);
+void orc_vp_sphere_grid(const double *para, const double *length, const double *ori, int n, double fx, double cx, double cy,
+                        double *grid /* 90 x 360 */, double *raw /* before smoothing, or NULL */);
+int  orc_vanishing_points(const orc_keyline *kl, int n, float fx, float fy, float cx, float cy, uint32_t seed, double th_angle,
+                          double *vps /* 3 x 3 */, int *best_idx, double *best_score, int32_t *vp_idx /* n */,
+                          double *scores /* iterations * 360 or NULL */, double *grid /* 90 x 360 or NULL */);
+
 #ifdef __cplusplus
 }
 #endif

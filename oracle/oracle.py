@@ -253,6 +253,26 @@ def lines_3d(kl, depth, seed=1, fx=535.4, fy=539.2, cx=320.1, cy=247.6, depth_fa
     return out
 
 
+def vanishing_points(kl, seed=1, th_angle=None, fx=535.4, fy=539.2, cx=320.1, cy=247.6, want_scores=False):
+    """Frame::getVPHypVia2Lines .. line2Vps (src/Frame.cc:442-778) -> dict(vps (3,3), best, score, vp_idx (n), grid (90,360)[, scores])"""
+    kl = np.ascontiguousarray(kl); n = len(kl)
+    if th_angle is None:
+        th_angle = 1.0 / 180.0 * 3.1415926535897932384626433832795
+    L = lib()
+    L.orc_vanishing_points.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 4 + [C.c_uint32, C.c_double] + [C.c_void_p] * 6
+    L.orc_vp_iterations.restype = C.c_int
+    vps = np.zeros((3, 3)); best = C.c_int(0); score = C.c_double(0); idx = np.full(n, 3, np.int32); grid = np.zeros((90, 360))
+    scores = np.zeros(L.orc_vp_iterations() * 360) if want_scores else None
+    rc = L.orc_vanishing_points(_p(kl), n, fx, fy, cx, cy, seed, th_angle, _p(vps), C.byref(best), C.byref(score), _p(idx),
+                                _p(scores) if want_scores else None, _p(grid))
+    if rc != 0:
+        return None
+    out = dict(vps=vps, best=best.value, score=score.value, vp_idx=idx, grid=grid)
+    if want_scores:
+        out["scores"] = scores
+    return out
+
+
 PLANE_CLOUD_DT = np.dtype([("coef", "<f4", 4), ("valid", "<i4"), ("gate_ok", "<i4"), ("first", "<i4"), ("n_points", "<i4"), ("n_pixels", "<i4"), ("n_inliers", "<i4")])
 SURFACE_NORMAL_DT = np.dtype([("normal", "<f4", 3), ("position", "<f4", 3), ("frame_x", "<i4"), ("frame_y", "<i4")])
 
