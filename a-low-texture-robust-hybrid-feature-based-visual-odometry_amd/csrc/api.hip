@@ -140,11 +140,11 @@ int hvo_batch_run(hvo_ctx *ctx, unsigned stages)
     if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
     for (int i = 0; i < ctx->nprof; i++) ctx->prof[i].used = false;
     int rc;
-    // The serial stages go first so that their long single-wave kernels overlap the streaming ones.
-    if (stages & HVO_STAGE_PLANES) {
-        if (!ctx->have_depth) return HVO_ERR_INVALID_ARG;
-        rc = peac_run(ctx, ctx->batch_n); if (rc) return rc;
-    }
+    if ((stages & HVO_STAGE_PLANES) && !ctx->have_depth) return HVO_ERR_INVALID_ARG;
+    // The serial stages go first so that their long single-wave kernels overlap the streaming ones (sched 0-2);
+    // sched 3 / 4 (experiments): the plane stage is enqueued last, after LSD then ORB (3) or ORB then LSD (4)
+    const bool peac_last = ctx->sched >= 3 && !ctx->serialize;
+    if ((stages & HVO_STAGE_PLANES) && !peac_last) { rc = peac_run(ctx, ctx->batch_n); if (rc) return rc; }
     // Overlap policy.  k_lsd_grow takes almost all of a CU's LDS for >100 ms; streaming kernels gain nothing
     // from running side by side; the latency-bound kernels (k_lsd_grow, k_peac_cluster) leave most issue
     // slots idle.  sched 2: ORB starts at once and its only LDS kernel (k_fast_cells) is ordered BEFORE
@@ -154,7 +154,10 @@ int hvo_batch_run(hvo_ctx *ctx, unsigned stages)
     const bool want_cull = (stages & HVO_STAGE_LSD_CULL) != 0;
     const bool want_orb = (stages & HVO_STAGE_ORB) != 0, want_lsd = (stages & HVO_STAGE_LSD) != 0 || want_cull;
     if (want_lsd) ctx->last_cull = want_cull;
-    if (ctx->sched == 2 && want_orb && !ctx->serialize) {
+    if (ctx->sched == 4 && want_orb && !ctx->serialize) {
+        rc = orb_run(ctx, ctx->batch_n); if (rc) return rc;
+        if (want_lsd) { rc = lsd_run(ctx, ctx->batch_n, want_cull); if (rc) return rc; }
+    } else if (ctx->sched == 2 && want_orb && !ctx->serialize) {
         rc = orb_run(ctx, ctx->batch_n); if (rc) return rc;                 // records ev_fast
         if (want_lsd) { rc = lsd_run(ctx, ctx->batch_n, want_cull); if (rc) return rc; }   // k_lsd_grow waits for ev_fast
     } else {
@@ -164,6 +167,7 @@ int hvo_batch_run(hvo_ctx *ctx, unsigned stages)
             rc = orb_run(ctx, ctx->batch_n); if (rc) return rc;
         }
     }
+    if ((stages & HVO_STAGE_PLANES) && peac_last) { rc = peac_run(ctx, ctx->batch_n); if (rc) return rc; }
     HVO_HIP(hipStreamSynchronize(ctx->s_peac));
     HVO_HIP(hipStreamSynchronize(ctx->s_lsd));
     HVO_HIP(hipStreamSynchronize(ctx->stream));

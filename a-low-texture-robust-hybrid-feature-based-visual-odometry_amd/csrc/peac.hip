@@ -666,9 +666,9 @@ static __device__ void gpool_gc(HotNode *hot, int nseg, int *&pool, int *&pool2,
 // is the smallest-id tied candidate with N >= mse, or the largest-id tied candidate if there is none.
 // That is three reductions (min mse; min id with N >= mse; max id), so lists need no order, merging
 // two lists is mark / test / compact in parallel, and removing an id is replace-or-swap-with-last.
-#define ACH 3                // chunks (of GL neighbours) of the popped node whose list edits travel in one round trip
+#define ACH 1                // chunks (of GL neighbours) of the popped node whose list edits travel in one round trip
 template <int GL>
-static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQueue &Q, int &hn, int &nseg, int &pooltop,
+static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQueue &Q, double *psl, int &hn, int &nseg, int &pooltop,
                                           int *&pool, int *&pool2, int *ext, int &next, int &flags)
 {
     const int gl = Grp<GL>::gl(), gb = Grp<GL>::gb();
@@ -705,10 +705,15 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
         HotNode *hp = hot + (p < 0 ? 0 : p);
         const bool live = act;                                 // every queued node is in use (nothing is deleted lazily)
         const int pcnt = live ? n_cnt : 0, poff = n_off, pN = n_N, prid = n_rid, pdsr = n_dsr, pdss = n_dss;
-        double ps[9], pn[3];                                   // popped node: sums and normal (uniform per group)
+        // popped node: sums and normal, uniform per group -> 12 doubles of LDS per group instead of 24 registers in every lane
+        // (the kernel's register count decides how many waves of OTHER kernels fit beside it)
+        if (gl == 0) {
 #pragma unroll
-        for (int q = 0; q < 9; q++) ps[q] = nps[q];
-        pn[0] = npn[0]; pn[1] = npn[1]; pn[2] = npn[2];
+            for (int q = 0; q < 9; q++) psl[q] = nps[q];
+            psl[9] = npn[0]; psl[10] = npn[1]; psl[11] = npn[2];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double *ps = psl, *pn = psl + 9;
         const int a0 = gl < pcnt ? a0n : -1;                   // first chunk of p's list, reused by the merge
         // ---- evaluate the merge with every neighbour, one candidate per lane; each lane keeps its best ----
         bool bhas = false; double bm = 0; int bid = 0x7FFFFFFF, bN = 0, gid = 0x7FFFFFFF, xid = -1;
@@ -1025,6 +1030,7 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
     asm volatile("v_mov_b32 v231, 0" ::: "v231");
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char tq_lds[];          // NG groups x n0 x (double + int)
+    __shared__ double ps_lds[NG][12];
     const int lane = threadIdx.x, gl = Grp<GL>::gl(), gid = lane / GL;
     int frame = blockIdx.x * NG + gid;
     const bool galive = frame < nframes;
@@ -1118,7 +1124,7 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
     int nseg = nblk, pooltop = nblk * 4, next = 0, flags = 0;
     int *ext = a.extracted + (size_t)frame * 2 * MAX_PLANES;
     __syncthreads();
-    ah_cluster_grouped<GL>(a, frame, Q, hn, nseg, pooltop, pool, pool2, ext, next, flags);
+    ah_cluster_grouped<GL>(a, frame, Q, ps_lds[gid], hn, nseg, pooltop, pool, pool2, ext, next, flags);
     if (galive && gl == 0) {
         int *meta = a.meta + (size_t)frame * 16;
         meta[0] = nseg; meta[1] = 0; meta[2] = next; meta[3] = flags; meta[6] = 0;      // the lists are dead: k_peac_final starts an empty pool
