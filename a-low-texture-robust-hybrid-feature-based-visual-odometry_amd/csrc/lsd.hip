@@ -573,13 +573,8 @@ static __device__ int cull_line_count(int w, int h, float fx1, float fy1, float 
     return (int)((dx > dy ? dx : dy) + 1);
 }
 
-// Eight waves per SIMD (64 VGPRs, 2.8 KB of LDS): the kernel is one dependent chain per frame, frames in flight are its only
-// source of throughput; measured 69 -> 58 ms per 8192 frames against the compiler's own choice (91 VGPRs, five waves)
-#ifndef HVO_WPE_GROW
-#define HVO_WPE_GROW 8
-#endif
-__attribute__((amdgpu_waves_per_eu(HVO_WPE_GROW)))
-__global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
+// The kernel body; two kernels wrap it (below).
+static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
 {
     __shared__ double b0[64], b1[64], b2[64];
     __shared__ int n_addr[64];
@@ -689,6 +684,17 @@ __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g)
 #endif
     }
 }
+
+// k_lsd_grow: the compiler's own register budget (91 VGPRs, five waves per SIMD): the fastest single frame (12 ms).
+// k_lsd_grow_dense: eight waves per SIMD (64 VGPRs, some spills): the kernel is one dependent chain per frame, so frames in
+// flight are its only source of throughput once a batch fills the wave slots; measured 69 -> 58 ms per 8192 frames, but
+// 12 -> 18 ms for a lone frame -- hence two kernels and a choice by batch size (lsd_run).
+__global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g) { lsd_grow_body(g); }
+#ifndef HVO_WPE_GROW
+#define HVO_WPE_GROW 8
+#endif
+__attribute__((amdgpu_waves_per_eu(HVO_WPE_GROW)))
+__global__ __launch_bounds__(64) void k_lsd_grow_dense(GrowArgs g) { lsd_grow_body(g); }
 
 // ------------------------------------------------------------------------------------------------
 // LBD: blur 5x5 (u8 fixed point, same rounding rules as the ORB blur), Sobel, descriptor
@@ -1261,7 +1267,10 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     g.stats = P->d_stats; g.kl_all = P->d_kl_all; g.kl = P->d_kl; g.fn = P->d_fn; g.nkl = P->d_nkl; g.flags = P->d_flags;
     g.sw = sw; g.sh = sh; g.nwords = P->nwords; g.w = w; g.h = h; g.nfeat = P->nfeat; g.kl_cap = P->nfeat;
     g.rho = P->rho; g.prec = P->prec; g.p = P->p; g.min_reg = P->min_reg;
-    hipLaunchKernelGGL(k_lsd_grow, dim3(n), dim3(64), 0, st, g);
+    bool dense = n > 5 * 1024;
+    { const char *e = getenv("HVO_LSD_DENSE"); if (e) dense = atoi(e) != 0; }              // tests force either kernel on small batches
+    if (dense) hipLaunchKernelGGL(k_lsd_grow_dense, dim3(n), dim3(64), 0, st, g);     // more frames than five waves per SIMD hold
+    else hipLaunchKernelGGL(k_lsd_grow, dim3(n), dim3(64), 0, st, g);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lbd_sobel", st);
     if (getenv("HVO_LBD_SPLIT")) {                  // the two-kernel formulation (blurred u8 image materialised), kept for A/B runs

@@ -28,6 +28,24 @@ def test_lines_parity_640(gpu_ctx, orc, synth, kind, seed):
     check(kl_g, d_g, fn_g, kl_o, d_o, fn_o)
 
 
+@pytest.mark.parametrize("dense", ["0", "1"])
+def test_lines_both_grow_kernels(hvo, orc, synth, monkeypatch, dense):
+    """k_lsd_grow (five waves per SIMD, small batches) and k_lsd_grow_dense (eight, batches that fill the wave slots) are the
+    same body under two register budgets; HVO_LSD_DENSE forces either on a small batch"""
+    monkeypatch.setenv("HVO_LSD_DENSE", dense)
+    g = np.stack([synth.make_gray(k, s) for k, s in (("std", 0x5EED0002), ("lowtex", 0x5EED0001), ("std", 0x5EED1003))])
+    ctx = hvo.Context(max_batch=3)
+    try:
+        ctx.batch_upload(g, np.zeros((3, 480, 640), np.uint16))
+        ctx.batch_run(hvo.STAGE_LSD)
+        res = ctx.batch_download(hvo.STAGE_LSD)
+    finally:
+        ctx.close()
+    for b in range(3):
+        kl_o, d_o, fn_o = orc.line_extract(g[b])
+        check(res[b]["kl"], res[b]["ldesc"], res[b]["linefn"], kl_o, d_o, fn_o)
+
+
 @pytest.mark.parametrize("hh,ww", [(397, 501), (479, 638), (400, 642)])
 def test_lines_odd_geometry(hvo, orc, synth, hh, ww):
     """widths that are not a multiple of 4 (scalar tails of the LBD blur / Sobel strips, unaligned Sobel rows) and lines
