@@ -536,6 +536,10 @@ template <int GL> struct Grp {
     template <class T> static __device__ __forceinline__ T shfl(T v, int l) { return __shfl(v, gb() + l); }
 };
 
+static __device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 // Butterfly partner inside a 16-lane row through DPP (a VALU move) instead of a permute through LDS.
 // STEP 1,2: quad_perm xor; STEP 4: row_half_mirror; STEP 8: row_mirror.  The mirrors pair lane i with
 // 7-i / 15-i rather than i^4 / i^8, which is the same for an all-reduce of a commutative operation whose
@@ -631,6 +635,79 @@ struct TQUpdate {
         for (int t = 0; t < 3; t++) if (writer && t < nx) { Q.M0k[x[t] >> 8] = sk[t]; Q.M0i[x[t] >> 8] = si[t]; }
         row_min16(k, i);
         return k < TQ_INF ? i : -1;
+    }
+};
+
+// The same update for a frame that has the whole wave (GL = 64): the three positions are handled by three 16-lane rows side
+// by side -- one bucket reduction, one super-bucket reduction and one top reduction instead of seven reductions in a row
+// (a lone wave pays 5-8 cycles per instruction, and the queue update was a third of a single frame's iteration).
+struct TQUpdateRows {
+    double kk, mk, kn[3]; int mi, x[3], nx;
+    __device__ __forceinline__ void issue(const TQueue &Q, int lane, int nx_, int x0, double k0, int x1, double k1, int x2, double k2)
+    {
+        nx = nx_; x[0] = x0; x[1] = x1; x[2] = x2; kn[0] = k0; kn[1] = k1; kn[2] = k2;
+        const int row = lane >> 4, rl = lane & 15;
+        const int xt = row == 0 ? x0 : row == 1 ? x1 : x2;
+        kk = TQ_INF; mk = TQ_INF; mi = 0x7FFFFFFF;
+        if (row < nx) { kk = Q.K[(xt & ~15) + rl]; const int j = ((xt >> 8) << 4) + rl; mk = Q.M1k[j]; mi = Q.M1i[j]; }
+    }
+    __device__ __forceinline__ int take(const TQueue &Q, int lane)
+    {
+        const int row = lane >> 4, rl = lane & 15;
+        const int xt = row == 0 ? x[0] : row == 1 ? x[1] : x[2];
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < 3; t++) if (t < nx) Q.K[x[t]] = kn[t];
+        }
+        // my row's bucket
+        double k = kk; int i = (xt & ~15) + rl;
+#pragma unroll
+        for (int u = 0; u < 3; u++) if (u < nx && ((x[u] ^ xt) >> 4) == 0 && (x[u] & 15) == rl) k = kn[u];
+        if (row >= nx) { k = TQ_INF; i = 0x7FFFFFFF; }
+        row_min16(k, i);
+        double bk[3]; int bi[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            bk[u] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(k), 16 * u), __builtin_amdgcn_readlane(__double2loint(k), 16 * u));
+            bi[u] = __builtin_amdgcn_readlane(i, 16 * u);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < 3; t++) if (t < nx) { Q.M1k[x[t] >> 4] = bk[t]; Q.M1i[x[t] >> 4] = bi[t]; }
+        }
+        // my row's super-bucket
+        k = mk; i = mi;
+#pragma unroll
+        for (int u = 0; u < 3; u++) if (u < nx && ((x[u] ^ xt) >> 8) == 0 && ((x[u] >> 4) & 15) == rl) { k = bk[u]; i = bi[u]; }
+        if (row >= nx) { k = TQ_INF; i = 0x7FFFFFFF; }
+        row_min16(k, i);
+        double sk[3]; int si[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            sk[u] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(k), 16 * u), __builtin_amdgcn_readlane(__double2loint(k), 16 * u));
+            si[u] = __builtin_amdgcn_readlane(i, 16 * u);
+        }
+        // the top: 64 entries of M0 per step, a row reduction, then the four rows' results
+        k = TQ_INF; i = 0x7FFFFFFF;
+        for (int j = lane; j < Q.n0; j += 64) {
+            double a = Q.M0k[j]; int b = Q.M0i[j];
+#pragma unroll
+            for (int u = 0; u < 3; u++) if (u < nx && (x[u] >> 8) == j) { a = sk[u]; b = si[u]; }
+            if (hless(a, b, k, i)) { k = a; i = b; }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < 3; t++) if (t < nx) { Q.M0k[x[t] >> 8] = sk[t]; Q.M0i[x[t] >> 8] = si[t]; }
+        }
+        row_min16(k, i);
+        double tk = TQ_INF; int ti = 0x7FFFFFFF;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double rk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(k), 16 * r), __builtin_amdgcn_readlane(__double2loint(k), 16 * r));
+            const int ri = __builtin_amdgcn_readlane(i, 16 * r);
+            if (hless(rk, ri, tk, ti)) { tk = rk; ti = ri; }
+        }
+        return tk < TQ_INF ? ti : -1;
     }
 };
 
@@ -768,12 +845,17 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
         // ---- group reductions: min mse, then the tie rule ----
         double gmin = bhas ? bm : 1.7976931348623157e308;
 #define GM_STEP(o) if (o < GL) { const double t = row_partner<o>(gmin); gmin = t < gmin ? t : gmin; }
-        GM_STEP(1) GM_STEP(2) GM_STEP(4) GM_STEP(8) GM_STEP(16) GM_STEP(32)
+        // a frame that owns the wave (GL = 64) rarely has more than one row of candidates: row 0's result is then the group's,
+        // broadcast through a scalar instead of two more cross-row steps
+        const bool one_row = GL == 64 && pcnt <= 16;
+        GM_STEP(1) GM_STEP(2) GM_STEP(4) GM_STEP(8)
+        if (one_row) gmin = readlane_f64(gmin, 0); else { GM_STEP(16) GM_STEP(32) }
 #undef GM_STEP
         const bool tied = bhas && bm == gmin;
         int rg = tied ? gid : 0x7FFFFFFF, rx = tied ? xid : -1;
 #define GM_STEP(o) if (o < GL) { const int t0 = row_partner<o>(rg), t1 = row_partner<o>(rx); rg = min(rg, t0); rx = max(rx, t1); }
-        GM_STEP(1) GM_STEP(2) GM_STEP(4) GM_STEP(8) GM_STEP(16) GM_STEP(32)
+        GM_STEP(1) GM_STEP(2) GM_STEP(4) GM_STEP(8)
+        if (one_row) { rg = __builtin_amdgcn_readlane(rg, 0); rx = __builtin_amdgcn_readlane(rx, 0); } else { GM_STEP(16) GM_STEP(32) }
 #undef GM_STEP
         const bool any_cand = Grp<GL>::ballot(bhas) != 0;
         const int win = rg != 0x7FFFFFFF ? rg : rx;            // neighbour id to merge with (if any_cand)
@@ -841,18 +923,19 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
         //     iteration may still edit).
         const int moff = pooltop;
         if (act) hn -= 1;                                       // merge: -2 + 1
-        TQUpdate qu;
+        TQUpdate qu; TQUpdateRows qr;                          // (GL = 64 uses the row-parallel form)
         // stage 0: the partner's first chunk, my member's list header, the queue's lines
         bool editA[ACH]; ListFind fa[ACH];                     // (the headers of p's members came with the evaluation's loads)
 #pragma unroll
         for (int u = 0; u < ACH; u++) { editA[u] = aid[u] >= 0 && ((do_merge && aid[u] != nb) || no_merge); fa[u].issue(pool, aoff[u], editA[u] ? acnt[u] : 0); }
         const int vB = gl < ncnt ? pool[noff + gl] : -1;        // ncnt == 0 unless this group merges
-        qu.issue(Q, rl, act ? (do_merge ? 3 : 1) : 0, p, TQ_INF, nb, TQ_INF, id, m);
+        if (GL == 64) qr.issue(Q, gl, act ? (do_merge ? 3 : 1) : 0, p, TQ_INF, nb, TQ_INF, id, m);
+        else qu.issue(Q, rl, act ? (do_merge ? 3 : 1) : 0, p, TQ_INF, nb, TQ_INF, id, m);
         // stage 1: B's members' list headers, A's lists, the next top's record
         const bool inB = vB >= 0 && vB != p;
         int qb_off = 0, qb_cnt = 0;
         if (inB) { qb_off = hot[vB].off; qb_cnt = hot[vB].cnt; }
-        ptop = qu.take(Q, rl, gl == 0);
+        ptop = GL == 64 ? qr.take(Q, gl) : qu.take(Q, rl, gl == 0);
         if (hn <= 0) ptop = -1;
         PT(1)
         fetch_next(ptop);
