@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 TRAFFIC_PROFILE = "profiles/r02_hbm_traffic.json"
 SQ_PROFILE = "profiles/r02_sq_utilisation.json"
-BYTES_PER_FRAME_640 = 25.2e6      # resident footprint of one 640x480 frame (profiles/r02_hbm_footprint.txt)
+BYTES_PER_FRAME_640 = 26.0e6      # resident footprint of one 640x480 frame (profiles/r02_hbm_footprint.txt)
 
 
 def parse_args():
