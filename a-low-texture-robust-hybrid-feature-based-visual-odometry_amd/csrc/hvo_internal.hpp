@@ -167,7 +167,7 @@ int hvo_staged_d2h(hvo_ctx *ctx, hipStream_t st, const void *dev_base, size_t de
 int orb_init_tables(hvo_ctx *ctx);
 int orb_ensure_plan(hvo_ctx *ctx, int w, int h, int batch);
 void orb_free_plan(hvo_ctx *ctx);
-int orb_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h);
+int orb_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool sync = true);   // sync = false: the caller waits for ctx->stream
 int orb_run(hvo_ctx *ctx, int n);
 int orb_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
 
@@ -218,7 +218,7 @@ int lines3d_enqueue(hvo_ctx *ctx, hipStream_t st, const hvo_keyline *d_kl, const
 // peac.hip
 struct PeacView { uint16_t *d_depth; int pitch; size_t dframe; int8_t *d_labels8; hvo_plane *d_planes; int *d_meta; int npix, max_planes; };
 int peac_prepare(hvo_ctx *ctx, int w, int h, int batch, PeacView *v);      // plan for this geometry + where its inputs / results live
-int peac_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h);
+int peac_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool sync = true);  // sync = false: the caller waits for ctx->s_peac
 int peac_run(hvo_ctx *ctx, int n);
 int peac_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
 void peac_free(hvo_ctx *ctx);

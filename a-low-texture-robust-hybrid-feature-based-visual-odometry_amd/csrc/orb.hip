@@ -1030,17 +1030,25 @@ static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     return HVO_OK;
 }
 
-int orb_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h)
+int orb_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool sync)
 {
     int rc = orb_ensure_plan(ctx, w, h, std::max(n, ctx->p.max_batch));
     if (rc) return rc;
     OrbPlan &P = ctx->orb;
-    for (int f = 0; f < n; f++) {
-        if (!in[f].gray) return HVO_ERR_INVALID_ARG;
-        HVO_HIP(hipMemcpy2DAsync(P.d_pyr + (size_t)f * P.pyr_bytes, P.lev[0].pitch, in[f].gray, in[f].gray_stride,
-                                 w, h, hipMemcpyHostToDevice, ctx->stream));
+    for (int f = 0; f < n; f++) if (!in[f].gray) return HVO_ERR_INVALID_ARG;
+    // Frames that are dense (stride == width == device pitch) and evenly spaced in host memory go up as ONE 2-D copy whose "rows"
+    // are whole frames: a copy call costs ~20 us, which at one call per frame was the whole upload (2048 frames: 82 ms for 0.6 GB).
+    bool regular = n > 1 && P.lev[0].pitch == w;
+    const ptrdiff_t step = n > 1 ? in[1].gray - in[0].gray : 0;
+    for (int f = 0; regular && f < n; f++) regular = in[f].gray_stride == w && in[f].gray - in[0].gray == step * f;
+    if (regular && step >= (ptrdiff_t)w * h) {
+        HVO_HIP(hipMemcpy2DAsync(P.d_pyr, P.pyr_bytes, in[0].gray, (size_t)step, (size_t)w * h, n, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        for (int f = 0; f < n; f++)
+            HVO_HIP(hipMemcpy2DAsync(P.d_pyr + (size_t)f * P.pyr_bytes, P.lev[0].pitch, in[f].gray, in[f].gray_stride,
+                                     w, h, hipMemcpyHostToDevice, ctx->stream));
     }
-    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    if (sync) HVO_HIP(hipStreamSynchronize(ctx->stream));
     return HVO_OK;
 }
 

@@ -1851,18 +1851,25 @@ int peac_prepare(hvo_ctx *ctx, int w, int h, int batch, PeacView *v)
     return HVO_OK;
 }
 
-int peac_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h)
+int peac_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool sync)
 {
     int rc = peac_ensure_plan(ctx, w, h, std::max(n, ctx->p.max_batch));
     if (rc) return rc;
     PeacPlan *P = plan_of(ctx);
     const size_t dframe = (size_t)P->pitch * (h + 1);
-    for (int f = 0; f < n; f++) {
-        if (!in[f].depth) return HVO_ERR_INVALID_ARG;
-        HVO_HIP(hipMemcpy2DAsync(P->d_depth + f * dframe, P->pitch * sizeof(uint16_t), in[f].depth, in[f].depth_stride,
-                                 (size_t)w * sizeof(uint16_t), h, hipMemcpyHostToDevice, ctx->s_peac));
+    for (int f = 0; f < n; f++) if (!in[f].depth) return HVO_ERR_INVALID_ARG;
+    // dense, evenly spaced host frames: one 2-D copy whose rows are whole frames (see orb_upload)
+    bool regular = n > 1 && P->pitch == w;
+    const ptrdiff_t step = n > 1 ? (const char *)in[1].depth - (const char *)in[0].depth : 0;
+    for (int f = 0; regular && f < n; f++) regular = in[f].depth_stride == (int)(w * sizeof(uint16_t)) && (const char *)in[f].depth - (const char *)in[0].depth == step * f;
+    if (regular && step >= (ptrdiff_t)((size_t)w * h * sizeof(uint16_t))) {
+        HVO_HIP(hipMemcpy2DAsync(P->d_depth, dframe * sizeof(uint16_t), in[0].depth, (size_t)step, (size_t)w * h * sizeof(uint16_t), n, hipMemcpyHostToDevice, ctx->s_peac));
+    } else {
+        for (int f = 0; f < n; f++)
+            HVO_HIP(hipMemcpy2DAsync(P->d_depth + f * dframe, P->pitch * sizeof(uint16_t), in[f].depth, in[f].depth_stride,
+                                     (size_t)w * sizeof(uint16_t), h, hipMemcpyHostToDevice, ctx->s_peac));
     }
-    HVO_HIP(hipStreamSynchronize(ctx->s_peac));
+    if (sync) HVO_HIP(hipStreamSynchronize(ctx->s_peac));
     return HVO_OK;
 }
 
