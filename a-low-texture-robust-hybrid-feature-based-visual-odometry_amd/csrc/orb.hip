@@ -1071,6 +1071,19 @@ int orb_run(hvo_ctx *ctx, int n)
                                P.d_rs_yofs + D.ry_off, P.d_rs_ybeta + D.ry_off);
     }
     hvo_prof_end(ctx, id);
+    // the blur (input: the pyramid; output: what k_brief samples) goes first: a VALU-bound streaming kernel that the long
+    // kernels of the other streams absorb, instead of one more link in the chain octree -> orient -> BRIEF that ends the step
+    id = hvo_prof_begin(ctx, "orb_blur", st);
+    // OpenCV fixed-point Gaussian taps for ksize 7, sigma 2: getGaussianKernel(CV_32F) * 256, rounded
+    static int k7[4] = { 0, 0, 0, 0 };
+    if (!k7[3]) {
+        float cf[7]; double sum = 0;
+        for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)exp(-0.5 / 4.0 * x * x); sum += cf[i]; }
+        sum = 1. / sum;
+        for (int i = 0; i < 4; i++) k7[i] = round_half_even_f((float)(cf[i] * sum) * 256.f);
+    }
+    hipLaunchKernelGGL(k_blur7, dim3(P.ntiles, n), dim3(256), 0, st, P.d_pyr, P.d_blur, P.pyr_bytes, P.d_lev, P.d_tiles, k7[0], k7[1], k7[2], k7[3]);
+    hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "orb_fast_cells", st);
     if (P.max_cell <= 45)
         hipLaunchKernelGGL(k_fast_cells<48>, dim3((P.ncells + 3) / 4, n), dim3(256), 0, st, P.d_pyr, P.pyr_bytes, P.d_lev, P.d_cells, P.ncells,
@@ -1091,17 +1104,6 @@ int orb_run(hvo_ctx *ctx, int n)
     id = hvo_prof_begin(ctx, "orb_orient", st);
     hipLaunchKernelGGL(k_orient, dim3((P.kp_cap + 15) / 16, n), dim3(256), 0, st, P.d_pyr, P.pyr_bytes, P.d_lev, nl, P.d_lvl_kp, P.d_lvl_cnt,
                        P.kp_total, ctx->d_umax, P.d_kp, P.d_nkp, P.kp_cap);
-    hvo_prof_end(ctx, id);
-    id = hvo_prof_begin(ctx, "orb_blur", st);
-    // OpenCV fixed-point Gaussian taps for ksize 7, sigma 2: getGaussianKernel(CV_32F) * 256, rounded
-    static int k7[4] = { 0, 0, 0, 0 };
-    if (!k7[3]) {
-        float cf[7]; double sum = 0;
-        for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)exp(-0.5 / 4.0 * x * x); sum += cf[i]; }
-        sum = 1. / sum;
-        for (int i = 0; i < 4; i++) k7[i] = round_half_even_f((float)(cf[i] * sum) * 256.f);
-    }
-    hipLaunchKernelGGL(k_blur7, dim3(P.ntiles, n), dim3(256), 0, st, P.d_pyr, P.d_blur, P.pyr_bytes, P.d_lev, P.d_tiles, k7[0], k7[1], k7[2], k7[3]);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "orb_brief", st);
     hipLaunchKernelGGL(k_brief, dim3((P.kp_cap + 15) / 16, n), dim3(256), 0, st, P.d_blur, P.pyr_bytes, P.d_lev, ctx->d_pattern, P.d_kp, P.d_nkp,
