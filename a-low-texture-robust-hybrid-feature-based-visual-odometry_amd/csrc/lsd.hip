@@ -679,6 +679,9 @@ static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
         g.nkl[f] = n; g.flags[f] = flags;
         long long *st = g.stats + (size_t)f * 8;
         st[0] = st_seeds; st[1] = st_pts; st[2] = st_big; st[3] = st_tg; st[4] = st_tr; st[5] = st_tf; st[6] = wall_clock64() - t_begin; st[7] = nseg;
+#ifdef HVO_LSD_STAT_T0
+        st[7] = t_begin;                                               // diagnostics build: when the wave started (100 MHz wall clock)
+#endif
 #ifdef HVO_LSD_TIMING
         st[2] = S.n_rounds; st[4] = S.t_gather; st[5] = S.t_add;      // diagnostics build: rounds, gather ticks, add ticks
 #endif

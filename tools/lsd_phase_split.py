@@ -19,6 +19,11 @@ acc = np.zeros(8)
 for f in range(64):
     out = (ctypes.c_longlong * 8)(); L.hvo_debug_lsd_stats(ctx.h, f, out); acc += np.array(list(out), float)
 acc /= 64
+per = []
+for f in range(64):
+    out = (ctypes.c_longlong * 8)(); L.hvo_debug_lsd_stats(ctx.h, f, out); per.append((out[6] / 1e5, out[0], out[1]))
+per.sort()
+print("wave lifetime of the 64 distinct frames, ms (seeds, points): shortest", per[:3], "median", per[32], "longest", per[-4:])
 tot = acc[6]
 print("per frame: seeds %.0f points %.0f regions kept %.0f segments %.0f" % (acc[0], acc[1], acc[2], acc[7]))
 print("ticks (100 MHz): total %.0f = %.2f ms | grow %.1f %% | region2rect %.1f %% | refine %.1f %% | rest (seed scan, key lines, top-N, line functions) %.1f %%"
