@@ -11,6 +11,25 @@
 #include <new>
 #include <vector>
 
+const int *hvo_frame_perm(hvo_ctx *ctx, int n)
+{
+    if (n < 2) return nullptr;
+    { const char *e = getenv("HVO_FRAME_PERM"); if (e && atoi(e) == 0) return nullptr; }      // A/B knob
+    for (auto &e : ctx->perms) if (e.first == n) return e.second;
+    int bits = 0; while ((1 << bits) < n) bits++;
+    std::vector<int> p; p.reserve(n);
+    for (unsigned i = 0; i < (1u << bits); i++) {
+        unsigned r = 0; for (int b = 0; b < bits; b++) r |= ((i >> b) & 1u) << (bits - 1 - b);
+        if ((int)r < n) p.push_back((int)r);
+    }
+    if (ctx->perms.size() >= 8) { for (auto &e : ctx->perms) (void)hipFree(e.second); ctx->perms.clear(); }      // (lengths change with the batch: keep a few)
+    int *d = nullptr;
+    if (hipMalloc((void **)&d, (size_t)n * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, p.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    ctx->perms.emplace_back(n, d);
+    return d;
+}
+
 extern "C" {
 
 int hvo_abi_version(void) { return HVO_ABI_VERSION; }
@@ -82,6 +101,8 @@ void hvo_destroy(hvo_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    for (auto &e : ctx->perms) (void)hipFree(e.second);
+    ctx->perms.clear();
     orb_free_plan(ctx);
     match_free(ctx);
     peac_free(ctx);

@@ -74,6 +74,7 @@ struct hvo_ctx {
     hipEvent_t ev_fast = nullptr;          // recorded on the ORB stream after k_fast_cells (the only ORB kernel that needs LDS)
     bool fast_recorded = false;
     int sched = 1;                         // overlap policy of hvo_batch_run, see api.hip
+    std::vector<std::pair<int, int *>> perms;   // launch orders (hvo_frame_perm), one device array per length asked for
     double cull_dis = 5.0, cull_angle = 2.5, cull_endpoint = 15.0;   // Frame::cullingLine(im, 5, 2.5, 15, 30), Frame.cc:934
     bool last_cull = false;                // the resident batch was run with HVO_STAGE_LSD_CULL
     unsigned last_stages = 0;              // stages hvo_batch_run has computed for the resident batch (hvo_batch_download reports only these)
@@ -167,6 +168,11 @@ int hvo_staged_d2h(hvo_ctx *ctx, hipStream_t st, const void *dev_base, size_t de
 int orb_init_tables(hvo_ctx *ctx);
 int orb_ensure_plan(hvo_ctx *ctx, int w, int h, int batch);
 void orb_free_plan(hvo_ctx *ctx);
+// Bit-reversed order of the frames 0..n-1 (device array; nullptr when n < 2 or on failure = identity).  The kernels that give a
+// frame one wave for its whole life (k_lsd_grow, k_peac_flood) take workgroup b's frame from it: the waves that share a SIMD are
+// workgroups a fixed stride apart, and frames a fixed stride apart in a batch tend to be alike (the same camera, or a synthetic
+// batch's period), so whole SIMDs got only long or only short frames and the kernel lasted as long as the unluckiest one.
+const int *hvo_frame_perm(hvo_ctx *ctx, int n);
 int orb_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool sync = true);   // sync = false: the caller waits for ctx->stream
 int orb_run(hvo_ctx *ctx, int n);
 int orb_download(hvo_ctx *ctx, int n, hvo_frame_out *out);

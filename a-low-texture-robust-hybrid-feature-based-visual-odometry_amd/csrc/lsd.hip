@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_lsd_resize_grad(const double *__restric
 // k_lsd_grow: the serial heart of LSD, one wave per frame
 // ------------------------------------------------------------------------------------------------
 struct GrowArgs {
-    const double4 *px4; unsigned *avail; int *reg; float *segs;
+    const double4 *px4; unsigned *avail; int *reg; float *segs; const int *perm;
     hvo_keyline *kl_all, *kl; double *fn; int *nkl; int *flags; long long *stats;
     int sw, sh, nwords, w, h, nfeat, kl_cap;
     double rho, prec, p; unsigned min_reg;
@@ -579,7 +579,7 @@ static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
     __shared__ double b0[64], b1[64], b2[64];
     __shared__ int n_addr[64];
     __shared__ int ring[LSD_RING];
-    const int f = blockIdx.x, lane = threadIdx.x;
+    const int f = g.perm ? g.perm[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;       // hvo_frame_perm
     const int sw = g.sw, sh = g.sh, wpr = (sw + 31) / 32, nwords = g.nwords;
     const size_t np = (size_t)sw * sh;
     GrowState S;
@@ -1266,7 +1266,7 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     if (ctx->sched == 2 && ctx->fast_recorded && !ctx->serialize) HVO_HIP(hipStreamWaitEvent(st, ctx->ev_fast, 0));
     id = hvo_prof_begin(ctx, "lsd_grow", st);
     GrowArgs g;
-    g.px4 = P->d_px; g.avail = P->d_defined; g.reg = P->d_reg; g.segs = P->d_segs;
+    g.px4 = P->d_px; g.avail = P->d_defined; g.reg = P->d_reg; g.segs = P->d_segs; g.perm = hvo_frame_perm(ctx, n);
     g.stats = P->d_stats; g.kl_all = P->d_kl_all; g.kl = P->d_kl; g.fn = P->d_fn; g.nkl = P->d_nkl; g.flags = P->d_flags;
     g.sw = sw; g.sh = sh; g.nwords = P->nwords; g.w = w; g.h = h; g.nfeat = P->nfeat; g.kl_cap = P->nfeat;
     g.rho = P->rho; g.prec = P->prec; g.p = P->p; g.min_reg = P->min_reg;

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(64) void k_peac_blocks(const uint16_t *__restrict__
 struct ClArgs {
     double *segD; int *segI; int *pool; int *pool2; int *parent; int *dsize; int *eflag; int *meta; int *extracted;
     struct HotNode *hot;                            // the grouped kernel's node records (one 128-byte line each)
+    const int *perm;                                // wave b works on frames NG * perm[b] .. (hvo_frame_perm over the waves), or nullptr
     double *tqK, *tqM1k; int *tqM1i; int tq_n0;      // the grouped kernel's min-MSE queue (TQueue): n0 * 256 keys, n0 * 16 bucket minima per frame
     int segcap, poolcap, nblk, Nw, Nh;
     double c15, c60;
@@ -1115,7 +1116,7 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
     extern __shared__ __attribute__((aligned(16))) unsigned char tq_lds[];          // NG groups x n0 x (double + int)
     __shared__ double ps_lds[NG][12];
     const int lane = threadIdx.x, gl = Grp<GL>::gl(), gid = lane / GL;
-    int frame = blockIdx.x * NG + gid;
+    int frame = (a.perm ? a.perm[blockIdx.x] : (int)blockIdx.x) * NG + gid;
     const bool galive = frame < nframes;
     if (!galive) frame = nframes - 1;                          // idle group: aliases a frame read-only, writes nothing
     const int nblk = a.nblk, Nw = a.Nw, Nh = a.Nh;
@@ -1287,7 +1288,7 @@ struct RfArgs {
     ClArgs c;
     const uint16_t *depth; size_t dframe; int pitch, w, h;
     float fx, fy, cx, cy, dfac;
-    int *blkmap; int *isvalid; uint2 *state; int *queue; int qcap; int *plidmap;
+    int *blkmap; int *isvalid; uint2 *state; int *queue; int qcap; int *plidmap; const int *perm;
     hvo_plane *planes; double c30;
 };
 
@@ -1342,7 +1343,7 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
     __shared__ int wsum[EPL * NW], psum[FLOOD_NP * NW];
     __shared__ int s_nq, s_cx[2];
     const ClArgs &a = r.c;
-    const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int frame = r.perm ? r.perm[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;     // hvo_frame_perm
     const int w = r.w, h = r.h, Nw = a.Nw, nblk = a.nblk;
     int *meta = a.meta + (size_t)frame * 16;
     const int nold = meta[2];
@@ -1888,7 +1889,7 @@ int peac_run(hvo_ctx *ctx, int n)
     ClArgs a;
     a.segD = P->d_segD; a.segI = P->d_segI; a.pool = P->d_pool; a.pool2 = P->d_pool2; a.parent = P->d_parent; a.dsize = P->d_dsize; a.eflag = P->d_eflag;
     a.meta = P->d_meta; a.extracted = P->d_extracted; a.segcap = P->segcap; a.poolcap = P->poolcap; a.nblk = P->nblk; a.Nw = P->Nw; a.Nh = P->Nh;
-    a.c15 = P->c15; a.c60 = P->c60; a.hot = (HotNode *)P->d_hot; a.tqK = P->d_hkey; a.tqM1k = P->d_m1k; a.tqM1i = P->d_hid; a.tq_n0 = (P->segcap + 255) / 256;
+    a.c15 = P->c15; a.c60 = P->c60; a.hot = (HotNode *)P->d_hot; a.perm = nullptr; a.tqK = P->d_hkey; a.tqM1k = P->d_m1k; a.tqM1i = P->d_hid; a.tq_n0 = (P->segcap + 255) / 256;
     a.ang_factor = P->ang_factor; a.ang_near = P->ang_near;
     id = hvo_prof_begin(ctx, "peac_cluster", st);
     // k_peac_cluster_lat (one frame per workgroup, queue in LDS, adjacency inline in 256-byte node records): an experiment in
@@ -1914,6 +1915,10 @@ int peac_run(hvo_ctx *ctx, int n)
         const int gl = e ? atoi(e) : -1;
         const int use = gl > 0 ? gl : (n >= 3072 ? 16 : 64);
         const size_t lq = (size_t)a.tq_n0 * 12;                  // LDS per group: the queue's top level
+        // the waves that share a SIMD are a fixed stride apart: their frames are decorrelated (hvo_frame_perm over the waves; the
+        // frames of one wave stay consecutive, lockstep likes them alike); HVO_PEAC_PERM=0 for A/B runs
+        a.perm = hvo_frame_perm(ctx, (n + (64 / use) - 1) / (64 / use));
+        { const char *e4 = getenv("HVO_PEAC_PERM"); if (e4 && atoi(e4) == 0) a.perm = nullptr; }
         if (use == 64) hipLaunchKernelGGL(k_peac_cluster<64>, dim3(n), dim3(64), lq, st, a, n);
         else if (use == 32) hipLaunchKernelGGL(k_peac_cluster<32>, dim3((n + 1) / 2), dim3(64), 2 * lq, st, a, n);
         else hipLaunchKernelGGL(k_peac_cluster<16>, dim3((n + 3) / 4), dim3(64), 4 * lq, st, a, n);
@@ -1925,7 +1930,7 @@ int peac_run(hvo_ctx *ctx, int n)
     RfArgs r;
     r.c = a; r.depth = P->d_depth; r.dframe = dframe; r.pitch = P->pitch; r.w = P->w; r.h = P->h;
     r.fx = p.fx; r.fy = p.fy; r.cx = p.cx; r.cy = p.cy; r.dfac = p.depth_map_factor;
-    r.blkmap = P->d_blkmap; r.isvalid = P->d_isvalid; r.state = P->d_state; r.queue = P->d_queue;
+    r.blkmap = P->d_blkmap; r.isvalid = P->d_isvalid; r.state = P->d_state; r.queue = P->d_queue; r.perm = nullptr;
     r.qcap = P->qcap; r.plidmap = P->d_plidmap; r.planes = P->d_planes; r.c30 = P->c30;
     {
         // threads per frame (one queue entry = 4 events per thread and round); HVO_FLOOD_T overrides
@@ -1935,6 +1940,8 @@ int peac_run(hvo_ctx *ctx, int n)
         const int ft = flood_t > 0 ? flood_t : (n >= 6144 ? 64 : 256);
         const char *e2 = getenv("HVO_FLOOD_EPL");          // queue entries per thread and round (one-wave variant only)
         const int fe = e2 ? atoi(e2) : 1;
+        r.perm = hvo_frame_perm(ctx, n);                   // one wave per frame for its whole life: frames of a SIMD decorrelated
+        { const char *e3 = getenv("HVO_FLOOD_PERM"); if (e3 && atoi(e3) == 0) r.perm = nullptr; }
         if (ft == 64 && fe == 2) hipLaunchKernelGGL((k_peac_flood<64, 2>), dim3(n), dim3(64), 0, st, r, P->d_adj);
         else if (ft == 64) hipLaunchKernelGGL((k_peac_flood<64, 1>), dim3(n), dim3(64), 0, st, r, P->d_adj);
         else if (ft == 256) hipLaunchKernelGGL((k_peac_flood<256, 1>), dim3(n), dim3(256), 0, st, r, P->d_adj);
