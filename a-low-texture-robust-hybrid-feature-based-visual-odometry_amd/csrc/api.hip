@@ -82,7 +82,7 @@ int hvo_create(const hvo_params *p, hvo_ctx **out)
     if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) { delete ctx; return HVO_ERR_NO_DEVICE; }
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete ctx; return HVO_ERR_NO_DEVICE; }   // code object is gfx950 only
     // stream priorities (experiment knob HVO_PRIO="orb,lsd,peac", lower number = higher priority)
-    int pr[3] = { 0, -1, 1 };          // measured best: the LSD chain is the longest, the PEAC kernels fill in
+    int pr[3] = { 0, 0, 0 };           // measured (profiles/r02_sched_sweep.txt): equal priorities with sched 2; round 1's best was 0,-1,1
     { const char *e = getenv("HVO_PRIO"); if (e) sscanf(e, "%d,%d,%d", &pr[0], &pr[1], &pr[2]); }
     if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, pr[0]) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->s_lsd, hipStreamNonBlocking, pr[1]) != hipSuccess ||
@@ -173,7 +173,8 @@ int hvo_batch_run(hvo_ctx *ctx, unsigned stages)
     // Overlap policy.  k_lsd_grow takes almost all of a CU's LDS for >100 ms; streaming kernels gain nothing
     // from running side by side; the latency-bound kernels (k_lsd_grow, k_peac_cluster) leave most issue
     // slots idle.  sched 2: ORB starts at once and its only LDS kernel (k_fast_cells) is ordered BEFORE
-    // k_lsd_grow, the rest of ORB then runs underneath it.  sched 1: ORB waits for the LSD preamble.
+    // k_lsd_grow, the rest of ORB then runs underneath it (the default since the serial kernels' launch order is
+    // decorrelated: 214 ms per 8192-frame step against 218.5 for sched 1).  sched 1: ORB waits for the LSD preamble.
     // sched 0: no cross-stream ordering.
     ctx->lsd_pre_recorded = ctx->fast_recorded = false;
     const bool want_cull = (stages & HVO_STAGE_LSD_CULL) != 0;
