@@ -90,6 +90,7 @@ int hvo_create(const hvo_params *p, hvo_ctx **out)
         hipEventCreateWithFlags(&ctx->ev_lsd_pre, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fast, hipEventDisableTiming) != hipSuccess) { hvo_destroy(ctx); return HVO_ERR_HIP; }
     { const char *e = getenv("HVO_SCHED"); if (e) ctx->sched = atoi(e); }
+    { const char *e = getenv("HVO_ORB_BLUR_LATE"); if (e) ctx->orb_blur_late = atoi(e) != 0; }
     int rc = orb_init_tables(ctx);
     if (rc) { hvo_destroy(ctx); return rc; }
     *out = ctx;
@@ -168,19 +169,22 @@ int hvo_batch_run(hvo_ctx *ctx, unsigned stages)
     if ((stages & HVO_STAGE_PLANES) && !ctx->have_depth) return HVO_ERR_INVALID_ARG;
     // The serial stages go first so that their long single-wave kernels overlap the streaming ones (sched 0-2);
     // sched 3 / 4 (experiments): the plane stage is enqueued last, after LSD then ORB (3) or ORB then LSD (4)
-    const bool peac_last = ctx->sched >= 3 && !ctx->serialize;
+    const bool peac_last = ctx->sched >= 3 && ctx->sched != 5 && ctx->sched != 7 && !ctx->serialize;
+    const bool orb_first = (ctx->sched == 5 || ctx->sched == 7) && !ctx->serialize && (stages & HVO_STAGE_ORB);      // sched 5 (experiment): ORB, planes (flood behind k_fast_cells), LSD
+    if (orb_first) { ctx->fast_recorded = false; rc = orb_run(ctx, ctx->batch_n); if (rc) return rc; }
     if ((stages & HVO_STAGE_PLANES) && !peac_last) { rc = peac_run(ctx, ctx->batch_n); if (rc) return rc; }
-    // Overlap policy.  k_lsd_grow takes almost all of a CU's LDS for >100 ms; streaming kernels gain nothing
-    // from running side by side; the latency-bound kernels (k_lsd_grow, k_peac_cluster) leave most issue
-    // slots idle.  sched 2: ORB starts at once and its only LDS kernel (k_fast_cells) is ordered BEFORE
-    // k_lsd_grow, the rest of ORB then runs underneath it (the default since the serial kernels' launch order is
-    // decorrelated: 214 ms per 8192-frame step against 218.5 for sched 1).  sched 1: ORB waits for the LSD preamble.
-    // sched 0: no cross-stream ordering.
-    ctx->lsd_pre_recorded = ctx->fast_recorded = false;
+    // Overlap policy (HVO_SCHED; measured in profiles/r02_sched_sweep.txt).  The long serial kernels mostly exclude each other and
+    // stretch whatever streams beside them; what the order CAN do is keep them from starving a kernel the others wait for.
+    //   5 (default): ORB is enqueued first, then the plane stage, then LSD; k_peac_flood (all of a CU's LDS for ~40 ms) and
+    //      k_lsd_grow (every wave slot) both wait for k_fast_cells, the one ORB kernel that needs LDS: FAST runs beside the AHC
+    //      (registers only), then flood, growing and ORB's quadtree share the machine, then the short tails.
+    //   2: ORB first, only k_lsd_grow waits for k_fast_cells.  1: ORB waits for the LSD preamble (round 1's best).
+    //   0: no cross-stream ordering.  3 / 4: planes enqueued last.  6: the AHC waits for all streaming kernels.  7: as 5, growing does not wait.
+    ctx->lsd_pre_recorded = false; if (!orb_first) ctx->fast_recorded = false;
     const bool want_cull = (stages & HVO_STAGE_LSD_CULL) != 0;
-    const bool want_orb = (stages & HVO_STAGE_ORB) != 0, want_lsd = (stages & HVO_STAGE_LSD) != 0 || want_cull;
+    const bool want_orb = (stages & HVO_STAGE_ORB) != 0 && !orb_first, want_lsd = (stages & HVO_STAGE_LSD) != 0 || want_cull;
     if (want_lsd) ctx->last_cull = want_cull;
-    if (ctx->sched == 4 && want_orb && !ctx->serialize) {
+    if ((ctx->sched == 4 || ctx->sched == 6) && want_orb && !ctx->serialize) {      // 6 (experiment): as 4, and the AHC waits for the streaming kernels
         rc = orb_run(ctx, ctx->batch_n); if (rc) return rc;
         if (want_lsd) { rc = lsd_run(ctx, ctx->batch_n, want_cull); if (rc) return rc; }
     } else if (ctx->sched == 2 && want_orb && !ctx->serialize) {

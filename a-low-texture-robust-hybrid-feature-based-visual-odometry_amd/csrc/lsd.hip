@@ -1263,7 +1263,7 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
                        P->d_px, P->d_defined, P->nwords, P->rho);
     hvo_prof_end(ctx, id);
     if (ctx->ev_lsd_pre && !ctx->serialize) { HVO_HIP(hipEventRecord(ctx->ev_lsd_pre, st)); ctx->lsd_pre_recorded = true; }
-    if (ctx->sched == 2 && ctx->fast_recorded && !ctx->serialize) HVO_HIP(hipStreamWaitEvent(st, ctx->ev_fast, 0));
+    if ((ctx->sched == 2 || ctx->sched == 5 || ctx->sched == 6) && ctx->fast_recorded && !ctx->serialize) HVO_HIP(hipStreamWaitEvent(st, ctx->ev_fast, 0));
     id = hvo_prof_begin(ctx, "lsd_grow", st);
     GrowArgs g;
     g.px4 = P->d_px; g.avail = P->d_defined; g.reg = P->d_reg; g.segs = P->d_segs; g.perm = hvo_frame_perm(ctx, n);

@@ -1071,19 +1071,24 @@ int orb_run(hvo_ctx *ctx, int n)
                                P.d_rs_yofs + D.ry_off, P.d_rs_ybeta + D.ry_off);
     }
     hvo_prof_end(ctx, id);
-    // the blur (input: the pyramid; output: what k_brief samples) goes first: a VALU-bound streaming kernel that the long
-    // kernels of the other streams absorb, instead of one more link in the chain octree -> orient -> BRIEF that ends the step
-    id = hvo_prof_begin(ctx, "orb_blur", st);
-    // OpenCV fixed-point Gaussian taps for ksize 7, sigma 2: getGaussianKernel(CV_32F) * 256, rounded
-    static int k7[4] = { 0, 0, 0, 0 };
-    if (!k7[3]) {
-        float cf[7]; double sum = 0;
-        for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)exp(-0.5 / 4.0 * x * x); sum += cf[i]; }
-        sum = 1. / sum;
-        for (int i = 0; i < 4; i++) k7[i] = round_half_even_f((float)(cf[i] * sum) * 256.f);
-    }
-    hipLaunchKernelGGL(k_blur7, dim3(P.ntiles, n), dim3(256), 0, st, P.d_pyr, P.d_blur, P.pyr_bytes, P.d_lev, P.d_tiles, k7[0], k7[1], k7[2], k7[3]);
-    hvo_prof_end(ctx, id);
+    // the blur (input: the pyramid; output: what k_brief samples) is no link of the chain FAST -> octree -> orient -> BRIEF: it goes
+    // either before k_fast_cells or right behind it (blur_late), wherever the other streams' long kernels absorb it best
+    const bool blur_late = ctx->orb_blur_late;
+    auto run_blur = [&]() -> int {
+        id = hvo_prof_begin(ctx, "orb_blur", st);
+        // OpenCV fixed-point Gaussian taps for ksize 7, sigma 2: getGaussianKernel(CV_32F) * 256, rounded
+        static int k7[4] = { 0, 0, 0, 0 };
+        if (!k7[3]) {
+            float cf[7]; double sum = 0;
+            for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)exp(-0.5 / 4.0 * x * x); sum += cf[i]; }
+            sum = 1. / sum;
+            for (int i = 0; i < 4; i++) k7[i] = round_half_even_f((float)(cf[i] * sum) * 256.f);
+        }
+        hipLaunchKernelGGL(k_blur7, dim3(P.ntiles, n), dim3(256), 0, st, P.d_pyr, P.d_blur, P.pyr_bytes, P.d_lev, P.d_tiles, k7[0], k7[1], k7[2], k7[3]);
+        hvo_prof_end(ctx, id);
+        return HVO_OK;
+    };
+    if (!blur_late) { const int rb = run_blur(); if (rb) return rb; }
     id = hvo_prof_begin(ctx, "orb_fast_cells", st);
     if (P.max_cell <= 45)
         hipLaunchKernelGGL(k_fast_cells<48>, dim3((P.ncells + 3) / 4, n), dim3(256), 0, st, P.d_pyr, P.pyr_bytes, P.d_lev, P.d_cells, P.ncells,
@@ -1093,6 +1098,7 @@ int orb_run(hvo_ctx *ctx, int n)
                            P.d_cell_kp, P.d_cell_cnt, ctx->p.orb_ini_th_fast, ctx->p.orb_min_th_fast, P.d_flags);
     hvo_prof_end(ctx, id);
     if (ctx->ev_fast && !ctx->serialize) { HVO_HIP(hipEventRecord(ctx->ev_fast, st)); ctx->fast_recorded = true; }
+    if (blur_late) { const int rb = run_blur(); if (rb) return rb; }
     id = hvo_prof_begin(ctx, "orb_octree", st);
     OctArgs oa;
     oa.lev = P.d_lev; oa.cell_kp = P.d_cell_kp; oa.cell_cnt = P.d_cell_cnt; oa.ncells = P.ncells;

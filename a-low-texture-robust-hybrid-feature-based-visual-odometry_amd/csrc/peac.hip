@@ -1891,6 +1891,10 @@ int peac_run(hvo_ctx *ctx, int n)
     a.meta = P->d_meta; a.extracted = P->d_extracted; a.segcap = P->segcap; a.poolcap = P->poolcap; a.nblk = P->nblk; a.Nw = P->Nw; a.Nh = P->Nh;
     a.c15 = P->c15; a.c60 = P->c60; a.hot = (HotNode *)P->d_hot; a.perm = nullptr; a.tqK = P->d_hkey; a.tqM1k = P->d_m1k; a.tqM1i = P->d_hid; a.tq_n0 = (P->segcap + 255) / 256;
     a.ang_factor = P->ang_factor; a.ang_near = P->ang_near;
+    if (ctx->sched == 6 && !ctx->serialize) {               // experiment: the streaming kernels of the other stages first, then the serial ones together
+        if (ctx->fast_recorded) HVO_HIP(hipStreamWaitEvent(st, ctx->ev_fast, 0));
+        if (ctx->lsd_pre_recorded) HVO_HIP(hipStreamWaitEvent(st, ctx->ev_lsd_pre, 0));
+    }
     id = hvo_prof_begin(ctx, "peac_cluster", st);
     // k_peac_cluster_lat (one frame per workgroup, queue in LDS, adjacency inline in 256-byte node records): an experiment in
     // trading memory round trips for instructions that did not pay (a lone wave issues one instruction every 5-8 cycles,
@@ -1941,6 +1945,7 @@ int peac_run(hvo_ctx *ctx, int n)
         const char *e2 = getenv("HVO_FLOOD_EPL");          // queue entries per thread and round (one-wave variant only)
         const int fe = e2 ? atoi(e2) : 1;
         r.perm = hvo_frame_perm(ctx, n);                   // one wave per frame for its whole life: frames of a SIMD decorrelated
+        if ((ctx->sched == 5 || ctx->sched == 7) && ctx->fast_recorded && !ctx->serialize) HVO_HIP(hipStreamWaitEvent(st, ctx->ev_fast, 0));      // experiment: the flood takes all LDS, k_fast_cells needs some
         { const char *e3 = getenv("HVO_FLOOD_PERM"); if (e3 && atoi(e3) == 0) r.perm = nullptr; }
         if (ft == 64 && fe == 2) hipLaunchKernelGGL((k_peac_flood<64, 2>), dim3(n), dim3(64), 0, st, r, P->d_adj);
         else if (ft == 64) hipLaunchKernelGGL((k_peac_flood<64, 1>), dim3(n), dim3(64), 0, st, r, P->d_adj);
