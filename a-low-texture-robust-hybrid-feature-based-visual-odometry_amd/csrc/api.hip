@@ -89,7 +89,7 @@ int hvo_create(const hvo_params *p, hvo_ctx **out)
         hipStreamCreateWithPriority(&ctx->s_peac, hipStreamNonBlocking, pr[2]) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lsd_pre, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fast, hipEventDisableTiming) != hipSuccess) { hvo_destroy(ctx); return HVO_ERR_HIP; }
-    { const char *e = getenv("HVO_SCHED"); if (e) ctx->sched = atoi(e); }
+    { const char *e = getenv("HVO_SCHED"); if (e) ctx->sched_cfg = atoi(e); }
     { const char *e = getenv("HVO_ORB_BLUR_LATE"); if (e) ctx->orb_blur_late = atoi(e) != 0; }
     int rc = orb_init_tables(ctx);
     if (rc) { hvo_destroy(ctx); return rc; }
@@ -169,6 +169,9 @@ int hvo_batch_run(hvo_ctx *ctx, unsigned stages)
     if ((stages & HVO_STAGE_PLANES) && !ctx->have_depth) return HVO_ERR_INVALID_ARG;
     // The serial stages go first so that their long single-wave kernels overlap the streaming ones (sched 0-2);
     // sched 3 / 4 (experiments): the plane stage is enqueued last, after LSD then ORB (3) or ORB then LSD (4)
+    // measured (profiles/r02_sched_sweep.txt): policy 5 wins once the batch fills the wave slots (8192 frames: 207 against 218 ms,
+    // 4096: 112 against 115), policy 1 below (2048 frames: 69 against 77 ms; 2048 frames of 1280x960: 344 against 387)
+    ctx->sched = ctx->sched_cfg >= 0 ? ctx->sched_cfg : (ctx->batch_n >= 3072 ? 5 : 1);
     const bool peac_last = ctx->sched >= 3 && ctx->sched != 5 && ctx->sched != 7 && !ctx->serialize;
     const bool orb_first = (ctx->sched == 5 || ctx->sched == 7) && !ctx->serialize && (stages & HVO_STAGE_ORB);      // sched 5 (experiment): ORB, planes (flood behind k_fast_cells), LSD
     if (orb_first) { ctx->fast_recorded = false; rc = orb_run(ctx, ctx->batch_n); if (rc) return rc; }

@@ -73,7 +73,8 @@ struct hvo_ctx {
     bool lsd_pre_recorded = false;
     hipEvent_t ev_fast = nullptr;          // recorded on the ORB stream after k_fast_cells (the only ORB kernel that needs LDS)
     bool fast_recorded = false;
-    int sched = 5;                         // overlap policy of hvo_batch_run, see api.hip
+    int sched = 1;                         // overlap policy in force (hvo_batch_run sets it per batch), see api.hip
+    int sched_cfg = -1;                    // HVO_SCHED, or -1 = by batch size: 5 from 3072 resident frames on, 1 below
     bool orb_blur_late = false;            // k_blur7 behind k_fast_cells instead of before it (HVO_ORB_BLUR_LATE)
     std::vector<std::pair<int, int *>> perms;   // launch orders (hvo_frame_perm), one device array per length asked for
     double cull_dis = 5.0, cull_angle = 2.5, cull_endpoint = 15.0;   // Frame::cullingLine(im, 5, 2.5, 15, 30), Frame.cc:934

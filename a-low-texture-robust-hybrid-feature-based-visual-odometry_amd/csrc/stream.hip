@@ -99,7 +99,7 @@ int hvo_stream_create(const hvo_params *p, const hvo_stream_params *sp, hvo_stre
     for (int i = 0; i < s->depth && !rc; i++) {
         StreamSlot &S = s->slot[i];
         if ((rc = hvo_create(&s->p, &S.ctx))) break;
-        S.ctx->sched = 0;                                      // no cross-stream ordering inside a slot: the frames overlap instead
+        S.ctx->sched = 0; S.ctx->sched_cfg = 0;                                      // no cross-stream ordering inside a slot: the frames overlap instead
         // Three HIP streams per frame in flight (points, lines, planes; priorities 0 / -1 / +1), as in the batch mode.  The runtime
         // maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues per priority level and streams that share a queue
         // serialise: measured (profiles/r02_stream_scaling.txt) 32.8 / 64.6 / 64.9 / 93.9 frames/s at 1 / 2 / 3 / 5 frames in
