@@ -89,6 +89,7 @@ int hvo_create(const hvo_params *p, hvo_ctx **out)
         hipStreamCreateWithPriority(&ctx->s_peac, hipStreamNonBlocking, pr[2]) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lsd_pre, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fast, hipEventDisableTiming) != hipSuccess) { hvo_destroy(ctx); return HVO_ERR_HIP; }
+    { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); if (hipStreamCreateWithPriority(&ctx->s_copy, hipStreamNonBlocking, hi) != hipSuccess) ctx->s_copy = nullptr; }
     { const char *e = getenv("HVO_SCHED"); if (e) ctx->sched_cfg = atoi(e); }
     { const char *e = getenv("HVO_ORB_BLUR_LATE"); if (e) ctx->orb_blur_late = atoi(e) != 0; }
     int rc = orb_init_tables(ctx);
@@ -113,6 +114,7 @@ void hvo_destroy(hvo_ctx *ctx)
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     for (int i = 0; i < 2; i++) if (ctx->ev_stage[i]) (void)hipEventDestroy(ctx->ev_stage[i]);
     for (auto &r : ctx->prof) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
+    if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->s_lsd) (void)hipStreamDestroy(ctx->s_lsd);
     if (ctx->s_peac) (void)hipStreamDestroy(ctx->s_peac);
@@ -142,19 +144,21 @@ int hvo_profile_last(const hvo_ctx *ctx, const char **names, float *ms, int cap)
     return n;
 }
 
+struct CopyHi { hvo_ctx *c; explicit CopyHi(hvo_ctx *c_) : c(c_) { c->copy_hi = true; } ~CopyHi() { c->copy_hi = false; } };
+
 int hvo_batch_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h)
 {
     if (!ctx || !in || n < 1) return HVO_ERR_INVALID_ARG;
+    CopyHi hi_(ctx);
     if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
-    // grey images and depth images travel on two streams at once (two DMA engines: one stream alone reaches ~23 GB/s of the link)
-    int rc = orb_upload(ctx, n, in, w, h, false);
+    // grey images, then depth images, one after the other: both at once (two streams, two DMA engines) upload no faster -- the link's
+    // ~23.6 GB/s is the bound -- and leave no engine to the download another context of a BatchPipeline is making meanwhile (measured:
+    // its download leg went from ~40 to 80-140 ms per 2048 frames)
+    int rc = orb_upload(ctx, n, in, w, h);
+    if (rc) return rc;
     ctx->have_depth = true;
     for (int f = 0; f < n; f++) if (!in[f].depth) ctx->have_depth = false;
-    int rc2 = (!rc && ctx->have_depth) ? peac_upload(ctx, n, in, w, h, false) : HVO_OK;
-    const hipError_t e1 = hipStreamSynchronize(ctx->stream), e2 = hipStreamSynchronize(ctx->s_peac);     // the host buffers are the caller's again on return
-    if (rc) return rc;
-    if (rc2) return rc2;
-    if (e1 != hipSuccess || e2 != hipSuccess) { ctx->last_error = std::string("hvo_batch_upload: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2); return HVO_ERR_HIP; }
+    if (ctx->have_depth) { rc = peac_upload(ctx, n, in, w, h); if (rc) return rc; }
     ctx->batch_n = n; ctx->batch_w = w; ctx->batch_h = h;
     ctx->last_stages = 0;                                  // nothing has been computed for this batch yet
     return HVO_OK;
@@ -215,6 +219,7 @@ int hvo_batch_run(hvo_ctx *ctx, unsigned stages)
 int hvo_batch_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
 {
     if (!ctx || !out || n < 1 || n > ctx->batch_n) return HVO_ERR_INVALID_ARG;
+    CopyHi hi_(ctx);
     if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
     for (int f = 0; f < n; f++) { out[f].status = HVO_OK; out[f].n_kp = out[f].n_kl = out[f].n_planes = 0; }
     // only what hvo_batch_run computed for THIS resident batch is reported: a stage that did not run leaves its counts

@@ -76,6 +76,7 @@ struct hvo_ctx {
     int sched = 1;                         // overlap policy in force (hvo_batch_run sets it per batch), see api.hip
     int sched_cfg = -1;                    // HVO_SCHED, or -1 = by batch size: 5 from 3072 resident frames on, 1 below
     bool orb_blur_late = false;            // k_blur7 behind k_fast_cells instead of before it (HVO_ORB_BLUR_LATE)
+    hipStream_t s_copy = nullptr; bool copy_hi = false;   // batch uploads / downloads go on a stream of their own, above the compute streams (hvo_copy_stream)
     std::vector<std::pair<int, int *>> perms;   // launch orders (hvo_frame_perm), one device array per length asked for
     double cull_dis = 5.0, cull_angle = 2.5, cull_endpoint = 15.0;   // Frame::cullingLine(im, 5, 2.5, 15, 30), Frame.cc:934
     bool last_cull = false;                // the resident batch was run with HVO_STAGE_LSD_CULL
@@ -175,6 +176,10 @@ void orb_free_plan(hvo_ctx *ctx);
 // workgroups a fixed stride apart, and frames a fixed stride apart in a batch tend to be alike (the same camera, or a synthetic
 // batch's period), so whole SIMDs got only long or only short frames and the kernel lasted as long as the unluckiest one.
 const int *hvo_frame_perm(hvo_ctx *ctx, int n);
+// Strided copies between pinned host memory and device slabs are executed by copy kernels, which queue like any other kernel: beside
+// another context's compute on streams of equal priority a BatchPipeline's download took 80-140 ms instead of 30.  hvo_batch_upload /
+// hvo_batch_download therefore move their copies to ctx->s_copy (highest priority); everything else keeps its compute stream's order.
+static inline hipStream_t hvo_copy_stream(hvo_ctx *c, hipStream_t dflt) { return (c->copy_hi && c->s_copy) ? c->s_copy : dflt; }
 int orb_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool sync = true);   // sync = false: the caller waits for ctx->stream
 int orb_run(hvo_ctx *ctx, int n);
 int orb_download(hvo_ctx *ctx, int n, hvo_frame_out *out);

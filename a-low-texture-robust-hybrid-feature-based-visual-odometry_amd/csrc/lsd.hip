@@ -1302,14 +1302,15 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
 
 int lsd_download(hvo_ctx *ctx, int n, hvo_frame_out *out, bool culled)
 {
+    const hipStream_t cs = hvo_copy_stream(ctx, ctx->s_lsd);
     LsdPlan *P = plan_of(ctx);
     if (!P) return HVO_ERR_INVALID_ARG;
     const hvo_keyline *d_kl = culled ? P->d_kl2 : P->d_kl; const uint8_t *d_desc = culled ? P->d_desc2 : P->d_desc;
     const double *d_fn = culled ? P->d_fn2 : P->d_fn; const int *d_nkl = culled ? P->d_nkl2 : P->d_nkl;
     std::vector<int> nk(n), fl(n);
-    HVO_HIP(hipMemcpyAsync(nk.data(), d_nkl, n * sizeof(int), hipMemcpyDeviceToHost, ctx->s_lsd));
-    HVO_HIP(hipMemcpyAsync(fl.data(), P->d_flags, n * sizeof(int), hipMemcpyDeviceToHost, ctx->s_lsd));
-    HVO_HIP(hipStreamSynchronize(ctx->s_lsd));
+    HVO_HIP(hipMemcpyAsync(nk.data(), d_nkl, n * sizeof(int), hipMemcpyDeviceToHost, cs));
+    HVO_HIP(hipMemcpyAsync(fl.data(), P->d_flags, n * sizeof(int), hipMemcpyDeviceToHost, cs));
+    HVO_HIP(hipStreamSynchronize(cs));
     std::vector<void *> d0(n, nullptr), d1(n, nullptr), d2(n, nullptr); std::vector<size_t> b0(n, 0), b1(n, 0), b2(n, 0);
     for (int f = 0; f < n; f++) {
         int m = nk[f];
@@ -1324,11 +1325,11 @@ int lsd_download(hvo_ctx *ctx, int n, hvo_frame_out *out, bool culled)
         }
         out[f].n_kl = m;
     }
-    int rc = hvo_staged_d2h(ctx, ctx->s_lsd, d_kl, (size_t)P->nfeat * sizeof(hvo_keyline), n, d0.data(), b0.data());
+    int rc = hvo_staged_d2h(ctx, cs, d_kl, (size_t)P->nfeat * sizeof(hvo_keyline), n, d0.data(), b0.data());
     if (rc) return rc;
-    if ((rc = hvo_staged_d2h(ctx, ctx->s_lsd, d_desc, (size_t)P->nfeat * 32, n, d1.data(), b1.data()))) return rc;
-    if ((rc = hvo_staged_d2h(ctx, ctx->s_lsd, d_fn, (size_t)P->nfeat * 24, n, d2.data(), b2.data()))) return rc;
-    HVO_HIP(hipStreamSynchronize(ctx->s_lsd));
+    if ((rc = hvo_staged_d2h(ctx, cs, d_desc, (size_t)P->nfeat * 32, n, d1.data(), b1.data()))) return rc;
+    if ((rc = hvo_staged_d2h(ctx, cs, d_fn, (size_t)P->nfeat * 24, n, d2.data(), b2.data()))) return rc;
+    HVO_HIP(hipStreamSynchronize(cs));
     return HVO_OK;
 }
 

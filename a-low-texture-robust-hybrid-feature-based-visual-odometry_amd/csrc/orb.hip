@@ -1032,23 +1032,24 @@ static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch)
 
 int orb_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool sync)
 {
+    const hipStream_t cs = hvo_copy_stream(ctx, ctx->stream);
     int rc = orb_ensure_plan(ctx, w, h, std::max(n, ctx->p.max_batch));
     if (rc) return rc;
     OrbPlan &P = ctx->orb;
     for (int f = 0; f < n; f++) if (!in[f].gray) return HVO_ERR_INVALID_ARG;
     // Frames that are dense (stride == width == device pitch) and evenly spaced in host memory go up as ONE 2-D copy whose "rows"
     // are whole frames: a copy call costs ~20 us, which at one call per frame was the whole upload (2048 frames: 82 ms for 0.6 GB).
-    bool regular = n > 1 && P.lev[0].pitch == w;
+    bool regular = n > 1 && P.lev[0].pitch == w && !(getenv("HVO_UPLOAD_SINGLE") && atoi(getenv("HVO_UPLOAD_SINGLE")) == 0);
     const ptrdiff_t step = n > 1 ? in[1].gray - in[0].gray : 0;
     for (int f = 0; regular && f < n; f++) regular = in[f].gray_stride == w && in[f].gray - in[0].gray == step * f;
     if (regular && step >= (ptrdiff_t)w * h) {
-        HVO_HIP(hipMemcpy2DAsync(P.d_pyr, P.pyr_bytes, in[0].gray, (size_t)step, (size_t)w * h, n, hipMemcpyHostToDevice, ctx->stream));
+        HVO_HIP(hipMemcpy2DAsync(P.d_pyr, P.pyr_bytes, in[0].gray, (size_t)step, (size_t)w * h, n, hipMemcpyHostToDevice, cs));
     } else {
         for (int f = 0; f < n; f++)
             HVO_HIP(hipMemcpy2DAsync(P.d_pyr + (size_t)f * P.pyr_bytes, P.lev[0].pitch, in[f].gray, in[f].gray_stride,
-                                     w, h, hipMemcpyHostToDevice, ctx->stream));
+                                     w, h, hipMemcpyHostToDevice, cs));
     }
-    if (sync) HVO_HIP(hipStreamSynchronize(ctx->stream));
+    if (sync) HVO_HIP(hipStreamSynchronize(cs));
     return HVO_OK;
 }
 
@@ -1121,11 +1122,12 @@ int orb_run(hvo_ctx *ctx, int n)
 
 int orb_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
 {
+    const hipStream_t cs = hvo_copy_stream(ctx, ctx->stream);
     OrbPlan &P = ctx->orb;
     std::vector<int> nk(n), fl(n);
-    HVO_HIP(hipMemcpyAsync(nk.data(), P.d_nkp, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HVO_HIP(hipMemcpyAsync(fl.data(), P.d_flags, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    HVO_HIP(hipMemcpyAsync(nk.data(), P.d_nkp, n * sizeof(int), hipMemcpyDeviceToHost, cs));
+    HVO_HIP(hipMemcpyAsync(fl.data(), P.d_flags, n * sizeof(int), hipMemcpyDeviceToHost, cs));
+    HVO_HIP(hipStreamSynchronize(cs));
     std::vector<void *> dk(n, nullptr), dd(n, nullptr); std::vector<size_t> bk(n, 0), bd(n, 0);
     for (int f = 0; f < n; f++) {
         int m = nk[f];
@@ -1139,9 +1141,9 @@ int orb_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
         }
         out[f].n_kp = m;
     }
-    int rc = hvo_staged_d2h(ctx, ctx->stream, P.d_kp, (size_t)P.kp_cap * sizeof(hvo_keypoint), n, dk.data(), bk.data());
+    int rc = hvo_staged_d2h(ctx, cs, P.d_kp, (size_t)P.kp_cap * sizeof(hvo_keypoint), n, dk.data(), bk.data());
     if (rc) return rc;
-    if ((rc = hvo_staged_d2h(ctx, ctx->stream, P.d_desc, (size_t)P.kp_cap * 32, n, dd.data(), bd.data()))) return rc;
-    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    if ((rc = hvo_staged_d2h(ctx, cs, P.d_desc, (size_t)P.kp_cap * 32, n, dd.data(), bd.data()))) return rc;
+    HVO_HIP(hipStreamSynchronize(cs));
     return HVO_OK;
 }

@@ -1854,23 +1854,24 @@ int peac_prepare(hvo_ctx *ctx, int w, int h, int batch, PeacView *v)
 
 int peac_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool sync)
 {
+    const hipStream_t cs = hvo_copy_stream(ctx, ctx->s_peac);
     int rc = peac_ensure_plan(ctx, w, h, std::max(n, ctx->p.max_batch));
     if (rc) return rc;
     PeacPlan *P = plan_of(ctx);
     const size_t dframe = (size_t)P->pitch * (h + 1);
     for (int f = 0; f < n; f++) if (!in[f].depth) return HVO_ERR_INVALID_ARG;
     // dense, evenly spaced host frames: one 2-D copy whose rows are whole frames (see orb_upload)
-    bool regular = n > 1 && P->pitch == w;
+    bool regular = n > 1 && P->pitch == w && !(getenv("HVO_UPLOAD_SINGLE") && atoi(getenv("HVO_UPLOAD_SINGLE")) == 0);
     const ptrdiff_t step = n > 1 ? (const char *)in[1].depth - (const char *)in[0].depth : 0;
     for (int f = 0; regular && f < n; f++) regular = in[f].depth_stride == (int)(w * sizeof(uint16_t)) && (const char *)in[f].depth - (const char *)in[0].depth == step * f;
     if (regular && step >= (ptrdiff_t)((size_t)w * h * sizeof(uint16_t))) {
-        HVO_HIP(hipMemcpy2DAsync(P->d_depth, dframe * sizeof(uint16_t), in[0].depth, (size_t)step, (size_t)w * h * sizeof(uint16_t), n, hipMemcpyHostToDevice, ctx->s_peac));
+        HVO_HIP(hipMemcpy2DAsync(P->d_depth, dframe * sizeof(uint16_t), in[0].depth, (size_t)step, (size_t)w * h * sizeof(uint16_t), n, hipMemcpyHostToDevice, cs));
     } else {
         for (int f = 0; f < n; f++)
             HVO_HIP(hipMemcpy2DAsync(P->d_depth + f * dframe, P->pitch * sizeof(uint16_t), in[f].depth, in[f].depth_stride,
-                                     (size_t)w * sizeof(uint16_t), h, hipMemcpyHostToDevice, ctx->s_peac));
+                                     (size_t)w * sizeof(uint16_t), h, hipMemcpyHostToDevice, cs));
     }
-    if (sync) HVO_HIP(hipStreamSynchronize(ctx->s_peac));
+    if (sync) HVO_HIP(hipStreamSynchronize(cs));
     return HVO_OK;
 }
 
@@ -1961,11 +1962,12 @@ int peac_run(hvo_ctx *ctx, int n)
 
 int peac_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
 {
+    const hipStream_t cs = hvo_copy_stream(ctx, ctx->s_peac);
     PeacPlan *P = plan_of(ctx);
     if (!P) return HVO_ERR_INVALID_ARG;
     std::vector<int> meta((size_t)n * 16);
-    HVO_HIP(hipMemcpyAsync(meta.data(), P->d_meta, meta.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->s_peac));
-    HVO_HIP(hipStreamSynchronize(ctx->s_peac));
+    HVO_HIP(hipMemcpyAsync(meta.data(), P->d_meta, meta.size() * sizeof(int), hipMemcpyDeviceToHost, cs));
+    HVO_HIP(hipStreamSynchronize(cs));
     const size_t npix = (size_t)P->w * P->h;
     std::vector<void *> dl(n, nullptr), dl8(n, nullptr), dp(n, nullptr); std::vector<size_t> bl(n, 0), bl8(n, 0), bp(n, 0);
     bool any32 = false, any8 = false;
@@ -1983,10 +1985,10 @@ int peac_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
         out[f].n_planes = m;
     }
     int rc = HVO_OK;
-    if (any32 && (rc = hvo_staged_d2h(ctx, ctx->s_peac, P->d_labels, (npix + 3) & ~(size_t)3, n, dl.data(), bl.data(), 1))) return rc;
-    if (any8 && (rc = hvo_staged_d2h(ctx, ctx->s_peac, P->d_labels, (npix + 3) & ~(size_t)3, n, dl8.data(), bl8.data(), 0))) return rc;
-    if ((rc = hvo_staged_d2h(ctx, ctx->s_peac, P->d_planes, (size_t)MAX_PLANES * sizeof(hvo_plane), n, dp.data(), bp.data()))) return rc;
-    HVO_HIP(hipStreamSynchronize(ctx->s_peac));
+    if (any32 && (rc = hvo_staged_d2h(ctx, cs, P->d_labels, (npix + 3) & ~(size_t)3, n, dl.data(), bl.data(), 1))) return rc;
+    if (any8 && (rc = hvo_staged_d2h(ctx, cs, P->d_labels, (npix + 3) & ~(size_t)3, n, dl8.data(), bl8.data(), 0))) return rc;
+    if ((rc = hvo_staged_d2h(ctx, cs, P->d_planes, (size_t)MAX_PLANES * sizeof(hvo_plane), n, dp.data(), bp.data()))) return rc;
+    HVO_HIP(hipStreamSynchronize(cs));
     return HVO_OK;
 }
 
