@@ -82,14 +82,17 @@ int hvo_create(const hvo_params *p, hvo_ctx **out)
     if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) { delete ctx; return HVO_ERR_NO_DEVICE; }
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete ctx; return HVO_ERR_NO_DEVICE; }   // code object is gfx950 only
     // stream priorities (experiment knob HVO_PRIO="orb,lsd,peac", lower number = higher priority)
-    int pr[3] = { 0, 0, 0 };           // measured (profiles/r02_sched_sweep.txt): equal priorities with sched 2; round 1's best was 0,-1,1
+    // Three priority classes, not one: a priority class has its own hardware queues (4 by default), and the streamed mode keeps
+    // depth x 3 streams busy -- with equal priorities its frames in flight serialised (92 -> 65 frames/s at depth 4).  For the
+    // batch that fills the machine equal priorities are 1.5 % faster (profiles/r02_sched_sweep.txt): contexts made for one get them.
+    int pr[3] = { 0, -1, 1 };
+    if (ctx->p.max_batch >= 3072) pr[1] = pr[2] = 0;
     { const char *e = getenv("HVO_PRIO"); if (e) sscanf(e, "%d,%d,%d", &pr[0], &pr[1], &pr[2]); }
     if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, pr[0]) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->s_lsd, hipStreamNonBlocking, pr[1]) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->s_peac, hipStreamNonBlocking, pr[2]) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lsd_pre, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fast, hipEventDisableTiming) != hipSuccess) { hvo_destroy(ctx); return HVO_ERR_HIP; }
-    { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); if (hipStreamCreateWithPriority(&ctx->s_copy, hipStreamNonBlocking, hi) != hipSuccess) ctx->s_copy = nullptr; }
     { const char *e = getenv("HVO_SCHED"); if (e) ctx->sched_cfg = atoi(e); }
     { const char *e = getenv("HVO_ORB_BLUR_LATE"); if (e) ctx->orb_blur_late = atoi(e) != 0; }
     int rc = orb_init_tables(ctx);
@@ -144,7 +147,16 @@ int hvo_profile_last(const hvo_ctx *ctx, const char **names, float *ms, int cap)
     return n;
 }
 
-struct CopyHi { hvo_ctx *c; explicit CopyHi(hvo_ctx *c_) : c(c_) { c->copy_hi = true; } ~CopyHi() { c->copy_hi = false; } };
+// (the copy stream is created on first use: contexts of the streamed mode never need one, and every stream costs a hardware queue)
+struct CopyHi {
+    hvo_ctx *c;
+    explicit CopyHi(hvo_ctx *c_) : c(c_)
+    {
+        if (!c->s_copy) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); if (hipStreamCreateWithPriority(&c->s_copy, hipStreamNonBlocking, hi) != hipSuccess) c->s_copy = nullptr; }
+        c->copy_hi = true;
+    }
+    ~CopyHi() { c->copy_hi = false; }
+};
 
 int hvo_batch_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h)
 {
