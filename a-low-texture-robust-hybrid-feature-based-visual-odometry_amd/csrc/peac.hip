@@ -783,15 +783,23 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
         HotNode *hp = hot + (p < 0 ? 0 : p);
         const bool live = act;                                 // every queued node is in use (nothing is deleted lazily)
         const int pcnt = live ? n_cnt : 0, poff = n_off, pN = n_N, prid = n_rid, pdsr = n_dsr, pdss = n_dss;
-        // popped node: sums and normal, uniform per group -> 12 doubles of LDS per group instead of 24 registers in every lane
-        // (the kernel's register count decides how many waves of OTHER kernels fit beside it)
+        // popped node: sums and normal, uniform per group; staged in LDS for the -DHVO_PEAC_PS_LDS form (see below)
         if (gl == 0) {
 #pragma unroll
             for (int q = 0; q < 9; q++) psl[q] = nps[q];
             psl[9] = npn[0]; psl[10] = npn[1]; psl[11] = npn[2];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifndef HVO_PEAC_PS_LDS         // default: 24 registers per lane (56 ms alone); -DHVO_PEAC_PS_LDS: 12 doubles of LDS per group (157 registers, 60 ms alone,
+                               // more room for the kernels beside it: worth 15 ms of the step under overlap policy 1, nothing under policy 5)
+        double ps_r[9], pn_r[3];
+#pragma unroll
+        for (int q = 0; q < 9; q++) ps_r[q] = nps[q];
+        pn_r[0] = npn[0]; pn_r[1] = npn[1]; pn_r[2] = npn[2];
+        const double *ps = ps_r, *pn = pn_r;
+#else
         const double *ps = psl, *pn = psl + 9;
+#endif
         const int a0 = gl < pcnt ? a0n : -1;                   // first chunk of p's list, reused by the merge
         // ---- evaluate the merge with every neighbour, one candidate per lane; each lane keeps its best ----
         bool bhas = false; double bm = 0; int bid = 0x7FFFFFFF, bN = 0, gid = 0x7FFFFFFF, xid = -1;
