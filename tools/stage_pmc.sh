@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counter passes over one stage alone (tools/stage_batch_sweep.py STAGE 8192): memory-pipeline view of its kernels.
-#   bash tools/planes_pmc.sh [planes|lsd|orb]         (through gpurun, from the repo root)
+#   bash tools/stage_pmc.sh [planes|lsd|orb]         (through gpurun, from the repo root)
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 ST=${1:-planes}
