@@ -72,3 +72,31 @@ def test_stress_depth(gpu_ctx, orc, synth):
              and np.allclose(pg["normal"], po["normal"], rtol=1e-9, atol=1e-12) and np.allclose(pg["mse"], po["mse"], rtol=1e-9, atol=1e-12)))
         if not ok: bad.append((name, len(pg), len(po)))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("env", [{"HVO_SCHED": "5"}, {"HVO_SCHED": "2", "HVO_PRIO": "0,0,0"}, {"HVO_SCHED": "0", "HVO_FRAME_PERM": "0", "HVO_PEAC_PERM": "0"},
+                                 {"HVO_SCHED": "5", "HVO_PEAC_GL": "16", "HVO_FLOOD_T": "64", "HVO_LSD_DENSE": "1", "HVO_ORB_BLUR_LATE": "1"}])
+def test_overlap_policy_and_launch_order_do_not_change_results(hvo, orc, synth, monkeypatch, env):
+    """which stream waits for which kernel (HVO_SCHED), the stream priorities and the order in which the serial kernels take their
+    frames (hvo_frame_perm; 11 frames: not a power of two) are scheduling only: every configuration returns the oracle's results"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = 11
+    gray = np.stack([synth.make_gray("std" if i % 3 else "lowtex", 0x5EED3000 + i) for i in range(n)])
+    depth = np.stack([synth.make_depth(0x5EED3000 + i) for i in range(n)])
+    ctx = hvo.Context(max_batch=n)
+    try:
+        ctx.batch_upload(gray, depth)
+        ctx.batch_run(hvo.STAGE_ALL)
+        res = ctx.batch_download(hvo.STAGE_ALL)
+    finally:
+        ctx.close()
+    o = orc.Orb()
+    for b in (0, 4, 7, 10):
+        assert res[b]["status"] == 0
+        kp_o, dd_o = o.extract(gray[b])
+        assert len(res[b]["kp"]) == len(kp_o) and np.array_equal(res[b]["desc"], dd_o)
+        kl_o, d_o, fn_o = orc.line_extract(gray[b])
+        assert len(res[b]["kl"]) == len(kl_o) and np.array_equal(res[b]["ldesc"], d_o)
+        lo, po = orc.peac(depth[b])
+        assert np.array_equal(res[b]["labels"], lo) and len(res[b]["planes"]) == len(po)
