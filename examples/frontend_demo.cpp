@@ -45,6 +45,24 @@ int main(int argc, char **argv)
         printf("kp %zu desc %016llx lines %zu ldesc %016llx planes %d labels %016llx matches %d\n", kps.size(),
                (unsigned long long)fnv(desc.data(), desc.size()), kls.size(), (unsigned long long)fnv(ldesc.data(), ldesc.size()),
                planes.plane_num_, (unsigned long long)fnv(planes.membership.data(), planes.membership.size() * 4), nm);
+        // round 2: isLineGood, the vanishing-point clustering, the ComputePlanes tail, one frame through the streamed mode
+        lsd.setCamera(535.4f, 539.2f, 320.1f, 247.6f, 1.0f / 5000.0f);
+        std::vector<hvo_line3d> l3; lsd.isLineGood(kls, hvo::Image16{ depth.data(), W, H, W * 2 }, 7u, l3);
+        int good = 0; for (const hvo_line3d &l : l3) good += l.good;
+        std::vector<int32_t> vpi; const hvo_vp_result vp = lsd.line2Vps(kls, 7u, vpi);
+        int vc[4] = { 0, 0, 0, 0 }; for (int32_t v : vpi) vc[v]++;
+        std::vector<hvo_plane_cloud> pc; std::vector<float> xyz; planes.planeClouds(0.05, pc, xyz);
+        int valid = 0; for (const hvo_plane_cloud &c : pc) valid += c.valid;
+        std::vector<hvo_surface_normal> sn; planes.surfaceNormals(sn);
+        hvo_params p; hvo_default_params(&p);
+        hvo_stream_params sp = hvo_stream_params(); sp.width = W; sp.height = H; sp.depth = 2; sp.stages = HVO_STAGE_ORB | HVO_STAGE_LSD | HVO_STAGE_PLANES; sp.bf = 40.f;
+        hvo::FrameStream fs(p, sp);
+        const int64_t t = fs.submit(hvo::Image8{ gray.data(), W, H, W }, hvo::Image16{ depth.data(), W, H, W * 2 });
+        std::vector<hvo::KeyPoint> skp(fs.kpCap()); std::vector<uint8_t> sdesc((size_t)fs.kpCap() * 32);
+        hvo_frame_out fo = hvo_frame_out(); fo.kp = skp.data(); fo.desc = sdesc.data(); fo.kp_cap = fs.kpCap();
+        fs.collect(t, fo);
+        printf("l3d %d vp %d %d %d %d best %d clouds %d cloudpts %zu normals %zu stream %d %016llx\n", good, vc[0], vc[1], vc[2], vc[3], vp.best, valid, xyz.size() / 3,
+               sn.size(), fo.n_kp, (unsigned long long)fnv(sdesc.data(), (size_t)fo.n_kp * 32));
     } catch (const hvo::Error &e) { fprintf(stderr, "hvo error: %s\n", e.what()); return 1; }
     return 0;
 }

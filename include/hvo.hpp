@@ -123,6 +123,27 @@ public:
         check(hvo_extract_lsd_culled(ctx_->get(), image.data, image.width, image.height, image.stride, keylines.data(), descriptors.data(), lineVec2d.data(), cap, &n), "hvo_extract_lsd_culled");
         keylines.resize(n); descriptors.resize((size_t)n * 32); lineVec2d.resize((size_t)n * 3);
     }
+    // Frame::isLineGood (Frame.cc:1205-1322): the 3-D line of every key line from the raw depth image; intrinsics and depth factor
+    // are the constructor's (setCamera); the reference's time-seeded rand() is an explicit seed here
+    void setCamera(float fx, float fy, float cx, float cy, float depthMapFactor)
+    {
+        hvo_params p; hvo_default_params(&p);
+        p.lsd_num_octaves = numOctaves_; p.lsd_scale = scale_; p.lsd_nfeatures = nfeat_; p.fx = fx; p.fy = fy; p.cx = cx; p.cy = cy; p.depth_map_factor = depthMapFactor;
+        ctx_.reset(new Context(p));
+    }
+    void isLineGood(const std::vector<KeyLine> &keylines, const Image16 &depth, uint32_t seed, std::vector<hvo_line3d> &lines3d)
+    {
+        lines3d.assign(keylines.size(), hvo_line3d());
+        if (keylines.empty() || depth.empty()) return;
+        check(hvo_lines_3d(ctx_->get(), keylines.data(), (int)keylines.size(), depth.data, depth.width, depth.height, depth.stride, seed, lines3d.data()), "hvo_lines_3d");
+    }
+    // the vanishing-point block of the Frame constructor (Frame.cc:328-337): tmp_vps and local_vp_ids (3 = no structure line)
+    hvo_vp_result line2Vps(const std::vector<KeyLine> &keylines, uint32_t seed, std::vector<int32_t> &vp_idx, double thAngle = 1.0 / 180.0 * 3.14159265358979323846)
+    {
+        hvo_vp_result r; vp_idx.assign(keylines.size(), 3);
+        check(hvo_vanishing_points(ctx_->get(), keylines.data(), (int)keylines.size(), seed, thAngle, &r, vp_idx.data(), nullptr), "hvo_vanishing_points");
+        return r;
+    }
     int GetLevels() const { return numOctaves_; }
     float GetScaleFactor() const { return scale_; }
 private:
@@ -161,6 +182,25 @@ public:
         planes.resize(n); plane_num_ = n;
         plane_vertices_.assign(n, std::vector<int>());
         for (int i = 0; i < w * h; i++) if (membership[i] >= 0) plane_vertices_[membership[i]].push_back(i);   // raster order, like refineDetails
+    }
+    // the tail of Frame::ComputePlanes (Frame.cc:2110-2212): per plane the 0.1 m voxel cloud, the distance gate and the RANSAC refit
+    // (mvPlanePoints / mvPlaneCoefficients = the entries with valid == 1), and the integral-image surface normals (vSurfaceNormal)
+    void planeClouds(double distanceThreshold, std::vector<hvo_plane_cloud> &clouds, std::vector<float> &xyz, int cap = 200000)
+    {
+        clouds.assign(planes.size(), hvo_plane_cloud()); xyz.assign((size_t)cap * 3, 0.f);
+        int total = 0;
+        if (!planes.empty())
+            check(hvo_plane_clouds(ctx_->get(), depth_.data, depth_.width, depth_.height, depth_.stride, membership.data(), planes.data(), (int)planes.size(),
+                                   distanceThreshold, xyz.data(), cap, clouds.data(), &total), "hvo_plane_clouds");
+        xyz.resize((size_t)total * 3);
+    }
+    void surfaceNormals(std::vector<hvo_surface_normal> &normals)
+    {
+        const int cap = (depth_.height / 3 / 2 + 1) * (depth_.width / 3 / 2 + 1);
+        normals.assign(cap, hvo_surface_normal());
+        int n = 0;
+        check(hvo_surface_normals(ctx_->get(), depth_.data, depth_.width, depth_.height, depth_.stride, normals.data(), cap, &n), "hvo_surface_normals");
+        normals.resize(n);
     }
 private:
     int device_; Image16 depth_{ nullptr, 0, 0, 0 };
@@ -282,6 +322,46 @@ public:
     }
 private:
     hvo_ctx *ctx_;
+};
+
+
+// One camera, one frame at a time (Tracking.cc:262 -> Frame.cc:205-233, then the matching of Tracking.cc:2299 / 2396): a ring of
+// frames in flight whose results stay on the device for matching against the previous frame (hvo_stream_*, see hvo.h).
+class FrameStream {
+public:
+    FrameStream(const hvo_params &p, const hvo_stream_params &sp)
+    {
+        check(hvo_stream_create(&p, &sp, &s_), "hvo_stream_create");
+        check(hvo_stream_capacity(s_, &kp_cap_, &kl_cap_, &pl_cap_), "hvo_stream_capacity");
+    }
+    ~FrameStream() { if (s_) hvo_stream_destroy(s_); }
+    FrameStream(const FrameStream &) = delete;
+    FrameStream &operator=(const FrameStream &) = delete;
+    int64_t submit(const Image8 &gray, const Image16 &depth)
+    {
+        int64_t t = -1;
+        check(hvo_stream_submit(s_, gray.data, gray.stride, depth.data, depth.stride, &t), "hvo_stream_submit");
+        return t;
+    }
+    bool done(int64_t ticket) { const int r = hvo_stream_poll(s_, ticket); if (r < 0) throw Error(r, "hvo_stream_poll"); return r == 1; }
+    // waits for the frame; any pointer of out may be null (hvo_batch_download's conventions)
+    void collect(int64_t ticket, hvo_frame_out &out, hvo_keypoint *kp_un = nullptr, float *uright = nullptr, float *zdepth = nullptr)
+    {
+        check(hvo_stream_collect(s_, ticket, &out, kp_un, uright, zdepth), "hvo_stream_collect");
+    }
+    // LSDmatcher::match / FrameBFMatch / SearchDouble between two resident frames (mode = HVO_LINE_MATCH_*)
+    int matchLines(int64_t from, int64_t to, int mode, float th, float nnratio, std::vector<int32_t> &matches12)
+    {
+        matches12.assign(kl_cap_, -1);
+        int nfrom = 0, nm = 0;
+        check(hvo_stream_match_lines(s_, from, to, mode, th, nnratio, matches12.data(), &nfrom, &nm), "hvo_stream_match_lines");
+        matches12.resize(nfrom);
+        return nm;
+    }
+    hvo_stream *get() const { return s_; }
+    int kpCap() const { return kp_cap_; } int klCap() const { return kl_cap_; } int plCap() const { return pl_cap_; }
+private:
+    hvo_stream *s_ = nullptr; int kp_cap_ = 0, kl_cap_ = 0, pl_cap_ = 0;
 };
 
 }  // namespace hvo

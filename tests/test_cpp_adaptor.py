@@ -48,3 +48,13 @@ def test_cpp_demo_matches_oracle(tmp_path, orc, synth):
     assert int(out[5]) == len(kl_o) and int(out[7], 16) == _fnv(ld_o.tobytes())
     assert int(out[9]) == len(pl_o) and int(out[11], 16) == _fnv(lab_o.tobytes())
     assert int(out[13]) == nm
+    # second line: "l3d GOOD vp N0 N1 N2 N3 best B clouds VALID cloudpts N normals N stream NKP HASH"
+    out = out[14:]
+    l3 = orc.lines_3d(kl_o, d, seed=7)
+    vp = orc.vanishing_points(kl_o, seed=7)
+    pcs, cloud = orc.plane_clouds(d, lab_o, pl_o, dist_th=0.05)
+    sn = orc.surface_normals(d)
+    assert int(out[1]) == int(l3["good"].sum())
+    assert [int(x) for x in out[3:7]] == np.bincount(vp["vp_idx"], minlength=4).tolist()
+    assert int(out[10]) == int(pcs["valid"].sum()) and int(out[12]) == len(cloud) and int(out[14]) == len(sn)
+    assert int(out[16]) == len(kp_o) and int(out[17], 16) == _fnv(d_o.tobytes())
