@@ -919,8 +919,8 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
         if (no_merge) { PT_CNT(11, 1) }
         PT(4)
         // From here on an iteration is three independent chains of dependent loads: pass B (the partner's list -> its members'
-        // list headers -> their lists), pass A (p's members' list headers -> their lists) and the heap (one level of children
-        // after the other).  They are issued together, stage by stage, so that a stage costs ONE memory round trip for all
+        // list headers -> their lists), pass A (p's members' lists; their headers came with the evaluation) and the queue update.
+        // They are issued together, stage by stage, so that a stage costs ONE memory round trip for all
         // three (loads of a wave return in order): 3-4 round trips instead of the 8-9 of running them one after the other.
         //   * new.nbs = (p.nbs U nb.nbs) \ {p, nb}, and every member's own list gets p / nb replaced by the new id.  Pass B walks
         //     nb's list: a member that also holds p is left to pass A (read only here); the others are copied and get nb -> id.
@@ -1063,7 +1063,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
             if (gl == 0) hp->cnt = 0;
         }
         PT(7)
-        __syncthreads();                                       // this iteration's records, lists and heap stores
+        __syncthreads();                                       // this iteration's records, lists and queue stores
         // the next top's list (and all of its record when it is the node this iteration created)
         {
             const bool fresh = do_merge && ptop == id;
