@@ -25,6 +25,11 @@ _CSRC = os.path.join(_HERE, "csrc")
 # HVO_LIB: developer knob, points the binding at an experimental build of the same library (A/B measurements)
 _LIBPATH = os.environ.get("HVO_LIB") or os.path.join(_CSRC, "libhvo.so")
 _LIB = None
+# Load-order rule (multi-GPU path): torch's wheel carries its own HIP runtime; whichever of torch / libhvo.so is loaded first decides
+# which libamdhip64 the process runs on, and a process that loaded libhvo.so first cannot initialise torch.cuda afterwards.  lib()
+# records the order and torch_order_check() (called by every entry point that hands device memory to torch, dist.py) raises a clear
+# error instead of the runtime's obscure one.
+_LOADED_BEFORE_TORCH = False
 
 HVO_OK = 0
 STAGE_ORB, STAGE_LSD, STAGE_PLANES, STAGE_ALL = 1, 2, 4, 7
@@ -104,11 +109,22 @@ def build(force=False):
     subprocess.check_call(["make", "-s", "-j4", "-C", _CSRC])
 
 
+def torch_order_check():
+    """raise if libhvo.so was loaded into this process before torch (see _LOADED_BEFORE_TORCH): `import torch` must come first
+    in every process that shares device memory between the two (dist.device_slabs, dist.gather_device_slabs, bench.py --gpus N)"""
+    if _LIB is not None and _LOADED_BEFORE_TORCH:
+        raise RuntimeError("libhvo.so was loaded before torch in this process: torch.cuda cannot be initialised on top of it. "
+                           "Import torch (and call torch.cuda.init()) BEFORE the first hvo call in processes that use hvo_amd.dist.")
+
+
 def lib():
     global _LIB
     if _LIB is None:
         if not os.path.exists(_LIBPATH):
             raise HvoError(-3, "libhvo.so not built (run __graft_entry__.build())")
+        import sys
+        global _LOADED_BEFORE_TORCH
+        _LOADED_BEFORE_TORCH = "torch" not in sys.modules
         L = C.CDLL(_LIBPATH)
         L.hvo_strerror.restype = C.c_char_p
         L.hvo_strerror.argtypes = [C.c_int]

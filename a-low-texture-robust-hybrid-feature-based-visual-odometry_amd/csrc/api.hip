@@ -161,8 +161,8 @@ struct CopyHi {
 int hvo_batch_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h)
 {
     if (!ctx || !in || n < 1) return HVO_ERR_INVALID_ARG;
-    CopyHi hi_(ctx);
     if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    CopyHi hi_(ctx);                                       // after hipSetDevice: the copy stream is created on the CONTEXT's device, whatever the calling thread's was
     // grey images, then depth images, one after the other: both at once (two streams, two DMA engines) upload no faster -- the link's
     // ~23.6 GB/s is the bound -- and leave no engine to the download another context of a BatchPipeline is making meanwhile (measured:
     // its download leg went from ~40 to 80-140 ms per 2048 frames)
@@ -231,8 +231,8 @@ int hvo_batch_run(hvo_ctx *ctx, unsigned stages)
 int hvo_batch_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
 {
     if (!ctx || !out || n < 1 || n > ctx->batch_n) return HVO_ERR_INVALID_ARG;
-    CopyHi hi_(ctx);
     if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    CopyHi hi_(ctx);                                       // after hipSetDevice (see hvo_batch_upload)
     for (int f = 0; f < n; f++) { out[f].status = HVO_OK; out[f].n_kp = out[f].n_kl = out[f].n_planes = 0; }
     // only what hvo_batch_run computed for THIS resident batch is reported: a stage that did not run leaves its counts
     // at 0 (its device slabs hold the results of some earlier batch or nothing at all)

@@ -171,6 +171,8 @@ int hvo_stream_capacity(const hvo_stream *s, int *kp_cap, int *kl_cap, int *pl_c
     return HVO_OK;
 }
 
+static int stream_submit_enqueue(hvo_stream *s, StreamSlot &S, const uint8_t *gray, int gray_stride, const uint16_t *depth, int depth_stride);
+
 int hvo_stream_submit(hvo_stream *s, const uint8_t *gray, int gray_stride, const uint16_t *depth, int depth_stride, int64_t *ticket)
 {
     if (!s || !gray || gray_stride < s->w || !ticket) return HVO_ERR_INVALID_ARG;
@@ -180,6 +182,25 @@ int hvo_stream_submit(hvo_stream *s, const uint8_t *gray, int gray_stride, const
     StreamSlot &S = s->slot[s->next % s->depth];
     if (S.busy) return HVO_ERR_BUSY;                           // the frame that used this slot has not been collected
     if (hipSetDevice(s->p.device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    const int rc = stream_submit_enqueue(s, S, gray, gray_stride, depth, depth_stride);
+    if (rc) {
+        // Part of the frame may be in flight (uploads reading the pinned staging, kernels, only some events recorded): drain the slot's
+        // three streams before handing it back, so that a retried submit does not overwrite staging an async copy is still reading and
+        // no later poll / collect waits on events of a frame that was never completely enqueued.
+        hvo_ctx *c = S.ctx;
+        (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->s_lsd); (void)hipStreamSynchronize(c->s_peac);
+        (void)hipGetLastError();
+        S.busy = false; S.ticket = -1;
+        return rc;
+    }
+    S.ticket = s->next; S.busy = true;
+    *ticket = s->next++;
+    return HVO_OK;
+}
+
+static int stream_submit_enqueue(hvo_stream *s, StreamSlot &S, const uint8_t *gray, int gray_stride, const uint16_t *depth, int depth_stride)
+{
+    const unsigned stages = s->sp.stages;
     hvo_ctx *c = S.ctx;
     const int w = s->w, h = s->h;
     const bool want_orb = (stages & HVO_STAGE_ORB) != 0, want_lsd = (stages & (HVO_STAGE_LSD | HVO_STAGE_LSD_CULL)) != 0, want_pl = (stages & HVO_STAGE_PLANES) != 0;
@@ -241,8 +262,6 @@ int hvo_stream_submit(hvo_stream *s, const uint8_t *gray, int gray_stride, const
         ST_HIP(hipMemcpyAsync(ho + L.fn, S.lv.d_fn, (size_t)s->nfeat * 24, hipMemcpyDeviceToHost, LS));
     }
     ST_HIP(hipEventRecord(S.ev_lsd, LS));
-    S.ticket = s->next; S.busy = true;
-    *ticket = s->next++;
     return HVO_OK;
 }
 
@@ -362,6 +381,11 @@ int hvo_stream_search_by_projection(hvo_stream *s, int64_t cur, int64_t last, in
     // the current frame's key-point count is needed on the host for the launch geometry: it arrived with the frame's download
     ST_HIP(hipEventSynchronize(C->ev_orb));
     const int nt = ((const int *)(C->h_out + s->lay.counts))[0];
+    // q_index addresses the last frame's key points and descriptors on the device: an index outside [0, n_last) would be an
+    // out-of-bounds gather there (a GPU fault aborts the process), so it is refused here
+    ST_HIP(hipEventSynchronize(Lz->ev_orb));
+    const int n_last = ((const int *)(Lz->h_out + s->lay.counts))[0];
+    for (int i = 0; i < nq; i++) if (q_index[i] < 0 || q_index[i] >= n_last) return HVO_ERR_INVALID_ARG;
     for (int i = 0; i < nq; i++) { match_idx[i] = -1; match_dist[i] = 256; }
     if (nt <= 0) return HVO_OK;
     char *d = s->d_ms, *hh = s->h_ms; size_t off = 0;

@@ -19,6 +19,7 @@
 #define VP_LO 360
 #define VP_CELLS (VP_LA * VP_LO)
 #define VP_MAX_LINES 1024
+#define VP_REDRAWS 64
 
 static __device__ __forceinline__ void vcross(const double *a, const double *b, double *c)
 {
@@ -116,7 +117,13 @@ __global__ __launch_bounds__(384) void k_vp_hyp(const double *__restrict__ para,
     const int i = blockIdx.x, j = threadIdx.x;
     unsigned rs = seed ^ (0x9E3779B9u * (unsigned)(i + 1)); if (rs == 0) rs = 0x6D2B79F5u;
     double vp1[3];
-    for (;;) {                                       // uniform over the block: every thread draws the same pair
+    // The reference redraws without bound (src/Frame.cc:487-491); with every pair of lines meeting at infinity that is a hang, on a GPU
+    // an unrecoverable one.  After VP_REDRAWS draws the group gives up: 360 zero hypotheses of score 0 (the rule of oracle/vps.c).
+    for (int tries = 0;; tries++) {                  // uniform over the block: every thread draws the same pair
+        if (tries >= VP_REDRAWS) {
+            if (j < VP_NUM2) { const size_t h = (size_t)i * VP_NUM2 + j; for (int q = 0; q < 9; q++) hyp[h * 9 + q] = 0.0; score[h] = 0.0; }
+            return;
+        }
         const int idx1 = (int)((vxs32(rs) & 0x7fffffffu) % (unsigned)n);
         int idx2 = (int)((vxs32(rs) & 0x7fffffffu) % (unsigned)n);
         while (idx2 == idx1) idx2 = (int)((vxs32(rs) & 0x7fffffffu) % (unsigned)n);

@@ -62,6 +62,8 @@ def unpack_results(pkg, slabs, kp_cap, kl_cap, pl_cap=64):
 def device_slabs(ctx, n):
     """the first n frames' result slabs of ctx's resident batch as a CUDA uint8 tensor [n, slab_bytes]: packed on the device by
     hvo_batch_pack_results (no host round trip); the layout is slab_layout(pkg, *ctx.slab_layout()[:3])"""
+    from . import torch_order_check
+    torch_order_check()
     import torch
     _, _, _, sb = ctx.slab_layout()
     t = torch.empty((n, sb), dtype=torch.uint8, device="cuda")
@@ -72,7 +74,7 @@ def device_slabs(ctx, n):
 def gather_device_slabs(ctx, n, reduce_device="cuda"):
     """the path's one collective: all_gather of every rank's n result slabs.  With the nccl (= RCCL) backend the slabs go
     from HBM to HBM over xGMI (all_gather_into_tensor on the packed tensor); with gloo (CPU rehearsal) they are staged
-    through the host.  Returns (ranks whose slabs arrived with results in them, slab bytes per frame, gathered tensor)."""
+    through the host.  Returns (ranks whose slabs arrived with results in them, slab bytes per frame)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()

@@ -218,6 +218,8 @@ int  orc_vp_iterations(void);                                                   
 void orc_vp_line_params(const orc_keyline *kl, int n, double *para, double *length, double *ori);
 void orc_vp_sphere_grid(const double *para, const double *length, const double *ori, int n, double fx, double cx, double cy,
                         double *grid /* 90 x 360 */, double *raw /* before smoothing, or NULL */);
+void orc_vp_line2vps(const orc_keyline *kl, int n, float fx, float fy, float cx, float cy, const double *vps, double th_angle, int32_t *vp_idx);
+void orc_vp_hypothesis(const orc_keyline *kl, int n, float fx, float cx, float cy, uint32_t seed, int index, double *hyp9);
 int  orc_vanishing_points(const orc_keyline *kl, int n, float fx, float fy, float cx, float cy, uint32_t seed, double th_angle,
                           double *vps /* 3 x 3 */, int *best_idx, double *best_score, int32_t *vp_idx /* n */,
                           double *scores /* iterations * 360 or NULL */, double *grid /* 90 x 360 or NULL */);

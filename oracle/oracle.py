@@ -273,6 +273,30 @@ def vanishing_points(kl, seed=1, th_angle=None, fx=535.4, fy=539.2, cx=320.1, cy
     return out
 
 
+def vp_line2vps(kl, vps, th_angle=None, fx=535.4, fy=539.2, cx=320.1, cy=247.6):
+    """Frame::line2Vps (src/Frame.cc:708-778) for a given hypothesis triple -> vp_idx (n)"""
+    kl = np.ascontiguousarray(kl); n = len(kl)
+    if th_angle is None:
+        th_angle = 1.0 / 180.0 * 3.1415926535897932384626433832795
+    L = lib()
+    L.orc_vp_line2vps.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 4 + [C.c_void_p, C.c_double, C.c_void_p]
+    L.orc_vp_line2vps.restype = None
+    vps = np.ascontiguousarray(vps, np.float64); idx = np.full(n, 3, np.int32)
+    L.orc_vp_line2vps(_p(kl), n, fx, fy, cx, cy, _p(vps), th_angle, _p(idx))
+    return idx
+
+
+def vp_hypothesis(kl, seed, index, fx=535.4, cx=320.1, cy=247.6):
+    """the hypothesis triple (3,3) the path draws at `index` (group index // 360, rotation index % 360)"""
+    kl = np.ascontiguousarray(kl)
+    L = lib()
+    L.orc_vp_hypothesis.argtypes = [C.c_void_p, C.c_int] + [C.c_float] * 3 + [C.c_uint32, C.c_int, C.c_void_p]
+    L.orc_vp_hypothesis.restype = None
+    h = np.zeros((3, 3))
+    L.orc_vp_hypothesis(_p(kl), len(kl), fx, cx, cy, seed, index, _p(h))
+    return h
+
+
 PLANE_CLOUD_DT = np.dtype([("coef", "<f4", 4), ("valid", "<i4"), ("gate_ok", "<i4"), ("first", "<i4"), ("n_points", "<i4"), ("n_pixels", "<i4"), ("n_inliers", "<i4")])
 SURFACE_NORMAL_DT = np.dtype([("normal", "<f4", 3), ("position", "<f4", 3), ("frame_x", "<i4"), ("frame_y", "<i4")])
 

@@ -53,13 +53,19 @@ void orc_vp_line_params(const orc_keyline *kl, int n, double *para, double *leng
     }
 }
 
+#define ORC_VP_REDRAWS 64
 /* the 360 hypotheses of group i: hyp[(j * 3 + v) * 3 + c]; returns the pair drawn */
 static void vp_group(const double *para, int n, double fx, double cx, double cy, unsigned seed, int i, double *hyp, int *pair)
 {
     unsigned rs = seed ^ (0x9E3779B9u * (unsigned)(i + 1)); if (rs == 0) rs = 0x6D2B79F5u;
     const int numVp2 = 360; const double stepVp2 = 2.0 * CV_PI / numVp2;
     double vp1[3];
-    for (;;) {
+    /* The reference redraws without bound (`i--; continue`, src/Frame.cc:487-491) and never ends when every pair of lines meets at
+     * infinity (all lines parallel in the image).  Bounded here and in k_vp_hyp: after ORC_VP_REDRAWS draws the group gives up and its
+     * 360 hypotheses are all zero, which score 0 (vp_score skips z == 0) and can never be the best one unless every group gave up. */
+    int tries = 0;
+    for (;; tries++) {
+        if (tries >= ORC_VP_REDRAWS) { memset(hyp, 0, sizeof(double) * 9 * numVp2); pair[0] = pair[1] = -1; return; }
         const int idx1 = (int)((xs32(&rs) & 0x7fffffffu) % (unsigned)n);
         int idx2 = (int)((xs32(&rs) & 0x7fffffffu) % (unsigned)n);
         while (idx2 == idx1) idx2 = (int)((xs32(&rs) & 0x7fffffffu) % (unsigned)n);
@@ -142,31 +148,10 @@ static double vp_score(const double *grid, const double *h)
     return s;
 }
 
-/* The whole path.  vps: 3 x 3 (the best hypothesis); vp_idx: n entries (0..2, 3 = none: local_vp_ids / isStructLine = idx < 3);
- * scores: optional, iterations * 360 entries.  Returns 0, or -1 when n < 2 (the reference skips the path then). */
-int orc_vanishing_points(const orc_keyline *kl, int n, float fx_, float fy_, float cx_, float cy_, uint32_t seed, double th_angle,
-                         double *vps, int *best_idx, double *best_score, int32_t *vp_idx, double *scores, double *grid_out)
+/* line2Vps (src/Frame.cc:708-778): the cluster of every line under the hypothesis vps (3 x 3); 3 = none */
+void orc_vp_line2vps(const orc_keyline *kl, int n, float fx_, float fy_, float cx_, float cy_, const double *vps, double th_angle, int32_t *vp_idx)
 {
-    if (n < 2) return -1;
     const double fx = fx_, fy = fy_, cx = cx_, cy = cy_;
-    double *para = (double *)malloc(sizeof(double) * 5 * (size_t)n), *length = para + 3 * (size_t)n, *ori = length + n;
-    orc_vp_line_params(kl, n, para, length, ori);
-    const int it = orc_vp_iterations();
-    double *hyp = (double *)malloc(sizeof(double) * 9 * 360 * (size_t)it);
-    int pair[2];
-    for (int i = 0; i < it; i++) vp_group(para, n, fx, cx, cy, seed, i, hyp + (size_t)i * 360 * 9, pair);
-    double *grid = (double *)malloc(sizeof(double) * 90 * 360);
-    orc_vp_sphere_grid(para, length, ori, n, fx, cx, cy, grid, NULL);
-    if (grid_out) memcpy(grid_out, grid, sizeof(double) * 90 * 360);
-    int best = 0; double maxLength = 0.0;
-    for (int i = 0; i < it * 360; i++) {
-        const double s = vp_score(grid, hyp + (size_t)i * 9);
-        if (scores) scores[i] = s;
-        if (s > maxLength) { maxLength = s; best = i; }
-    }
-    memcpy(vps, hyp + (size_t)best * 9, 72);
-    *best_idx = best; *best_score = maxLength;
-    /* line2Vps */
     double vx[3], vy[3];
     for (int j = 0; j < 3; j++) { vx[j] = vps[3 * j] * fx / vps[3 * j + 2] + cx; vy[j] = vps[3 * j + 1] * fy / vps[3 * j + 2] + cy; }
     for (int i = 0; i < n; i++) {
@@ -189,6 +174,45 @@ int orc_vanishing_points(const orc_keyline *kl, int n, float fx_, float fy_, flo
         }
         vp_idx[i] = minAngle < th_angle ? bj : 3;
     }
+}
+
+/* hypothesis `index` (group index / 360, rotation index % 360) as the whole path draws it: 9 doubles */
+void orc_vp_hypothesis(const orc_keyline *kl, int n, float fx_, float cx_, float cy_, uint32_t seed, int index, double *hyp9)
+{
+    double *para = (double *)malloc(sizeof(double) * 5 * (size_t)n), *length = para + 3 * (size_t)n, *ori = length + n;
+    double *hyp = (double *)malloc(sizeof(double) * 9 * 360);
+    int pair[2];
+    orc_vp_line_params(kl, n, para, length, ori);
+    vp_group(para, n, fx_, cx_, cy_, seed, index / 360, hyp, pair);
+    memcpy(hyp9, hyp + (size_t)(index % 360) * 9, 72);
+    free(hyp); free(para);
+}
+
+/* The whole path.  vps: 3 x 3 (the best hypothesis); vp_idx: n entries (0..2, 3 = none: local_vp_ids / isStructLine = idx < 3);
+ * scores: optional, iterations * 360 entries.  Returns 0, or -1 when n < 2 (the reference skips the path then). */
+int orc_vanishing_points(const orc_keyline *kl, int n, float fx_, float fy_, float cx_, float cy_, uint32_t seed, double th_angle,
+                         double *vps, int *best_idx, double *best_score, int32_t *vp_idx, double *scores, double *grid_out)
+{
+    if (n < 2) return -1;
+    const double fx = fx_, cx = cx_, cy = cy_;
+    double *para = (double *)malloc(sizeof(double) * 5 * (size_t)n), *length = para + 3 * (size_t)n, *ori = length + n;
+    orc_vp_line_params(kl, n, para, length, ori);
+    const int it = orc_vp_iterations();
+    double *hyp = (double *)malloc(sizeof(double) * 9 * 360 * (size_t)it);
+    int pair[2];
+    for (int i = 0; i < it; i++) vp_group(para, n, fx, cx, cy, seed, i, hyp + (size_t)i * 360 * 9, pair);
+    double *grid = (double *)malloc(sizeof(double) * 90 * 360);
+    orc_vp_sphere_grid(para, length, ori, n, fx, cx, cy, grid, NULL);
+    if (grid_out) memcpy(grid_out, grid, sizeof(double) * 90 * 360);
+    int best = 0; double maxLength = 0.0;
+    for (int i = 0; i < it * 360; i++) {
+        const double s = vp_score(grid, hyp + (size_t)i * 9);
+        if (scores) scores[i] = s;
+        if (s > maxLength) { maxLength = s; best = i; }
+    }
+    memcpy(vps, hyp + (size_t)best * 9, 72);
+    *best_idx = best; *best_score = maxLength;
+    orc_vp_line2vps(kl, n, fx_, fy_, cx_, cy_, vps, th_angle, vp_idx);
     free(grid); free(hyp); free(para);
     return 0;
 }

@@ -137,3 +137,57 @@ def test_device_result_slabs_match_download():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, "-c", SLAB_SCRIPT % root], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "slabs ok" in p.stdout, p.stderr[-3000:]
+
+
+NCCL_SCRIPT = r"""
+import importlib, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+torch.cuda.init()
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "%d"
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+hvo = ge.package(); synth = importlib.import_module("hvo_amd.synth"); hd = importlib.import_module("hvo_amd.dist")
+g, d = synth.make_batch("std", 0x5EED1000, 2)
+ctx = hvo.Context(max_batch=2)
+ctx.batch_upload(g, d); ctx.batch_run(hvo.STAGE_ALL)
+seen, sb = hd.gather_device_slabs(ctx, 2)               # device tensor -> all_gather_into_tensor (RCCL), world size 1
+assert seen == 1 and sb == ctx.slab_layout()[3], (seen, sb)
+ctx.close()
+dist.destroy_process_group()
+print("nccl gather ok")
+"""
+
+ORDER_SCRIPT = r"""
+import importlib, sys
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+hvo = ge.package(); hd = importlib.import_module("hvo_amd.dist")
+ctx = hvo.Context(max_batch=1)                          # loads libhvo.so; torch has not been imported
+try:
+    hd.device_slabs(ctx, 1)
+except RuntimeError as e:
+    assert "before torch" in str(e), e
+    print("order rule ok")
+ctx.close()
+"""
+
+
+def test_rccl_gather_world1():
+    """the one collective of the path (dist.gather_device_slabs: packed device slabs -> all_gather_into_tensor) through backend
+    nccl (= RCCL) on hardware, world size 1: the code path an 8-GPU node runs, minus the peers"""
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    p = subprocess.run([sys.executable, "-c", NCCL_SCRIPT % (port, root)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "nccl gather ok" in p.stdout, p.stderr[-3000:]
+
+
+def test_torch_load_order_rule_is_reported():
+    """libhvo.so before torch: the package says so instead of letting torch.cuda fail obscurely"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", ORDER_SCRIPT % root], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "order rule ok" in p.stdout, p.stderr[-3000:]

@@ -80,6 +80,16 @@ def test_plane_clouds_parity(gpu_ctx, orc, synth, seed):
     assert np.array_equal(cg, co)                                                        # voxel centroids: bit-exact
     # the refit runs float atan2 / cos / sin (pcl::eigen33) in the host's and the device's libm: coefficients to 1e-5
     assert np.allclose(pg["coef"], po["coef"], rtol=0, atol=1e-5)
+    # n_inliers counts the points within dist_th of the REFIT plane, whose normal comes out of pcl::eigen33's float atan2 / cos / sin:
+    # a last-bit difference between the host's and the device's libm moves points that sit on the threshold.  Pinned exactly instead
+    # of tolerated: recounted here from the device's own coefficients in the reference's float order (dot4, then |.| < th in double),
+    # the device's count must be reproduced to the point -- so the libm calls inside eigen33 are the only thing that may differ.
+    for k in np.nonzero(pg["valid"] == 1)[0]:
+        pts = cg[pg["first"][k]: pg["first"][k] + pg["n_points"][k]].astype(np.float32)
+        for coef, cnt in ((pg["coef"][k], pg["n_inliers"][k]), (po["coef"][k], po["n_inliers"][k])):
+            c = coef.astype(np.float32)
+            dist = ((c[0] * pts[:, 0] + c[1] * pts[:, 1]) + c[2] * pts[:, 2]) + c[3]
+            assert int((np.abs(dist.astype(np.float64)) < 0.05).sum()) == int(cnt), (k, cnt)
     assert np.all(np.abs(pg["n_inliers"] - po["n_inliers"]) <= 2)
     assert po["valid"].sum() >= 2
     # a looser gate: more planes pass

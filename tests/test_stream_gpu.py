@@ -28,12 +28,13 @@ def check_frame(r, g, d, orc, orb):
     assert len(r["kp"]) == len(kpo) and np.array_equal(r["desc"], desco)
     for f in ("x", "y", "octave", "response", "size", "angle"):
         assert np.array_equal(r["kp"][f], kpo[f]), f
+    # whole key-line records, line functions and plane records, as the single-call tests compare them
     klo, ldo, fno = orc.line_extract(g)
-    assert len(r["kl"]) == len(klo) and np.array_equal(r["ldesc"], ldo)
-    assert np.array_equal(r["kl"]["sx"], klo["sx"]) and np.array_equal(r["kl"]["ey"], klo["ey"])
+    from test_lsd_gpu import check as check_lines
+    from test_peac_gpu import check as check_planes
+    check_lines(r["kl"], r["ldesc"], r["linefn"], klo, ldo, fno)
     lo, po = orc.peac(d)
-    assert np.array_equal(r["labels"], lo) and len(r["planes"]) == len(po)
-    assert np.array_equal(r["planes"]["n_points"], po["n_points"])
+    check_planes(r["labels"], r["planes"], lo, po)
     # TUM3: no distortion -> UndistortKeyPoints copies (src/Frame.cc:1703-1707); ComputeStereoFromRGBD vs the oracle
     assert np.array_equal(r["kp_un"], r["kp"])
     uro, zo = orc.stereo_from_rgbd(kpo, kpo, d, float(np.float32(1.0) / np.float32(5000.0)), BF)

@@ -57,6 +57,36 @@ def test_vp_manhattan_scene(orc):
     assert np.array_equal(orc.vanishing_points(kl, seed=11, th_angle=3.0 / 180 * np.pi)["vp_idx"], got)    # reproducible under a seed
 
 
+def _parallel_lines(orc, n=3):
+    """n exactly horizontal key lines: every pair meets at infinity (z == 0 exactly)"""
+    kl = np.zeros(n, orc.KEYLINE_DT)
+    for i in range(n):
+        kl["sx"][i], kl["ex"][i] = 10.0 + i, 200.0 + 3 * i
+        kl["sy"][i] = kl["ey"][i] = 40.0 + 25 * i
+    return kl
+
+
+def test_vp_all_pairs_at_infinity_terminates(orc):
+    """the reference redraws such pairs for ever; the bounded rule gives zero hypotheses, score 0, no structure lines"""
+    kl = _parallel_lines(orc)
+    o = orc.vanishing_points(kl, seed=5, want_scores=True)
+    assert o["score"] == 0 and o["best"] == 0 and not o["scores"].any() and not o["vps"].any()
+    assert o["vp_idx"].tolist() == [3, 3, 3]
+    assert np.array_equal(orc.vp_line2vps(kl, orc.vp_hypothesis(kl, 5, 0)), o["vp_idx"])
+
+
+@pytest.mark.gpu
+def test_vp_gpu_all_pairs_at_infinity(hvo, orc):
+    kl = _parallel_lines(orc)
+    ctx = hvo.Context()
+    try:
+        got = ctx.vanishing_points(kl, seed=5)
+    finally:
+        ctx.close()
+    assert got["score"] == 0 and got["best"] == 0 and not np.asarray(got["vps"]).any()
+    assert got["vp_idx"].tolist() == [3, 3, 3]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,seed,rs", [("std", 0x5EED0002, 7), ("std", 0x5EED1001, 1), ("lowtex", 0x5EED2000, 3)])
 def test_vp_gpu_vs_oracle(hvo, orc, synth, kind, seed, rs):
@@ -74,6 +104,10 @@ def test_vp_gpu_vs_oracle(hvo, orc, synth, kind, seed, rs):
     if got["best"] != ref["best"]:
         # two hypotheses may tie exactly (rotation j and j + 180 give the same triple): then the device's last-bit differences pick the twin
         assert abs(ref["scores"][got["best"]] - ref["score"]) <= 1e-9 * max(1.0, ref["score"])
+        # ... and what the device reports must still be the oracle's hypothesis at that index and the oracle's clusters under it
+        twin = orc.vp_hypothesis(kl, rs, got["best"])
+        assert np.allclose(got["vps"], twin, atol=1e-12)
+        assert np.array_equal(got["vp_idx"], orc.vp_line2vps(kl, twin))
     else:
         assert np.allclose(got["vps"], ref["vps"], atol=1e-12)
         assert np.array_equal(got["vp_idx"], ref["vp_idx"])
