@@ -39,12 +39,25 @@ struct CellDesc {   // one FAST cell view (ORBextractor.cc:787-806)
     short level, x0, y0, vw, vh, ox, oy, pad;
 };
 
+// one tile of the fused per-level pass (orb_level.hip): the rectangle it owns for blur / resize, the FAST interior of the
+// reference's cell it holds (fw == 0: a margin tile), and the next level's pixels whose upper-left source pixel it owns
+struct OrbTile {
+    short bx0, by0, bw, bh;             // owned rectangle (bx0, bw multiples of 4)
+    short fx0, fw;                      // FAST interior columns [fx0, fx0 + fw); interior rows = the owned rows
+    short cell;                         // index into the frame's cell table (-1: none)
+    short dxa, dxb, dya, dyb;           // next level: columns [dxa, dxb) x rows [dya, dyb)
+    short pad[5];
+};
+
 struct OrbPlan {
     int w = 0, h = 0, nlevels = 0, batch = 0;
     LevelGeom lev[HVO_MAX_LEVELS];
     int ncells = 0, cand_total = 0, node_total = 0, kp_total = 0, ntiles = 0, max_cell = 0;
     size_t pyr_bytes = 0;               // per frame
     bool resize_dw[HVO_MAX_LEVELS] = {};  // level is produced by k_resize_dw (dword loads) instead of k_resize
+    bool fused = false;                 // the fused per-level pass (orb_level.hip) serves this geometry
+    int lt_off[HVO_MAX_LEVELS] = {}, lt_cnt[HVO_MAX_LEVELS] = {}, lt_tpw = 4;
+    OrbTile *d_ltiles = nullptr;
     int kp_cap = 0;                     // output capacity per frame
     // device
     LevelGeom *d_lev = nullptr;
@@ -53,6 +66,7 @@ struct OrbPlan {
     int *d_rs_yofs = nullptr; int *d_rs_ybeta = nullptr;    // per level: dh entries (yofs packs sy0|sy1<<16)
     int4 *d_tiles = nullptr;            // blur tiles (level, tx, ty, 0)
     uint8_t *d_pyr = nullptr, *d_blur = nullptr;            // batch * pyr_bytes
+    uint8_t *d_pyr_base = nullptr;                          // the allocation behind d_pyr (256 guard bytes in front: orb_level.hip's 16-byte tile loads may start 4 bytes before a row)
     uint32_t *d_cell_kp = nullptr; int *d_cell_cnt = nullptr;
     uint32_t *d_cand = nullptr; int *d_keys = nullptr, *d_keys_tmp = nullptr;
     int4 *d_nodeA = nullptr, *d_nodeB = nullptr; int2 *d_vs = nullptr, *d_vp = nullptr; int *d_order = nullptr;
@@ -183,6 +197,9 @@ static inline hipStream_t hvo_copy_stream(hvo_ctx *c, hipStream_t dflt) { return
 int orb_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool sync = true);   // sync = false: the caller waits for ctx->stream
 int orb_run(hvo_ctx *ctx, int n);
 int orb_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
+// orb_level.hip
+bool orb_level_build(OrbPlan &P, const std::vector<CellDesc> &cells, const std::vector<int> &xofs, const std::vector<int> &yofs, std::vector<OrbTile> &tiles);
+int orb_level_run(hvo_ctx *ctx, int n, hipStream_t st, int k0, int k1, int k2, int k3);
 
 // match.hip
 #define HVO_SBP_K 16

@@ -856,9 +856,9 @@ int orb_init_tables(hvo_ctx *ctx)
 void orb_free_plan(hvo_ctx *ctx)
 {
     OrbPlan &P = ctx->orb;
-    void *ptrs[] = { P.d_lev, P.d_cells, P.d_rs_xofs, P.d_rs_xalpha, P.d_rs_yofs, P.d_rs_ybeta, P.d_tiles, P.d_pyr, P.d_blur,
+    void *ptrs[] = { P.d_lev, P.d_cells, P.d_rs_xofs, P.d_rs_xalpha, P.d_rs_yofs, P.d_rs_ybeta, P.d_tiles, P.d_pyr_base, P.d_blur,
                      P.d_cell_kp, P.d_cell_cnt, P.d_cand, P.d_keys, P.d_keys_tmp, P.d_nodeA, P.d_nodeB, P.d_vs, P.d_vp,
-                     P.d_order, P.d_lvl_kp, P.d_lvl_cnt, P.d_kp, P.d_desc, P.d_nkp, P.d_flags };
+                     P.d_order, P.d_lvl_kp, P.d_lvl_cnt, P.d_kp, P.d_desc, P.d_nkp, P.d_flags, P.d_ltiles };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     P = OrbPlan();
 }
@@ -1003,7 +1003,15 @@ static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     if ((rc = dev_upload(ctx, &P.d_rs_yofs, yofs))) return rc;
     if ((rc = dev_upload(ctx, &P.d_rs_ybeta, ybeta))) return rc;
     if ((rc = dev_upload(ctx, &P.d_tiles, tiles))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_pyr, B * P.pyr_bytes + 256))) return rc;
+    {   // the fused per-level pass (orb_level.hip); HVO_ORB_FUSED=0 keeps the three separate kernels
+        std::vector<OrbTile> lt;
+        const bool want = !(getenv("HVO_ORB_FUSED") && atoi(getenv("HVO_ORB_FUSED")) == 0);
+        P.fused = want && orb_level_build(P, cells, xofs, yofs, lt);
+        if (getenv("HVO_ORB_TPW")) P.lt_tpw = std::max(1, atoi(getenv("HVO_ORB_TPW")));
+        if (P.fused && (rc = dev_upload(ctx, &P.d_ltiles, lt))) return rc;
+    }
+    if ((rc = dev_alloc(ctx, &P.d_pyr_base, B * P.pyr_bytes + 512))) return rc;
+    P.d_pyr = P.d_pyr_base + 256;
     if ((rc = dev_alloc(ctx, &P.d_blur, B * P.pyr_bytes + 256))) return rc;
     if ((rc = dev_alloc(ctx, &P.d_cell_kp, B * P.ncells * HVO_CELL_CAP))) return rc;
     if ((rc = dev_alloc(ctx, &P.d_cell_cnt, B * P.ncells))) return rc;
@@ -1022,7 +1030,7 @@ static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     if ((rc = dev_alloc(ctx, &P.d_nkp, B))) return rc;
     if ((rc = dev_alloc(ctx, &P.d_flags, B))) return rc;
     // stream-ordered fills: a null-stream hipMemset is not ordered against the non-blocking ctx stream
-    HVO_HIP(hipMemsetAsync(P.d_pyr, 0, B * P.pyr_bytes + 256, ctx->stream));
+    HVO_HIP(hipMemsetAsync(P.d_pyr_base, 0, B * P.pyr_bytes + 512, ctx->stream));
     HVO_HIP(hipMemsetAsync(P.d_blur, 0, B * P.pyr_bytes + 256, ctx->stream));
     HVO_HIP(hipMemsetAsync(P.d_flags, 0, B * sizeof(int), ctx->stream));
     HVO_HIP(hipMemsetAsync(P.d_nkp, 0, B * sizeof(int), ctx->stream));
@@ -1060,7 +1068,24 @@ int orb_run(hvo_ctx *ctx, int n)
     hipStream_t st = ctx->stream;
     const int nl = P.nlevels;
     HVO_HIP(hipMemsetAsync(P.d_flags, 0, n * sizeof(int), st));
-    int id = hvo_prof_begin(ctx, "orb_pyramid", st);
+    // OpenCV fixed-point Gaussian taps for ksize 7, sigma 2: getGaussianKernel(CV_32F) * 256, rounded
+    static int k7[4] = { 0, 0, 0, 0 };
+    if (!k7[3]) {
+        float cf[7]; double sum = 0;
+        for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)exp(-0.5 / 4.0 * x * x); sum += cf[i]; }
+        sum = 1. / sum;
+        for (int i = 0; i < 4; i++) k7[i] = round_half_even_f((float)(cf[i] * sum) * 256.f);
+    }
+    int id;
+    if (P.fused) {
+        // one launch per level: level l is read once into LDS tiles and gives its FAST corners, its blurred image and level l+1
+        id = hvo_prof_begin(ctx, "orb_levels", st);
+        const int rl = orb_level_run(ctx, n, st, k7[0], k7[1], k7[2], k7[3]);
+        hvo_prof_end(ctx, id);
+        if (rl) return rl;
+        if (ctx->ev_fast && !ctx->serialize) { HVO_HIP(hipEventRecord(ctx->ev_fast, st)); ctx->fast_recorded = true; }
+    } else {
+    id = hvo_prof_begin(ctx, "orb_pyramid", st);
     for (int l = 1; l < nl; l++) {
         const LevelGeom &S = P.lev[l - 1], &D = P.lev[l];
         dim3 blk(64, 4), grd((D.w + 255) / 256, (D.h + 4 * RESIZE_ROWS - 1) / (4 * RESIZE_ROWS), n);
@@ -1077,14 +1102,6 @@ int orb_run(hvo_ctx *ctx, int n)
     const bool blur_late = ctx->orb_blur_late;
     auto run_blur = [&]() -> int {
         id = hvo_prof_begin(ctx, "orb_blur", st);
-        // OpenCV fixed-point Gaussian taps for ksize 7, sigma 2: getGaussianKernel(CV_32F) * 256, rounded
-        static int k7[4] = { 0, 0, 0, 0 };
-        if (!k7[3]) {
-            float cf[7]; double sum = 0;
-            for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)exp(-0.5 / 4.0 * x * x); sum += cf[i]; }
-            sum = 1. / sum;
-            for (int i = 0; i < 4; i++) k7[i] = round_half_even_f((float)(cf[i] * sum) * 256.f);
-        }
         hipLaunchKernelGGL(k_blur7, dim3(P.ntiles, n), dim3(256), 0, st, P.d_pyr, P.d_blur, P.pyr_bytes, P.d_lev, P.d_tiles, k7[0], k7[1], k7[2], k7[3]);
         hvo_prof_end(ctx, id);
         return HVO_OK;
@@ -1100,6 +1117,7 @@ int orb_run(hvo_ctx *ctx, int n)
     hvo_prof_end(ctx, id);
     if (ctx->ev_fast && !ctx->serialize) { HVO_HIP(hipEventRecord(ctx->ev_fast, st)); ctx->fast_recorded = true; }
     if (blur_late) { const int rb = run_blur(); if (rb) return rb; }
+    }
     id = hvo_prof_begin(ctx, "orb_octree", st);
     OctArgs oa;
     oa.lev = P.d_lev; oa.cell_kp = P.d_cell_kp; oa.cell_cnt = P.d_cell_cnt; oa.ncells = P.ncells;

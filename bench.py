@@ -88,6 +88,7 @@ def algorithmic_bytes(w, h, nkp, nlines):
     table = {
         "orb_pyramid": sum(areas[:-1]) + sum(areas[1:]),          # read levels 0..6, write 1..7
         "orb_fast_cells": S + 4 * 8 * nkp,                        # read every level once, emit candidates
+        "orb_levels": sum(areas[:-1]) + sum(areas[1:]) + S + 4 * 8 * nkp + 2 * S,   # the fused pass: pyramid + FAST + blur of the same levels
         "orb_octree": 4 * 8 * nkp + 4 * nkp,
         "orb_orient": 749 * nkp + 28 * nkp,
         "orb_blur": 2 * S,                                        # read level, write blurred level
@@ -499,7 +500,7 @@ def main():
                     "bytes_per_launch": int(table.get(dom, 0) * B), "ms_per_launch": round(groups[dom], 4),
                     "limiter": "dependent-latency chain (serial semantics), not HBM bandwidth: see valu_busy_frac / DESIGN.md section 4"}
             roof.update(sq_utilisation(value))
-            orb_ms = sum(v for k, v in groups.items() if k in ("orb_pyramid", "orb_fast_cells", "orb_blur", "orb_brief", "orb_orient"))
+            orb_ms = sum(v for k, v in groups.items() if k in ("orb_pyramid", "orb_fast_cells", "orb_blur", "orb_levels", "orb_brief", "orb_orient", "orb_describe"))
             if orb_ms > 0:
                 roof["orb_pyramid_brief_pass_GBps"] = round(pass_bytes * B / (orb_ms * 1e-3) / 1e9, 2)
                 roof["orb_pyramid_brief_pass_frac"] = round(pass_bytes * B / (orb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
