@@ -58,6 +58,7 @@ struct OrbPlan {
     bool fused = false;                 // the fused per-level pass (orb_level.hip) serves this geometry
     int lt_off[HVO_MAX_LEVELS] = {}, lt_cnt[HVO_MAX_LEVELS] = {}, lt_tpw = 4;
     OrbTile *d_ltiles = nullptr;
+    int2 *d_kpchunks = nullptr; int n_kpchunks = 0;     // (level, first slot) of every 32-slot chunk of the per-level key-point slabs (orb_describe.hip)
     int kp_cap = 0;                     // output capacity per frame
     // device
     LevelGeom *d_lev = nullptr;
@@ -200,6 +201,9 @@ int orb_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
 // orb_level.hip
 bool orb_level_build(OrbPlan &P, const std::vector<CellDesc> &cells, const std::vector<int> &xofs, const std::vector<int> &yofs, std::vector<OrbTile> &tiles);
 int orb_level_run(hvo_ctx *ctx, int n, hipStream_t st, int k0, int k1, int k2, int k3);
+// orb_describe.hip
+int orb_describe_build(hvo_ctx *ctx);
+int orb_describe_run(hvo_ctx *ctx, int n, hipStream_t st);
 
 // match.hip
 #define HVO_SBP_K 16

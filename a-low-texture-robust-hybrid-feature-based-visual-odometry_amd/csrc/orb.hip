@@ -6,9 +6,9 @@
 //                   formulation for scale factors > 4/3 or HVO_RESIZE_BYTES=1)
 //   k_fast_cells    per-cell cv::FAST + fallback      ORBextractor.cc:787-827
 //   k_octree        DistributeOctTree / DivideNode    ORBextractor.cc:537-761, 479-535
-//   k_orient        IC_Angle + fastAtan2              ORBextractor.cc:75-102, 470-477
+//   (orientation and descriptors: orb_describe.hip; the fused per-level pass that replaces k_resize / k_fast_cells / k_blur7
+//    where the geometry fits its LDS tile: orb_level.hip)
 //   k_blur7         GaussianBlur 7x7 sigma 2          ORBextractor.cc:1083-1084
-//   k_brief         computeOrbDescriptor              ORBextractor.cc:106-145
 //
 // Data layout in HBM (per frame): one pyramid slab holding the nlevels u8 images back to back
 // (row pitch = width rounded up to 64 B, no apron: REFLECT_101 is applied by index reflection
@@ -593,87 +593,6 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
 }
 
 // =====================================================================================
-// K4: orientation (IC_Angle) + keypoint records.  One wave per keypoint.
-// =====================================================================================
-static __device__ __forceinline__ float fast_atan2_deg(float y, float x)
-{
-    // cv::fastAtan2 (OpenCV 3.2) -- float polynomial, evaluated without contraction
-    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
-    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
-    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
-    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
-    const float eps = (float)2.2204460492503131e-16;
-    float ax = fabsf(x), ay = fabsf(y), r, c, c2;
-    if (ax >= ay) {
-        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
-        c2 = __fmul_rn(c, c);
-        r = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
-    } else {
-        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
-        c2 = __fmul_rn(c, c);
-        r = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
-    }
-    if (x < 0) r = __fsub_rn(180.f, r);
-    if (y < 0) r = __fsub_rn(360.f, r);
-    return r;
-}
-
-// maps a per-frame keypoint index to (level, index inside the level); returns false past the end
-static __device__ __forceinline__ bool locate_kp(const int *lvl_cnt, int nlevels, int cap, int idx, int &level, int &k, int &total)
-{
-    int acc = 0; level = -1; k = 0;
-    for (int l = 0; l < nlevels; l++) {
-        int c = lvl_cnt[l];
-        if (level < 0 && idx < acc + c) { level = l; k = idx - acc; }
-        acc += c;
-    }
-    total = min(acc, cap);
-    return level >= 0 && idx < total;
-}
-
-__global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr, size_t frame_stride,
-                                                const LevelGeom *__restrict__ lev, int nlevels,
-                                                const uint32_t *__restrict__ lvl_kp, const int *__restrict__ lvl_cnt, int kp_total,
-                                                const int *__restrict__ umax,
-                                                hvo_keypoint *__restrict__ kp_out, int *__restrict__ nkp, int cap)
-{
-    const int frame = blockIdx.y, lane = threadIdx.x & 63;
-    for (int rep = 0; rep < 4; rep++) {
-    const int idx = blockIdx.x * 16 + rep * 4 + (threadIdx.x >> 6);
-    int level, k, total;
-    bool ok = locate_kp(lvl_cnt + (size_t)frame * nlevels, nlevels, cap, idx, level, k, total);
-    if (blockIdx.x == 0 && threadIdx.x == 0) nkp[frame] = total;
-    if (!ok) return;
-    const LevelGeom L = lev[level];
-    const uint32_t c = lvl_kp[(size_t)frame * kp_total + L.kp_off + k];
-    const int x = cand_x(c) + L.minBX, y = cand_y(c) + L.minBY;
-    const uint8_t *img = pyr + (size_t)frame * frame_stride + L.img_off;
-    // lanes 0..61: row v = (lane>>1) - 15 in [-15, 15], half = lane & 1 (u < 0 / u >= 0)
-    int m10 = 0, m01 = 0;
-    const int v = (lane >> 1) - 15;
-    if (lane < 62) {
-        const int d = umax[v < 0 ? -v : v];
-        const uint8_t *row = img + (size_t)(y + v) * L.pitch + x;
-        int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
-        int s = 0, su = 0;
-        for (int u = u0; u <= u1; u++) { int p = row[u]; s += p; su += u * p; }
-        m10 = su; m01 = v * s;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { m10 += __shfl_xor(m10, o); m01 += __shfl_xor(m01, o); }
-    if (lane == 0) {
-        hvo_keypoint kp;
-        kp.x = (float)x; kp.y = (float)y;           // level coordinates; k_brief rescales
-        kp.size = (float)L.scaled_patch;
-        kp.angle = fast_atan2_deg((float)m01, (float)m10);
-        kp.response = (float)cand_s(c);
-        kp.octave = level; kp.class_id = -1;
-        kp_out[(size_t)frame * cap + idx] = kp;
-    }
-    }   // rep
-}
-
-// =====================================================================================
 // K5a: 7x7 Gaussian blur, sigma 2, u8 -> u8 (OpenCV 3.2 fixed-point path)
 // =====================================================================================
 // Row pass with integer taps {18,34,49,55,49,34,18} (sum 257) fits u16; column pass in int32,
@@ -768,55 +687,6 @@ __global__ __launch_bounds__(256) void k_blur7(const uint8_t *__restrict__ pyr, 
 }
 
 // =====================================================================================
-// K5b: steered BRIEF-256.  One wave per keypoint; lane l produces descriptor bits 4l..4l+3.
-// =====================================================================================
-__global__ __launch_bounds__(256) void k_brief(const uint8_t *__restrict__ blur, size_t frame_stride,
-                                               const LevelGeom *__restrict__ lev,
-                                               const int8_t *__restrict__ pattern,
-                                               hvo_keypoint *__restrict__ kps, const int *__restrict__ nkp, int cap,
-                                               uint8_t *__restrict__ desc)
-{
-    const int frame = blockIdx.y, lane = threadIdx.x & 63;
-    for (int rep = 0; rep < 4; rep++) {
-    const int idx = blockIdx.x * 16 + rep * 4 + (threadIdx.x >> 6);
-    if (idx >= nkp[frame]) return;
-    hvo_keypoint *kp = kps + (size_t)frame * cap + idx;
-    const float kx = kp->x, ky = kp->y, ang = kp->angle;
-    const int level = kp->octave;
-    const LevelGeom L = lev[level];
-    const uint8_t *img = blur + (size_t)frame * frame_stride + L.img_off;
-    // float angle = kpt.angle * factorPI; a = (float)cos(angle), b = (float)sin(angle)
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    const float angle = __fmul_rn(ang, factorPI);
-    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
-    const int cx = __float2int_rn(kx), cy = __float2int_rn(ky);
-    const int4 praw = *reinterpret_cast<const int4 *>(pattern + 16 * lane);
-    const int8_t *pp = reinterpret_cast<const int8_t *>(&praw);
-    unsigned nib = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        int t[2];
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-            float x = (float)pp[4 * q + 2 * e], y = (float)pp[4 * q + 2 * e + 1];
-            int ry = __float2int_rn(__fadd_rn(__fmul_rn(x, b), __fmul_rn(y, a)));
-            int rx = __float2int_rn(__fsub_rn(__fmul_rn(x, a), __fmul_rn(y, b)));
-            int yy = reflect101(cy + ry, L.h), xx = reflect101(cx + rx, L.w);
-            t[e] = img[(size_t)yy * L.pitch + xx];
-        }
-        nib |= (unsigned)(t[0] < t[1]) << q;
-    }
-    unsigned byte = nib | (__shfl_down(nib, 1) << 4);                      // valid on even lanes
-    unsigned w = byte | (__shfl_down(byte, 2) << 8) | (__shfl_down(byte, 4) << 16) | (__shfl_down(byte, 6) << 24);
-    if ((lane & 7) == 0) reinterpret_cast<uint32_t *>(desc + ((size_t)frame * cap + idx) * 32)[lane >> 3] = w;
-    if (lane == 0 && level != 0) {     // keypoint->pt *= scale (ORBextractor.cc:1093-1099)
-        kp->x = __fmul_rn(kx, L.scale);
-        kp->y = __fmul_rn(ky, L.scale);
-    }
-    }   // rep
-}
-
-// =====================================================================================
 // host side
 // =====================================================================================
 static int round_half_even_f(float v) { return (int)lrintf(v); }
@@ -858,7 +728,7 @@ void orb_free_plan(hvo_ctx *ctx)
     OrbPlan &P = ctx->orb;
     void *ptrs[] = { P.d_lev, P.d_cells, P.d_rs_xofs, P.d_rs_xalpha, P.d_rs_yofs, P.d_rs_ybeta, P.d_tiles, P.d_pyr_base, P.d_blur,
                      P.d_cell_kp, P.d_cell_cnt, P.d_cand, P.d_keys, P.d_keys_tmp, P.d_nodeA, P.d_nodeB, P.d_vs, P.d_vp,
-                     P.d_order, P.d_lvl_kp, P.d_lvl_cnt, P.d_kp, P.d_desc, P.d_nkp, P.d_flags, P.d_ltiles };
+                     P.d_order, P.d_lvl_kp, P.d_lvl_cnt, P.d_kp, P.d_desc, P.d_nkp, P.d_flags, P.d_ltiles, P.d_kpchunks };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     P = OrbPlan();
 }
@@ -1010,6 +880,7 @@ static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch)
         if (getenv("HVO_ORB_TPW")) P.lt_tpw = std::max(1, atoi(getenv("HVO_ORB_TPW")));
         if (P.fused && (rc = dev_upload(ctx, &P.d_ltiles, lt))) return rc;
     }
+    if ((rc = orb_describe_build(ctx))) return rc;
     if ((rc = dev_alloc(ctx, &P.d_pyr_base, B * P.pyr_bytes + 512))) return rc;
     P.d_pyr = P.d_pyr_base + 256;
     if ((rc = dev_alloc(ctx, &P.d_blur, B * P.pyr_bytes + 256))) return rc;
@@ -1126,14 +997,7 @@ int orb_run(hvo_ctx *ctx, int n)
     oa.cand_total = P.cand_total; oa.node_total = P.node_total; oa.kp_total = P.kp_total; oa.nlevels = nl;
     hipLaunchKernelGGL(k_octree, dim3(nl, n), dim3(64), 0, st, oa);
     hvo_prof_end(ctx, id);
-    id = hvo_prof_begin(ctx, "orb_orient", st);
-    hipLaunchKernelGGL(k_orient, dim3((P.kp_cap + 15) / 16, n), dim3(256), 0, st, P.d_pyr, P.pyr_bytes, P.d_lev, nl, P.d_lvl_kp, P.d_lvl_cnt,
-                       P.kp_total, ctx->d_umax, P.d_kp, P.d_nkp, P.kp_cap);
-    hvo_prof_end(ctx, id);
-    id = hvo_prof_begin(ctx, "orb_brief", st);
-    hipLaunchKernelGGL(k_brief, dim3((P.kp_cap + 15) / 16, n), dim3(256), 0, st, P.d_blur, P.pyr_bytes, P.d_lev, ctx->d_pattern, P.d_kp, P.d_nkp,
-                       P.kp_cap, P.d_desc);
-    hvo_prof_end(ctx, id);
+    { const int rd = orb_describe_run(ctx, n, st); if (rd) return rd; }
     HVO_HIP(hipGetLastError());
     return HVO_OK;
 }
