@@ -34,6 +34,9 @@ _LOADED_BEFORE_TORCH = False
 HVO_OK = 0
 STAGE_ORB, STAGE_LSD, STAGE_PLANES, STAGE_ALL = 1, 2, 4, 7
 STAGE_LSD_CULL = 8        # STAGE_LSD followed by Frame::cullingLine (merged lines replace the extractor's)
+# the rest of the Frame constructor as pipeline stages (include/hvo.h): isLineGood, vanishing points, ComputePlanes' tail, the two grids
+STAGE_LINES3D, STAGE_VP, STAGE_PLANE_TAIL, STAGE_GRIDS = 16, 32, 64, 128
+STAGE_FRAME = 1 | 2 | 8 | 4 | 16 | 32 | 64 | 128
 LINE_MATCH_NNR, LINE_MATCH_BF, LINE_MATCH_DOUBLE = 0, 1, 2
 
 KEYPOINT_DT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
@@ -67,6 +70,7 @@ EXPORTS = [
     "hvo_stream_create", "hvo_stream_destroy", "hvo_stream_last_error", "hvo_stream_capacity", "hvo_stream_image_bounds",
     "hvo_stream_submit", "hvo_stream_poll", "hvo_stream_collect", "hvo_stream_stage_ms",
     "hvo_stream_search_by_projection", "hvo_stream_match_lines",
+    "hvo_tail_capacity", "hvo_set_tail_params", "hvo_batch_download_tail", "hvo_stream_collect_tail",
 ]
 
 
@@ -99,7 +103,46 @@ class FrameOut(C.Structure):
 
 class StreamParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("depth", C.c_int32), ("stages", C.c_uint32),
-                ("dist5", C.c_float * 5), ("bf", C.c_float)]
+                ("dist5", C.c_float * 5), ("bf", C.c_float), ("seed", C.c_uint32), ("plane_dist_th", C.c_float), ("vp_th_angle", C.c_float)]
+
+
+class FrameTail(C.Structure):
+    _fields_ = [("lines3d", C.c_void_p), ("vp", C.c_void_p), ("vp_idx", C.c_void_p),
+                ("plane_clouds", C.c_void_p), ("cloud_xyz", C.c_void_p), ("cloud_cap", C.c_int), ("n_cloud", C.c_int),
+                ("normals", C.c_void_p), ("normals_cap", C.c_int), ("n_normals", C.c_int),
+                ("pt_cell_start", C.c_void_p), ("pt_cell_items", C.c_void_p), ("pt_items_cap", C.c_int), ("n_pt_items", C.c_int),
+                ("ln_cell_start", C.c_void_p), ("ln_cell_items", C.c_void_p), ("ln_items_cap", C.c_int), ("n_ln_items", C.c_int),
+                ("status", C.c_int)]
+
+
+def _tail_buffers(kp_cap, kl_cap, w, h):
+    """numpy result arrays of one frame's tail stages + the FrameTail that points at them"""
+    cc = C.c_int(0); nn = C.c_int(0); lc = C.c_int(0)
+    lib().hvo_tail_capacity(kl_cap, w, h, C.byref(cc), C.byref(nn), C.byref(lc))
+    b = dict(lines3d=np.zeros(kl_cap, LINE3D_DT), vp=VpResult(), vp_idx=np.full(kl_cap, 3, np.int32), plane_clouds=np.zeros(64, PLANE_CLOUD_DT),
+             cloud_xyz=np.zeros((cc.value, 3), np.float32), normals=np.zeros(max(nn.value, 1), SURFACE_NORMAL_DT),
+             pt_cell_start=np.zeros(64 * 48 + 1, np.int32), pt_cell_items=np.zeros(max(kp_cap, 1), np.int32),
+             ln_cell_start=np.zeros(64 * 48 + 1, np.int32), ln_cell_items=np.zeros(max(lc.value, 1), np.int32))
+    t = FrameTail()
+    t.lines3d = b["lines3d"].ctypes.data; t.vp = C.addressof(b["vp"]); t.vp_idx = b["vp_idx"].ctypes.data
+    t.plane_clouds = b["plane_clouds"].ctypes.data; t.cloud_xyz = b["cloud_xyz"].ctypes.data; t.cloud_cap = cc.value
+    t.normals = b["normals"].ctypes.data; t.normals_cap = nn.value
+    t.pt_cell_start = b["pt_cell_start"].ctypes.data; t.pt_cell_items = b["pt_cell_items"].ctypes.data; t.pt_items_cap = kp_cap
+    t.ln_cell_start = b["ln_cell_start"].ctypes.data; t.ln_cell_items = b["ln_cell_items"].ctypes.data; t.ln_items_cap = lc.value
+    return b, t
+
+
+def _tail_result(b, t, n_kl, n_planes, stages):
+    r = {"tail_status": t.status}
+    if stages & STAGE_LINES3D: r["lines3d"] = b["lines3d"][:n_kl]
+    if stages & STAGE_VP:
+        v = b["vp"]
+        r["vp"] = dict(vps=np.array([[v.vps[i][j] for j in range(3)] for i in range(3)]), score=v.score, best=v.best, n_hypotheses=v.n_hypotheses, vp_idx=b["vp_idx"][:n_kl])
+    if stages & STAGE_PLANE_TAIL:
+        r["plane_clouds"] = b["plane_clouds"][:n_planes]; r["cloud_xyz"] = b["cloud_xyz"][: t.n_cloud]; r["normals"] = b["normals"][: t.n_normals]
+    if stages & STAGE_GRIDS:
+        r["pt_grid"] = (b["pt_cell_start"], b["pt_cell_items"][: t.n_pt_items]); r["ln_grid"] = (b["ln_cell_start"], b["ln_cell_items"][: t.n_ln_items])
+    return r
 
 
 def build(force=False):
@@ -180,6 +223,10 @@ def lib():
         L.hvo_stream_stage_ms.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.hvo_stream_search_by_projection.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.hvo_stream_match_lines.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.hvo_tail_capacity.argtypes = [C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 3
+        L.hvo_set_tail_params.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double]
+        L.hvo_batch_download_tail.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameTail)]
+        L.hvo_stream_collect_tail.argtypes = [C.c_void_p, C.c_int64, C.POINTER(FrameTail)]
         _LIB = L
     return _LIB
 
@@ -442,6 +489,24 @@ class Context:
     def batch_run(self, stages=STAGE_ALL):
         self._chk(lib().hvo_batch_run(self.h, stages), "batch_run")
 
+    def set_tail_params(self, seed=1, plane_dist_th=0.05, vp_th_angle=0.0):
+        """seed (frame f draws with seed + f), Plane.DistanceThreshold and line2Vps' angle for the tail stages of batch_run"""
+        self._chk(lib().hvo_set_tail_params(self.h, seed, plane_dist_th, vp_th_angle), "set_tail_params")
+
+    def batch_download_tail(self, stages, results):
+        """results of the tail stages (STAGE_LINES3D | STAGE_VP | STAGE_PLANE_TAIL | STAGE_GRIDS) of the resident batch, merged into the
+        per-frame dicts `results` of batch_download (their line / plane counts size the arrays)"""
+        n = len(results)
+        kc, lc, _, _ = self.slab_layout()
+        bufs = []; arr = (FrameTail * n)()
+        for f in range(n):
+            b, t = _tail_buffers(kc, lc, self._w, self._h)
+            bufs.append(b); arr[f] = t
+        self._chk(lib().hvo_batch_download_tail(self.h, n, arr), "batch_download_tail")
+        for f in range(n):
+            results[f].update(_tail_result(bufs[f], arr[f], len(results[f].get("kl", ())), len(results[f].get("planes", ())), stages))
+        return results
+
     def batch_download(self, stages=STAGE_ALL, pl_cap=64, n=None, reuse=False, labels8=False, pinned=False):
         """results of the first n (default all) frames of the resident batch.  reuse=True keeps the host result arrays of the
         previous call with the same shape (a caller that consumes the results before the next download avoids re-faulting
@@ -559,9 +624,10 @@ class Stream:
     """hvo_stream: the streamed-sequence mode (one Frame construction per camera image, src/Tracking.cc:262, with `depth`
     frames in flight and the last `depth` frames' results resident in HBM for frame-to-frame matching)."""
 
-    def __init__(self, width=640, height=480, depth=4, stages=STAGE_ALL, dist5=(0, 0, 0, 0, 0), bf=40.0, params=None, **kw):
+    def __init__(self, width=640, height=480, depth=4, stages=STAGE_ALL, dist5=(0, 0, 0, 0, 0), bf=40.0, params=None, seed=1, plane_dist_th=0.05, vp_th_angle=0.0, **kw):
         self.params = params if params is not None else default_params(**kw)
         sp = StreamParams(); sp.width = width; sp.height = height; sp.depth = depth; sp.stages = stages; sp.bf = bf
+        sp.seed = seed; sp.plane_dist_th = plane_dist_th; sp.vp_th_angle = vp_th_angle; self.seed = seed
         for k in range(5):
             sp.dist5[k] = dist5[k]
         h = C.c_void_p()
@@ -604,6 +670,10 @@ class Stream:
 
     def collect(self, ticket, labels=True):
         fo = FrameOut(); r = {}
+        tail_stages = self.stages & (STAGE_LINES3D | STAGE_VP | STAGE_PLANE_TAIL | STAGE_GRIDS)
+        if tail_stages:                                   # the tail block is read before hvo_stream_collect releases the slot
+            tb, tt = _tail_buffers(self.kp_cap, self.kl_cap, self.w, self.hgt)
+            self._chk(lib().hvo_stream_collect_tail(self.h, ticket, C.byref(tt)), "stream_collect_tail")
         if self.stages & STAGE_ORB:
             kp = np.zeros(self.kp_cap, KEYPOINT_DT); desc = np.zeros((self.kp_cap, 32), np.uint8); kpu = np.zeros(self.kp_cap, KEYPOINT_DT)
             ur = np.zeros(self.kp_cap, np.float32); zd = np.zeros(self.kp_cap, np.float32)
@@ -629,6 +699,8 @@ class Stream:
             if labels:
                 r["labels"] = lab
         r["status"] = fo.status
+        if tail_stages:
+            r.update(_tail_result(tb, tt, fo.n_kl, fo.n_planes, tail_stages))
         return r
 
     def stage_ms(self, ticket):

@@ -108,6 +108,8 @@ void hvo_destroy(hvo_ctx *ctx)
     (void)hipDeviceSynchronize();
     for (auto &e : ctx->perms) (void)hipFree(e.second);
     ctx->perms.clear();
+    tail_batch_free(ctx);
+    if (ctx->call_arena) (void)hipFree(ctx->call_arena);
     orb_free_plan(ctx);
     match_free(ctx);
     peac_free(ctx);
@@ -225,7 +227,9 @@ int hvo_batch_run(hvo_ctx *ctx, unsigned stages)
             if (ctx->prof[i].used) HVO_HIP(hipEventElapsedTime(&ctx->prof[i].ms, ctx->prof[i].e0, ctx->prof[i].e1));
     ctx->last_stages |= stages & (HVO_STAGE_ORB | HVO_STAGE_PLANES);
     if (want_lsd) ctx->last_stages = (ctx->last_stages & ~(HVO_STAGE_LSD | HVO_STAGE_LSD_CULL)) | HVO_STAGE_LSD | (want_cull ? HVO_STAGE_LSD_CULL : 0u);
-    return HVO_OK;
+    // the rest of the Frame constructor on the resident results (tail.hip)
+    ctx->last_stages &= ~(HVO_STAGE_LINES3D | HVO_STAGE_VP | HVO_STAGE_PLANE_TAIL | HVO_STAGE_GRIDS);
+    return tail_batch_run(ctx, stages);
 }
 
 int hvo_batch_download(hvo_ctx *ctx, int n, hvo_frame_out *out)

@@ -40,19 +40,23 @@ __global__ __launch_bounds__(256) void k_undistort(const hvo_keypoint *__restric
     out[i] = k;
 }
 
-__global__ __launch_bounds__(256) void k_point_cells(const hvo_keypoint *__restrict__ kp, int n, float minx, float miny, float winv, float hinv,
+__global__ __launch_bounds__(256) void k_point_cells(const hvo_keypoint *__restrict__ kp, const int *__restrict__ n_ptr, int n_fixed, float minx, float miny, float winv, float hinv,
                                                      int *__restrict__ cell)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    const int n = n_ptr ? min(*n_ptr, n_fixed) : n_fixed;
+    if (i >= n_fixed) return;
+    if (i >= n) { cell[i] = -1; return; }
     const int px = (int)roundf(__fmul_rn(__fsub_rn(kp[i].x, minx), winv)), py = (int)roundf(__fmul_rn(__fsub_rn(kp[i].y, miny), hinv));
     cell[i] = (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) ? -1 : px * GRID_ROWS + py;
 }
 
-__global__ __launch_bounds__(64) void k_line_cells(const hvo_keyline *__restrict__ kl, int n, float winv, float hinv, int *__restrict__ cell)
+__global__ __launch_bounds__(64) void k_line_cells(const hvo_keyline *__restrict__ kl, const int *__restrict__ n_ptr, int n_fixed, float winv, float hinv, int *__restrict__ cell)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
+    const int n = n_ptr ? min(*n_ptr, n_fixed) : n_fixed;
+    if (i >= n_fixed) return;
+    if (i >= n) { for (int m = 0; m < LINE_CELL_CAP; m++) cell[(size_t)i * LINE_CELL_CAP + m] = -1; return; }
     double x1 = (double)__fmul_rn(kl[i].sx, winv), y1 = (double)__fmul_rn(kl[i].sy, hinv);
     double x2 = (double)__fmul_rn(kl[i].ex, winv), y2 = (double)__fmul_rn(kl[i].ey, hinv);
     const bool steep = fabs(y2 - y1) > fabs(x2 - x1);
@@ -107,43 +111,19 @@ __global__ __launch_bounds__(1024) void k_cells_to_csr(const int *__restrict__ c
     (void)s_total;
 }
 
-static int grid_csr(hvo_ctx *ctx, const int *d_cell, int n_items, int per_item, int32_t *cell_start, int32_t *cell_items, int cap, int *n_out)
-{
-    int *d_start = nullptr, *d_items = nullptr, *d_total = nullptr;
-    int rc = HVO_OK, total = 0;
-    if (hipMalloc((void **)&d_start, (GRID_CELLS + 1) * sizeof(int)) != hipSuccess || hipMalloc((void **)&d_items, (size_t)(cap > 0 ? cap : 1) * sizeof(int)) != hipSuccess ||
-        hipMalloc((void **)&d_total, sizeof(int)) != hipSuccess) rc = HVO_ERR_HIP;
-    if (!rc) {
-        hipLaunchKernelGGL(k_cells_to_csr, dim3(1), dim3(1024), 0, ctx->stream, d_cell, n_items, per_item, d_start, d_items, cap, d_total);
-        (void)hipMemcpyAsync(cell_start, d_start, (GRID_CELLS + 1) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-        (void)hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = HVO_ERR_HIP;
-        if (!rc && total > 0 && hipMemcpy(cell_items, d_items, (size_t)(total < cap ? total : cap) * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = HVO_ERR_HIP;
-    }
-    if (d_start) (void)hipFree(d_start);
-    if (d_items) (void)hipFree(d_items);
-    if (d_total) (void)hipFree(d_total);
-    *n_out = total;
-    if (!rc && total > cap) rc = HVO_ERR_CAPACITY;
-    return rc;
-}
-
 int frame_undistort(hvo_ctx *ctx, const hvo_keypoint *kp, int n, const float *dist5, hvo_keypoint *kp_un)
 {
     if (dist5[0] == 0.0f) { memcpy(kp_un, kp, (size_t)n * sizeof(hvo_keypoint)); return HVO_OK; }     // Frame.cc:1703-1707
-    hvo_keypoint *d_in = nullptr, *d_out = nullptr;
-    int rc = HVO_OK;
-    if (hipMalloc((void **)&d_in, (size_t)n * sizeof(hvo_keypoint)) != hipSuccess || hipMalloc((void **)&d_out, (size_t)n * sizeof(hvo_keypoint)) != hipSuccess) rc = HVO_ERR_HIP;
-    if (!rc) {
-        (void)hipMemcpyAsync(d_in, kp, (size_t)n * sizeof(hvo_keypoint), hipMemcpyHostToDevice, ctx->stream);
-        hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_in, n, (const int *)nullptr, (double)ctx->p.fx, (double)ctx->p.fy, (double)ctx->p.cx, (double)ctx->p.cy,
-                           (double)dist5[0], (double)dist5[1], (double)dist5[2], (double)dist5[3], (double)dist5[4], d_out);
-        (void)hipMemcpyAsync(kp_un, d_out, (size_t)n * sizeof(hvo_keypoint), hipMemcpyDeviceToHost, ctx->stream);
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = HVO_ERR_HIP;
-    }
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
-    return rc;
+    const size_t bk = ((size_t)n * sizeof(hvo_keypoint) + 255) & ~(size_t)255;
+    char *a = (char *)hvo_call_arena(ctx, 2 * bk);                // the context's staging arena: no allocation per call
+    if (!a) return HVO_ERR_HIP;
+    hvo_keypoint *d_in = (hvo_keypoint *)a, *d_out = (hvo_keypoint *)(a + bk);
+    HVO_HIP(hipMemcpyAsync(d_in, kp, (size_t)n * sizeof(hvo_keypoint), hipMemcpyHostToDevice, ctx->stream));
+    const int rc = frame_undistort_enqueue(ctx, ctx->stream, d_in, nullptr, n, dist5, d_out);
+    if (rc) return rc;
+    HVO_HIP(hipMemcpyAsync(kp_un, d_out, (size_t)n * sizeof(hvo_keypoint), hipMemcpyDeviceToHost, ctx->stream));
+    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    return HVO_OK;
 }
 
 // device-resident Frame::UndistortKeyPoints: d_kp -> d_out for the first *d_n (<= n_max) key points; k1 == 0 copies (Frame.cc:1703-1707)
@@ -180,34 +160,56 @@ int frame_image_bounds(hvo_ctx *ctx, int w, int h, const float *dist5, float *bo
     return HVO_OK;
 }
 
-int frame_points_to_grid(hvo_ctx *ctx, const hvo_keypoint *kp_un, int n, const float *b, int32_t *cell_start, int32_t *cell_items, int *n_out)
+// ---- the two grids, device-resident: key points / key lines and their counts (d_n, capped by n_max; or n_max when null) in HBM.
+// d_cell: scratch of n_max (points) or n_max * 128 (lines) ints; d_start: 64*48+1 ints; d_items: cap ints; d_total: 1 int
+// (*d_total > cap means the item list was truncated).  Nothing is allocated, nothing synchronises.
+size_t frame_grid_scratch_ints(int n_max, bool lines) { return (size_t)n_max * (lines ? LINE_CELL_CAP : 1); }
+int frame_points_grid_enqueue(hvo_ctx *ctx, hipStream_t st, const hvo_keypoint *d_kp_un, const int *d_n, int n_max, const float *b,
+                              int *d_cell, int32_t *d_start, int32_t *d_items, int cap, int *d_total)
 {
     const float winv = (float)GRID_COLS / (b[1] - b[0]), hinv = (float)GRID_ROWS / (b[3] - b[2]);
-    hvo_keypoint *d_kp = nullptr; int *d_cell = nullptr;
-    int rc = HVO_OK;
-    if (hipMalloc((void **)&d_kp, (size_t)n * sizeof(hvo_keypoint)) != hipSuccess || hipMalloc((void **)&d_cell, (size_t)n * sizeof(int)) != hipSuccess) rc = HVO_ERR_HIP;
-    if (!rc) {
-        (void)hipMemcpyAsync(d_kp, kp_un, (size_t)n * sizeof(hvo_keypoint), hipMemcpyHostToDevice, ctx->stream);
-        hipLaunchKernelGGL(k_point_cells, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_kp, n, b[0], b[2], winv, hinv, d_cell);
-        rc = grid_csr(ctx, d_cell, n, 1, cell_start, cell_items, n, n_out);
-    }
-    if (d_kp) (void)hipFree(d_kp);
-    if (d_cell) (void)hipFree(d_cell);
-    return rc;
+    if (n_max > 0) hipLaunchKernelGGL(k_point_cells, dim3((n_max + 255) / 256), dim3(256), 0, st, d_kp_un, d_n, n_max, b[0], b[2], winv, hinv, d_cell);
+    hipLaunchKernelGGL(k_cells_to_csr, dim3(1), dim3(1024), 0, st, d_cell, n_max, 1, d_start, d_items, cap, d_total);
+    HVO_HIP(hipGetLastError());
+    return HVO_OK;
+}
+int frame_lines_grid_enqueue(hvo_ctx *ctx, hipStream_t st, const hvo_keyline *d_kl, const int *d_n, int n_max, const float *b,
+                             int *d_cell, int32_t *d_start, int32_t *d_items, int cap, int *d_total)
+{
+    const float winv = (float)GRID_COLS / (b[1] - b[0]), hinv = (float)GRID_ROWS / (b[3] - b[2]);
+    if (n_max > 0) hipLaunchKernelGGL(k_line_cells, dim3((n_max + 63) / 64), dim3(64), 0, st, d_kl, d_n, n_max, winv, hinv, d_cell);
+    hipLaunchKernelGGL(k_cells_to_csr, dim3(1), dim3(1024), 0, st, d_cell, n_max * LINE_CELL_CAP, LINE_CELL_CAP, d_start, d_items, cap, d_total);
+    HVO_HIP(hipGetLastError());
+    return HVO_OK;
 }
 
+// host-array forms: thin wrappers over the enqueue functions through the context's staging arena
+static int grid_host(hvo_ctx *ctx, bool lines, const void *items, int n, size_t item_bytes, const float *b, int32_t *cell_start, int32_t *cell_items, int cap, int *n_out)
+{
+    const size_t b_in = ((size_t)n * item_bytes + 255) & ~(size_t)255, b_cell = (frame_grid_scratch_ints(n, lines) * 4 + 255) & ~(size_t)255,
+                 b_start = ((GRID_CELLS + 1) * 4 + 255) & ~(size_t)255, b_items = ((size_t)(cap > 0 ? cap : 1) * 4 + 255) & ~(size_t)255;
+    char *a = (char *)hvo_call_arena(ctx, b_in + b_cell + b_start + b_items + 256);
+    if (!a) return HVO_ERR_HIP;
+    int *d_cell = (int *)(a + b_in); int32_t *d_start = (int32_t *)(a + b_in + b_cell), *d_items = (int32_t *)(a + b_in + b_cell + b_start);
+    int *d_total = (int *)(a + b_in + b_cell + b_start + b_items);
+    hipStream_t st = ctx->stream;
+    HVO_HIP(hipMemcpyAsync(a, items, (size_t)n * item_bytes, hipMemcpyHostToDevice, st));
+    const int rc = lines ? frame_lines_grid_enqueue(ctx, st, (const hvo_keyline *)a, nullptr, n, b, d_cell, d_start, d_items, cap, d_total)
+                         : frame_points_grid_enqueue(ctx, st, (const hvo_keypoint *)a, nullptr, n, b, d_cell, d_start, d_items, cap, d_total);
+    if (rc) return rc;
+    int total = 0;
+    HVO_HIP(hipMemcpyAsync(cell_start, d_start, (GRID_CELLS + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+    HVO_HIP(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
+    HVO_HIP(hipStreamSynchronize(st));
+    if (total > 0) HVO_HIP(hipMemcpy(cell_items, d_items, (size_t)(total < cap ? total : cap) * sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = total;
+    return total > cap ? HVO_ERR_CAPACITY : HVO_OK;
+}
+int frame_points_to_grid(hvo_ctx *ctx, const hvo_keypoint *kp_un, int n, const float *b, int32_t *cell_start, int32_t *cell_items, int *n_out)
+{
+    return grid_host(ctx, false, kp_un, n, sizeof(hvo_keypoint), b, cell_start, cell_items, n, n_out);
+}
 int frame_lines_to_grid(hvo_ctx *ctx, const hvo_keyline *kl, int n, const float *b, int32_t *cell_start, int32_t *cell_items, int cap, int *n_out)
 {
-    const float winv = (float)GRID_COLS / (b[1] - b[0]), hinv = (float)GRID_ROWS / (b[3] - b[2]);
-    hvo_keyline *d_kl = nullptr; int *d_cell = nullptr;
-    int rc = HVO_OK;
-    if (hipMalloc((void **)&d_kl, (size_t)n * sizeof(hvo_keyline)) != hipSuccess || hipMalloc((void **)&d_cell, (size_t)n * LINE_CELL_CAP * sizeof(int)) != hipSuccess) rc = HVO_ERR_HIP;
-    if (!rc) {
-        (void)hipMemcpyAsync(d_kl, kl, (size_t)n * sizeof(hvo_keyline), hipMemcpyHostToDevice, ctx->stream);
-        hipLaunchKernelGGL(k_line_cells, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_kl, n, winv, hinv, d_cell);
-        rc = grid_csr(ctx, d_cell, n * LINE_CELL_CAP, LINE_CELL_CAP, cell_start, cell_items, cap, n_out);
-    }
-    if (d_kl) (void)hipFree(d_kl);
-    if (d_cell) (void)hipFree(d_cell);
-    return rc;
+    return grid_host(ctx, true, kl, n, sizeof(hvo_keyline), b, cell_start, cell_items, cap, n_out);
 }

@@ -116,6 +116,10 @@ struct hvo_ctx {
     bool serialize = false;                // profiling mode 2: all stages on one stream (clean per-kernel times)
     bool lsd_on_orb_stream = false;        // streamed mode: ORB (0.6 ms) then the line chain on one stream, planes on the other (two HW queues per frame in flight)
     ProfileRec prof[HVO_MAX_PROFILE]; int nprof = 0;
+    // staging arena of the host-array entry points of the Frame tail (hvo_lines_3d, hvo_vanishing_points, hvo_plane_clouds, ...): one
+    // grow-only device buffer per context instead of hipMalloc / hipFree per call (hvo_call_arena)
+    void *call_arena = nullptr; size_t call_arena_cap = 0;
+    void *tail = nullptr;                  // resident-batch Frame tail (tail.hip)
     // opaque per-subsystem state (peac.hip / lsd.hip own these)
     void *peac = nullptr;
     void *lsd = nullptr;
@@ -245,9 +249,46 @@ void frame_gather_angles_enqueue(hipStream_t st, const hvo_keypoint *d_kp, const
 int frame_points_to_grid(hvo_ctx *ctx, const hvo_keypoint *kp_un, int n, const float *bounds4, int32_t *cell_start, int32_t *cell_items, int *n_out);
 int frame_lines_to_grid(hvo_ctx *ctx, const hvo_keyline *kl, int n, const float *bounds4, int32_t *cell_start, int32_t *cell_items, int cap, int *n_out);
 
+// api.hip: device buffer of at least `bytes` that lives as long as the context (grows by reallocation after draining the context's streams)
+void *hvo_call_arena(hvo_ctx *ctx, size_t bytes);
+
 // line3d.hip
 int lines3d_enqueue(hvo_ctx *ctx, hipStream_t st, const hvo_keyline *d_kl, const int *d_n, int n_max, const uint16_t *d_depth, int pitch, int w, int h,
                     unsigned seed, hvo_line3d *d_out);
+
+// vps.hip / planes_tail.hip / frame.hip: device-resident forms of the Frame tail (scratch from the caller, no allocation, no sync)
+size_t vp_scratch_bytes(int nmax);
+int vp_enqueue(hvo_ctx *ctx, hipStream_t st, const hvo_keyline *d_kl, const int *d_n, int nmax, unsigned seed, double th_angle,
+               void *scratch, hvo_vp_result *d_res, int32_t *d_idx, double *d_grid_out);
+size_t pc_scratch_bytes(int cap);
+int pc_enqueue(hvo_ctx *ctx, hipStream_t st, const uint16_t *d_depth, int pitch, int w, int h, const int8_t *d_labels8, const hvo_plane *d_planes,
+               const int *d_npl, int npl_fixed, double dist_th, void *scratch, float *d_cloud, int cap, hvo_plane_cloud *d_out, int *d_out_n);
+size_t sn_scratch_bytes(int w, int h);
+int sn_count(int w, int h);
+int sn_enqueue(hvo_ctx *ctx, hipStream_t st, const uint16_t *d_depth, int pitch, int w, int h, void *scratch, hvo_surface_normal *d_out);
+size_t frame_grid_scratch_ints(int n_max, bool lines);
+int frame_points_grid_enqueue(hvo_ctx *ctx, hipStream_t st, const hvo_keypoint *d_kp_un, const int *d_n, int n_max, const float *b,
+                              int *d_cell, int32_t *d_start, int32_t *d_items, int cap, int *d_total);
+int frame_lines_grid_enqueue(hvo_ctx *ctx, hipStream_t st, const hvo_keyline *d_kl, const int *d_n, int n_max, const float *b,
+                             int *d_cell, int32_t *d_start, int32_t *d_items, int cap, int *d_total);
+
+// tail.hip: the rest of the Frame constructor on the resident results
+#define HVO_TAIL_CLOUD_CAP 16384           // voxel-grid points of all planes of a frame (0.1 m leaves: a few thousand at most)
+struct TailLayout {
+    int w, h, kp_cap, nfeat, cloud_cap, n_normals, ln_cap;
+    size_t counts, lines3d, vp_res, vp_idx, pclouds, cloud, normals, pt_start, pt_items, ln_start, ln_items, total;   // a frame's result block
+    size_t s_vp, s_pc, s_sn, s_ptcell, s_lncell, scratch_total;                                                       // a frame's scratch
+};
+void tail_layout(int w, int h, int kp_cap, int nfeat, TailLayout &L);
+int tail_enqueue_lines(hvo_ctx *ctx, hipStream_t st, unsigned stages, const TailLayout &L, char *d_out, char *d_scratch,
+                       const hvo_keyline *d_kl, const int *d_nkl, const uint16_t *d_depth, int pitch, unsigned seed, double vp_th_angle, const float *bounds4);
+int tail_enqueue_planes(hvo_ctx *ctx, hipStream_t st, unsigned stages, const TailLayout &L, char *d_out, char *d_scratch,
+                        const uint16_t *d_depth, int pitch, const int8_t *d_labels8, const hvo_plane *d_planes, const int *d_npl, double dist_th);
+int tail_enqueue_points(hvo_ctx *ctx, hipStream_t st, unsigned stages, const TailLayout &L, char *d_out, char *d_scratch,
+                        const hvo_keypoint *d_kp_un, const int *d_nkp, const float *bounds4);
+int tail_unpack(const TailLayout &L, unsigned stages, const char *ho, int n_kl, hvo_frame_tail *out);
+int tail_batch_run(hvo_ctx *ctx, unsigned stages);
+void tail_batch_free(hvo_ctx *ctx);
 
 // peac.hip
 struct PeacView { uint16_t *d_depth; int pitch; size_t dframe; int8_t *d_labels8; hvo_plane *d_planes; int *d_meta; int npix, max_planes; };

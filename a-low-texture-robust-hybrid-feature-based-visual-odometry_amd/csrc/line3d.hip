@@ -303,27 +303,22 @@ int lines3d_enqueue(hvo_ctx *ctx, hipStream_t st, const hvo_keyline *d_kl, const
     return HVO_OK;
 }
 
+// host-array form: a thin wrapper over lines3d_enqueue through the context's staging arena (no allocation per call)
 extern "C" int hvo_lines_3d(hvo_ctx *ctx, const hvo_keyline *kl, int n, const uint16_t *depth, int w, int h, int stride, uint32_t seed, hvo_line3d *out)
 {
     if (!ctx || n < 0) return HVO_ERR_INVALID_ARG;
     if (n == 0) return HVO_OK;
     if (!kl || !depth || !out || w <= 0 || h <= 0 || stride < 2 * w) return HVO_ERR_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
-    hvo_keyline *dk = nullptr; uint16_t *dd = nullptr; hvo_line3d *dout = nullptr;
-    int rc = HVO_OK;
-    if (hipMalloc((void **)&dk, (size_t)n * sizeof(hvo_keyline)) != hipSuccess || hipMalloc((void **)&dd, (size_t)w * h * 2) != hipSuccess ||
-        hipMalloc((void **)&dout, (size_t)n * sizeof(hvo_line3d)) != hipSuccess) rc = HVO_ERR_HIP;
-    if (!rc) {
-        (void)hipMemcpyAsync(dk, kl, (size_t)n * sizeof(hvo_keyline), hipMemcpyHostToDevice, ctx->stream);
-        (void)hipMemcpy2DAsync(dd, (size_t)w * 2, depth, stride, (size_t)w * 2, h, hipMemcpyHostToDevice, ctx->stream);
-        rc = lines3d_enqueue(ctx, ctx->stream, dk, nullptr, n, dd, w, w, h, seed, dout);
-        if (!rc) {
-            (void)hipMemcpyAsync(out, dout, (size_t)n * sizeof(hvo_line3d), hipMemcpyDeviceToHost, ctx->stream);
-            if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = HVO_ERR_HIP;
-        }
-    }
-    if (dk) (void)hipFree(dk);
-    if (dd) (void)hipFree(dd);
-    if (dout) (void)hipFree(dout);
-    return rc;
+    const size_t b_k = ((size_t)n * sizeof(hvo_keyline) + 255) & ~(size_t)255, b_d = ((size_t)w * h * 2 + 255) & ~(size_t)255;
+    char *a = (char *)hvo_call_arena(ctx, b_k + b_d + (size_t)n * sizeof(hvo_line3d));
+    if (!a) return HVO_ERR_HIP;
+    hvo_keyline *dk = (hvo_keyline *)a; uint16_t *dd = (uint16_t *)(a + b_k); hvo_line3d *dout = (hvo_line3d *)(a + b_k + b_d);
+    HVO_HIP(hipMemcpyAsync(dk, kl, (size_t)n * sizeof(hvo_keyline), hipMemcpyHostToDevice, ctx->stream));
+    HVO_HIP(hipMemcpy2DAsync(dd, (size_t)w * 2, depth, stride, (size_t)w * 2, h, hipMemcpyHostToDevice, ctx->stream));
+    const int rc = lines3d_enqueue(ctx, ctx->stream, dk, nullptr, n, dd, w, w, h, seed, dout);
+    if (rc) return rc;
+    HVO_HIP(hipMemcpyAsync(out, dout, (size_t)n * sizeof(hvo_line3d), hipMemcpyDeviceToHost, ctx->stream));
+    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    return HVO_OK;
 }

@@ -50,16 +50,19 @@ static __device__ __forceinline__ void pixel_point(const uint16_t *depth, int pi
     p[0] = (float)(((double)j - (double)cx) * z / (double)fx); p[1] = (float)(((double)i - (double)cy) * z / (double)fy); p[2] = (float)z;
 }
 
-__global__ __launch_bounds__(256) void k_pc_bbox(const uint16_t *__restrict__ depth, int pitch, int w, int h, const int *__restrict__ labels, int npl,
+// (labels: int32 at the ABI, int8 where the plane stage left them in HBM; npl_ptr: the plane count when it only exists on the device)
+template <class LT>
+__global__ __launch_bounds__(256) void k_pc_bbox(const uint16_t *__restrict__ depth, int pitch, int w, int h, const LT *__restrict__ labels, const int *__restrict__ npl_ptr, int npl_fixed,
                                                  float fx, float fy, float cx, float cy, float dfac, PcPlane *__restrict__ P)
 {
     __shared__ unsigned smn[PT_MAXPL][3], smx[PT_MAXPL][3]; __shared__ int scnt[PT_MAXPL];
+    const int npl = npl_ptr ? min(*npl_ptr, npl_fixed) : npl_fixed;
     const int tid = threadIdx.x;
     if (tid < PT_MAXPL) { for (int k = 0; k < 3; k++) { smn[tid][k] = 0xFFFFFFFFu; smx[tid][k] = 0u; } scnt[tid] = 0; }
     __syncthreads();
     const int npix = w * h;
     for (int px = blockIdx.x * 256 + tid; px < npix; px += gridDim.x * 256) {
-        const int l = labels[px];
+        const int l = (int)labels[px];
         if (l < 0 || l >= npl) continue;
         const int i = px / w, j = px - i * w;
         float p[3]; pixel_point(depth, pitch, i, j, fx, fy, cx, cy, dfac, p);
@@ -73,9 +76,17 @@ __global__ __launch_bounds__(256) void k_pc_bbox(const uint16_t *__restrict__ de
     }
 }
 
-__global__ void k_pc_setup(PcPlane *__restrict__ P, const hvo_plane *__restrict__ planes, int npl, int *__restrict__ flags)
+__global__ void k_pc_init(PcPlane *__restrict__ P, int *__restrict__ misc)
+{
+    const int t = threadIdx.x;
+    if (t < PT_MAXPL) { PcPlane q; memset(&q, 0, sizeof(q)); for (int k = 0; k < 3; k++) { q.bmin[k] = 0xFFFFFFFFu; q.bmax[k] = 0u; } P[t] = q; }
+    if (t < 2) misc[t] = 0;
+}
+
+__global__ void k_pc_setup(PcPlane *__restrict__ P, const hvo_plane *__restrict__ planes, const int *__restrict__ npl_ptr, int npl_fixed, int *__restrict__ flags)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int npl = npl_ptr ? min(*npl_ptr, npl_fixed) : npl_fixed;
     int off = 0;
     const float inv_leaf = __fdiv_rn(1.0f, 0.1f);
     for (int pl = 0; pl < npl; pl++) {
@@ -100,13 +111,15 @@ __global__ void k_pc_setup(PcPlane *__restrict__ P, const hvo_plane *__restrict_
 
 struct PcVox { unsigned long long s[3]; unsigned n; unsigned pad; };
 
-__global__ __launch_bounds__(256) void k_pc_accum(const uint16_t *__restrict__ depth, int pitch, int w, int h, const int *__restrict__ labels, int npl,
+template <class LT>
+__global__ __launch_bounds__(256) void k_pc_accum(const uint16_t *__restrict__ depth, int pitch, int w, int h, const LT *__restrict__ labels, const int *__restrict__ npl_ptr, int npl_fixed,
                                                   float fx, float fy, float cx, float cy, float dfac, const PcPlane *__restrict__ P, PcVox *__restrict__ tab)
 {
+    const int npl = npl_ptr ? min(*npl_ptr, npl_fixed) : npl_fixed;
     const int npix = w * h;
     const float inv_leaf = __fdiv_rn(1.0f, 0.1f);
     for (int px = blockIdx.x * 256 + threadIdx.x; px < npix; px += gridDim.x * 256) {
-        const int l = labels[px];
+        const int l = (int)labels[px];
         if (l < 0 || l >= npl) continue;
         const PcPlane &q = P[l];
         if (q.cells == 0) continue;
@@ -133,9 +146,10 @@ __global__ __launch_bounds__(256) void k_pc_count(PcPlane *__restrict__ P, const
     if (threadIdx.x == 0) q.npts = s_cnt;
 }
 
-__global__ void k_pc_prefix(PcPlane *__restrict__ P, int npl, int *__restrict__ total)
+__global__ void k_pc_prefix(PcPlane *__restrict__ P, const int *__restrict__ npl_ptr, int npl_fixed, int *__restrict__ total)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int npl = npl_ptr ? min(*npl_ptr, npl_fixed) : npl_fixed;
     int t = 0;
     for (int pl = 0; pl < npl; pl++) { P[pl].first = t; t += P[pl].npts; }
     *total = t;
@@ -507,8 +521,63 @@ __global__ __launch_bounds__(256) void k_sn_normals(SnArgs a)
 #undef FS
 
 // =================================================================================================== host side
-template <class T> static int dmalloc(hvo_ctx *ctx, T **p, size_t n) { *p = nullptr; HVO_HIP(hipMalloc((void **)p, n * sizeof(T))); return HVO_OK; }
+// PcPlane -> the ABI's hvo_plane_cloud records (+ the totals: out_n[0] = voxel points of all planes, out_n[1] = capacity flag)
+__global__ void k_pc_export(const PcPlane *__restrict__ P, const int *__restrict__ npl_ptr, int npl_fixed, const int *__restrict__ misc, int cap,
+                            hvo_plane_cloud *__restrict__ out, int *__restrict__ out_n)
+{
+    const int npl = npl_ptr ? min(*npl_ptr, npl_fixed) : npl_fixed;
+    const int i = threadIdx.x;
+    if (i < PT_MAXPL) {
+        hvo_plane_cloud o; memset(&o, 0, sizeof(o));
+        if (i < npl) {
+            const PcPlane &q = P[i];
+            for (int k = 0; k < 4; k++) o.coef[k] = q.coef[k];
+            o.valid = q.valid; o.gate_ok = q.gate_ok; o.first = q.first; o.n_points = q.npts; o.n_pixels = q.npix; o.n_inliers = q.ninl;
+        }
+        out[i] = o;
+    }
+    if (i == 0) { out_n[0] = misc[1]; out_n[1] = (misc[0] || misc[1] > cap) ? 1 : 0; }
+}
 
+size_t pc_scratch_bytes(int cap)
+{
+    return PT_MAXPL * sizeof(PcPlane) + (size_t)PT_TABCAP * sizeof(PcVox) + (size_t)cap * sizeof(int) + 256;
+}
+
+// device-resident form of the per-plane tail: depth, labels (int8 or int32), the planes and their count (d_npl, or npl_fixed when
+// null) already in HBM; scratch of pc_scratch_bytes(cap).  d_cloud: cap x 3 floats; d_out: PT_MAXPL records; d_out_n: 2 ints.
+template <class LT>
+static int pc_enqueue_t(hvo_ctx *ctx, hipStream_t st, const uint16_t *d_depth, int pitch, int w, int h, const LT *d_labels, const hvo_plane *d_planes,
+                        const int *d_npl, int npl_fixed, double dist_th, void *scratch, float *d_cloud, int cap, hvo_plane_cloud *d_out, int *d_out_n)
+{
+    PcPlane *dP = (PcPlane *)scratch; PcVox *tab = (PcVox *)(dP + PT_MAXPL); int *dshuf = (int *)(tab + PT_TABCAP); int *dmisc = dshuf + cap;
+    const hvo_params &p = ctx->p;
+    const int nb = std::min((w * h + 255) / 256, 1024);
+    const int nplb = d_npl ? PT_MAXPL : npl_fixed;              // per-plane kernels: blocks past the count return at once (q.npix == 0 / q.cells == 0)
+    HVO_HIP(hipMemsetAsync(tab, 0, (size_t)PT_TABCAP * sizeof(PcVox), st));
+    hipLaunchKernelGGL(k_pc_init, dim3(1), dim3(64), 0, st, dP, dmisc);
+    hipLaunchKernelGGL(k_pc_bbox<LT>, dim3(nb), dim3(256), 0, st, d_depth, pitch, w, h, d_labels, d_npl, npl_fixed, p.fx, p.fy, p.cx, p.cy, p.depth_map_factor, dP);
+    hipLaunchKernelGGL(k_pc_setup, dim3(1), dim3(1), 0, st, dP, d_planes, d_npl, npl_fixed, dmisc);
+    hipLaunchKernelGGL(k_pc_accum<LT>, dim3(nb), dim3(256), 0, st, d_depth, pitch, w, h, d_labels, d_npl, npl_fixed, p.fx, p.fy, p.cx, p.cy, p.depth_map_factor, dP, tab);
+    if (nplb > 0) hipLaunchKernelGGL(k_pc_count, dim3(nplb), dim3(256), 0, st, dP, tab);
+    hipLaunchKernelGGL(k_pc_prefix, dim3(1), dim3(1), 0, st, dP, d_npl, npl_fixed, dmisc + 1);
+    if (nplb > 0) {
+        hipLaunchKernelGGL(k_pc_emit, dim3(nplb), dim3(256), 0, st, dP, tab, d_cloud, cap, dist_th);
+        hipLaunchKernelGGL(k_pc_refit, dim3(nplb), dim3(256), 0, st, dP, d_cloud, cap, dshuf, dist_th);
+    }
+    hipLaunchKernelGGL(k_pc_export, dim3(1), dim3(64), 0, st, dP, d_npl, npl_fixed, dmisc, cap, d_out, d_out_n);
+    HVO_HIP(hipGetLastError());
+    return HVO_OK;
+}
+int pc_enqueue(hvo_ctx *ctx, hipStream_t st, const uint16_t *d_depth, int pitch, int w, int h, const int8_t *d_labels8, const hvo_plane *d_planes,
+               const int *d_npl, int npl_fixed, double dist_th, void *scratch, float *d_cloud, int cap, hvo_plane_cloud *d_out, int *d_out_n)
+{
+    return pc_enqueue_t<int8_t>(ctx, st, d_depth, pitch, w, h, d_labels8, d_planes, d_npl, npl_fixed, dist_th, scratch, d_cloud, cap, d_out, d_out_n);
+}
+
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// host-array form: a thin wrapper over the enqueue function through the context's staging arena (no allocation per call)
 extern "C" int hvo_plane_clouds(hvo_ctx *ctx, const uint16_t *depth, int w, int h, int stride, const int32_t *labels, const hvo_plane *planes, int n_planes,
                                 double dist_th, float *cloud_xyz, int cap, hvo_plane_cloud *out, int *n_total)
 {
@@ -518,45 +587,60 @@ extern "C" int hvo_plane_clouds(hvo_ctx *ctx, const uint16_t *depth, int w, int 
     if (!depth || !labels || !planes || !cloud_xyz || !out || cap < 1 || w <= 0 || h <= 0 || stride < 2 * w) return HVO_ERR_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
     hipStream_t st = ctx->stream;
-    uint16_t *dd = nullptr; int *dl = nullptr; hvo_plane *dpl = nullptr; PcPlane *dP = nullptr; PcVox *tab = nullptr; float *dc = nullptr; int *dshuf = nullptr, *dmisc = nullptr;
-    int rc = HVO_OK;
-    std::vector<PcPlane> hp(n_planes);
-    int misc[2] = { 0, 0 };
-    if ((rc = dmalloc(ctx, &dd, (size_t)w * h)) || (rc = dmalloc(ctx, &dl, (size_t)w * h)) || (rc = dmalloc(ctx, &dpl, (size_t)n_planes)) || (rc = dmalloc(ctx, &dP, (size_t)n_planes)) ||
-        (rc = dmalloc(ctx, &tab, (size_t)PT_TABCAP)) || (rc = dmalloc(ctx, &dc, (size_t)cap * 3)) || (rc = dmalloc(ctx, &dshuf, (size_t)cap)) || (rc = dmalloc(ctx, &dmisc, 2))) goto done;
-    for (auto &q : hp) { memset(&q, 0, sizeof(q)); for (int k = 0; k < 3; k++) { q.bmin[k] = 0xFFFFFFFFu; q.bmax[k] = 0u; } }
-    (void)hipMemcpy2DAsync(dd, (size_t)w * 2, depth, stride, (size_t)w * 2, h, hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(dl, labels, (size_t)w * h * 4, hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(dpl, planes, (size_t)n_planes * sizeof(hvo_plane), hipMemcpyHostToDevice, st);
-    (void)hipMemcpyAsync(dP, hp.data(), (size_t)n_planes * sizeof(PcPlane), hipMemcpyHostToDevice, st);
-    (void)hipMemsetAsync(tab, 0, (size_t)PT_TABCAP * sizeof(PcVox), st);
-    (void)hipMemsetAsync(dmisc, 0, 2 * sizeof(int), st);
-    {
-        const hvo_params &p = ctx->p;
-        const int nb = std::min((w * h + 255) / 256, 1024);
-        hipLaunchKernelGGL(k_pc_bbox, dim3(nb), dim3(256), 0, st, dd, w, w, h, dl, n_planes, p.fx, p.fy, p.cx, p.cy, p.depth_map_factor, dP);
-        hipLaunchKernelGGL(k_pc_setup, dim3(1), dim3(1), 0, st, dP, dpl, n_planes, dmisc);
-        hipLaunchKernelGGL(k_pc_accum, dim3(nb), dim3(256), 0, st, dd, w, w, h, dl, n_planes, p.fx, p.fy, p.cx, p.cy, p.depth_map_factor, dP, tab);
-        hipLaunchKernelGGL(k_pc_count, dim3(n_planes), dim3(256), 0, st, dP, tab);
-        hipLaunchKernelGGL(k_pc_prefix, dim3(1), dim3(1), 0, st, dP, n_planes, dmisc + 1);
-        hipLaunchKernelGGL(k_pc_emit, dim3(n_planes), dim3(256), 0, st, dP, tab, dc, cap, dist_th);
-        hipLaunchKernelGGL(k_pc_refit, dim3(n_planes), dim3(256), 0, st, dP, dc, cap, dshuf, dist_th);
-    }
-    if (hipGetLastError() != hipSuccess) { rc = HVO_ERR_HIP; goto done; }
-    (void)hipMemcpyAsync(hp.data(), dP, (size_t)n_planes * sizeof(PcPlane), hipMemcpyDeviceToHost, st);
-    (void)hipMemcpyAsync(misc, dmisc, sizeof(misc), hipMemcpyDeviceToHost, st);
-    if (hipStreamSynchronize(st) != hipSuccess) { rc = HVO_ERR_HIP; goto done; }
-    *n_total = misc[1];
-    if (misc[1] > 0 && hipMemcpy(cloud_xyz, dc, (size_t)std::min(misc[1], cap) * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { rc = HVO_ERR_HIP; goto done; }
-    for (int i = 0; i < n_planes; i++) {
-        hvo_plane_cloud &o = out[i]; const PcPlane &q = hp[i];
-        for (int k = 0; k < 4; k++) o.coef[k] = q.coef[k];
-        o.valid = q.valid; o.gate_ok = q.gate_ok; o.first = q.first; o.n_points = q.npts; o.n_pixels = q.npix; o.n_inliers = q.ninl;
-    }
-    if (misc[0] || misc[1] > cap) rc = HVO_ERR_CAPACITY;
-done:
-    { void *ptrs[] = { dd, dl, dpl, dP, tab, dc, dshuf, dmisc }; for (void *q : ptrs) if (q) (void)hipFree(q); }
-    return rc;
+    const size_t b_d = al256((size_t)w * h * 2), b_l = al256((size_t)w * h * 4), b_p = al256(PT_MAXPL * sizeof(hvo_plane)), b_c = al256((size_t)cap * 12),
+                 b_o = al256(PT_MAXPL * sizeof(hvo_plane_cloud));
+    char *a = (char *)hvo_call_arena(ctx, b_d + b_l + b_p + b_c + b_o + 256 + pc_scratch_bytes(cap));
+    if (!a) return HVO_ERR_HIP;
+    uint16_t *dd = (uint16_t *)a; int *dl = (int *)(a + b_d); hvo_plane *dpl = (hvo_plane *)(a + b_d + b_l); float *dc = (float *)(a + b_d + b_l + b_p);
+    hvo_plane_cloud *dout = (hvo_plane_cloud *)(a + b_d + b_l + b_p + b_c); int *dn = (int *)(a + b_d + b_l + b_p + b_c + b_o);
+    void *scratch = a + b_d + b_l + b_p + b_c + b_o + 256;
+    HVO_HIP(hipMemcpy2DAsync(dd, (size_t)w * 2, depth, stride, (size_t)w * 2, h, hipMemcpyHostToDevice, st));
+    HVO_HIP(hipMemcpyAsync(dl, labels, (size_t)w * h * 4, hipMemcpyHostToDevice, st));
+    HVO_HIP(hipMemcpyAsync(dpl, planes, (size_t)n_planes * sizeof(hvo_plane), hipMemcpyHostToDevice, st));
+    int rc = pc_enqueue_t<int>(ctx, st, dd, w, w, h, dl, dpl, nullptr, n_planes, dist_th, scratch, dc, cap, dout, dn);
+    if (rc) return rc;
+    int hn[2] = { 0, 0 };
+    std::vector<hvo_plane_cloud> ho(PT_MAXPL);
+    HVO_HIP(hipMemcpyAsync(ho.data(), dout, PT_MAXPL * sizeof(hvo_plane_cloud), hipMemcpyDeviceToHost, st));
+    HVO_HIP(hipMemcpyAsync(hn, dn, sizeof(hn), hipMemcpyDeviceToHost, st));
+    HVO_HIP(hipStreamSynchronize(st));
+    *n_total = hn[0];
+    if (hn[0] > 0) HVO_HIP(hipMemcpy(cloud_xyz, dc, (size_t)std::min(hn[0], cap) * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n_planes; i++) out[i] = ho[i];
+    return hn[1] ? HVO_ERR_CAPACITY : HVO_OK;
+}
+
+static void sn_carve(SnArgs &a, int w, int h, char *base, size_t &bytes)
+{
+    a.w = w; a.h = h; a.W = (w + 2) / 3; a.H = (h + 2) / 3;
+    const size_t N = (size_t)a.W * a.H, IN = (size_t)(a.W + 1) * (a.H + 1);
+    size_t o = 0;
+    auto take = [&](size_t b) { char *p = base ? base + o : nullptr; o += al256(b); return p; };
+    a.P = (float *)take(3 * N * 4); a.chg = (unsigned char *)take(N + a.W + 2); float *dmbase = (float *)take((N + 2 * (size_t)a.W + 4) * 4);
+    a.gx = (float *)take(3 * N * 4); a.gy = (float *)take(3 * N * 4); a.IX = (double *)take(3 * IN * 8); a.IY = (double *)take(3 * IN * 8);
+    a.CX = (unsigned *)take(IN * 4); a.CY = (unsigned *)take(IN * 4);
+    a.dm = dmbase ? dmbase + a.W + 2 : nullptr;
+    bytes = o;
+}
+size_t sn_scratch_bytes(int w, int h) { SnArgs a; memset(&a, 0, sizeof(a)); size_t b; sn_carve(a, w, h, nullptr, b); return b; }
+int sn_count(int w, int h) { return (((h + 2) / 3) / 2) * (((w + 2) / 3) / 2); }
+
+// device-resident form: depth in HBM, scratch of sn_scratch_bytes(w, h), d_out with sn_count(w, h) entries
+int sn_enqueue(hvo_ctx *ctx, hipStream_t st, const uint16_t *d_depth, int pitch, int w, int h, void *scratch, hvo_surface_normal *d_out)
+{
+    SnArgs a; memset(&a, 0, sizeof(a));
+    size_t b; sn_carve(a, w, h, (char *)scratch, b);
+    a.pitch = pitch; a.depth = d_depth;
+    a.fx = ctx->p.fx; a.fy = ctx->p.fy; a.cx = ctx->p.cx; a.cy = ctx->p.cy; a.dfac = ctx->p.depth_map_factor;
+    const size_t N = (size_t)a.W * a.H;
+    const int nout = sn_count(w, h);
+    a.out = d_out; a.cap = nout;
+    hipLaunchKernelGGL(k_sn_cloud, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_sn_grad, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_sn_serial, dim3(1), dim3(576), 0, st, a);
+    if (nout > 0) hipLaunchKernelGGL(k_sn_normals, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, a);
+    HVO_HIP(hipGetLastError());
+    return HVO_OK;
 }
 
 extern "C" int hvo_surface_normals(hvo_ctx *ctx, const uint16_t *depth, int w, int h, int stride, hvo_surface_normal *out, int cap, int *n)
@@ -566,32 +650,18 @@ extern "C" int hvo_surface_normals(hvo_ctx *ctx, const uint16_t *depth, int w, i
     if (!depth || !out || cap < 0 || w < 3 || h < 3 || stride < 2 * w) return HVO_ERR_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
     hipStream_t st = ctx->stream;
-    SnArgs a; memset(&a, 0, sizeof(a));
-    a.w = w; a.h = h; a.W = (w + 2) / 3; a.H = (h + 2) / 3; a.pitch = w;
-    a.fx = ctx->p.fx; a.fy = ctx->p.fy; a.cx = ctx->p.cx; a.cy = ctx->p.cy; a.dfac = ctx->p.depth_map_factor;
-    const size_t N = (size_t)a.W * a.H, IN = (size_t)(a.W + 1) * (a.H + 1);
-    const int nout = (a.H / 2) * (a.W / 2);
-    uint16_t *dd = nullptr; float *dmbase = nullptr; hvo_surface_normal *dout = nullptr;
-    int rc = HVO_OK;
-    if ((rc = dmalloc(ctx, &dd, (size_t)w * h)) || (rc = dmalloc(ctx, &a.P, 3 * N)) || (rc = dmalloc(ctx, &a.chg, N + a.W + 2)) || (rc = dmalloc(ctx, &dmbase, N + 2 * (size_t)a.W + 4)) ||
-        (rc = dmalloc(ctx, &a.gx, 3 * N)) || (rc = dmalloc(ctx, &a.gy, 3 * N)) || (rc = dmalloc(ctx, &a.IX, 3 * IN)) || (rc = dmalloc(ctx, &a.IY, 3 * IN)) ||
-        (rc = dmalloc(ctx, &a.CX, IN)) || (rc = dmalloc(ctx, &a.CY, IN)) || (rc = dmalloc(ctx, &dout, (size_t)std::max(nout, 1)))) goto done;
-    a.depth = dd; a.dm = dmbase + a.W + 2; a.out = dout; a.cap = nout;
-    (void)hipMemcpy2DAsync(dd, (size_t)w * 2, depth, stride, (size_t)w * 2, h, hipMemcpyHostToDevice, st);
-    hipLaunchKernelGGL(k_sn_cloud, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_sn_grad, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_sn_serial, dim3(1), dim3(576), 0, st, a);
-    hipLaunchKernelGGL(k_sn_normals, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, a);
-    if (hipGetLastError() != hipSuccess) { rc = HVO_ERR_HIP; goto done; }
-    {
-        std::vector<hvo_surface_normal> tmp((size_t)std::max(nout, 1));
-        (void)hipMemcpyAsync(tmp.data(), dout, (size_t)nout * sizeof(hvo_surface_normal), hipMemcpyDeviceToHost, st);
-        if (hipStreamSynchronize(st) != hipSuccess) { rc = HVO_ERR_HIP; goto done; }
-        memcpy(out, tmp.data(), (size_t)std::min(nout, cap) * sizeof(hvo_surface_normal));
-        *n = nout;
-        if (nout > cap) rc = HVO_ERR_CAPACITY;
-    }
-done:
-    { void *ptrs[] = { dd, a.P, a.chg, dmbase, a.gx, a.gy, a.IX, a.IY, a.CX, a.CY, dout }; for (void *q : ptrs) if (q) (void)hipFree(q); }
-    return rc;
+    const int nout = sn_count(w, h);
+    const size_t b_d = al256((size_t)w * h * 2), b_o = al256((size_t)std::max(nout, 1) * sizeof(hvo_surface_normal));
+    char *a = (char *)hvo_call_arena(ctx, b_d + b_o + sn_scratch_bytes(w, h));
+    if (!a) return HVO_ERR_HIP;
+    uint16_t *dd = (uint16_t *)a; hvo_surface_normal *dout = (hvo_surface_normal *)(a + b_d);
+    HVO_HIP(hipMemcpy2DAsync(dd, (size_t)w * 2, depth, stride, (size_t)w * 2, h, hipMemcpyHostToDevice, st));
+    int rc = sn_enqueue(ctx, st, dd, w, w, h, a + b_d + b_o, dout);
+    if (rc) return rc;
+    std::vector<hvo_surface_normal> tmp((size_t)std::max(nout, 1));
+    HVO_HIP(hipMemcpyAsync(tmp.data(), dout, (size_t)nout * sizeof(hvo_surface_normal), hipMemcpyDeviceToHost, st));
+    HVO_HIP(hipStreamSynchronize(st));
+    memcpy(out, tmp.data(), (size_t)std::min(nout, cap) * sizeof(hvo_surface_normal));
+    *n = nout;
+    return nout > cap ? HVO_ERR_CAPACITY : HVO_OK;
 }

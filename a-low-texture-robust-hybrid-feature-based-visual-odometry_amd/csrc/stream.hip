@@ -27,6 +27,7 @@ struct StreamSlot {
     char *h_out = nullptr;
     // device extras
     hvo_keypoint *d_kp_un = nullptr; float *d_uright = nullptr, *d_zdepth = nullptr;
+    char *d_tail = nullptr, *d_tail_scratch = nullptr, *h_tail = nullptr;     // the Frame tail's result block (HBM + pinned copy) and scratch (tail.hip)
     hipEvent_t ev_gray = nullptr, ev_depth = nullptr, ev_orb = nullptr, ev_lsd = nullptr, ev_peac = nullptr;
     hipEvent_t ev_kern[3] = { nullptr, nullptr, nullptr };      // kernels done (before the downloads), per subsystem: latency accounting
     hipEvent_t ev_t0 = nullptr;
@@ -45,7 +46,9 @@ struct hvo_stream {
     StreamSlot slot[ST_MAX_DEPTH];
     OutLayout lay;
     int64_t next = 0;
+    TailLayout tl; unsigned tail_stages = 0; double tail_dist_th = 0.05, tail_vp_th = 1.0 / 180.0 * 3.1415926535897932384626433832795;
     float bounds[4];                       // mnMinX, mnMaxX, mnMinY, mnMaxY (Frame::ComputeImageBounds)
+    const float *bounds4() const { return bounds; }
     // matching scratch (device + pinned), sized for kp_cap queries
     char *d_ms = nullptr, *h_ms = nullptr; size_t ms_bytes = 0;
     hipStream_t s_match = nullptr;         // the matching calls run here, behind the two frames' events (not behind a frame's line chain)
@@ -73,6 +76,9 @@ void hvo_stream_destroy(hvo_stream *s)
         if (S.d_kp_un) (void)hipFree(S.d_kp_un);
         if (S.d_uright) (void)hipFree(S.d_uright);
         if (S.d_zdepth) (void)hipFree(S.d_zdepth);
+        if (S.d_tail) (void)hipFree(S.d_tail);
+        if (S.d_tail_scratch) (void)hipFree(S.d_tail_scratch);
+        if (S.h_tail) (void)hipHostFree(S.h_tail);
         if (S.ctx) hvo_destroy(S.ctx);
     }
     if (s->d_ms) (void)hipFree(s->d_ms);
@@ -94,6 +100,13 @@ int hvo_stream_create(const hvo_params *p, const hvo_stream_params *sp, hvo_stre
     s->p = *p; s->sp = *sp; s->depth = sp->depth; s->w = sp->width; s->h = sp->height;
     s->p.max_batch = 1;
     s->culled = (sp->stages & HVO_STAGE_LSD_CULL) != 0;
+    s->tail_stages = sp->stages & (HVO_STAGE_LINES3D | HVO_STAGE_VP | HVO_STAGE_PLANE_TAIL | HVO_STAGE_GRIDS);
+    if (sp->plane_dist_th > 0) s->tail_dist_th = sp->plane_dist_th;
+    if (sp->vp_th_angle > 0) s->tail_vp_th = sp->vp_th_angle;
+    {   // every tail stage needs the stage that produces its input
+        const bool lsd = (sp->stages & (HVO_STAGE_LSD | HVO_STAGE_LSD_CULL)) != 0, orb = (sp->stages & HVO_STAGE_ORB) != 0, pl = (sp->stages & HVO_STAGE_PLANES) != 0;
+        if (((s->tail_stages & (HVO_STAGE_LINES3D | HVO_STAGE_VP)) && !lsd) || ((s->tail_stages & HVO_STAGE_PLANE_TAIL) && !pl) || ((s->tail_stages & HVO_STAGE_GRIDS) && !(lsd && orb))) { delete s; return HVO_ERR_INVALID_ARG; }
+    }
     const int w = s->w, h = s->h;
     int rc = HVO_OK;
     for (int i = 0; i < s->depth && !rc; i++) {
@@ -131,6 +144,12 @@ int hvo_stream_create(const hvo_params *p, const hvo_stream_params *sp, hvo_stre
             hipMalloc((void **)&S.d_kp_un, (size_t)s->kp_cap * sizeof(hvo_keypoint)) != hipSuccess ||
             hipMalloc((void **)&S.d_uright, (size_t)s->kp_cap * 4) != hipSuccess ||
             hipMalloc((void **)&S.d_zdepth, (size_t)s->kp_cap * 4) != hipSuccess) { rc = HVO_ERR_HIP; break; }
+        if (s->tail_stages) {
+            if (i == 0) tail_layout(w, h, S.ctx->orb.kp_cap, S.lv.nfeat > 0 ? S.lv.nfeat : s->p.lsd_nfeatures, s->tl);
+            if (hipMalloc((void **)&S.d_tail, s->tl.total) != hipSuccess || hipMalloc((void **)&S.d_tail_scratch, 3 * s->tl.scratch_total) != hipSuccess ||
+                hipHostMalloc((void **)&S.h_tail, s->tl.total, hipHostMallocDefault) != hipSuccess) { rc = HVO_ERR_HIP; break; }
+            (void)hipMemset(S.d_tail, 0, s->tl.total); memset(S.h_tail, 0, s->tl.total);
+        }
         hipEvent_t *evs[] = { &S.ev_gray, &S.ev_depth, &S.ev_orb, &S.ev_lsd, &S.ev_peac };
         for (hipEvent_t *e : evs) if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) rc = HVO_ERR_HIP;
         for (int k = 0; k < 3; k++) if (hipEventCreate(&S.ev_kern[k]) != hipSuccess) rc = HVO_ERR_HIP;
@@ -223,7 +242,15 @@ static int stream_submit_enqueue(hvo_stream *s, StreamSlot &S, const uint8_t *gr
     // 2. planes (the longest chain first), lines, points: three streams, no host synchronisation
     if (want_pl) {
         if ((rc = peac_run(c, 1))) { s->last_error = c->last_error; return rc; }
+        // ComputePlanes' tail on the resident depth, labels and planes (src/Frame.cc:2110-2274)
+        if ((rc = tail_enqueue_planes(c, c->s_peac, s->tail_stages, s->tl, S.d_tail, S.d_tail_scratch + s->tl.scratch_total, S.pv.d_depth, S.pv.pitch, S.pv.d_labels8, S.pv.d_planes,
+                                      S.pv.d_meta + 4, s->tail_dist_th))) return rc;
         ST_HIP(hipEventRecord(S.ev_kern[2], c->s_peac));
+        if (s->tail_stages & HVO_STAGE_PLANE_TAIL) {
+            const TailLayout &T = s->tl;
+            ST_HIP(hipMemcpyAsync(S.h_tail + T.counts, S.d_tail + T.counts, 2 * sizeof(int), hipMemcpyDeviceToHost, c->s_peac));
+            ST_HIP(hipMemcpyAsync(S.h_tail + T.pclouds, S.d_tail + T.pclouds, T.normals + (size_t)T.n_normals * sizeof(hvo_surface_normal) - T.pclouds, hipMemcpyDeviceToHost, c->s_peac));
+        }
         ST_HIP(hipMemcpyAsync(hc + 16, S.pv.d_meta, 16 * sizeof(int), hipMemcpyDeviceToHost, c->s_peac));
         ST_HIP(hipMemcpyAsync(ho + L.planes, S.pv.d_planes, (size_t)S.pv.max_planes * sizeof(hvo_plane), hipMemcpyDeviceToHost, c->s_peac));
         ST_HIP(hipMemcpyAsync(ho + L.labels, S.pv.d_labels8, (size_t)w * h, hipMemcpyDeviceToHost, c->s_peac));
@@ -238,7 +265,13 @@ static int stream_submit_enqueue(hvo_stream *s, StreamSlot &S, const uint8_t *gr
             if ((rc = match_stereo_enqueue(c->stream, O.d_kp, S.d_kp_un, O.d_nkp, s->kp_cap, S.pv.d_depth, S.pv.pitch, w, h, s->p.depth_map_factor, s->sp.bf,
                                            S.d_uright, S.d_zdepth))) return rc;
         }
+        if ((rc = tail_enqueue_points(c, c->stream, s->tail_stages, s->tl, S.d_tail, S.d_tail_scratch + 2 * s->tl.scratch_total, S.d_kp_un, O.d_nkp, s->bounds4()))) return rc;
         ST_HIP(hipEventRecord(S.ev_kern[0], c->stream));
+        if (s->tail_stages & HVO_STAGE_GRIDS) {
+            const TailLayout &T = s->tl;
+            ST_HIP(hipMemcpyAsync(S.h_tail + T.counts + 2 * sizeof(int), S.d_tail + T.counts + 2 * sizeof(int), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            ST_HIP(hipMemcpyAsync(S.h_tail + T.pt_start, S.d_tail + T.pt_start, T.ln_start - T.pt_start, hipMemcpyDeviceToHost, c->stream));
+        }
         ST_HIP(hipMemcpyAsync(hc + 0, O.d_nkp, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         ST_HIP(hipMemcpyAsync(hc + 1, O.d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         ST_HIP(hipMemcpyAsync(ho + L.kp, O.d_kp, (size_t)s->kp_cap * sizeof(hvo_keypoint), hipMemcpyDeviceToHost, c->stream));
@@ -254,7 +287,22 @@ static int stream_submit_enqueue(hvo_stream *s, StreamSlot &S, const uint8_t *gr
     if (want_lsd) {
         if (!c->lsd_on_orb_stream) ST_HIP(hipStreamWaitEvent(c->s_lsd, S.ev_gray, 0));
         if ((rc = lsd_run(c, 1, s->culled))) { s->last_error = c->last_error; return rc; }
+        // isLineGood, vanishing points and the line grid on the resident key lines (src/Frame.cc:328-337, 934-939, 849-872)
+        if (s->tail_stages & (HVO_STAGE_LINES3D | HVO_STAGE_VP | HVO_STAGE_GRIDS)) {
+            const bool l3 = (s->tail_stages & HVO_STAGE_LINES3D) && depth;
+            if (l3) ST_HIP(hipStreamWaitEvent(LS, S.ev_depth, 0));
+            if ((rc = tail_enqueue_lines(c, LS, s->tail_stages, s->tl, S.d_tail, S.d_tail_scratch, S.lv.d_kl, S.lv.d_nkl, l3 ? S.pv.d_depth : nullptr, S.pv.pitch,
+                                         s->sp.seed + (unsigned)s->next, s->tail_vp_th, s->bounds4()))) return rc;
+        }
         ST_HIP(hipEventRecord(S.ev_kern[1], LS));
+        if (s->tail_stages & (HVO_STAGE_LINES3D | HVO_STAGE_VP | HVO_STAGE_GRIDS)) {
+            const TailLayout &T = s->tl;
+            ST_HIP(hipMemcpyAsync(S.h_tail + T.lines3d, S.d_tail + T.lines3d, T.pclouds - T.lines3d, hipMemcpyDeviceToHost, LS));
+            if (s->tail_stages & HVO_STAGE_GRIDS) {
+                ST_HIP(hipMemcpyAsync(S.h_tail + T.counts + 3 * sizeof(int), S.d_tail + T.counts + 3 * sizeof(int), sizeof(int), hipMemcpyDeviceToHost, LS));
+                ST_HIP(hipMemcpyAsync(S.h_tail + T.ln_start, S.d_tail + T.ln_start, T.total - T.ln_start, hipMemcpyDeviceToHost, LS));
+            }
+        }
         ST_HIP(hipMemcpyAsync(hc + 4, S.lv.d_nkl, sizeof(int), hipMemcpyDeviceToHost, LS));
         ST_HIP(hipMemcpyAsync(hc + 5, S.lv.d_flags, sizeof(int), hipMemcpyDeviceToHost, LS));
         ST_HIP(hipMemcpyAsync(ho + L.kl, S.lv.d_kl, (size_t)s->nfeat * sizeof(hvo_keyline), hipMemcpyDeviceToHost, LS));
@@ -340,6 +388,21 @@ int hvo_stream_collect(hvo_stream *s, int64_t ticket, hvo_frame_out *out, hvo_ke
         }
     }
     return HVO_OK;
+}
+
+// the frame's tail results (waits for the frame like hvo_stream_collect; the slot stays busy until hvo_stream_collect releases it)
+int hvo_stream_collect_tail(hvo_stream *s, int64_t ticket, hvo_frame_tail *tail)
+{
+    if (!s || !tail) return HVO_ERR_INVALID_ARG;
+    StreamSlot *Sp = slot_of(s, ticket);
+    if (!Sp || !Sp->busy || !s->tail_stages) return HVO_ERR_INVALID_ARG;
+    ST_HIP(hipEventSynchronize(Sp->ev_orb));
+    ST_HIP(hipEventSynchronize(Sp->ev_lsd));
+    ST_HIP(hipEventSynchronize(Sp->ev_peac));
+    unsigned st = s->tail_stages;
+    if (!Sp->had_depth) st &= ~(HVO_STAGE_LINES3D | HVO_STAGE_PLANE_TAIL);
+    const int n_kl = ((const int *)(Sp->h_out + s->lay.counts))[4];
+    return tail_unpack(s->tl, st, Sp->h_tail, n_kl, tail);
 }
 
 // device time of the frame's stages: ms from the start of its upload to the end of the ORB / line / plane kernels

@@ -28,8 +28,10 @@ static __device__ __forceinline__ void vcross(const double *a, const double *b, 
 static __device__ __forceinline__ unsigned vxs32(unsigned &s) { unsigned x = s; x ^= x << 13; x ^= x >> 17; x ^= x << 5; s = x; return x; }
 
 // src/Frame.cc:454-473
-__global__ __launch_bounds__(256) void k_vp_lines(const hvo_keyline *__restrict__ kl, int n, double *__restrict__ para, double *__restrict__ len, double *__restrict__ ori)
+// (every kernel takes the line count from n_ptr when it is given: in the pipelines it only exists on the device)
+__global__ __launch_bounds__(256) void k_vp_lines(const hvo_keyline *__restrict__ kl, const int *__restrict__ n_ptr, int n_fixed, double *__restrict__ para, double *__restrict__ len, double *__restrict__ ori)
 {
+    const int n = n_ptr ? min(*n_ptr, n_fixed) : n_fixed;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const double p1[3] = { (double)kl[i].sx, (double)kl[i].sy, 1.0 }, p2[3] = { (double)kl[i].ex, (double)kl[i].ey, 1.0 };
@@ -44,9 +46,10 @@ __global__ __launch_bounds__(256) void k_vp_lines(const hvo_keyline *__restrict_
 }
 
 // one thread per pair (i < j), written at the pair's rank in the reference's loop order: cell (-1: contributes nothing), value
-__global__ __launch_bounds__(256) void k_vp_pairs(const double *__restrict__ para, const double *__restrict__ len, const double *__restrict__ ori, int n,
+__global__ __launch_bounds__(256) void k_vp_pairs(const double *__restrict__ para, const double *__restrict__ len, const double *__restrict__ ori, const int *__restrict__ n_ptr, int n_fixed,
                                                   double fx, double cx, double cy, int *__restrict__ cell, double *__restrict__ val)
 {
+    const int n = n_ptr ? min(*n_ptr, n_fixed) : n_fixed;
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     if (j <= i || j >= n) return;
     const size_t p = (size_t)i * (2 * (size_t)n - i - 1) / 2 + (j - i - 1);
@@ -68,8 +71,10 @@ __global__ __launch_bounds__(256) void k_vp_pairs(const double *__restrict__ par
 }
 
 // a thread owns a cell and adds the values of its pairs in pair order; the pair list is staged through LDS, 2048 at a time
-__global__ __launch_bounds__(256) void k_vp_grid(const int *__restrict__ cell, const double *__restrict__ val, size_t npairs, double *__restrict__ raw)
+__global__ __launch_bounds__(256) void k_vp_grid(const int *__restrict__ cell, const double *__restrict__ val, const int *__restrict__ n_ptr, int n_fixed, double *__restrict__ raw)
 {
+    const int n = n_ptr ? min(*n_ptr, n_fixed) : n_fixed;
+    const size_t npairs = n < 2 ? 0 : (size_t)n * (n - 1) / 2;
     __shared__ int sc[2048]; __shared__ double sv[2048];
     const int me = blockIdx.x * 256 + threadIdx.x;
     const int lo = blockIdx.x * 256, hi = lo + 256;
@@ -105,16 +110,24 @@ static __device__ __forceinline__ double vp_cell_of(const double *grid, const do
     if (v[2] == 0.0) return 0.0;
     const double latitude = acos(v[2]), longitude = atan2(v[0], v[1]) + VP_PI;
     int LA = (int)(latitude / oneDegree); if (LA == 90) LA = 89;
-    int LO = (int)(longitude / oneDegree); if (LO == 360) LO = 359;
+    // a longitude within 1e-6 degree of a whole degree goes to that degree's cell: the determinism rule of oracle/vps.c vp_score (every
+    // hypothesis' second direction sits on a cell boundary by construction, and the reference's choice there is libm rounding noise)
+    const double lo_f = longitude / oneDegree, lo_r = nearbyint(lo_f);
+    int LO = fabs(lo_f - lo_r) < 1e-6 ? (int)lo_r : (int)lo_f; if (LO >= 360) LO = 359;
     if (LA < 0 || LA > 89 || LO < 0 || LO > 359) return 0.0;     // cannot happen for unit vectors with z >= 0; keeps a NaN hypothesis from reading outside
     return grid[LA * VP_LO + LO];
 }
 
 // block = hypothesis group i (one pair of lines), thread = j of its 360 hypotheses: vp1, vp2, vp3 and the score
-__global__ __launch_bounds__(384) void k_vp_hyp(const double *__restrict__ para, int n, double fx, double cx, double cy, unsigned seed,
+__global__ __launch_bounds__(384) void k_vp_hyp(const double *__restrict__ para, const int *__restrict__ n_ptr, int n_fixed, double fx, double cx, double cy, unsigned seed,
                                                 const double *__restrict__ grid, double *__restrict__ hyp, double *__restrict__ score)
 {
+    const int n = n_ptr ? min(*n_ptr, n_fixed) : n_fixed;
     const int i = blockIdx.x, j = threadIdx.x;
+    if (n < 2) {                                     // the reference skips the path (src/Frame.cc:328): zero hypotheses of score 0
+        if (j < VP_NUM2) { const size_t h = (size_t)i * VP_NUM2 + j; for (int q = 0; q < 9; q++) hyp[h * 9 + q] = 0.0; score[h] = 0.0; }
+        return;
+    }
     unsigned rs = seed ^ (0x9E3779B9u * (unsigned)(i + 1)); if (rs == 0) rs = 0x6D2B79F5u;
     double vp1[3];
     // The reference redraws without bound (src/Frame.cc:487-491); with every pair of lines meeting at infinity that is a hang, on a GPU
@@ -161,10 +174,11 @@ __global__ __launch_bounds__(384) void k_vp_hyp(const double *__restrict__ para,
 
 // first maximum above 0 (index 0 when there is none), then line2Vps: one workgroup
 __global__ __launch_bounds__(1024) void k_vp_best(const double *__restrict__ score, int nh, const double *__restrict__ hyp,
-                                                  const hvo_keyline *__restrict__ kl, int n, double fx, double fy, double cx, double cy, double th_angle,
+                                                  const hvo_keyline *__restrict__ kl, const int *__restrict__ n_ptr, int n_fixed, double fx, double fy, double cx, double cy, double th_angle,
                                                   hvo_vp_result *__restrict__ res, int32_t *__restrict__ vp_idx)
 {
     __shared__ double bs[1024]; __shared__ int bi[1024];
+    const int n = n_ptr ? min(*n_ptr, n_fixed) : n_fixed;
     const int tid = threadIdx.x;
     double s = 0.0; int b = 0x7FFFFFFF;
     for (int h = tid; h < nh; h += 1024) { const double v = score[h]; if (v > s) { s = v; b = h; } }     // ascending h: the first of this thread's maxima
@@ -182,7 +196,9 @@ __global__ __launch_bounds__(1024) void k_vp_best(const double *__restrict__ sco
     if (tid == 0) {
         for (int q = 0; q < 9; q++) res->vps[q / 3][q % 3] = v[q];
         res->score = bs[0]; res->best = best; res->n_hypotheses = nh;
+        if (n < 2) { for (int q = 0; q < 9; q++) res->vps[q / 3][q % 3] = 0.0; res->score = 0.0; res->best = 0; res->n_hypotheses = 0; }
     }
+    if (n < 2) { for (int i = tid; i < n; i += 1024) vp_idx[i] = 3; return; }
     double vx[3], vy[3];
     for (int j = 0; j < 3; j++) { vx[j] = v[3 * j] * fx / v[3 * j + 2] + cx; vy[j] = v[3 * j + 1] * fy / v[3 * j + 2] + cy; }
     for (int i = tid; i < n; i += 1024) {
@@ -213,6 +229,38 @@ static int vp_iterations()
     return (int)(log(1 - confEfficience) / log(1.0 - p));
 }
 
+size_t vp_scratch_bytes(int nmax)
+{
+    const size_t npairs = (size_t)nmax * (nmax > 0 ? nmax - 1 : 0) / 2, nh = (size_t)vp_iterations() * VP_NUM2;
+    return (5 * (size_t)nmax + npairs + 2 * VP_CELLS + 10 * nh) * sizeof(double) + npairs * sizeof(int) + 256;
+}
+
+// device-resident form: key lines and their count (d_n, capped by nmax; or nmax itself when d_n is null) already in HBM; scratch of
+// vp_scratch_bytes(nmax); d_res / d_idx (nmax entries) / d_grid (optional, 90 x 360 doubles) receive the results.  Nothing is
+// allocated, nothing synchronises.
+int vp_enqueue(hvo_ctx *ctx, hipStream_t st, const hvo_keyline *d_kl, const int *d_n, int nmax, unsigned seed, double th_angle,
+               void *scratch, hvo_vp_result *d_res, int32_t *d_idx, double *d_grid_out)
+{
+    if (nmax < 1) return HVO_OK;
+    const hvo_params &P = ctx->p;
+    const int it = vp_iterations(), nh = it * VP_NUM2;
+    const size_t npairs = (size_t)nmax * (nmax - 1) / 2;
+    double *para = (double *)scratch, *len = para + 3 * (size_t)nmax, *ori = len + nmax, *val = ori + nmax, *raw = val + npairs, *grid = raw + VP_CELLS,
+           *hyp = grid + VP_CELLS, *score = hyp + 9 * (size_t)nh;
+    int *dcell = (int *)(score + nh);
+    const double fx = P.fx, fy = P.fy, cx = P.cx, cy = P.cy;
+    hipLaunchKernelGGL(k_vp_lines, dim3((nmax + 255) / 256), dim3(256), 0, st, d_kl, d_n, nmax, para, len, ori);
+    if (nmax > 1) hipLaunchKernelGGL(k_vp_pairs, dim3((nmax + 255) / 256, nmax - 1), dim3(256), 0, st, para, len, ori, d_n, nmax, fx, cx, cy, dcell, val);
+    hipLaunchKernelGGL(k_vp_grid, dim3((VP_CELLS + 255) / 256), dim3(256), 0, st, dcell, val, d_n, nmax, raw);
+    hipLaunchKernelGGL(k_vp_smooth, dim3((VP_CELLS + 255) / 256), dim3(256), 0, st, raw, grid);
+    hipLaunchKernelGGL(k_vp_hyp, dim3(it), dim3(384), 0, st, para, d_n, nmax, fx, cx, cy, seed, grid, hyp, score);
+    hipLaunchKernelGGL(k_vp_best, dim3(1), dim3(1024), 0, st, score, nh, hyp, d_kl, d_n, nmax, fx, fy, cx, cy, th_angle, d_res, d_idx);
+    if (d_grid_out) HVO_HIP(hipMemcpyAsync(d_grid_out, grid, VP_CELLS * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HVO_HIP(hipGetLastError());
+    return HVO_OK;
+}
+
+// host-array form: a thin wrapper over vp_enqueue through the context's staging arena (tail.hip): no allocation per call
 extern "C" int hvo_vanishing_points(hvo_ctx *ctx, const hvo_keyline *kl, int n, uint32_t seed, double th_angle,
                                     hvo_vp_result *res, int32_t *vp_idx, double *grid_out)
 {
@@ -224,37 +272,18 @@ extern "C" int hvo_vanishing_points(hvo_ctx *ctx, const hvo_keyline *kl, int n, 
     }
     if (!kl || !vp_idx) return HVO_ERR_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
-    const hvo_params &P = ctx->p;
-    const int it = vp_iterations(), nh = it * VP_NUM2;
-    const size_t npairs = (size_t)n * (n - 1) / 2;
     hipStream_t st = ctx->stream;
-    hvo_keyline *dk = nullptr; double *dd = nullptr; int *dcell = nullptr; hvo_vp_result *dres = nullptr; int32_t *didx = nullptr;
-    // doubles: para 3n, len n, ori n, val npairs, raw CELLS, grid CELLS, hyp 9 nh, score nh
-    const size_t nd = 5 * (size_t)n + npairs + 2 * VP_CELLS + 10 * (size_t)nh;
-    int rc = HVO_OK;
-    if (hipMalloc((void **)&dk, (size_t)n * sizeof(hvo_keyline)) != hipSuccess || hipMalloc((void **)&dd, nd * sizeof(double)) != hipSuccess ||
-        hipMalloc((void **)&dcell, npairs * sizeof(int)) != hipSuccess || hipMalloc((void **)&dres, sizeof(hvo_vp_result)) != hipSuccess ||
-        hipMalloc((void **)&didx, (size_t)n * sizeof(int32_t)) != hipSuccess) rc = HVO_ERR_HIP;
-    if (!rc) {
-        double *para = dd, *len = para + 3 * (size_t)n, *ori = len + n, *val = ori + n, *raw = val + npairs, *grid = raw + VP_CELLS,
-               *hyp = grid + VP_CELLS, *score = hyp + 9 * (size_t)nh;
-        const double fx = P.fx, fy = P.fy, cx = P.cx, cy = P.cy;
-        (void)hipMemcpyAsync(dk, kl, (size_t)n * sizeof(hvo_keyline), hipMemcpyHostToDevice, st);
-        hipLaunchKernelGGL(k_vp_lines, dim3((n + 255) / 256), dim3(256), 0, st, dk, n, para, len, ori);
-        hipLaunchKernelGGL(k_vp_pairs, dim3((n + 255) / 256, n - 1), dim3(256), 0, st, para, len, ori, n, fx, cx, cy, dcell, val);
-        hipLaunchKernelGGL(k_vp_grid, dim3((VP_CELLS + 255) / 256), dim3(256), 0, st, dcell, val, npairs, raw);
-        hipLaunchKernelGGL(k_vp_smooth, dim3((VP_CELLS + 255) / 256), dim3(256), 0, st, raw, grid);
-        hipLaunchKernelGGL(k_vp_hyp, dim3(it), dim3(384), 0, st, para, n, fx, cx, cy, seed, grid, hyp, score);
-        hipLaunchKernelGGL(k_vp_best, dim3(1), dim3(1024), 0, st, score, nh, hyp, dk, n, fx, fy, cx, cy, th_angle, dres, didx);
-        (void)hipMemcpyAsync(res, dres, sizeof(hvo_vp_result), hipMemcpyDeviceToHost, st);
-        (void)hipMemcpyAsync(vp_idx, didx, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st);
-        if (grid_out) (void)hipMemcpyAsync(grid_out, grid, VP_CELLS * sizeof(double), hipMemcpyDeviceToHost, st);
-        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) rc = HVO_ERR_HIP;
-    }
-    if (dk) (void)hipFree(dk);
-    if (dd) (void)hipFree(dd);
-    if (dcell) (void)hipFree(dcell);
-    if (dres) (void)hipFree(dres);
-    if (didx) (void)hipFree(didx);
-    return rc;
+    const size_t b_kl = ((size_t)n * sizeof(hvo_keyline) + 255) & ~(size_t)255, b_idx = ((size_t)n * 4 + 255) & ~(size_t)255, b_grid = VP_CELLS * sizeof(double);
+    char *a = (char *)hvo_call_arena(ctx, b_kl + 256 + b_idx + b_grid + vp_scratch_bytes(n));
+    if (!a) return HVO_ERR_HIP;
+    hvo_keyline *dk = (hvo_keyline *)a; hvo_vp_result *dres = (hvo_vp_result *)(a + b_kl); int32_t *didx = (int32_t *)(a + b_kl + 256);
+    double *dgrid = (double *)(a + b_kl + 256 + b_idx); void *scratch = a + b_kl + 256 + b_idx + b_grid;
+    HVO_HIP(hipMemcpyAsync(dk, kl, (size_t)n * sizeof(hvo_keyline), hipMemcpyHostToDevice, st));
+    int rc = vp_enqueue(ctx, st, dk, nullptr, n, seed, th_angle, scratch, dres, didx, grid_out ? dgrid : nullptr);
+    if (rc) return rc;
+    HVO_HIP(hipMemcpyAsync(res, dres, sizeof(hvo_vp_result), hipMemcpyDeviceToHost, st));
+    HVO_HIP(hipMemcpyAsync(vp_idx, didx, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (grid_out) HVO_HIP(hipMemcpyAsync(grid_out, dgrid, VP_CELLS * sizeof(double), hipMemcpyDeviceToHost, st));
+    HVO_HIP(hipStreamSynchronize(st));
+    return HVO_OK;
 }

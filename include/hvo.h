@@ -39,7 +39,8 @@
 extern "C" {
 #endif
 
-#define HVO_ABI_VERSION 2      /* 2: streamed-sequence entry points (hvo_stream_*), HVO_ERR_BUSY */
+#define HVO_ABI_VERSION 3      /* 2: streamed-sequence entry points (hvo_stream_*), HVO_ERR_BUSY; 3: the Frame tail as pipeline stages
+                                  (HVO_STAGE_LINES3D / _VP / _PLANE_TAIL / _GRIDS, hvo_frame_tail), hvo_stream_params grew three fields */
 
 typedef enum {
     HVO_OK = 0,
@@ -270,6 +271,13 @@ int hvo_stereo_from_rgbd(hvo_ctx *ctx, const hvo_keypoint *kp, const hvo_keypoin
 #define HVO_STAGE_PLANES 4u
 #define HVO_STAGE_ALL    7u
 #define HVO_STAGE_LSD_CULL 8u    /* HVO_STAGE_LSD followed by Frame::cullingLine: the frame's kl / ldesc / linefn are the merged lines */
+/* The rest of the Frame constructor (reference src/Frame.cc:205-233) as stages of the same pipelines: they read the key lines, depth image,
+ * label image, planes and key points where the stages above left them in HBM (nothing is uploaded twice, nothing allocated per frame). */
+#define HVO_STAGE_LINES3D    16u  /* Frame::isLineGood of every key line (src/Frame.cc:934-939, 1205-1322) = hvo_lines_3d; needs LSD + depth */
+#define HVO_STAGE_VP         32u  /* vanishing points + line2Vps (src/Frame.cc:328-337, 442-778) = hvo_vanishing_points; needs LSD */
+#define HVO_STAGE_PLANE_TAIL 64u  /* ComputePlanes' tail (src/Frame.cc:2110-2274) = hvo_plane_clouds + hvo_surface_normals; needs PLANES */
+#define HVO_STAGE_GRIDS     128u  /* AssignFeaturesToGrid / ForLine (src/Frame.cc:832-872) = hvo_assign_*_to_grid; needs ORB + LSD */
+#define HVO_STAGE_FRAME     (HVO_STAGE_ORB | HVO_STAGE_LSD_CULL | HVO_STAGE_LSD | HVO_STAGE_PLANES | HVO_STAGE_LINES3D | HVO_STAGE_VP | HVO_STAGE_PLANE_TAIL | HVO_STAGE_GRIDS)
 
 typedef struct {
     const uint8_t  *gray;  int gray_stride;    /* bytes */
@@ -284,6 +292,26 @@ typedef struct {
     int8_t *labels8;                             /* optional: the label image as int8 (w*h bytes, -1 = none; plane ids < 64), i.e. as it
                                                     crosses PCIe, without the widening to CV_32S that `labels` gets (ABI version 2) */
 } hvo_frame_out;
+
+/* Results of the tail stages for one frame; any pointer may be NULL.  Capacities: lines3d / vp_idx kl_cap entries, plane_clouds 64,
+ * cloud_xyz cloud_cap x 3 floats (hvo_tail_capacity), normals normals_cap, pt_cell_start / ln_cell_start 64*48+1, pt_cell_items kp_cap,
+ * ln_cell_items kl_cap * 128.  The random draws of isLineGood and of the vanishing-point hypotheses use seed + frame index (batch) or
+ * seed + ticket (stream): hvo_set_tail_params / hvo_stream_params.seed. */
+typedef struct {
+    hvo_line3d *lines3d;
+    hvo_vp_result *vp; int32_t *vp_idx;
+    hvo_plane_cloud *plane_clouds; float *cloud_xyz; int cloud_cap; int n_cloud;
+    hvo_surface_normal *normals; int normals_cap; int n_normals;
+    int32_t *pt_cell_start, *pt_cell_items; int pt_items_cap; int n_pt_items;
+    int32_t *ln_cell_start, *ln_cell_items; int ln_items_cap; int n_ln_items;
+    int status;
+} hvo_frame_tail;
+/* capacities of the tail results for a geometry: voxel-cloud points per frame, surface normals, line-grid items */
+int hvo_tail_capacity(int kl_cap, int w, int h, int *cloud_cap, int *n_normals, int *ln_items_cap);
+/* seed of the random draws, Plane.DistanceThreshold (default 0.05) and line2Vps' angle in radians (default 1 degree) for hvo_batch_run's tail stages */
+int hvo_set_tail_params(hvo_ctx *ctx, uint32_t seed, double plane_dist_th, double vp_th_angle);
+/* results of the tail stages of the first n frames of the resident batch (after hvo_batch_run with those stages) */
+int hvo_batch_download_tail(hvo_ctx *ctx, int n, hvo_frame_tail *out);
 
 /* host -> HBM copy of n (<= max_batch) frames of one geometry */
 int hvo_batch_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h);
@@ -321,6 +349,9 @@ typedef struct {
     uint32_t stages;            /* HVO_STAGE_* mask */
     float    dist5[5];          /* k1 k2 p1 p2 k3 for UndistortKeyPoints (k1 == 0: key points are copied, Frame.cc:1703-1707) */
     float    bf;                /* ComputeStereoFromRGBD's mbf; <= 0: mvuRight / mvDepth are not computed */
+    uint32_t seed;              /* tail stages: frame `ticket` draws with seed + ticket (ABI 3) */
+    float    plane_dist_th;     /* Plane.DistanceThreshold of the settings file; <= 0: 0.05 */
+    float    vp_th_angle;       /* line2Vps' thAngle in radians; <= 0: 1 degree (Frame.h:365) */
 } hvo_stream_params;
 #define HVO_LINE_MATCH_NNR 0    /* LSDmatcher::match -> matchNNR (src/LSDmatcher.cpp:803-863): d0 < nnr * d1 */
 #define HVO_LINE_MATCH_BF 1     /* LSDmatcher::FrameBFMatch (942-966) */
@@ -338,6 +369,9 @@ int  hvo_stream_submit(hvo_stream *s, const uint8_t *gray, int gray_stride, cons
 int  hvo_stream_poll(hvo_stream *s, int64_t ticket);                 /* 1: complete, 0: still running */
 /* out as in hvo_batch_download (any pointer may be NULL); kp_un / uright / zdepth: kp_cap entries, may be NULL */
 int  hvo_stream_collect(hvo_stream *s, int64_t ticket, hvo_frame_out *out, hvo_keypoint *kp_un, float *uright, float *zdepth);
+/* results of the frame's tail stages (HVO_STAGE_LINES3D / _VP / _PLANE_TAIL / _GRIDS of hvo_stream_params.stages); call BEFORE hvo_stream_collect
+ * releases the slot, or instead of it with out == NULL there: hvo_stream_collect_tail waits for the frame like hvo_stream_collect does */
+int  hvo_stream_collect_tail(hvo_stream *s, int64_t ticket, hvo_frame_tail *tail);
 /* device time from the start of the frame's upload to the end of its ORB / line / plane kernels (ms) */
 int  hvo_stream_stage_ms(hvo_stream *s, int64_t ticket, float ms3[3]);
 /* SearchByProjection(Cur, Last) core between two resident frames.  Query i = last-frame feature q_index[i] (its descriptor and

@@ -142,7 +142,13 @@ static double vp_score(const double *grid, const double *h)
         if (v[2] == 0.0) continue;
         const double latitude = acos(v[2]), longitude = atan2(v[0], v[1]) + CV_PI;
         int LA = (int)(latitude / oneDegree); if (LA == 90) LA = 89;
-        int LO = (int)(longitude / oneDegree); if (LO == 360) LO = 359;
+        /* Determinism rule.  The second direction of every hypothesis is built from lambda = j degrees, so in exact arithmetic its
+         * longitude IS a whole number of degrees (lambda or lambda +- 180): it sits on a cell boundary, and which of the two cells the
+         * reference takes is the rounding noise of its libm's sin / cos / atan / atan2 (observed: 17.00000000000001 and
+         * 34.999999999999986).  No two libms agree on that, so a longitude within 1e-6 degree of a whole degree is assigned to
+         * that degree's cell on both sides (vps.hip vp_cell_of). */
+        const double lo_f = longitude / oneDegree, lo_r = nearbyint(lo_f);
+        int LO = fabs(lo_f - lo_r) < 1e-6 ? (int)lo_r : (int)lo_f; if (LO >= 360) LO = 359;
         s += grid[LA * 360 + LO];
     }
     return s;

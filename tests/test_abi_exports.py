@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(hvo):
     assert not missing, missing
     assert sorted(hvo.EXPORTS) == _declared()
     lib.hvo_abi_version.restype = ctypes.c_int
-    assert lib.hvo_abi_version() == 2
+    assert lib.hvo_abi_version() == 3
 
 
 def test_default_params_match_tum3(hvo):
