@@ -284,6 +284,7 @@ int tail_enqueue_lines(hvo_ctx *ctx, hipStream_t st, unsigned stages, const Tail
                        const hvo_keyline *d_kl, const int *d_nkl, const uint16_t *d_depth, int pitch, unsigned seed, double vp_th_angle, const float *bounds4);
 int tail_enqueue_planes(hvo_ctx *ctx, hipStream_t st, unsigned stages, const TailLayout &L, char *d_out, char *d_scratch,
                         const uint16_t *d_depth, int pitch, const int8_t *d_labels8, const hvo_plane *d_planes, const int *d_npl, double dist_th);
+int tail_enqueue_normals(hvo_ctx *ctx, hipStream_t st, unsigned stages, const TailLayout &L, char *d_out, char *d_scratch, const uint16_t *d_depth, int pitch);
 int tail_enqueue_points(hvo_ctx *ctx, hipStream_t st, unsigned stages, const TailLayout &L, char *d_out, char *d_scratch,
                         const hvo_keypoint *d_kp_un, const int *d_nkp, const float *bounds4);
 int tail_unpack(const TailLayout &L, unsigned stages, const char *ho, int n_kl, hvo_frame_tail *out);

@@ -916,17 +916,23 @@ int orb_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool s
     if (rc) return rc;
     OrbPlan &P = ctx->orb;
     for (int f = 0; f < n; f++) if (!in[f].gray) return HVO_ERR_INVALID_ARG;
-    // Frames that are dense (stride == width == device pitch) and evenly spaced in host memory go up as ONE 2-D copy whose "rows"
-    // are whole frames: a copy call costs ~20 us, which at one call per frame was the whole upload (2048 frames: 82 ms for 0.6 GB).
-    bool regular = n > 1 && P.lev[0].pitch == w && !(getenv("HVO_UPLOAD_SINGLE") && atoi(getenv("HVO_UPLOAD_SINGLE")) == 0);
-    const ptrdiff_t step = n > 1 ? in[1].gray - in[0].gray : 0;
-    for (int f = 0; regular && f < n; f++) regular = in[f].gray_stride == w && in[f].gray - in[0].gray == step * f;
-    if (regular && step >= (ptrdiff_t)w * h) {
-        HVO_HIP(hipMemcpy2DAsync(P.d_pyr, P.pyr_bytes, in[0].gray, (size_t)step, (size_t)w * h, n, hipMemcpyHostToDevice, cs));
-    } else {
-        for (int f = 0; f < n; f++)
-            HVO_HIP(hipMemcpy2DAsync(P.d_pyr + (size_t)f * P.pyr_bytes, P.lev[0].pitch, in[f].gray, in[f].gray_stride,
-                                     w, h, hipMemcpyHostToDevice, cs));
+    // Frames that are dense (stride == width == device pitch) go up in RUNS: consecutive frames evenly spaced in host memory are ONE 2-D
+    // copy whose "rows" are whole frames.  A copy call costs ~20 us, which at one call per frame is the whole upload (2048 frames of
+    // 307 KB: 20 GB/s against the link's 57, profiles/r03_pcie_raw.txt); a batch that cycles through k distinct host frames is k-spaced
+    // runs -- a handful of calls.
+    const bool dense = P.lev[0].pitch == w && !(getenv("HVO_UPLOAD_SINGLE") && atoi(getenv("HVO_UPLOAD_SINGLE")) == 0);
+    for (int f = 0; f < n;) {
+        int run = 1;
+        if (dense && in[f].gray_stride == w && f + 1 < n && in[f + 1].gray_stride == w) {
+            const ptrdiff_t step = in[f + 1].gray - in[f].gray;
+            if (step >= (ptrdiff_t)w * h) {
+                while (f + run < n && in[f + run].gray_stride == w && in[f + run].gray - in[f + run - 1].gray == step) run++;
+                if (run > 1) HVO_HIP(hipMemcpy2DAsync(P.d_pyr + (size_t)f * P.pyr_bytes, P.pyr_bytes, in[f].gray, (size_t)step, (size_t)w * h, run, hipMemcpyHostToDevice, cs));
+            }
+        }
+        if (run == 1)
+            HVO_HIP(hipMemcpy2DAsync(P.d_pyr + (size_t)f * P.pyr_bytes, P.lev[0].pitch, in[f].gray, in[f].gray_stride, w, h, hipMemcpyHostToDevice, cs));
+        f += run;
     }
     if (sync) HVO_HIP(hipStreamSynchronize(cs));
     return HVO_OK;

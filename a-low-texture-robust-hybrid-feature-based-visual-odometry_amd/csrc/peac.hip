@@ -1868,16 +1868,22 @@ int peac_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool 
     PeacPlan *P = plan_of(ctx);
     const size_t dframe = (size_t)P->pitch * (h + 1);
     for (int f = 0; f < n; f++) if (!in[f].depth) return HVO_ERR_INVALID_ARG;
-    // dense, evenly spaced host frames: one 2-D copy whose rows are whole frames (see orb_upload)
-    bool regular = n > 1 && P->pitch == w && !(getenv("HVO_UPLOAD_SINGLE") && atoi(getenv("HVO_UPLOAD_SINGLE")) == 0);
-    const ptrdiff_t step = n > 1 ? (const char *)in[1].depth - (const char *)in[0].depth : 0;
-    for (int f = 0; regular && f < n; f++) regular = in[f].depth_stride == (int)(w * sizeof(uint16_t)) && (const char *)in[f].depth - (const char *)in[0].depth == step * f;
-    if (regular && step >= (ptrdiff_t)((size_t)w * h * sizeof(uint16_t))) {
-        HVO_HIP(hipMemcpy2DAsync(P->d_depth, dframe * sizeof(uint16_t), in[0].depth, (size_t)step, (size_t)w * h * sizeof(uint16_t), n, hipMemcpyHostToDevice, cs));
-    } else {
-        for (int f = 0; f < n; f++)
-            HVO_HIP(hipMemcpy2DAsync(P->d_depth + f * dframe, P->pitch * sizeof(uint16_t), in[f].depth, in[f].depth_stride,
+    // dense host frames go up in runs of evenly spaced frames: one 2-D copy per run whose rows are whole frames (see orb_upload)
+    const bool dense = P->pitch == w && !(getenv("HVO_UPLOAD_SINGLE") && atoi(getenv("HVO_UPLOAD_SINGLE")) == 0);
+    const int dstride = (int)(w * sizeof(uint16_t));
+    for (int f = 0; f < n;) {
+        int run = 1;
+        if (dense && in[f].depth_stride == dstride && f + 1 < n && in[f + 1].depth_stride == dstride) {
+            const ptrdiff_t step = (const char *)in[f + 1].depth - (const char *)in[f].depth;
+            if (step >= (ptrdiff_t)((size_t)w * h * sizeof(uint16_t))) {
+                while (f + run < n && in[f + run].depth_stride == dstride && (const char *)in[f + run].depth - (const char *)in[f + run - 1].depth == step) run++;
+                if (run > 1) HVO_HIP(hipMemcpy2DAsync(P->d_depth + (size_t)f * dframe, dframe * sizeof(uint16_t), in[f].depth, (size_t)step, (size_t)w * h * sizeof(uint16_t), run, hipMemcpyHostToDevice, cs));
+            }
+        }
+        if (run == 1)
+            HVO_HIP(hipMemcpy2DAsync(P->d_depth + (size_t)f * dframe, P->pitch * sizeof(uint16_t), in[f].depth, in[f].depth_stride,
                                      (size_t)w * sizeof(uint16_t), h, hipMemcpyHostToDevice, cs));
+        f += run;
     }
     if (sync) HVO_HIP(hipStreamSynchronize(cs));
     return HVO_OK;

@@ -418,61 +418,123 @@ __global__ __launch_bounds__(256) void k_sn_grad(SnArgs a)
     }
 }
 
-// nine independent serial chains, one per wave (lane 0): wave 0 the chamfer distance map, waves 1-6 the integral images of
-// the six gradient channels, waves 7-8 the finite-element counts
+// Nine independent order-dependent chains, one per wave: wave 0 the two-pass chamfer distance map, waves 1-6 the integral images of the
+// six gradient channels (double sums in PCL's recurrence order), waves 7-8 the finite-element counts.  What is sequential in each is ONE
+// value carried along a row (the running minimum + 1, the running sum); everything a step needs besides that value -- the previous row,
+// the row's own inputs -- is independent of the chain.  So per row the wave's 64 lanes fetch those into the wave's LDS rows, lane 0 walks
+// the row out of LDS (a few dependent ALU operations per element instead of a global-memory round trip), and the lanes store the
+// finished row.  Same operations in the same order as the one-lane formulation (18 ms per 640x480 frame) at ~0.6 ms.
 __global__ __launch_bounds__(576) void k_sn_serial(SnArgs a)
 {
-    if ((threadIdx.x & 63) != 0) return;
-    const int task = threadIdx.x >> 6, W = a.W, H = a.H, N = W * H, IW = W + 1;
-    if (task == 0) {
+    extern __shared__ double sn_lds[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, W = a.W, H = a.H, N = W * H, IW = W + 1;
+    double *Lw = sn_lds + (size_t)wv * 3 * (W + 2);
+    if (wv == 0) {
         float *dm = a.dm;                                                 // (slack of W + 2 floats on both sides for the row-wrapping reads)
-        for (int i = -W - 2; i < 0; i++) dm[i] = (float)(W + H);
-        for (int i = N; i < N + W + 2; i++) dm[i] = (float)(W + H);
-        for (int i = 0; i < N; i++) dm[i] = a.chg[i] == 0 ? 0.0f : (float)(W + H);
-        for (int ri = 1; ri < H; ri++) {
-            float *prev = dm + (size_t)(ri - 1) * W, *cur = dm + (size_t)ri * W;
-            for (int ci = 1; ci < W; ci++) {
-                const float upLeft = FA(prev[ci - 1], 1.4f), up = FA(prev[ci], 1.0f), upRight = FA(prev[ci + 1], 1.4f), left = FA(cur[ci - 1], 1.0f), center = cur[ci];
-                const float x = upLeft < up ? upLeft : up, y = left < upRight ? left : upRight, mv = x < y ? x : y;
-                if (mv < center) cur[ci] = mv;
+        float *prv = (float *)Lw, *cur = prv + (W + 2), *av = cur + (W + 2);
+        const float big = (float)(W + H);
+        for (int i = lane; i < W + 2; i += 64) { dm[i - W - 2] = big; dm[N + i] = big; }
+        for (int i = lane; i < N; i += 64) dm[i] = a.chg[i] == 0 ? 0.0f : big;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();
+        for (int c = lane; c < W; c += 64) prv[c] = dm[c];
+        for (int ri = 1; ri < H; ri++) {                                  // forward: cur[ci] = min(centre, upLeft + 1.4, up + 1, upRight + 1.4, cur[ci-1] + 1)
+            float *row = dm + (size_t)ri * W;
+            for (int c = lane; c < W; c += 64) cur[c] = row[c];
+            __builtin_amdgcn_wave_barrier();
+            for (int c = lane; c < W; c += 64) {
+                float v = cur[c];
+                if (c >= 1) {
+                    const float upLeft = FA(prv[c - 1], 1.4f), up = FA(prv[c], 1.0f), upRight = FA(c + 1 < W ? prv[c + 1] : cur[0], 1.4f);   // prev[W] is this row's first element
+                    const float x = upLeft < up ? upLeft : up, m3 = x < upRight ? x : upRight;
+                    if (m3 < v) v = m3;
+                }
+                av[c] = v;
             }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                float v = av[0];
+                cur[0] = v;
+#pragma unroll 8
+                for (int c = 1; c < W; c++) { const float l = FA(v, 1.0f), q = av[c]; v = l < q ? l : q; cur[c] = v; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int c = lane; c < W; c += 64) row[c] = cur[c];
+            float *t = prv; prv = cur; cur = t;
         }
+        // backward: cur[ci] = min(centre, lowerLeft + 1.4, lower + 1, lowerRight + 1.4, cur[ci+1] + 1); prv holds row H-1
         for (int ri = H - 2; ri >= 0; ri--) {
-            float *next = dm + (size_t)(ri + 1) * W, *cur = dm + (size_t)ri * W;
-            for (int ci = W - 2; ci >= 0; ci--) {
-                const float lowerLeft = FA(next[ci - 1], 1.4f), lower = FA(next[ci], 1.0f), lowerRight = FA(next[ci + 1], 1.4f), right = FA(cur[ci + 1], 1.0f), center = cur[ci];
-                const float x = lowerLeft < lower ? lowerLeft : lower, y = right < lowerRight ? right : lowerRight, mv = x < y ? x : y;
-                if (mv < center) cur[ci] = mv;
+            float *row = dm + (size_t)ri * W;
+            for (int c = lane; c < W; c += 64) cur[c] = row[c];
+            __builtin_amdgcn_wave_barrier();
+            for (int c = lane; c < W; c += 64) {
+                float v = cur[c];
+                if (c <= W - 2) {
+                    const float lowerLeft = FA(c >= 1 ? prv[c - 1] : cur[W - 1], 1.4f), lower = FA(prv[c], 1.0f), lowerRight = FA(prv[c + 1], 1.4f);     // next[-1] is this row's last element
+                    const float x = lowerLeft < lower ? lowerLeft : lower, m3 = x < lowerRight ? x : lowerRight;
+                    if (m3 < v) v = m3;
+                }
+                av[c] = v;
             }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                float v = av[W - 1];
+                cur[W - 1] = v;
+#pragma unroll 8
+                for (int c = W - 2; c >= 0; c--) { const float l = FA(v, 1.0f), q = av[c]; v = l < q ? l : q; cur[c] = v; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int c = lane; c < W; c += 64) row[c] = cur[c];
+            float *t = prv; prv = cur; cur = t;
         }
-    } else if (task <= 6) {
-        const int im = (task - 1) / 3, k = (task - 1) % 3;
+    } else if (wv <= 6) {
+        const int im = (wv - 1) / 3, k = (wv - 1) % 3;
         double *I = im ? a.IY : a.IX; const float *g = im ? a.gy : a.gx;
-        for (int c = 0; c <= W; c++) I[3 * c + k] = 0;
+        double *prv = Lw, *cur = Lw + (W + 2), *ev = cur + (W + 2);         // ev[c]: the element's contribution, NaN-free: (finite ? e[k] : "skip")
+        for (int c = lane; c <= W; c += 64) { I[3 * c + k] = 0; prv[c] = 0; }
         for (int r = 0; r < H; r++) {
-            double *prev = I + (size_t)r * IW * 3, *cur = prev + (size_t)IW * 3;
-            cur[k] = 0;
-            double left = 0, upleft = prev[k];
-            for (int c = 0; c < W; c++) {
-                const double up = prev[3 * (c + 1) + k];
-                double v = up + left - upleft;
+            __builtin_amdgcn_wave_barrier();
+            for (int c = lane; c < W; c += 64) {
                 const float *e = g + 3 * ((size_t)r * W + c);
-                if (isfinite(FA(FA(e[0], e[1]), e[2]))) v += (double)e[k];
-                cur[3 * (c + 1) + k] = v;
-                left = v; upleft = up;
+                const bool ok = isfinite(FA(FA(e[0], e[1]), e[2]));
+                ev[c] = ok ? (double)e[k] : __longlong_as_double(0x7FF8000000000000ll);      // NaN marks "not added"
             }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                cur[0] = 0;
+                double left = 0, upleft = prv[0];
+#pragma unroll 4
+                for (int c = 0; c < W; c++) {
+                    const double up = prv[c + 1];
+                    double v = up + left - upleft;
+                    const double e = ev[c];
+                    if (e == e) v += e;
+                    cur[c + 1] = v;
+                    left = v; upleft = up;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            double *out = I + (size_t)(r + 1) * IW * 3;
+            for (int c = lane; c <= W; c += 64) out[3 * c + k] = cur[c];
+            double *t = prv; prv = cur; cur = t;
         }
     } else {
-        const int im = task - 7;
+        const int im = wv - 7;
         unsigned *Cn = im ? a.CY : a.CX; const float *g = im ? a.gy : a.gx;
-        for (int c = 0; c <= W; c++) Cn[c] = 0;
+        unsigned *prv = (unsigned *)Lw, *cur = prv + (W + 2), *fv = cur + (W + 2);
+        for (int c = lane; c <= W; c += 64) { Cn[c] = 0; prv[c] = 0; }
         for (int r = 0; r < H; r++) {
-            unsigned *cp = Cn + (size_t)r * IW, *cc = cp + IW;
-            cc[0] = 0;
-            for (int c = 0; c < W; c++) {
-                const float *e = g + 3 * ((size_t)r * W + c);
-                cc[c + 1] = cp[c + 1] + cc[c] - cp[c] + (isfinite(FA(FA(e[0], e[1]), e[2])) ? 1u : 0u);
+            __builtin_amdgcn_wave_barrier();
+            for (int c = lane; c < W; c += 64) { const float *e = g + 3 * ((size_t)r * W + c); fv[c] = isfinite(FA(FA(e[0], e[1]), e[2])) ? 1u : 0u; }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                cur[0] = 0;
+                unsigned run = 0;                                          // cc[c+1] = cp[c+1] + cc[c] - cp[c] + f  (exact: unsigned)
+                for (int c = 0; c < W; c++) { run = prv[c + 1] + run - prv[c] + fv[c]; cur[c + 1] = run; }
             }
+            __builtin_amdgcn_wave_barrier();
+            unsigned *out = Cn + (size_t)(r + 1) * IW;
+            for (int c = lane; c <= W; c += 64) out[c] = cur[c];
+            unsigned *t = prv; prv = cur; cur = t;
         }
     }
 }
@@ -637,7 +699,12 @@ int sn_enqueue(hvo_ctx *ctx, hipStream_t st, const uint16_t *d_depth, int pitch,
     a.out = d_out; a.cap = nout;
     hipLaunchKernelGGL(k_sn_cloud, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_sn_grad, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_sn_serial, dim3(1), dim3(576), 0, st, a);
+    {
+        const size_t lds = (size_t)9 * 3 * (a.W + 2) * sizeof(double);
+        if (lds > 160 * 1024) return HVO_ERR_UNSUPPORTED;
+        if (lds > 64 * 1024) HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sn_serial), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_sn_serial, dim3(1), dim3(576), lds, st, a);
+    }
     if (nout > 0) hipLaunchKernelGGL(k_sn_normals, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, a);
     HVO_HIP(hipGetLastError());
     return HVO_OK;

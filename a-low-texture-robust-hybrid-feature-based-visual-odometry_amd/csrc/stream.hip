@@ -249,7 +249,7 @@ static int stream_submit_enqueue(hvo_stream *s, StreamSlot &S, const uint8_t *gr
         if (s->tail_stages & HVO_STAGE_PLANE_TAIL) {
             const TailLayout &T = s->tl;
             ST_HIP(hipMemcpyAsync(S.h_tail + T.counts, S.d_tail + T.counts, 2 * sizeof(int), hipMemcpyDeviceToHost, c->s_peac));
-            ST_HIP(hipMemcpyAsync(S.h_tail + T.pclouds, S.d_tail + T.pclouds, T.normals + (size_t)T.n_normals * sizeof(hvo_surface_normal) - T.pclouds, hipMemcpyDeviceToHost, c->s_peac));
+            ST_HIP(hipMemcpyAsync(S.h_tail + T.pclouds, S.d_tail + T.pclouds, T.normals - T.pclouds, hipMemcpyDeviceToHost, c->s_peac));
         }
         ST_HIP(hipMemcpyAsync(hc + 16, S.pv.d_meta, 16 * sizeof(int), hipMemcpyDeviceToHost, c->s_peac));
         ST_HIP(hipMemcpyAsync(ho + L.planes, S.pv.d_planes, (size_t)S.pv.max_planes * sizeof(hvo_plane), hipMemcpyDeviceToHost, c->s_peac));
@@ -281,6 +281,14 @@ static int stream_submit_enqueue(hvo_stream *s, StreamSlot &S, const uint8_t *gr
             ST_HIP(hipMemcpyAsync(ho + L.uright, S.d_uright, (size_t)s->kp_cap * 4, hipMemcpyDeviceToHost, c->stream));
             ST_HIP(hipMemcpyAsync(ho + L.zdepth, S.d_zdepth, (size_t)s->kp_cap * 4, hipMemcpyDeviceToHost, c->stream));
         }
+    }
+    // surface normals (ComputePlanes' tail, src/Frame.cc:2160-2212): they need the depth image only, so they run on this short stream
+    // beside the plane chain instead of behind its 20 ms
+    if (depth && want_pl && (s->tail_stages & HVO_STAGE_PLANE_TAIL)) {
+        const TailLayout &T = s->tl;
+        ST_HIP(hipStreamWaitEvent(c->stream, S.ev_depth, 0));
+        if ((rc = tail_enqueue_normals(c, c->stream, s->tail_stages, T, S.d_tail, S.d_tail_scratch + 2 * T.scratch_total, S.pv.d_depth, S.pv.pitch))) return rc;
+        ST_HIP(hipMemcpyAsync(S.h_tail + T.normals, S.d_tail + T.normals, (size_t)T.n_normals * sizeof(hvo_surface_normal), hipMemcpyDeviceToHost, c->stream));
     }
     ST_HIP(hipEventRecord(S.ev_orb, c->stream));
     hipStream_t LS = hvo_stream_lsd(c);

@@ -71,14 +71,20 @@ int tail_enqueue_lines(hvo_ctx *ctx, hipStream_t st, unsigned stages, const Tail
     return HVO_OK;
 }
 
-// planes of a frame: per-plane clouds + refit, surface normals -- on the stream the frame's plane chain runs on
+// planes of a frame: per-plane clouds + refit -- on the stream the frame's plane chain runs on
 int tail_enqueue_planes(hvo_ctx *ctx, hipStream_t st, unsigned stages, const TailLayout &L, char *d_out, char *d_scratch,
                         const uint16_t *d_depth, int pitch, const int8_t *d_labels8, const hvo_plane *d_planes, const int *d_npl, double dist_th)
 {
     if (!(stages & HVO_STAGE_PLANE_TAIL)) return HVO_OK;
-    int rc = pc_enqueue(ctx, st, d_depth, pitch, L.w, L.h, d_labels8, d_planes, d_npl, 64, dist_th, d_scratch + L.s_pc, (float *)(d_out + L.cloud), L.cloud_cap,
-                        (hvo_plane_cloud *)(d_out + L.pclouds), (int *)(d_out + L.counts));
-    if (rc) return rc;
+    return pc_enqueue(ctx, st, d_depth, pitch, L.w, L.h, d_labels8, d_planes, d_npl, 64, dist_th, d_scratch + L.s_pc, (float *)(d_out + L.cloud), L.cloud_cap,
+                      (hvo_plane_cloud *)(d_out + L.pclouds), (int *)(d_out + L.counts));
+}
+
+// the 1/3-resolution surface normals need the depth image only, not the planes: they run beside the plane chain (on the short ORB
+// stream) instead of behind its 20 ms
+int tail_enqueue_normals(hvo_ctx *ctx, hipStream_t st, unsigned stages, const TailLayout &L, char *d_out, char *d_scratch, const uint16_t *d_depth, int pitch)
+{
+    if (!(stages & HVO_STAGE_PLANE_TAIL) || !d_depth) return HVO_OK;
     return sn_enqueue(ctx, st, d_depth, pitch, L.w, L.h, d_scratch + L.s_sn, (hvo_surface_normal *)(d_out + L.normals));
 }
 
@@ -200,6 +206,7 @@ int tail_batch_run(hvo_ctx *ctx, unsigned stages)
         if (ts & HVO_STAGE_PLANE_TAIL)
             if ((rc = tail_enqueue_planes(ctx, s_pl, ts, L, out, T->d_scratch + L.scratch_total, depth, pv.pitch, pv.d_labels8 + (size_t)f * lstride, pv.d_planes + (size_t)f * 64,
                                           pv.d_meta + (size_t)f * 16 + 4, T->dist_th))) return rc;
+        if ((ts & HVO_STAGE_PLANE_TAIL) && (rc = tail_enqueue_normals(ctx, s_orb, ts, L, out, T->d_scratch + 2 * L.scratch_total, depth, pv.pitch))) return rc;
         if (ts & HVO_STAGE_GRIDS)
             if ((rc = tail_enqueue_points(ctx, s_orb, ts, L, out, T->d_scratch + 2 * L.scratch_total, ctx->orb.d_kp + (size_t)f * kp_cap, ctx->orb.d_nkp + f, bounds))) return rc;
     }

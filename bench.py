@@ -32,8 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
-TRAFFIC_PROFILE = "profiles/r02_hbm_traffic.json"
-SQ_PROFILE = "profiles/r02_sq_utilisation.json"
+TRAFFIC_PROFILE = "profiles/r03_hbm_traffic.json"
+SQ_PROFILE = "profiles/r03_sq_utilisation.json"
 BYTES_PER_FRAME_640 = 26.0e6      # resident footprint of one 640x480 frame (profiles/r02_hbm_footprint.txt)
 
 
@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--config", default="std640", choices=["std640", "big1280", "batch256"],
                     help="std640: BASELINE configs[1]; big1280: configs[2] (1280x960, 2000 ORB); batch256: configs[3] (256 frames over the ranks)")
     ap.add_argument("--batch", type=int, default=0, help="frames resident per GPU per step; 0 = per config (std640: the largest of 8192/4096/... that fits)")
-    ap.add_argument("--stages", default="orb,lsd,planes")
+    ap.add_argument("--stages", default="", help="comma list of orb,lsd,planes,tail (tail = isLineGood + vanishing points + ComputePlanes' tail + grids); default: orb,lsd,planes (batch), orb,lsd,planes,tail (stream: the whole Frame constructor)")
     ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic frames (3/4 std, 1/4 lowtex)")
     ap.add_argument("--depth", type=int, default=4, help="stream mode: frames in flight")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -136,7 +136,8 @@ def sq_utilisation(frames_per_s):
     try:
         tot = t["per_frame_total"]
         cap = t["simds"] * t["clock_hz"] / 4.0                     # SIMD quad-cycles per second
-        return {"valu_busy_frac": round(tot["sq_active_inst_valu"] * frames_per_s / cap, 4),
+        return {"valu_issue_frac": round(tot["sq_active_inst_valu"] * frames_per_s / cap, 4),      # VALU wave-instructions x 4 cycles / SIMD-cycles of the step
+                "valu_busy_frac": round(tot["sq_active_inst_valu"] * frames_per_s / cap, 4),
                 "resident_waves_per_simd": round(tot["sq_wave_cycles"] * frames_per_s / cap, 3),
                 "wave_time_with_inst_active": round(tot["sq_active_inst_any"] / tot["sq_wave_cycles"], 4),
                 "counters_source": SQ_PROFILE + " (replayed: PMC counters cannot be read in-process)"}
@@ -153,9 +154,20 @@ def cpu_reference_shaped(ge, stages, gray, depth, budget_s=8.0, max_frames=96):
     from concurrent.futures import ThreadPoolExecutor
     orc = ge.oracle(); orb = orc.Orb()
     jobs = []
+    tail = "tail" in stages
     if "orb" in stages: jobs.append(lambda g, d: orb.extract(g))
-    if "lsd" in stages: jobs.append(lambda g, d: orc.line_extract(g))
-    if "planes" in stages: jobs.append(lambda g, d: orc.peac(d))
+    def lines_job(g, d):
+        kl = orc.line_extract(g)[0]
+        if tail and len(kl):                                  # the line thread also runs isLineGood and the vanishing points (src/Frame.cc:895-939, 328-337)
+            orc.lines_3d(kl, d, seed=1); orc.vanishing_points(kl, seed=1)
+        return kl
+    def planes_job(g, d):
+        lab, pl = orc.peac(d)
+        if tail:                                              # ComputePlanes' tail (src/Frame.cc:2110-2212)
+            orc.plane_clouds(d, lab, pl, dist_th=0.05); orc.surface_normals(d)
+        return pl
+    if "lsd" in stages: jobs.append(lines_job)
+    if "planes" in stages: jobs.append(planes_job)
     lat = []
     with ThreadPoolExecutor(max(len(jobs), 1)) as pool:
         t_all = time.perf_counter()
@@ -198,6 +210,37 @@ def cpu_all_cores(ge, stages, gray, depth, per_thread=3):
     n = sum(done)
     return {"value": round(n / el, 2), "unit": "frames/s", "cores": nthr, "kind": "port",
             "sample": "%d frames, %d per thread on %d threads (every host core), oracle/liboracle.so" % (n, per_thread, nthr)}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# self-certification: sampled frames of the timed batch against the oracle (the checker, after the timed region)
+# ---------------------------------------------------------------------------------------------------------------
+def parity_sample(ge, np, stages, res, g0, d0, kinds, nfeat, want=32):
+    """Compares `want` frames of the resident batch (both scene kinds; res[f] is frame f, whose input is g0[f], d0[f]) with the CPU
+    oracle, stage by stage: key points (x, y, octave, response, size exact; angle 1e-4) and descriptor bytes; key lines (count, pixel
+    counts, descriptor bytes exact; end points 1e-4); label image and plane supports exact.  Returns (checked, failures, detail)."""
+    orc = ge.oracle(); orb = orc.Orb(nfeatures=nfeat)
+    n = min(len(res), len(g0))
+    step = max(1, n // want)
+    idx = sorted({min(n - 1, step * k + (k % 4)) for k in range(want)})
+    bad = []
+    for f in idx:
+        r = res[f]; why = []
+        if "orb" in stages:
+            kp, desc = orb.extract(g0[f])
+            if len(kp) != len(r["kp"]) or not np.array_equal(desc, r["desc"]): why.append("orb")
+            else:
+                if any(not np.array_equal(kp[k], r["kp"][k]) for k in ("x", "y", "octave", "response", "size")): why.append("orb-fields")
+                elif len(kp) and np.max(np.abs(kp["angle"] - r["kp"]["angle"])) > 1e-4: why.append("orb-angle")
+        if "lsd" in stages:
+            kl, ld, fn = orc.line_extract(g0[f])
+            if len(kl) != len(r["kl"]) or not np.array_equal(ld, r["ldesc"]) or not np.array_equal(kl["num_pixels"], r["kl"]["num_pixels"]): why.append("lsd")
+            elif len(kl) and max(np.max(np.abs(kl[k] - r["kl"][k])) for k in ("sx", "sy", "ex", "ey")) > 1e-4: why.append("lsd-ends")
+        if "planes" in stages:
+            lab, pl = orc.peac(d0[f])
+            if not np.array_equal(lab, r["labels"]) or len(pl) != len(r["planes"]) or not np.array_equal(pl["n_points"], r["planes"]["n_points"]): why.append("planes")
+        if why: bad.append("frame %d (%s): %s" % (f, kinds[f], ",".join(why)))
+    return len(idx), len(bad), bad[:4], sum(1 for f in idx if kinds[f] == "lowtex")
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -357,10 +400,11 @@ def main():
     hvo = ge.package()
     synth = importlib.import_module("hvo_amd.synth")
     hdist = importlib.import_module("hvo_amd.dist")
-    stages = [s for s in args.stages.split(",") if s]
+    stages = [s for s in (args.stages or ("orb,lsd,planes,tail" if args.mode == "stream" else "orb,lsd,planes")).split(",") if s]
     mask = 0
     for s in stages:
-        mask |= {"orb": hvo.STAGE_ORB, "lsd": hvo.STAGE_LSD, "planes": hvo.STAGE_PLANES}[s]
+        mask |= {"orb": hvo.STAGE_ORB, "lsd": hvo.STAGE_LSD, "planes": hvo.STAGE_PLANES,
+                 "tail": hvo.STAGE_LINES3D | hvo.STAGE_VP | hvo.STAGE_PLANE_TAIL | hvo.STAGE_GRIDS}[s]
     w, h, nfeat = geometry(args.config)
 
     def barrier():
@@ -388,9 +432,10 @@ def main():
                 "n_gpus": world, "steps": nframes, "warmup": args.warmup, "ms_per_step": round(el / nframes * 1e3, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16 integer + f32/f64", "data": "synthetic",
                 "config": {"workload": "stream-%d: %dx%d synthetic RGB-D sequence (smooth <= 4 px/frame drift), one frame at a time through hvo_stream_* "
-                                       "(upload + %d ORB + LSD + PEAC + download + SearchByProjection(Cur,Last) + line match per frame), %d frames in flight"
-                                       % (nframes, w, h, nfeat, args.depth),
+                                       "(upload + %d ORB + LSD + PEAC%s + download + SearchByProjection(Cur,Last) + line match per frame), %d frames in flight"
+                                       % (nframes, w, h, nfeat, " + isLineGood + vanishing points + plane clouds / refit / surface normals + grids" if "tail" in stages else "", args.depth),
                            "mode": "stream", "stages": stages, "depth": args.depth, "pcie_inclusive": True,
+                           "frame_constructor": "whole (src/Frame.cc:205-233: ORB || LSD(+isLineGood, vanishing points) || planes(+clouds, refit, surface normals), undistort, stereo, grids)" if "tail" in stages else "extraction + undistort + stereo",
                            "mean_point_matches": round(mpts, 1), "mean_line_matches": round(mlines, 1)},
                 "latency_ms": {"pipelined_p50": round(float(np.percentile(lat, 50)), 3), "pipelined_p99": round(float(np.percentile(lat, 99)), 3)},
                 "roofline": None,
@@ -479,6 +524,7 @@ def main():
     nplanes = float(np.mean([len(r["planes"]) for r in res])) if "planes" in stages else 0.0
     bad = sum(1 for r in res if r["status"] != 0)
     ctx.close()
+    parity = parity_sample(ge, np, stages, res, g0, d0, kinds, nfeat) if rank == 0 else None
 
     if rank == 0:
         frames = world * B * steps
@@ -498,8 +544,14 @@ def main():
                     "frac": kroof[dom]["frac"], "traffic": tr,
                     "traffic_source": (TRAFFIC_PROFILE + " (replayed: separate rocprofv3 --pmc passes of this command)") if tr is not None else None,
                     "bytes_per_launch": int(table.get(dom, 0) * B), "ms_per_launch": round(groups[dom], 4),
-                    "limiter": "dependent-latency chain (serial semantics), not HBM bandwidth: see valu_busy_frac / DESIGN.md section 4"}
+                    "limiter": "dependent-latency chain (serial semantics), not HBM bandwidth: see valu_issue_frac / DESIGN.md section 4"}
             roof.update(sq_utilisation(value))
+            vif = roof.get("valu_issue_frac")
+            if vif is not None:
+                # what limits the STEP (all kernels overlapped): the vector ALUs' issue slots once they are more than half taken; the dominant
+                # KERNEL alone is a dependent chain (its own HBM fraction is `frac`)
+                roof["step_limiter"] = ("valu-issue: %.0f %% of the SIMDs' issue cycles carry a VALU instruction (integer VALU, 4 cycles per wave instruction)" % (100 * vif)) if vif >= 0.5 \
+                    else "latency: the serial-semantics kernels wait on dependent memory round trips (VALU issue %.0f %%)" % (100 * vif)
             orb_ms = sum(v for k, v in groups.items() if k in ("orb_pyramid", "orb_fast_cells", "orb_blur", "orb_levels", "orb_brief", "orb_orient", "orb_describe"))
             if orb_ms > 0:
                 roof["orb_pyramid_brief_pass_GBps"] = round(pass_bytes * B / (orb_ms * 1e-3) / 1e9, 2)
@@ -509,8 +561,8 @@ def main():
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16 integer + f32/f64",
             "data": "synthetic",
-            "config": {"workload": "%dx%d synthetic RGB-D, %d ORB + LSD lines + PEAC planes, %d frames per GPU per step (%s)"
-                                   % (w, h, nfeat, B, args.config),
+            "config": {"workload": "%dx%d synthetic RGB-D, %d ORB (quota; %.0f realised per frame: 3/4 std + 1/4 lowtex scenes) + LSD lines + PEAC planes, %d frames per GPU per step (%s)"
+                                   % (w, h, nfeat, nkp, B, args.config),
                        "stages": stages, "frames_per_gpu": B, "parallelism": "frames sharded, %d rank(s), no data-path collective" % world,
                        "distinct_frames": ndistinct, "scene_mix": {k: kinds.count(k) for k in sorted(set(kinds))},
                        "mean_keypoints": round(nkp, 1), "mean_lines": round(nlines, 1), "mean_planes": round(nplanes, 2),
@@ -518,6 +570,8 @@ def main():
             "kernel_ms_per_step_serialised": {k: round(v, 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1])},
             "kernel_roofline": kroof,
             "roofline": roof,
+            "parity_checked_frames": parity[0], "parity_failures": parity[1], "parity_lowtex_frames": parity[3],
+            "parity_note": "frames of the timed resident batch compared with the CPU oracle after the timed region, every stage" + ("; FAILED: " + "; ".join(parity[2]) if parity[1] else ""),
         }
         if gather:
             out["gather"] = gather
