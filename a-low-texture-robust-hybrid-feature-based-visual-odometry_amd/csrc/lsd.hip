@@ -232,6 +232,7 @@ struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy; };
 struct GrowState {
     const double4 *px4; int *reg; unsigned *avail; int *ring;     // px4: {angle, cos, sin, modgrad}
     int sw, sh, wpr;          // wpr = mask words per row
+    bool lm;                  // the mask lives in LDS (lsd_lds_mask)
 #ifdef HVO_LSD_TIMING
     long long t_gather, t_add, n_rounds;      // diagnostics build (tools/lsd_timing.py)
 #endif
@@ -244,10 +245,29 @@ struct GrowState {
 // and leaves the LDS to the kernels that need it (k_fast_cells, k_peac_flood).  Reads bypass the per-CU
 // L1 (agent-scope atomic loads); updates are L2 atomics without return, made visible to the wave's later
 // reads by the vmcnt(0) of the __syncthreads() that closes every growing round.
+// Latency variant (k_lsd_grow_lat, small batches / the streamed mode): the frame's mask is copied into LDS at the start (24.5 KB at
+// 640x480, 98 KB at 1280x960) and every test / update of a round is an LDS access instead of an L2 round trip: with one frame per CU
+// the LDS is free anyway, and the round's chain shrinks to the one fetch of the candidates' records.  S.lm selects it (uniform).
+extern __shared__ unsigned lsd_lds_mask[];
 static __device__ __forceinline__ unsigned avail_word(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-static __device__ __forceinline__ bool used_get(const GrowState &S, int x, int y) { return !((avail_word(&S.avail[y * S.wpr + (x >> 5)]) >> (x & 31)) & 1u); }
-static __device__ __forceinline__ void used_set(const GrowState &S, int x, int y) { __hip_atomic_fetch_and(&S.avail[y * S.wpr + (x >> 5)], ~(1u << (x & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-static __device__ __forceinline__ void used_clr(const GrowState &S, int x, int y) { __hip_atomic_fetch_or(&S.avail[y * S.wpr + (x >> 5)], 1u << (x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ bool used_get(const GrowState &S, int x, int y)
+{
+    const int wi = y * S.wpr + (x >> 5);
+    const unsigned wv = S.lm ? lsd_lds_mask[wi] : avail_word(&S.avail[wi]);
+    return !((wv >> (x & 31)) & 1u);
+}
+static __device__ __forceinline__ void used_set(const GrowState &S, int x, int y)
+{
+    const int wi = y * S.wpr + (x >> 5);
+    if (S.lm) atomicAnd(&lsd_lds_mask[wi], ~(1u << (x & 31)));
+    else __hip_atomic_fetch_and(&S.avail[wi], ~(1u << (x & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ void used_clr(const GrowState &S, int x, int y)
+{
+    const int wi = y * S.wpr + (x >> 5);
+    if (S.lm) atomicOr(&lsd_lds_mask[wi], 1u << (x & 31));
+    else __hip_atomic_fetch_or(&S.avail[wi], 1u << (x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 static __device__ __forceinline__ double angle_diff_signed(double a, double b)
 {
@@ -574,6 +594,7 @@ static __device__ int cull_line_count(int w, int h, float fx1, float fy1, float 
 }
 
 // The kernel body; two kernels wrap it (below).
+template <bool LM>
 static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
 {
     __shared__ double b0[64], b1[64], b2[64];
@@ -584,7 +605,11 @@ static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
     const size_t np = (size_t)sw * sh;
     GrowState S;
     S.px4 = g.px4 + f * np;
-    S.reg = g.reg + f * np; S.avail = g.avail + (size_t)f * nwords; S.ring = ring; S.sw = sw; S.sh = sh; S.wpr = wpr;
+    S.reg = g.reg + f * np; S.avail = g.avail + (size_t)f * nwords; S.ring = ring; S.sw = sw; S.sh = sh; S.wpr = wpr; S.lm = LM;
+    if (LM) {
+        for (int i = lane; i < nwords; i += 64) lsd_lds_mask[i] = S.avail[i];
+        __syncthreads();
+    }
     float *segs = g.segs + (size_t)f * LSD_MAXSEG * 4;
 #ifdef HVO_LSD_TIMING
     S.t_gather = S.t_add = S.n_rounds = 0;
@@ -597,7 +622,7 @@ static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
         for (;;) {
             const int wi = wbase + lane;
             unsigned m = 0;
-            if (wi < nwords) m = avail_word(&S.avail[wi]);
+            if (wi < nwords) m = LM ? lsd_lds_mask[wi] : avail_word(&S.avail[wi]);
             const unsigned long long nz = __ballot(m != 0);
             if (!nz) break;
             const int wl = __ffsll((long long)nz) - 1;
@@ -692,12 +717,13 @@ static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
 // k_lsd_grow_dense: eight waves per SIMD (64 VGPRs, some spills): the kernel is one dependent chain per frame, so frames in
 // flight are its only source of throughput once a batch fills the wave slots; measured 69 -> 58 ms per 8192 frames, but
 // 12 -> 18 ms for a lone frame -- hence two kernels and a choice by batch size (lsd_run).
-__global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g) { lsd_grow_body(g); }
+__global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g) { lsd_grow_body<false>(g); }
+__global__ __launch_bounds__(64) void k_lsd_grow_lat(GrowArgs g) { lsd_grow_body<true>(g); }
 #ifndef HVO_WPE_GROW
 #define HVO_WPE_GROW 8
 #endif
 __attribute__((amdgpu_waves_per_eu(HVO_WPE_GROW)))
-__global__ __launch_bounds__(64) void k_lsd_grow_dense(GrowArgs g) { lsd_grow_body(g); }
+__global__ __launch_bounds__(64) void k_lsd_grow_dense(GrowArgs g) { lsd_grow_body<false>(g); }
 
 // ------------------------------------------------------------------------------------------------
 // LBD: blur 5x5 (u8 fixed point, same rounding rules as the ORB blur), Sobel, descriptor
@@ -1272,7 +1298,14 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     g.rho = P->rho; g.prec = P->prec; g.p = P->p; g.min_reg = P->min_reg;
     bool dense = n > 5 * 1024;
     { const char *e = getenv("HVO_LSD_DENSE"); if (e) dense = atoi(e) != 0; }              // tests force either kernel on small batches
-    if (dense) hipLaunchKernelGGL(k_lsd_grow_dense, dim3(n), dim3(64), 0, st, g);     // more frames than five waves per SIMD hold
+    // a handful of frames (the streamed mode, a tracker's small batches): the latency variant with the mask in LDS
+    bool lat = n <= 64 && (size_t)P->nwords * 4 <= 150 * 1024;
+    { const char *e = getenv("HVO_LSD_LAT"); if (e) lat = atoi(e) != 0 && (size_t)P->nwords * 4 <= 150 * 1024; }
+    if (lat) {
+        const size_t lds = (size_t)P->nwords * 4;
+        if (lds > 48 * 1024) HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lsd_grow_lat), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_lsd_grow_lat, dim3(n), dim3(64), lds, st, g);
+    } else if (dense) hipLaunchKernelGGL(k_lsd_grow_dense, dim3(n), dim3(64), 0, st, g);     // more frames than five waves per SIMD hold
     else hipLaunchKernelGGL(k_lsd_grow, dim3(n), dim3(64), 0, st, g);
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "lbd_sobel", st);
