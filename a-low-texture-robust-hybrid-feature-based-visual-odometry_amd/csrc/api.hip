@@ -140,10 +140,16 @@ int hvo_profile_last(const hvo_ctx *ctx, const char **names, float *ms, int cap)
 {
     if (!ctx) return HVO_ERR_INVALID_ARG;
     int n = 0;
-    for (int i = 0; i < ctx->nprof && n < cap; i++) {
+    for (int i = 0; i < ctx->nprof; i++) {
         if (!ctx->prof[i].used) continue;
+        int at = -1;
+        for (int k = 0; k < i; k++) if (ctx->prof[k].used && ctx->prof[k].name == ctx->prof[i].name) { at = k; break; }
+        if (at >= 0) continue;                              // a later interval of a group already reported
+        if (n >= cap) break;
+        float tot = 0.f;
+        for (int k = i; k < ctx->nprof; k++) if (ctx->prof[k].used && ctx->prof[k].name == ctx->prof[i].name) tot += ctx->prof[k].ms;
         if (names) names[n] = ctx->prof[i].name;
-        if (ms) ms[n] = ctx->prof[i].ms;
+        if (ms) ms[n] = tot;
         n++;
     }
     return n;
@@ -500,8 +506,9 @@ int hvo_stereo_from_rgbd(hvo_ctx *ctx, const hvo_keypoint *kp, const hvo_keypoin
 int hvo_prof_begin(hvo_ctx *ctx, const char *name, hipStream_t st)
 {
     if (!ctx->profile) return -1;
+    // one interval per call: a group enqueued once per chunk of the batch gets several, hvo_profile_last adds them up
     int id = -1;
-    for (int i = 0; i < ctx->nprof; i++) if (ctx->prof[i].name == name) id = i;
+    for (int i = 0; i < ctx->nprof; i++) if (ctx->prof[i].name == name && !ctx->prof[i].used) { id = i; break; }
     if (id < 0) {
         if (ctx->nprof >= HVO_MAX_PROFILE) return -1;
         id = ctx->nprof++;

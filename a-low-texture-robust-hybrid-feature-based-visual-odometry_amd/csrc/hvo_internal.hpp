@@ -14,7 +14,7 @@
 #define HVO_EDGE_THRESHOLD 19      // ORBextractor.cc:72
 #define HVO_CELL_TILE 72           // largest FAST cell view (wCell+6) the LDS tile holds
 #define HVO_CELL_CAP 256           // max NMS survivors kept per cell
-#define HVO_MAX_PROFILE 32
+#define HVO_MAX_PROFILE 768        // intervals, not groups: a group that runs once per chunk of the batch has one interval per chunk
 #define HVO_HAVE_PEAC 1           // peac.hip is built (stubs.hip drops its PEAC stubs)
 #define HVO_HAVE_LSD 1            // lsd.hip is built
 
@@ -29,7 +29,8 @@ struct LevelGeom {
     int kp_off, kp_cap;                 // per-frame per-level selected keypoints
     int scaled_patch;                   // (int)(31*scale)
     float scale;
-    unsigned long long img_off;         // byte offset of this level inside a frame's pyramid slab
+    unsigned long long img_off;         // byte offset of this level inside a frame's all-levels slab (the blurred pyramid)
+    unsigned long long lvl_off;         // byte offset inside a frame's levels >= 1 slab (level 0 is the frame's input image, a slab of its own)
     int rs_off;                         // offset into resize tables (x entries), y at ry_off
     int ry_off;
     int tile_off, ntx, nty;             // blur tiles
@@ -53,7 +54,9 @@ struct OrbPlan {
     int w = 0, h = 0, nlevels = 0, batch = 0;
     LevelGeom lev[HVO_MAX_LEVELS];
     int ncells = 0, cand_total = 0, node_total = 0, kp_total = 0, ntiles = 0, max_cell = 0;
-    size_t pyr_bytes = 0;               // per frame
+    size_t pyr_bytes = 0;               // stride of d_pyr: level 0 only (the input image, one per resident frame)
+    size_t lvl_bytes = 0, blur_bytes = 0;  // strides of d_lvl (levels >= 1) and d_blur (all levels): scratch, one per frame of a CHUNK
+    int chunk = 0;                      // frames the scratch slabs exist for: orb_run walks the batch chunk by chunk
     bool resize_dw[HVO_MAX_LEVELS] = {};  // level is produced by k_resize_dw (dword loads) instead of k_resize
     bool fused = false;                 // the fused per-level pass (orb_level.hip) serves this geometry
     int lt_off[HVO_MAX_LEVELS] = {}, lt_cnt[HVO_MAX_LEVELS] = {}, lt_tpw = 4;
@@ -66,7 +69,8 @@ struct OrbPlan {
     int *d_rs_xofs = nullptr; int *d_rs_xalpha = nullptr;   // per level: dw entries
     int *d_rs_yofs = nullptr; int *d_rs_ybeta = nullptr;    // per level: dh entries (yofs packs sy0|sy1<<16)
     int4 *d_tiles = nullptr;            // blur tiles (level, tx, ty, 0)
-    uint8_t *d_pyr = nullptr, *d_blur = nullptr;            // batch * pyr_bytes
+    uint8_t *d_pyr = nullptr, *d_blur = nullptr;            // batch * pyr_bytes; chunk * blur_bytes
+    uint8_t *d_lvl = nullptr, *d_lvl_base = nullptr;        // chunk * lvl_bytes (256 guard bytes in front, like d_pyr)
     uint8_t *d_pyr_base = nullptr;                          // the allocation behind d_pyr (256 guard bytes in front: orb_level.hip's 16-byte tile loads may start 4 bytes before a row)
     uint32_t *d_cell_kp = nullptr; int *d_cell_cnt = nullptr;
     uint32_t *d_cand = nullptr; int *d_keys = nullptr, *d_keys_tmp = nullptr;
@@ -204,10 +208,10 @@ int orb_run(hvo_ctx *ctx, int n);
 int orb_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
 // orb_level.hip
 bool orb_level_build(OrbPlan &P, const std::vector<CellDesc> &cells, const std::vector<int> &xofs, const std::vector<int> &yofs, std::vector<OrbTile> &tiles);
-int orb_level_run(hvo_ctx *ctx, int n, hipStream_t st, int k0, int k1, int k2, int k3);
+int orb_level_run(hvo_ctx *ctx, int c0, int n, hipStream_t st, int k0, int k1, int k2, int k3);   // frames [c0, c0 + n) = one chunk
 // orb_describe.hip
 int orb_describe_build(hvo_ctx *ctx);
-int orb_describe_run(hvo_ctx *ctx, int n, hipStream_t st);
+int orb_describe_run(hvo_ctx *ctx, int c0, int n, hipStream_t st);
 
 // match.hip
 #define HVO_SBP_K 16

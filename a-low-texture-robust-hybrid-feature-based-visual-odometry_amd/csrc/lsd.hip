@@ -40,7 +40,8 @@
 
 struct LsdPlan {
     int w = 0, h = 0, sw = 0, sh = 0, batch = 0, nfeat = 0, nwords = 0;
-    double *d_blur = nullptr;                               // w*h doubles
+    double *d_blur = nullptr;                               // w*h doubles per frame of a chunk
+    int chunk = 0;                                          // frames the transient images exist for
     double4 *d_px = nullptr;           // sw*sh x {angle, cos, sin, modgrad}: one 32-byte record per scaled pixel
     unsigned *d_defined = nullptr;                          // bitmask, nwords per frame
     int *d_reg = nullptr;                                   // sw*sh ints
@@ -1232,14 +1233,20 @@ static int lsd_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     for (int i = 0; i < 63; i++) gGf[i] = (float)P->gG[i];
     const size_t B = batch, npix = (size_t)w * h, nsp = (size_t)P->sw * P->sh;
 #define PA(ptr, n) HVO_HIP(hipMalloc((void **)&(ptr), (n)))
-    PA(P->d_blur, B * npix * 8);
+    // transient images (the fp64 blurred image between k_lsd_blur and k_lsd_resize_grad, the Sobel image between k_lbd_blur_sobel and
+    // k_lbd_desc) exist for a CHUNK of the batch only: lsd_run walks the batch chunk by chunk through those kernels (3.7 MB per frame saved)
+    P->chunk = (int)std::min<size_t>(B, 512);
+    { const char *e = getenv("HVO_LSD_CHUNK"); if (e && atoi(e) > 0) P->chunk = (int)std::min<size_t>(B, (size_t)atoi(e)); }
+    const size_t CB = (size_t)P->chunk;
+    PA(P->d_blur, CB * npix * 8);
     PA(P->d_px, B * nsp * sizeof(double4));
     PA(P->d_defined, B * P->nwords * 4); PA(P->d_reg, B * nsp * 4);
     PA(P->d_segs, B * LSD_MAXSEG * 16); PA(P->d_kl_all, B * LSD_MAXSEG * sizeof(hvo_keyline));
     PA(P->d_kl, B * P->nfeat * sizeof(hvo_keyline)); PA(P->d_desc, B * P->nfeat * 32); PA(P->d_fn, B * P->nfeat * 24);
     PA(P->d_nkl, B * 4); PA(P->d_flags, B * 4);
     PA(P->d_kl2, B * P->nfeat * sizeof(hvo_keyline)); PA(P->d_desc2, B * P->nfeat * 32); PA(P->d_fn2, B * P->nfeat * 24); PA(P->d_nkl2, B * 4);
-    PA(P->d_b5, B * npix); PA(P->d_dxy, B * npix * sizeof(short2));
+    if (getenv("HVO_LBD_SPLIT")) PA(P->d_b5, CB * npix);
+    PA(P->d_dxy, CB * npix * sizeof(short2));
     PA(P->d_xofs, P->sw * 4); PA(P->d_yofs, P->sh * 4); PA(P->d_xa, P->sw * 8); PA(P->d_yb, P->sh * 8);
     PA(P->d_gL, 21 * 4); PA(P->d_gG, 63 * 4); PA(P->d_stats, B * 64);
 #undef PA
@@ -1279,15 +1286,20 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     const int w = P->w, h = P->h, sw = P->sw, sh = P->sh;
     const uint8_t *gray = O.d_pyr + O.lev[0].img_off;
     const int gpitch = O.lev[0].pitch;
-    int id = hvo_prof_begin(ctx, "lsd_blur_scale", st);
-    hipLaunchKernelGGL(k_lsd_blur, dim3((w + 255) / 256, (h + LSD_BLUR_ROWS - 1) / LSD_BLUR_ROWS, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_blur, w, h,
-                       P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
-    hvo_prof_end(ctx, id);
-    id = hvo_prof_begin(ctx, "lsd_gradient", st);
+    int id;
+    const size_t nsp = (size_t)sw * sh;
     const int gx = (((sw + 31) & ~31) + 255) / 256;
-    hipLaunchKernelGGL(k_lsd_resize_grad, dim3(gx, (sh + GRAD_ROWS - 1) / GRAD_ROWS, n), dim3(256), 0, st, P->d_blur, w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb,
-                       P->d_px, P->d_defined, P->nwords, P->rho);
-    hvo_prof_end(ctx, id);
+    for (int c0 = 0; c0 < n; c0 += P->chunk) {
+        const int m = std::min(P->chunk, n - c0);
+        id = hvo_prof_begin(ctx, "lsd_blur_scale", st);
+        hipLaunchKernelGGL(k_lsd_blur, dim3((w + 255) / 256, (h + LSD_BLUR_ROWS - 1) / LSD_BLUR_ROWS, m), dim3(256), 0, st, gray + (size_t)c0 * O.pyr_bytes, O.pyr_bytes, gpitch, P->d_blur, w, h,
+                           P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
+        hvo_prof_end(ctx, id);
+        id = hvo_prof_begin(ctx, "lsd_gradient", st);
+        hipLaunchKernelGGL(k_lsd_resize_grad, dim3(gx, (sh + GRAD_ROWS - 1) / GRAD_ROWS, m), dim3(256), 0, st, P->d_blur, w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb,
+                           P->d_px + (size_t)c0 * nsp, P->d_defined + (size_t)c0 * P->nwords, P->nwords, P->rho);
+        hvo_prof_end(ctx, id);
+    }
     if (ctx->ev_lsd_pre && !ctx->serialize) { HVO_HIP(hipEventRecord(ctx->ev_lsd_pre, st)); ctx->lsd_pre_recorded = true; }
     if ((ctx->sched == 2 || ctx->sched == 5 || ctx->sched == 6) && ctx->fast_recorded && !ctx->serialize) HVO_HIP(hipStreamWaitEvent(st, ctx->ev_fast, 0));
     id = hvo_prof_begin(ctx, "lsd_grow", st);
@@ -1308,26 +1320,32 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     } else if (dense) hipLaunchKernelGGL(k_lsd_grow_dense, dim3(n), dim3(64), 0, st, g);     // more frames than five waves per SIMD hold
     else hipLaunchKernelGGL(k_lsd_grow, dim3(n), dim3(64), 0, st, g);
     hvo_prof_end(ctx, id);
-    id = hvo_prof_begin(ctx, "lbd_sobel", st);
-    if (getenv("HVO_LBD_SPLIT")) {                  // the two-kernel formulation (blurred u8 image materialised), kept for A/B runs
-        hipLaunchKernelGGL(k_lbd_blur5, dim3((w + 255) / 256, (h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_b5, w, h, P->k5[0], P->k5[1], P->k5[2]);
-        hipLaunchKernelGGL(k_lbd_sobel, dim3((w + 255) / 256, (h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS, n), dim3(256), 0, st, P->d_b5, P->d_dxy, w, h);
-    } else
-        hipLaunchKernelGGL(k_lbd_blur_sobel, dim3((((w + 3) / 4) * ((h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS) + 255) / 256, 1, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch, P->d_dxy, w, h,
-                           P->k5[0], P->k5[1], P->k5[2]);
-    hvo_prof_end(ctx, id);
-    id = hvo_prof_begin(ctx, "lbd_desc", st);
-    hipLaunchKernelGGL(k_lbd_desc, dim3(P->nfeat, n), dim3(64), 0, st, P->d_dxy, w, h, P->d_kl, P->d_nkl, P->nfeat, P->d_gL, P->d_gG, P->d_desc);
-    hvo_prof_end(ctx, id);
-    if (cull) {                                     // Frame::cullingLine + the second LBD pass (Frame.cc:934, 952-1116)
-        if (P->nfeat > CULL_MAXL) return HVO_ERR_UNSUPPORTED;
-        id = hvo_prof_begin(ctx, "lsd_cull", st);
-        CullArgs c;
-        c.kl = P->d_kl; c.fn = P->d_fn; c.nkl = P->d_nkl; c.tmp = P->d_kl_all; c.tmp_stride = LSD_MAXSEG; c.kl_out = P->d_kl2; c.fn_out = P->d_fn2; c.nkl_out = P->d_nkl2;
-        c.cap = P->nfeat; c.w = w; c.h = h; c.dis = ctx->cull_dis; c.cos_th = cos(ctx->cull_angle * 0.0174533); c.endpoint_dis = ctx->cull_endpoint;
-        hipLaunchKernelGGL(k_cull_lines, dim3(n), dim3(64), 0, st, c);
-        hipLaunchKernelGGL(k_lbd_desc, dim3(P->nfeat, n), dim3(64), 0, st, P->d_dxy, w, h, P->d_kl2, P->d_nkl2, P->nfeat, P->d_gL, P->d_gG, P->d_desc2);
+    if (cull && P->nfeat > CULL_MAXL) return HVO_ERR_UNSUPPORTED;
+    for (int c0 = 0; c0 < n; c0 += P->chunk) {
+        const int m = std::min(P->chunk, n - c0);
+        const uint8_t *gc = gray + (size_t)c0 * O.pyr_bytes;
+        const size_t ko = (size_t)c0 * P->nfeat;
+        id = hvo_prof_begin(ctx, "lbd_sobel", st);
+        if (P->d_b5) {                                  // the two-kernel formulation (blurred u8 image materialised), kept for A/B runs (HVO_LBD_SPLIT)
+            hipLaunchKernelGGL(k_lbd_blur5, dim3((w + 255) / 256, (h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS, m), dim3(256), 0, st, gc, O.pyr_bytes, gpitch, P->d_b5, w, h, P->k5[0], P->k5[1], P->k5[2]);
+            hipLaunchKernelGGL(k_lbd_sobel, dim3((w + 255) / 256, (h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS, m), dim3(256), 0, st, P->d_b5, P->d_dxy, w, h);
+        } else
+            hipLaunchKernelGGL(k_lbd_blur_sobel, dim3((((w + 3) / 4) * ((h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS) + 255) / 256, 1, m), dim3(256), 0, st, gc, O.pyr_bytes, gpitch, P->d_dxy, w, h,
+                               P->k5[0], P->k5[1], P->k5[2]);
         hvo_prof_end(ctx, id);
+        id = hvo_prof_begin(ctx, "lbd_desc", st);
+        hipLaunchKernelGGL(k_lbd_desc, dim3(P->nfeat, m), dim3(64), 0, st, P->d_dxy, w, h, P->d_kl + ko, P->d_nkl + c0, P->nfeat, P->d_gL, P->d_gG, P->d_desc + ko * 32);
+        hvo_prof_end(ctx, id);
+        if (cull) {                                     // Frame::cullingLine + the second LBD pass (Frame.cc:934, 952-1116)
+            id = hvo_prof_begin(ctx, "lsd_cull", st);
+            CullArgs c;
+            c.kl = P->d_kl + ko; c.fn = P->d_fn + ko * 3; c.nkl = P->d_nkl + c0; c.tmp = P->d_kl_all + (size_t)c0 * LSD_MAXSEG; c.tmp_stride = LSD_MAXSEG;
+            c.kl_out = P->d_kl2 + ko; c.fn_out = P->d_fn2 + ko * 3; c.nkl_out = P->d_nkl2 + c0;
+            c.cap = P->nfeat; c.w = w; c.h = h; c.dis = ctx->cull_dis; c.cos_th = cos(ctx->cull_angle * 0.0174533); c.endpoint_dis = ctx->cull_endpoint;
+            hipLaunchKernelGGL(k_cull_lines, dim3(m), dim3(64), 0, st, c);
+            hipLaunchKernelGGL(k_lbd_desc, dim3(P->nfeat, m), dim3(64), 0, st, P->d_dxy, w, h, P->d_kl2 + ko, P->d_nkl2 + c0, P->nfeat, P->d_gL, P->d_gG, P->d_desc2 + ko * 32);
+            hvo_prof_end(ctx, id);
+        }
     }
     HVO_HIP(hipGetLastError());
     return HVO_OK;

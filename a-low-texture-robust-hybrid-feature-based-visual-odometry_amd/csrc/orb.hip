@@ -45,16 +45,15 @@ static __device__ __forceinline__ unsigned long long lanemask_lt()
 #ifdef HVO_WPE_RESIZE
 __attribute__((amdgpu_waves_per_eu(HVO_WPE_RESIZE)))
 #endif
-__global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, size_t frame_stride,
+__global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src_base, size_t src_stride, uint8_t *__restrict__ dst_base, size_t dst_stride,
                                                 LevelGeom S, LevelGeom D,
                                                 const int *__restrict__ xofs, const int *__restrict__ xalpha,
                                                 const int *__restrict__ yofs, const int *__restrict__ ybeta)
 {
     const int dx0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (dx0 >= D.w) return;
-    uint8_t *base = pyr + (size_t)blockIdx.z * frame_stride;
-    const uint8_t *src = base + S.img_off;
-    uint8_t *dst = base + D.img_off;
+    const uint8_t *src = src_base + (size_t)blockIdx.z * src_stride;       // (the bases already point at the level inside frame 0's slab)
+    uint8_t *dst = dst_base + (size_t)blockIdx.z * dst_stride;
     // horizontal taps of this thread's 4 pixels are row independent: fetch them once
     int sx[4], sx1[4], a0[4], a1[4];
 #pragma unroll
@@ -95,16 +94,15 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, size_
 // so they are fetched as three dwords and picked with v_perm_b32 (selector fixed per thread); the right taps
 // come from the same window shifted by one byte.  The horizontal pass of a source row is kept for the next
 // output row, which reuses it whenever its upper source row is this row's lower one (5 rows in 6 at 1.2).
-__global__ __launch_bounds__(256) void k_resize_dw(uint8_t *__restrict__ pyr, size_t frame_stride,
+__global__ __launch_bounds__(256) void k_resize_dw(const uint8_t *__restrict__ src_base, size_t src_stride, uint8_t *__restrict__ dst_base, size_t dst_stride,
                                                    LevelGeom S, LevelGeom D,
                                                    const int *__restrict__ xofs, const int *__restrict__ xalpha,
                                                    const int *__restrict__ yofs, const int *__restrict__ ybeta)
 {
     const int dx0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (dx0 >= D.w) return;
-    uint8_t *base = pyr + (size_t)blockIdx.z * frame_stride;
-    const uint8_t *src = base + S.img_off;
-    uint8_t *dst = base + D.img_off;
+    const uint8_t *src = src_base + (size_t)blockIdx.z * src_stride;
+    uint8_t *dst = dst_base + (size_t)blockIdx.z * dst_stride;
     int a0[4], a1[4];
     unsigned sel = 0; int wbase = 0;
 #pragma unroll
@@ -194,7 +192,7 @@ template <int TILE>
 #ifdef HVO_WPE_FAST
 __attribute__((amdgpu_waves_per_eu(HVO_WPE_FAST)))
 #endif
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, size_t frame_stride,
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr0, size_t stride0, const uint8_t *__restrict__ lvl, size_t lvl_stride,
                                                     const LevelGeom *__restrict__ lev,
                                                     const CellDesc *__restrict__ cells, int ncells,
                                                     uint32_t *__restrict__ cell_kp, int *__restrict__ cell_cnt,
@@ -217,7 +215,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     uint8_t *tile = tile_[wv], *sc = sc_[wv];
     const CellDesc c = cells[cell];
     const LevelGeom L = lev[c.level];
-    const uint8_t *img = pyr + (size_t)frame * frame_stride + L.img_off;
+    const uint8_t *img = c.level == 0 ? pyr0 + (size_t)frame * stride0 : lvl + (size_t)frame * lvl_stride + L.lvl_off;
     const int vw = c.vw, vh = c.vh;
     const int ax0 = c.x0 & ~3, sh = c.x0 - ax0;                // aligned start, byte phase
     {
@@ -632,14 +630,14 @@ static __device__ __forceinline__ void blur_row_sums(const BlurWin &W, unsigned 
 #ifdef HVO_WPE_BLUR7
 __attribute__((amdgpu_waves_per_eu(HVO_WPE_BLUR7)))
 #endif
-__global__ __launch_bounds__(256) void k_blur7(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, size_t frame_stride,
-                                               const LevelGeom *__restrict__ lev, const int4 *__restrict__ tiles,
+__global__ __launch_bounds__(256) void k_blur7(const uint8_t *__restrict__ pyr0, size_t stride0, const uint8_t *__restrict__ lvl, size_t lvl_stride,
+                                               uint8_t *__restrict__ blur, size_t blur_stride, const LevelGeom *__restrict__ lev, const int4 *__restrict__ tiles,
                                                int k0, int k1, int k2, int k3)
 {
     const int4 t = tiles[blockIdx.x];
     const LevelGeom L = lev[t.x];
-    const uint8_t *src = pyr + (size_t)blockIdx.y * frame_stride + L.img_off;
-    uint8_t *dst = blur + (size_t)blockIdx.y * frame_stride + L.img_off;
+    const uint8_t *src = t.x == 0 ? pyr0 + (size_t)blockIdx.y * stride0 : lvl + (size_t)blockIdx.y * lvl_stride + L.lvl_off;
+    uint8_t *dst = blur + (size_t)blockIdx.y * blur_stride + L.img_off;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x0 = t.y * BLUR_TW + lane * 4;
     const int y0 = (t.z * 4 + wv) * BLUR_TH;
@@ -728,7 +726,7 @@ void orb_free_plan(hvo_ctx *ctx)
     OrbPlan &P = ctx->orb;
     void *ptrs[] = { P.d_lev, P.d_cells, P.d_rs_xofs, P.d_rs_xalpha, P.d_rs_yofs, P.d_rs_ybeta, P.d_tiles, P.d_pyr_base, P.d_blur,
                      P.d_cell_kp, P.d_cell_cnt, P.d_cand, P.d_keys, P.d_keys_tmp, P.d_nodeA, P.d_nodeB, P.d_vs, P.d_vp,
-                     P.d_order, P.d_lvl_kp, P.d_lvl_cnt, P.d_kp, P.d_desc, P.d_nkp, P.d_flags, P.d_ltiles, P.d_kpchunks };
+                     P.d_order, P.d_lvl_kp, P.d_lvl_cnt, P.d_kp, P.d_desc, P.d_nkp, P.d_flags, P.d_ltiles, P.d_kpchunks, P.d_lvl_base };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     P = OrbPlan();
 }
@@ -779,6 +777,7 @@ static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch)
         if (L.w < 38 || L.h < 38) return HVO_ERR_UNSUPPORTED;
         L.pitch = (L.w + 63) & ~63;
         L.img_off = off;
+        L.lvl_off = l >= 1 ? off - P.lev[0].img_off - (size_t)P.lev[0].pitch * P.lev[0].h : 0;
         off += (size_t)L.pitch * L.h;
         L.scale = ctx->scale[l];
         L.scaled_patch = (int)(31 * ctx->scale[l]);
@@ -859,7 +858,20 @@ static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch)
         L.ntx = (L.w + BLUR_TW - 1) / BLUR_TW; L.nty = (L.h + 4 * BLUR_TH - 1) / (4 * BLUR_TH);
         for (int ty = 0; ty < L.nty; ty++) for (int tx = 0; tx < L.ntx; tx++) tiles.push_back(make_int4(l, tx, ty, 0));
     }
-    P.pyr_bytes = (off + 255) & ~(size_t)255;
+    P.blur_bytes = (off + 255) & ~(size_t)255;                                     // all levels
+    P.pyr_bytes = ((size_t)P.lev[0].pitch * P.lev[0].h + 255) & ~(size_t)255;         // level 0: the input image
+    P.lvl_bytes = (off - (size_t)P.lev[0].pitch * P.lev[0].h + 255) & ~(size_t)255;  // levels >= 1
+    // Everything between the input image and the key points / descriptors is scratch: it exists for a CHUNK of the batch, and
+    // orb_run walks the batch chunk by chunk (5.5 of ORB's 5.9 MB per 640x480 frame are scratch).
+    // Chunk size: every chunk boundary costs a tail (k_octree is one wave per frame and level), so the chunk is as large as a scratch
+    // budget of 48 GB allows: the whole batch at 640x480 (8192 resident frames: 45 GB; two chunks of 4096 cost 5 ms of a 194 ms step),
+    // 1024 frames at 1280x960, where the memory buys resident frames instead.
+    {
+        const size_t per = P.lvl_bytes + P.blur_bytes + (size_t)cells.size() * HVO_CELL_CAP * 4 + (size_t)cand_total * 12 + (size_t)node_total * 52 + (size_t)kp_total * 4;
+        P.chunk = batch;
+        while (P.chunk > 1024 && (size_t)P.chunk * per > ((size_t)48 << 30)) P.chunk = (P.chunk + 1) / 2;
+    }
+    { const char *e = getenv("HVO_ORB_CHUNK"); if (e && atoi(e) > 0) P.chunk = std::min(batch, atoi(e)); }
     P.ncells = (int)cells.size(); P.cand_total = cand_total; P.node_total = node_total; P.kp_total = kp_total;
     P.ntiles = (int)tiles.size();
     P.kp_cap = kp_total;       // >= sum(nfeat)+8*nlevels: never truncates the octree output
@@ -883,26 +895,30 @@ static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     if ((rc = orb_describe_build(ctx))) return rc;
     if ((rc = dev_alloc(ctx, &P.d_pyr_base, B * P.pyr_bytes + 512))) return rc;
     P.d_pyr = P.d_pyr_base + 256;
-    if ((rc = dev_alloc(ctx, &P.d_blur, B * P.pyr_bytes + 256))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_cell_kp, B * P.ncells * HVO_CELL_CAP))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_cell_cnt, B * P.ncells))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_cand, B * cand_total))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_keys, B * cand_total))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_keys_tmp, B * cand_total))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_nodeA, B * node_total))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_nodeB, B * node_total))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_vs, B * node_total))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_vp, B * node_total))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_order, B * node_total))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_lvl_kp, B * kp_total))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_lvl_cnt, B * nl))) return rc;
+    const size_t CB = (size_t)P.chunk;
+    if ((rc = dev_alloc(ctx, &P.d_lvl_base, CB * P.lvl_bytes + 512))) return rc;
+    P.d_lvl = P.d_lvl_base + 256;
+    if ((rc = dev_alloc(ctx, &P.d_blur, CB * P.blur_bytes + 256))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_cell_kp, CB * P.ncells * HVO_CELL_CAP))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_cell_cnt, CB * P.ncells))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_cand, CB * cand_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_keys, CB * cand_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_keys_tmp, CB * cand_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_nodeA, CB * node_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_nodeB, CB * node_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_vs, CB * node_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_vp, CB * node_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_order, CB * node_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_lvl_kp, CB * kp_total))) return rc;
+    if ((rc = dev_alloc(ctx, &P.d_lvl_cnt, CB * nl))) return rc;
     if ((rc = dev_alloc(ctx, &P.d_kp, B * P.kp_cap))) return rc;
     if ((rc = dev_alloc(ctx, &P.d_desc, B * P.kp_cap * 32))) return rc;
     if ((rc = dev_alloc(ctx, &P.d_nkp, B))) return rc;
     if ((rc = dev_alloc(ctx, &P.d_flags, B))) return rc;
     // stream-ordered fills: a null-stream hipMemset is not ordered against the non-blocking ctx stream
     HVO_HIP(hipMemsetAsync(P.d_pyr_base, 0, B * P.pyr_bytes + 512, ctx->stream));
-    HVO_HIP(hipMemsetAsync(P.d_blur, 0, B * P.pyr_bytes + 256, ctx->stream));
+    HVO_HIP(hipMemsetAsync(P.d_lvl_base, 0, CB * P.lvl_bytes + 512, ctx->stream));
+    HVO_HIP(hipMemsetAsync(P.d_blur, 0, CB * P.blur_bytes + 256, ctx->stream));
     HVO_HIP(hipMemsetAsync(P.d_flags, 0, B * sizeof(int), ctx->stream));
     HVO_HIP(hipMemsetAsync(P.d_nkp, 0, B * sizeof(int), ctx->stream));
     HVO_HIP(hipDeviceSynchronize());     // also drains the null-stream table uploads above
@@ -954,23 +970,30 @@ int orb_run(hvo_ctx *ctx, int n)
         for (int i = 0; i < 4; i++) k7[i] = round_half_even_f((float)(cf[i] * sum) * 256.f);
     }
     int id;
+    // the batch, chunk by chunk: frames [c0, c0 + m) use the scratch slabs as their frames 0 .. m-1
+    for (int c0 = 0; c0 < n; c0 += P.chunk) {
+    const int m = std::min(P.chunk, n - c0);
+    const bool last = c0 + m >= n;
+    const uint8_t *pyr0 = P.d_pyr + (size_t)c0 * P.pyr_bytes;          // level 0 of the chunk's first frame
+    int *flags = P.d_flags + c0;
     if (P.fused) {
         // one launch per level: level l is read once into LDS tiles and gives its FAST corners, its blurred image and level l+1
         id = hvo_prof_begin(ctx, "orb_levels", st);
-        const int rl = orb_level_run(ctx, n, st, k7[0], k7[1], k7[2], k7[3]);
+        const int rl = orb_level_run(ctx, c0, m, st, k7[0], k7[1], k7[2], k7[3]);
         hvo_prof_end(ctx, id);
         if (rl) return rl;
-        if (ctx->ev_fast && !ctx->serialize) { HVO_HIP(hipEventRecord(ctx->ev_fast, st)); ctx->fast_recorded = true; }
+        if (last && ctx->ev_fast && !ctx->serialize) { HVO_HIP(hipEventRecord(ctx->ev_fast, st)); ctx->fast_recorded = true; }
     } else {
     id = hvo_prof_begin(ctx, "orb_pyramid", st);
     for (int l = 1; l < nl; l++) {
         const LevelGeom &S = P.lev[l - 1], &D = P.lev[l];
-        dim3 blk(64, 4), grd((D.w + 255) / 256, (D.h + 4 * RESIZE_ROWS - 1) / (4 * RESIZE_ROWS), n);
+        dim3 blk(64, 4), grd((D.w + 255) / 256, (D.h + 4 * RESIZE_ROWS - 1) / (4 * RESIZE_ROWS), m);
+        const uint8_t *sb = l == 1 ? pyr0 : P.d_lvl + S.lvl_off; const size_t ss = l == 1 ? P.pyr_bytes : P.lvl_bytes;
         if (P.resize_dw[l])
-            hipLaunchKernelGGL(k_resize_dw, grd, blk, 0, st, P.d_pyr, P.pyr_bytes, S, D, P.d_rs_xofs + D.rs_off, P.d_rs_xalpha + D.rs_off,
+            hipLaunchKernelGGL(k_resize_dw, grd, blk, 0, st, sb, ss, P.d_lvl + D.lvl_off, P.lvl_bytes, S, D, P.d_rs_xofs + D.rs_off, P.d_rs_xalpha + D.rs_off,
                                P.d_rs_yofs + D.ry_off, P.d_rs_ybeta + D.ry_off);
         else
-            hipLaunchKernelGGL(k_resize, grd, blk, 0, st, P.d_pyr, P.pyr_bytes, S, D, P.d_rs_xofs + D.rs_off, P.d_rs_xalpha + D.rs_off,
+            hipLaunchKernelGGL(k_resize, grd, blk, 0, st, sb, ss, P.d_lvl + D.lvl_off, P.lvl_bytes, S, D, P.d_rs_xofs + D.rs_off, P.d_rs_xalpha + D.rs_off,
                                P.d_rs_yofs + D.ry_off, P.d_rs_ybeta + D.ry_off);
     }
     hvo_prof_end(ctx, id);
@@ -979,31 +1002,32 @@ int orb_run(hvo_ctx *ctx, int n)
     const bool blur_late = ctx->orb_blur_late;
     auto run_blur = [&]() -> int {
         id = hvo_prof_begin(ctx, "orb_blur", st);
-        hipLaunchKernelGGL(k_blur7, dim3(P.ntiles, n), dim3(256), 0, st, P.d_pyr, P.d_blur, P.pyr_bytes, P.d_lev, P.d_tiles, k7[0], k7[1], k7[2], k7[3]);
+        hipLaunchKernelGGL(k_blur7, dim3(P.ntiles, m), dim3(256), 0, st, pyr0, P.pyr_bytes, P.d_lvl, P.lvl_bytes, P.d_blur, P.blur_bytes, P.d_lev, P.d_tiles, k7[0], k7[1], k7[2], k7[3]);
         hvo_prof_end(ctx, id);
         return HVO_OK;
     };
     if (!blur_late) { const int rb = run_blur(); if (rb) return rb; }
     id = hvo_prof_begin(ctx, "orb_fast_cells", st);
     if (P.max_cell <= 45)
-        hipLaunchKernelGGL(k_fast_cells<48>, dim3((P.ncells + 3) / 4, n), dim3(256), 0, st, P.d_pyr, P.pyr_bytes, P.d_lev, P.d_cells, P.ncells,
-                           P.d_cell_kp, P.d_cell_cnt, ctx->p.orb_ini_th_fast, ctx->p.orb_min_th_fast, P.d_flags);
+        hipLaunchKernelGGL(k_fast_cells<48>, dim3((P.ncells + 3) / 4, m), dim3(256), 0, st, pyr0, P.pyr_bytes, P.d_lvl, P.lvl_bytes, P.d_lev, P.d_cells, P.ncells,
+                           P.d_cell_kp, P.d_cell_cnt, ctx->p.orb_ini_th_fast, ctx->p.orb_min_th_fast, flags);
     else
-        hipLaunchKernelGGL(k_fast_cells<HVO_CELL_TILE>, dim3((P.ncells + 3) / 4, n), dim3(256), 0, st, P.d_pyr, P.pyr_bytes, P.d_lev, P.d_cells, P.ncells,
-                           P.d_cell_kp, P.d_cell_cnt, ctx->p.orb_ini_th_fast, ctx->p.orb_min_th_fast, P.d_flags);
+        hipLaunchKernelGGL(k_fast_cells<HVO_CELL_TILE>, dim3((P.ncells + 3) / 4, m), dim3(256), 0, st, pyr0, P.pyr_bytes, P.d_lvl, P.lvl_bytes, P.d_lev, P.d_cells, P.ncells,
+                           P.d_cell_kp, P.d_cell_cnt, ctx->p.orb_ini_th_fast, ctx->p.orb_min_th_fast, flags);
     hvo_prof_end(ctx, id);
-    if (ctx->ev_fast && !ctx->serialize) { HVO_HIP(hipEventRecord(ctx->ev_fast, st)); ctx->fast_recorded = true; }
+    if (last && ctx->ev_fast && !ctx->serialize) { HVO_HIP(hipEventRecord(ctx->ev_fast, st)); ctx->fast_recorded = true; }
     if (blur_late) { const int rb = run_blur(); if (rb) return rb; }
     }
     id = hvo_prof_begin(ctx, "orb_octree", st);
     OctArgs oa;
     oa.lev = P.d_lev; oa.cell_kp = P.d_cell_kp; oa.cell_cnt = P.d_cell_cnt; oa.ncells = P.ncells;
     oa.cand = P.d_cand; oa.keys = P.d_keys; oa.keys_tmp = P.d_keys_tmp; oa.nodeA = P.d_nodeA; oa.nodeB = P.d_nodeB;
-    oa.vs = P.d_vs; oa.vp = P.d_vp; oa.order = P.d_order; oa.lvl_kp = P.d_lvl_kp; oa.lvl_cnt = P.d_lvl_cnt; oa.flags = P.d_flags;
+    oa.vs = P.d_vs; oa.vp = P.d_vp; oa.order = P.d_order; oa.lvl_kp = P.d_lvl_kp; oa.lvl_cnt = P.d_lvl_cnt; oa.flags = flags;
     oa.cand_total = P.cand_total; oa.node_total = P.node_total; oa.kp_total = P.kp_total; oa.nlevels = nl;
-    hipLaunchKernelGGL(k_octree, dim3(nl, n), dim3(64), 0, st, oa);
+    hipLaunchKernelGGL(k_octree, dim3(nl, m), dim3(64), 0, st, oa);
     hvo_prof_end(ctx, id);
-    { const int rd = orb_describe_run(ctx, n, st); if (rd) return rd; }
+    { const int rd = orb_describe_run(ctx, c0, m, st); if (rd) return rd; }
+    }   // chunks
     HVO_HIP(hipGetLastError());
     return HVO_OK;
 }

@@ -48,7 +48,9 @@ static __device__ __forceinline__ float od_fast_atan2_deg(float y, float x)
 #define BR_PITCH 48                  // three 16-byte chunks: columns cx - 19 .. cx + 28
 
 struct DescArgs {
-    const uint8_t *pyr, *blur; size_t frame_stride;
+    const uint8_t *pyr0; size_t stride0;               // level 0 of the chunk's first frame (the per-frame input slab)
+    const uint8_t *lvl; size_t lvl_stride;             // levels >= 1 (scratch, chunk-local frames)
+    const uint8_t *blur; size_t blur_stride;           // all levels blurred (scratch)
     const LevelGeom *lev; int nlevels;
     const int2 *chunks; int nchunks, nframes;
     const uint32_t *lvl_kp; const int *lvl_cnt; int kp_total;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void k_moments(const DescArgs A)
     int frame, level, k0, cnt, base;
     if (!od_locate(A, frame, level, k0, cnt, base)) return;
     const LevelGeom L = A.lev[level];
-    const uint8_t *img = A.pyr + (size_t)frame * A.frame_stride + L.img_off;
+    const uint8_t *img = level == 0 ? A.pyr0 + (size_t)frame * A.stride0 : A.lvl + (size_t)frame * A.lvl_stride + L.lvl_off;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5, row = lane & 31;
     const int v = row - 15;
     const bool rowok = row < 31;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void k_brief(const DescArgs A)
     int frame, level, k0, cnt, base;
     if (!od_locate(A, frame, level, k0, cnt, base)) return;
     const LevelGeom L = A.lev[level];
-    const uint8_t *img = A.blur + (size_t)frame * A.frame_stride + L.img_off;
+    const uint8_t *img = A.blur + (size_t)frame * A.blur_stride + L.img_off;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int4 praw = *reinterpret_cast<const int4 *>(A.pattern + 16 * lane);
     const int8_t *pp = reinterpret_cast<const int8_t *>(&praw);
@@ -267,14 +269,15 @@ int orb_describe_build(hvo_ctx *ctx)
     return HVO_OK;
 }
 
-int orb_describe_run(hvo_ctx *ctx, int n, hipStream_t st)
+int orb_describe_run(hvo_ctx *ctx, int c0, int n, hipStream_t st)
 {
     OrbPlan &P = ctx->orb;
     DescArgs A;
-    A.pyr = P.d_pyr; A.blur = P.d_blur; A.frame_stride = P.pyr_bytes; A.lev = P.d_lev; A.nlevels = P.nlevels;
+    A.pyr0 = P.d_pyr + (size_t)c0 * P.pyr_bytes; A.stride0 = P.pyr_bytes; A.lvl = P.d_lvl; A.lvl_stride = P.lvl_bytes; A.blur = P.d_blur; A.blur_stride = P.blur_bytes;
+    A.lev = P.d_lev; A.nlevels = P.nlevels;
     A.chunks = P.d_kpchunks; A.nchunks = P.n_kpchunks; A.nframes = n;
     A.lvl_kp = P.d_lvl_kp; A.lvl_cnt = P.d_lvl_cnt; A.kp_total = P.kp_total; A.umax = ctx->d_umax; A.pattern = ctx->d_pattern;
-    A.kp = P.d_kp; A.nkp = P.d_nkp; A.cap = P.kp_cap; A.desc = P.d_desc;
+    A.kp = P.d_kp + (size_t)c0 * P.kp_cap; A.nkp = P.d_nkp + c0; A.cap = P.kp_cap; A.desc = P.d_desc + (size_t)c0 * P.kp_cap * 32;
     const unsigned nb = (unsigned)((n + 7) / 8 * 8 * P.n_kpchunks);
     int id = hvo_prof_begin(ctx, "orb_orient", st);
     hipLaunchKernelGGL(k_moments, dim3(nb), dim3(256), 0, st, A);

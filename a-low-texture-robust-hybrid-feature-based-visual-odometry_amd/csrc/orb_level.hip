@@ -47,7 +47,9 @@ struct __attribute__((aligned(16))) LtWave {
 static_assert(sizeof(LtWave) <= 8192, "five workgroups per CU");
 
 struct LevelArgs {
-    const uint8_t *pyr; uint8_t *pyr_w; uint8_t *blur; size_t frame_stride;
+    const uint8_t *rd; size_t rd_stride;               // the level read (frame 0 of the chunk): level 0 lives in the per-frame input slab, the others in the chunk's scratch
+    uint8_t *wr; size_t wr_stride;                     // the next level
+    uint8_t *blur; size_t blur_stride;                 // this level inside the all-levels blurred slab
     LevelGeom L, D; int has_next;
     const OrbTile *tiles; int ntiles, tpw, groups, nframes;
     const int *xofs, *xalpha, *yofs, *ybeta;
@@ -122,8 +124,8 @@ __global__ __launch_bounds__(64 * NW, 5) void k_orb_level(const LevelArgs A)
     if (frame >= A.nframes) return;
     LtWave &W = lds_[wv];
     const LevelGeom &L = A.L;
-    const uint8_t *img = A.pyr + (size_t)frame * A.frame_stride + L.img_off;
-    uint8_t *bdst = A.blur + (size_t)frame * A.frame_stride + L.img_off;
+    const uint8_t *img = A.rd + (size_t)frame * A.rd_stride;
+    uint8_t *bdst = A.blur + (size_t)frame * A.blur_stride;
     const uint8_t *T8 = reinterpret_cast<const uint8_t *>(W.T);
     const unsigned long long ltm = (1ull << lane) - 1ull;
 
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(64 * NW, 5) void k_orb_level(const LevelArgs A)
         // upper tap it owns).  The other three pixels' taps reach at most 5 columns past the owned rectangle: inside the 64-byte tile rows.
         if (A.has_next && t.dxb > t.dxa && t.dyb > t.dya && !(A.skip & 4)) {
             const LevelGeom &D = A.D;
-            uint8_t *dst = A.pyr_w + (size_t)frame * A.frame_stride + D.img_off;
+            uint8_t *dst = A.wr + (size_t)frame * A.wr_stride;
             const int dd0 = t.dxa >> 2, ndd = (t.dxb - t.dxa) >> 2;          // dxa, dxb are multiples of 4
             const int nr = t.dyb - t.dya;
             constexpr int RG = 4;
@@ -551,13 +553,15 @@ bool orb_level_build(OrbPlan &P, const std::vector<CellDesc> &cells, const std::
 }
 
 // the eight launches of the fused pass (levels in order: launch l writes level l+1)
-int orb_level_run(hvo_ctx *ctx, int n, hipStream_t st, int k0, int k1, int k2, int k3)
+int orb_level_run(hvo_ctx *ctx, int c0, int n, hipStream_t st, int k0, int k1, int k2, int k3)
 {
     OrbPlan &P = ctx->orb;
     for (int l = 0; l < P.nlevels; l++) {
         LevelArgs A;
-        A.pyr = P.d_pyr; A.pyr_w = P.d_pyr; A.blur = P.d_blur; A.frame_stride = P.pyr_bytes;
         A.L = P.lev[l]; A.has_next = l + 1 < P.nlevels; A.D = P.lev[A.has_next ? l + 1 : l];
+        if (l == 0) { A.rd = P.d_pyr + (size_t)c0 * P.pyr_bytes; A.rd_stride = P.pyr_bytes; } else { A.rd = P.d_lvl + A.L.lvl_off; A.rd_stride = P.lvl_bytes; }
+        A.wr = P.d_lvl + A.D.lvl_off; A.wr_stride = P.lvl_bytes;
+        A.blur = P.d_blur + A.L.img_off; A.blur_stride = P.blur_bytes;
         A.tiles = P.d_ltiles + P.lt_off[l]; A.ntiles = P.lt_cnt[l];
         const int nw = getenv("HVO_ORB_NW") ? atoi(getenv("HVO_ORB_NW")) : 4;
         A.tpw = P.lt_tpw; A.groups = (A.ntiles + nw * A.tpw - 1) / (nw * A.tpw); A.nframes = n;
@@ -565,7 +569,7 @@ int orb_level_run(hvo_ctx *ctx, int n, hipStream_t st, int k0, int k1, int k2, i
         A.cell_kp = P.d_cell_kp; A.cell_cnt = P.d_cell_cnt; A.ncells = P.ncells; A.iniTh = ctx->p.orb_ini_th_fast; A.minTh = ctx->p.orb_min_th_fast;
         A.res_dw = A.has_next && P.resize_dw[l + 1];
         A.skip = getenv("HVO_LT_SKIP") ? atoi(getenv("HVO_LT_SKIP")) : 0;
-        A.flags = P.d_flags; A.k0 = k0; A.k1 = k1; A.k2 = k2; A.k3 = k3;
+        A.flags = P.d_flags + c0; A.k0 = k0; A.k1 = k1; A.k2 = k2; A.k3 = k3;
         if (A.ntiles < 1) continue;
         const int n8 = (n + 7) / 8 * 8;
         if (nw == 1) hipLaunchKernelGGL(k_orb_level<1>, dim3((unsigned)(n8 * A.groups)), dim3(64), 0, st, A);

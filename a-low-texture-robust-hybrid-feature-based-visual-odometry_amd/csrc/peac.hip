@@ -215,6 +215,7 @@ struct ClArgs {
     struct HotNode *hot;                            // the grouped kernel's node records (one 128-byte line each)
     const int *perm;                                // wave b works on frames NG * perm[b] .. (hvo_frame_perm over the waves), or nullptr
     double *tqK, *tqM1k; int *tqM1i; int tq_n0;      // the grouped kernel's min-MSE queue (TQueue): n0 * 256 keys, n0 * 16 bucket minima per frame
+    int tq_lds_keys;                                 // GL = 64, a handful of frames: the keys and bucket minima live in LDS too (54 KB per frame)
     int segcap, poolcap, nblk, Nw, Nh;
     double c15, c60;
     double ang_factor, ang_near;   // T_ang(P_INIT): (angle_far - angle_near) / (z_far - z_near), angle_near (AHCParamSet.hpp:113-121)
@@ -1132,6 +1133,12 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
     Q.K = a.tqK + (size_t)frame * Q.n0 * 256; Q.M1k = a.tqM1k + (size_t)frame * Q.n0 * 16; Q.M1i = a.tqM1i + (size_t)frame * Q.n0 * 16;
     Q.M0k = reinterpret_cast<double *>(tq_lds) + (size_t)gid * Q.n0;
     Q.M0i = reinterpret_cast<int *>(tq_lds + (size_t)NG * Q.n0 * sizeof(double)) + (size_t)gid * Q.n0;
+    if (GL == 64 && a.tq_lds_keys) {
+        // a lone frame owns its CU: the whole queue in LDS turns the update's memory round trip (a third of a single frame's iteration)
+        // into LDS accesses
+        unsigned char *kb = tq_lds + (((size_t)Q.n0 * 12 + 15) & ~(size_t)15);
+        Q.K = reinterpret_cast<double *>(kb); Q.M1k = Q.K + (size_t)Q.n0 * 256; Q.M1i = reinterpret_cast<int *>(Q.M1k + (size_t)Q.n0 * 16);
+    }
     double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
     int *segI = a.segI + (size_t)frame * a.segcap * SEG_I;
     int *pool = a.pool + (size_t)frame * a.poolcap, *pool2 = a.pool2 + (size_t)frame * a.poolcap;
@@ -1938,7 +1945,19 @@ int peac_run(hvo_ctx *ctx, int n)
         // frames of one wave stay consecutive, lockstep likes them alike); HVO_PEAC_PERM=0 for A/B runs
         a.perm = hvo_frame_perm(ctx, (n + (64 / use) - 1) / (64 / use));
         { const char *e4 = getenv("HVO_PEAC_PERM"); if (e4 && atoi(e4) == 0) a.perm = nullptr; }
-        if (use == 64) hipLaunchKernelGGL(k_peac_cluster<64>, dim3(n), dim3(64), lq, st, a, n);
+        a.tq_lds_keys = 0;
+        if (use == 64) {
+            size_t lds = lq;
+            bool ldsq = n <= 256;                                  // at most one such frame per CU
+            { const char *e5 = getenv("HVO_PEAC_LDSQ"); if (e5) ldsq = atoi(e5) != 0; }
+            const size_t full = ((lq + 15) & ~(size_t)15) + (size_t)a.tq_n0 * (256 * 8 + 16 * 12);
+            if (ldsq && full <= 150 * 1024) {
+                a.tq_lds_keys = 1; lds = full;
+                static size_t lds_set2 = 0;
+                if (lds > 48 * 1024 && lds > lds_set2) { HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); lds_set2 = lds; }
+            }
+            hipLaunchKernelGGL(k_peac_cluster<64>, dim3(n), dim3(64), lds, st, a, n);
+        }
         else if (use == 32) hipLaunchKernelGGL(k_peac_cluster<32>, dim3((n + 1) / 2), dim3(64), 2 * lq, st, a, n);
         else hipLaunchKernelGGL(k_peac_cluster<16>, dim3((n + 3) / 4), dim3(64), 4 * lq, st, a, n);
     }

@@ -34,7 +34,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 TRAFFIC_PROFILE = "profiles/r03_hbm_traffic.json"
 SQ_PROFILE = "profiles/r03_sq_utilisation.json"
-BYTES_PER_FRAME_640 = 26.0e6      # resident footprint of one 640x480 frame (profiles/r02_hbm_footprint.txt)
+BYTES_PER_FRAME_640 = 23.0e6      # resident footprint of one 640x480 frame incl. its share of the chunk scratch (profiles/r03_hbm_footprint.txt)
+BYTES_PER_FRAME_1280 = 80.0e6     # 1280x960, 2000 ORB: 63 MB per frame + 32 GB of chunk scratch
 
 
 def parse_args():
@@ -215,7 +216,7 @@ def cpu_all_cores(ge, stages, gray, depth, per_thread=3):
 # ---------------------------------------------------------------------------------------------------------------
 # self-certification: sampled frames of the timed batch against the oracle (the checker, after the timed region)
 # ---------------------------------------------------------------------------------------------------------------
-def parity_sample(ge, np, stages, res, g0, d0, kinds, nfeat, want=32):
+def parity_sample(ge, np, stages, res, g0, d0, kinds, nfeat, want=32, scale=1.0):
     """Compares `want` frames of the resident batch (both scene kinds; res[f] is frame f, whose input is g0[f], d0[f]) with the CPU
     oracle, stage by stage: key points (x, y, octave, response, size exact; angle 1e-4) and descriptor bytes; key lines (count, pixel
     counts, descriptor bytes exact; end points 1e-4); label image and plane supports exact.  Returns (checked, failures, detail)."""
@@ -237,7 +238,7 @@ def parity_sample(ge, np, stages, res, g0, d0, kinds, nfeat, want=32):
             if len(kl) != len(r["kl"]) or not np.array_equal(ld, r["ldesc"]) or not np.array_equal(kl["num_pixels"], r["kl"]["num_pixels"]): why.append("lsd")
             elif len(kl) and max(np.max(np.abs(kl[k] - r["kl"][k])) for k in ("sx", "sy", "ex", "ey")) > 1e-4: why.append("lsd-ends")
         if "planes" in stages:
-            lab, pl = orc.peac(d0[f])
+            lab, pl = orc.peac(d0[f], fx=535.4 * scale, fy=539.2 * scale, cx=320.1 * scale, cy=247.6 * scale)
             if not np.array_equal(lab, r["labels"]) or len(pl) != len(r["planes"]) or not np.array_equal(pl["n_points"], r["planes"]["n_points"]): why.append("planes")
         if why: bad.append("frame %d (%s): %s" % (f, kinds[f], ",".join(why)))
     return len(idx), len(bad), bad[:4], sum(1 for f in idx if kinds[f] == "lowtex")
@@ -417,7 +418,16 @@ def main():
     if args.mode == "stream":
         nframes = args.steps if args.steps > 0 else 573          # length of Examples/RGB-D/associations/fr1_desk.txt
         ndist = min(nframes + args.warmup, 573)
-        g, d, off = synth.make_sequence("std", 0x5EED3000 + 1000 * rank, ndist, w, h)
+        data_kind = "synthetic"
+        tum_dir = os.environ.get("HVO_TUM_DIR")
+        if tum_dir and os.path.isdir(tum_dir):
+            # BASELINE configs[4] on the real sequence where it exists (e.g. rgbd_dataset_freiburg1_desk with its association file):
+            # frames in file order, the tracker's pose prediction replaced by "no drift" (shift 0) for SearchByProjection's queries
+            tum = importlib.import_module("hvo_amd.tum")
+            g, d = tum.load_sequence(tum_dir, limit=ndist, assoc=os.environ.get("HVO_TUM_ASSOC"))
+            off = np.zeros((len(g), 2), np.float32); h, w = g.shape[1:]; data_kind = "TUM RGB-D sequence " + os.path.basename(os.path.normpath(tum_dir))
+        else:
+            g, d, off = synth.make_sequence("std", 0x5EED3000 + 1000 * rank, ndist, w, h)
         run_stream(hvo, np, g, d, off, mask, args.depth, local_rank, max(args.warmup, 2))          # warm-up: plans, pinned buffers
         barrier()
         el, lat, mpts, mlines = run_stream(hvo, np, g, d, off, mask, args.depth, local_rank, nframes)
@@ -430,7 +440,7 @@ def main():
             out = {
                 "metric": "RGB-D frames/sec (640×480, 1k ORB + LSD + PEAC) at 1/2/4/8 GPUs", "value": round(world * nframes / el, 2), "unit": "frames/s",
                 "n_gpus": world, "steps": nframes, "warmup": args.warmup, "ms_per_step": round(el / nframes * 1e3, 4),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16 integer + f32/f64", "data": "synthetic",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16 integer + f32/f64", "data": data_kind,
                 "config": {"workload": "stream-%d: %dx%d synthetic RGB-D sequence (smooth <= 4 px/frame drift), one frame at a time through hvo_stream_* "
                                        "(upload + %d ORB + LSD + PEAC%s + download + SearchByProjection(Cur,Last) + line match per frame), %d frames in flight"
                                        % (nframes, w, h, nfeat, " + isLineGood + vanishing points + plane clouds / refit / surface normals + grids" if "tail" in stages else "", args.depth),
@@ -463,13 +473,13 @@ def main():
 
     # ======================================================= batch mode ===========================================
     B = args.batch
-    per_frame = BYTES_PER_FRAME_640 * (w * h) / (640.0 * 480.0) * (nfeat / 1000.0 * 0.15 + 0.85)
+    per_frame = BYTES_PER_FRAME_640 if w <= 640 else BYTES_PER_FRAME_1280
     if B <= 0:
         if args.config == "batch256":
             B = max(1, 256 // world)                                 # BASELINE configs[3]: 256 frames over the ranks
         else:
             free_b, _ = torch.cuda.mem_get_info()
-            B = next((c for c in (8192, 4096, 2048, 1024, 512, 256) if c * per_frame <= 0.85 * free_b), 128)
+            B = next((c for c in (8192, 6144, 4096, 3072, 2048, 1024, 512, 256) if c * per_frame <= 0.85 * free_b), 128)
         if dist is not None:                 # every rank must run the same workload
             t = torch.tensor([B], dtype=torch.int64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -524,7 +534,7 @@ def main():
     nplanes = float(np.mean([len(r["planes"]) for r in res])) if "planes" in stages else 0.0
     bad = sum(1 for r in res if r["status"] != 0)
     ctx.close()
-    parity = parity_sample(ge, np, stages, res, g0, d0, kinds, nfeat) if rank == 0 else None
+    parity = parity_sample(ge, np, stages, res, g0, d0, kinds, nfeat, scale=w / 640.0) if rank == 0 else None
 
     if rank == 0:
         frames = world * B * steps
