@@ -55,14 +55,18 @@ int main(int argc, char **argv)
         int valid = 0; for (const hvo_plane_cloud &c : pc) valid += c.valid;
         std::vector<hvo_surface_normal> sn; planes.surfaceNormals(sn);
         hvo_params p; hvo_default_params(&p);
-        hvo_stream_params sp = hvo_stream_params(); sp.width = W; sp.height = H; sp.depth = 2; sp.stages = HVO_STAGE_ORB | HVO_STAGE_LSD | HVO_STAGE_PLANES; sp.bf = 40.f;
+        hvo_stream_params sp = hvo_stream_params(); sp.width = W; sp.height = H; sp.depth = 2; sp.stages = HVO_STAGE_ORB | HVO_STAGE_LSD | HVO_STAGE_PLANES | HVO_STAGE_LINES3D | HVO_STAGE_VP | HVO_STAGE_PLANE_TAIL | HVO_STAGE_GRIDS; sp.bf = 40.f; sp.seed = 7u;   // the whole Frame constructor
         hvo::FrameStream fs(p, sp);
         const int64_t t = fs.submit(hvo::Image8{ gray.data(), W, H, W }, hvo::Image16{ depth.data(), W, H, W * 2 });
         std::vector<hvo::KeyPoint> skp(fs.kpCap()); std::vector<uint8_t> sdesc((size_t)fs.kpCap() * 32);
         hvo_frame_out fo = hvo_frame_out(); fo.kp = skp.data(); fo.desc = sdesc.data(); fo.kp_cap = fs.kpCap();
+        hvo::FrameStream::FrameTail tail; fs.collectTail(t, W, H, tail);        // before collect() hands the slot back
         fs.collect(t, fo);
+        int tgood = 0; for (int i = 0; i < fs.klCap(); i++) tgood += tail.lines3d[i].good;
+        int tvalid = 0; for (const hvo_plane_cloud &c : tail.plane_clouds) tvalid += c.valid;
         printf("l3d %d vp %d %d %d %d best %d clouds %d cloudpts %zu normals %zu stream %d %016llx\n", good, vc[0], vc[1], vc[2], vc[3], vp.best, valid, xyz.size() / 3,
                sn.size(), fo.n_kp, (unsigned long long)fnv(sdesc.data(), (size_t)fo.n_kp * 32));
+        printf("tail l3d %d vpbest %d clouds %d cloudpts %d normals %d ptitems %d lnitems %d\n", tgood, tail.vp.best, tvalid, tail.c.n_cloud, tail.c.n_normals, tail.c.n_pt_items, tail.c.n_ln_items);
     } catch (const hvo::Error &e) { fprintf(stderr, "hvo error: %s\n", e.what()); return 1; }
     return 0;
 }

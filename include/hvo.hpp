@@ -349,6 +349,28 @@ public:
     {
         check(hvo_stream_collect(s_, ticket, &out, kp_un, uright, zdepth), "hvo_stream_collect");
     }
+    // The rest of the Frame constructor (HVO_STAGE_LINES3D / _VP / _PLANE_TAIL / _GRIDS in hvo_stream_params.stages): isLineGood's 3-D
+    // lines, the vanishing points and line2Vps clusters, mvPlanePoints / mvPlaneCoefficients / vSurfaceNormal, the two 64 x 48 grids.
+    // Call before collect() releases the slot.  FrameTail owns its arrays, sized from the stream's capacities.
+    struct FrameTail {
+        std::vector<hvo_line3d> lines3d; hvo_vp_result vp{}; std::vector<int32_t> vp_idx;
+        std::vector<hvo_plane_cloud> plane_clouds; std::vector<float> cloud_xyz; std::vector<hvo_surface_normal> normals;
+        std::vector<int32_t> pt_cell_start, pt_cell_items, ln_cell_start, ln_cell_items;
+        hvo_frame_tail c{};
+    };
+    void collectTail(int64_t ticket, int w, int h, FrameTail &t)
+    {
+        int cc = 0, nn = 0, lc = 0;
+        check(hvo_tail_capacity(kl_cap_, w, h, &cc, &nn, &lc), "hvo_tail_capacity");
+        t.lines3d.resize(kl_cap_); t.vp_idx.assign(kl_cap_, 3); t.plane_clouds.resize(64); t.cloud_xyz.resize(3 * (size_t)cc); t.normals.resize(nn > 0 ? nn : 1);
+        t.pt_cell_start.resize(HVO_GRID_COLS * HVO_GRID_ROWS + 1); t.pt_cell_items.resize(kp_cap_ > 0 ? kp_cap_ : 1);
+        t.ln_cell_start.resize(HVO_GRID_COLS * HVO_GRID_ROWS + 1); t.ln_cell_items.resize(lc > 0 ? lc : 1);
+        hvo_frame_tail &c = t.c;
+        c.lines3d = t.lines3d.data(); c.vp = &t.vp; c.vp_idx = t.vp_idx.data(); c.plane_clouds = t.plane_clouds.data(); c.cloud_xyz = t.cloud_xyz.data(); c.cloud_cap = cc;
+        c.normals = t.normals.data(); c.normals_cap = nn; c.pt_cell_start = t.pt_cell_start.data(); c.pt_cell_items = t.pt_cell_items.data(); c.pt_items_cap = kp_cap_;
+        c.ln_cell_start = t.ln_cell_start.data(); c.ln_cell_items = t.ln_cell_items.data(); c.ln_items_cap = lc;
+        check(hvo_stream_collect_tail(s_, ticket, &c), "hvo_stream_collect_tail");
+    }
     // LSDmatcher::match / FrameBFMatch / SearchDouble between two resident frames (mode = HVO_LINE_MATCH_*)
     int matchLines(int64_t from, int64_t to, int mode, float th, float nnratio, std::vector<int32_t> &matches12)
     {

@@ -58,3 +58,8 @@ def test_cpp_demo_matches_oracle(tmp_path, orc, synth):
     assert [int(x) for x in out[3:7]] == np.bincount(vp["vp_idx"], minlength=4).tolist()
     assert int(out[10]) == int(pcs["valid"].sum()) and int(out[12]) == len(cloud) and int(out[14]) == len(sn)
     assert int(out[16]) == len(kp_o) and int(out[17], 16) == _fnv(d_o.tobytes())
+    # third line: the same frame through hvo::FrameStream with every stage of the Frame constructor (seed 7 + ticket 0)
+    # "tail l3d GOOD vpbest B clouds VALID cloudpts N normals N ptitems N lnitems N"
+    out = out[18:]
+    assert out[0] == "tail" and int(out[2]) == int(l3["good"].sum()) and int(out[6]) == int(pcs["valid"].sum()) and int(out[8]) == len(cloud) and int(out[10]) == len(sn)
+    assert int(out[12]) == len(gi) and int(out[14]) == len(li)

@@ -2,7 +2,7 @@
 # Regenerates the raw material of profiles/rNN_* on the GPU box (run through gpurun from the repo root, in two calls):
 #   bash tools/refresh_profiles.sh a      -> gpurun_out/prof/... (bench lines, kernel trace, counter passes)
 #   bash tools/refresh_profiles.sh b      -> gpurun_out/prof/... (stream / big1280 / batch256 lines, side measurements)
-# then, back in the container:  python tools/collect_profiles.py gpurun_out/prof r02
+# then, back in the container:  python tools/collect_profiles.py gpurun_out/prof r03
 # Counter passes are separate runs (--pmc is never combined with the trace domains); the program after `--` is python3 itself.
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
