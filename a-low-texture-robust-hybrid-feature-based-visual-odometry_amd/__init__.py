@@ -70,7 +70,7 @@ EXPORTS = [
     "hvo_stream_create", "hvo_stream_destroy", "hvo_stream_last_error", "hvo_stream_capacity", "hvo_stream_image_bounds",
     "hvo_stream_submit", "hvo_stream_poll", "hvo_stream_collect", "hvo_stream_stage_ms",
     "hvo_stream_search_by_projection", "hvo_stream_match_lines",
-    "hvo_tail_capacity", "hvo_set_tail_params", "hvo_batch_download_tail", "hvo_stream_collect_tail",
+    "hvo_tail_capacity", "hvo_set_tail_params", "hvo_batch_download_tail", "hvo_stream_collect_tail", "hvo_normals_lpvo",
 ]
 
 
@@ -223,6 +223,7 @@ def lib():
         L.hvo_stream_stage_ms.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.hvo_stream_search_by_projection.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.hvo_stream_match_lines.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.hvo_normals_lpvo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.hvo_tail_capacity.argtypes = [C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 3
         L.hvo_set_tail_params.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double]
         L.hvo_batch_download_tail.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameTail)]
@@ -352,6 +353,14 @@ class Context:
         out = np.zeros(len(planes), PLANE_CLOUD_DT); cloud = np.zeros((cap, 3), np.float32); n = C.c_int(0)
         self._chk(lib().hvo_plane_clouds(self.h, _p(depth), w, h, depth.strides[0], _p(labels), _p(planes), len(planes), dist_th, _p(cloud), cap, _p(out), C.byref(n)), "plane_clouds")
         return out, cloud[: n.value].copy()
+
+    def normals_lpvo(self, depth):
+        """Manhattan::computeNormalsLPVO (src/Manhattan.cpp:237-393), the CV_32F reading -> (normals (n,3) f64, depth (n) f32, pixel (n,2) i32)"""
+        depth = np.ascontiguousarray(depth, np.uint16); h, w = depth.shape
+        cap = ((h + 14) // 15) * ((w + 14) // 15)
+        nrm = np.zeros((cap, 3)); dz = np.zeros(cap, np.float32); px = np.zeros((cap, 2), np.int32); n = C.c_int(0)
+        self._chk(lib().hvo_normals_lpvo(self.h, _p(depth), w, h, depth.strides[0], _p(nrm), _p(dz), _p(px), cap, C.byref(n)), "normals_lpvo")
+        return nrm[: n.value], dz[: n.value], px[: n.value]
 
     def surface_normals(self, depth):
         """vSurfaceNormal of Frame::ComputePlanes (src/Frame.cc:2157-2212) -> SURFACE_NORMAL_DT array"""

@@ -230,6 +230,14 @@ int hvo_plane_clouds(hvo_ctx *ctx, const uint16_t *depth, int w, int h, int stri
                      double dist_th, float *cloud_xyz, int cap, hvo_plane_cloud *out, int *n_total);
 int hvo_surface_normals(hvo_ctx *ctx, const uint16_t *depth, int w, int h, int stride, hvo_surface_normal *out, int cap, int *n);
 
+/* Manhattan::computeNormalsLPVO (reference src/Manhattan.cpp:237-393, the second half of SURVEY.md 8f.4; run by the RGB-D Frame constructor
+ * through Frame::ExtractMainImgPtNormals, src/Frame.cc:222, until the coarse Manhattan frame is initialised): surface normals from 10 x 10
+ * box averages of the central-difference tangents at every 15th pixel.  The INTENDED reading is implemented -- depth in metres as CV_32F,
+ * integral images with their zero row / column removed -- not what the reference binary computes: as compiled it reads the raw CV_16U image
+ * through at<float> and moves half rows of its CV_64F integral images (undefined behaviour; csrc/lpvo.hip).
+ * normals3: cap x 3 doubles (unit, or 0 when the cross product vanishes); depth_out: the sample's z; pixel2: (u, v).  *n = samples found. */
+int hvo_normals_lpvo(hvo_ctx *ctx, const uint16_t *depth, int w, int h, int stride, double *normals3, float *depth_out, int32_t *pixel2, int cap, int *n);
+
 /* ---- Frame post-processing of the outputs above ----------------------------------------
  * dist5 = {k1, k2, p1, p2, k3} (Camera.k1.. of the settings file; k3 = 0 when absent); the intrinsics are the
  * context's (hvo_params fx, fy, cx, cy).  The 64 x 48 grids (FRAME_GRID_COLS x FRAME_GRID_ROWS) are returned as

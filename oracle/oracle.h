@@ -214,6 +214,8 @@ int  orc_surface_normals(const uint16_t *depth, int w, int h, int stride_bytes, 
                          orc_surface_normal *out, int cap);
 
 /* ---------------- vanishing-point clustering of the key lines (vps.c; reference src/Frame.cc:442-778) ---------------- */
+int  orc_normals_lpvo(const uint16_t *depth, int w, int h, int stride_bytes, float fx, float fy, float cx, float cy, float depth_factor,
+                      double *normals, float *depth_out, int *pixel, int cap);    /* Manhattan::computeNormalsLPVO, the CV_32F reading */
 int  orc_vp_iterations(void);                                                                     /* 105 */
 void orc_vp_line_params(const orc_keyline *kl, int n, double *para, double *length, double *ori);
 void orc_vp_sphere_grid(const double *para, const double *length, const double *ori, int n, double fx, double cx, double cy,

@@ -335,6 +335,19 @@ def surface_normals(depth, fx=535.4, fy=539.2, cx=320.1, cy=247.6, depth_factor=
     return out[:n].copy()
 
 
+def normals_lpvo(depth, fx=535.4, fy=539.2, cx=320.1, cy=247.6, depth_factor=None):
+    """Manhattan::computeNormalsLPVO (src/Manhattan.cpp:237-393), the CV_32F reading -> (normals (n,3) f64, depth (n) f32, pixel (n,2) i32 = (u, v))"""
+    depth = np.ascontiguousarray(depth, np.uint16); h, w = depth.shape
+    if depth_factor is None:
+        depth_factor = float(np.float32(1.0) / np.float32(5000.0))
+    cap = ((h + 14) // 15) * ((w + 14) // 15)
+    nrm = np.zeros((cap, 3)); dz = np.zeros(cap, np.float32); px = np.zeros((cap, 2), np.int32)
+    L = lib()
+    L.orc_normals_lpvo.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_float] * 5 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    n = L.orc_normals_lpvo(_p(depth), w, h, depth.strides[0], fx, fy, cx, cy, depth_factor, _p(nrm), _p(dz), _p(px), cap)
+    return nrm[:n], dz[:n], px[:n]
+
+
 def eig33_smallest(K):
     """the smallest eigenpair as Stats::compute uses it (orc_eig33_smallest) -> (lambda0, v)"""
     K = np.ascontiguousarray(K, np.float64); l = C.c_double(0); v = np.zeros(3)

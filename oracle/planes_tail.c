@@ -370,3 +370,66 @@ int orc_surface_normals(const uint16_t *depth, int w, int h, int stride_bytes, f
     free(P); free(chg); free(dm - W - 2); free(gx); free(gy); free(IX); free(IY); free(CX); free(CY);
     return nout;
 }
+
+/* ---------------------------------------------------------------- Manhattan::computeNormalsLPVO (src/Manhattan.cpp:237-393)
+ * The INTENDED reading: the depth image as CV_32F metres (raw * depth_factor, the
+ * conversion of src/Frame.cc:201-203 that the RGB-D constructor does NOT hand over -- as compiled the function reads the raw CV_16U
+ * image through at<float>), and removeMatRow / removeMatCol as their USE_CV_RECT branches (the integral image without its zero row and
+ * column, so I(v, u) is the inclusive sum over rows <= v, columns <= u).  cv::integral (CV_32F -> CV_64F, ASSUMED OpenCV 3.2): per row a
+ * running double sum s += src(y, x); sum(y+1, x+1) = sum(y, x+1) + s.  cv::normalize (NORM_L2): v / sqrt(v.v).
+ * normals: n x 3 doubles; depth: n floats; pixel: n x 2 ints (u, v).  Returns n (<= cap entries are written). */
+int orc_normals_lpvo(const uint16_t *depth, int w, int h, int stride_bytes, float fx, float fy, float cx, float cy, float depth_factor,
+                     double *normals, float *depth_out, int *pixel, int cap)
+{
+    const int cell_size = 10, norm_density = 15;
+    const float invfx = 1.0f / fx, invfy = 1.0f / fy;
+    const size_t N = (size_t)w * h;
+    float *Z = (float *)malloc(sizeof(float) * N), *V = (float *)calloc(3 * N, sizeof(float));
+    float *T[7];                                                 /* 0-2 u tangent, 3-5 v tangent, 6 mask */
+    double *I[7];
+    for (int k = 0; k < 7; k++) { T[k] = (float *)calloc(N, sizeof(float)); I[k] = (double *)malloc(sizeof(double) * N); }
+    for (int v = 0; v < h; v++)
+        for (int u = 0; u < w; u++) {
+            const uint16_t raw = *(const uint16_t *)((const uint8_t *)depth + (size_t)v * stride_bytes + 2 * (size_t)u);
+            const float z = (float)raw * depth_factor;
+            Z[(size_t)v * w + u] = z;
+            if (z > 0.2f && z < 7.0f) {
+                float *p = V + 3 * ((size_t)v * w + u);
+                p[0] = ((float)u - cx) * z * invfx; p[1] = ((float)v - cy) * z * invfy; p[2] = z;
+            }
+        }
+#define ZBAD(q) ((q) < 0.2f || (q) > 7.0f)
+    for (int u = 1; u < w - 1; u++)
+        for (int v = 1; v < h - 1; v++) {
+            const size_t i = (size_t)v * w + u;
+            if (ZBAD(Z[i]) || ZBAD(Z[i - 1]) || ZBAD(Z[i + 1]) || ZBAD(Z[i - w]) || ZBAD(Z[i + w])) continue;
+            T[6][i] = 1.0f;
+            for (int k = 0; k < 3; k++) { T[k][i] = V[3 * (i + 1) + k] - V[3 * (i - 1) + k]; T[3 + k][i] = V[3 * (i + w) + k] - V[3 * (i - w) + k]; }
+        }
+#undef ZBAD
+    for (int k = 0; k < 7; k++)                                  /* inclusive integral images, cv::integral's summation order */
+        for (int y = 0; y < h; y++) {
+            double s = 0;
+            for (int x = 0; x < w; x++) { s += (double)T[k][(size_t)y * w + x]; I[k][(size_t)y * w + x] = (y > 0 ? I[k][(size_t)(y - 1) * w + x] : 0.0) + s; }
+        }
+    int n = 0;
+#define BOX(k) (I[k][(size_t)v * w + u] - I[k][(size_t)(v - cell_size) * w + u] - I[k][(size_t)v * w + u - cell_size] + I[k][(size_t)(v - cell_size) * w + u - cell_size])
+    for (int v = cell_size; v < h - 1; v += norm_density)
+        for (int u = cell_size; u < w - 1; u += norm_density) {
+            if (T[6][(size_t)v * w + u] != 1) continue;
+            const int numPts = (int)BOX(6);
+            const double uv[3] = { BOX(0) / numPts, BOX(1) / numPts, BOX(2) / numPts }, vv[3] = { BOX(3) / numPts, BOX(4) / numPts, BOX(5) / numPts };
+            const double nv[3] = { vv[1] * uv[2] - vv[2] * uv[1], vv[2] * uv[0] - vv[0] * uv[2], vv[0] * uv[1] - vv[1] * uv[0] };
+            const double len = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+            if (n < cap) {
+                const double sc = len > DBL_EPSILON ? 1.0 / len : 0.0;       /* cv::normalize: scale = 1 / norm, 0 when the norm is <= DBL_EPSILON */
+                normals[3 * n] = nv[0] * sc; normals[3 * n + 1] = nv[1] * sc; normals[3 * n + 2] = nv[2] * sc;
+                depth_out[n] = V[3 * ((size_t)v * w + u) + 2]; pixel[2 * n] = u; pixel[2 * n + 1] = v;
+            }
+            n++;
+        }
+#undef BOX
+    for (int k = 0; k < 7; k++) { free(T[k]); free(I[k]); }
+    free(Z); free(V);
+    return n;
+}
