@@ -19,6 +19,7 @@
 // fp64 throughout, identical operation order to oracle/peac.c (no FMA contraction: -ffp-contract=off).
 // Tie rules where the reference is address dependent (std::set<PlaneSeg*>, priority_queue ties):
 // node creation order, see oracle/peac.c header.
+#include <type_traits>
 #include "hvo_internal.hpp"
 #include <math.h>
 #include <stdlib.h>
@@ -1233,6 +1234,7 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
 }
 
 #include "peac_lat.inc"
+#include "peac_heads.inc"
 
 // ------------------------------------------------------------------------------------------------
 // k_peac_blkmap: findBlockMembership (block erosion) + coarse membership image
@@ -1349,11 +1351,14 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
     constexpr int NENT = FLOOD_T * EPL, NEV = NENT * 4;                        // queue entries / events per round (EPL entries per thread)
     constexpr int FLOOD_HS = NEV * FLOOD_HS_MUL, FLOOD_HL = 4, FLOOD_NP = 4 * EPL;   // FLOOD_NP = passes that cover all NEV events
     constexpr int NW = FLOOD_T / 64;
-    static_assert(NEV <= 1024, "the group lists hold 10-bit event indices");
+    static_assert(NEV <= 2048, "the group lists hold 11-bit event indices");
+    constexpr int IXB = NEV > 1024 ? 11 : 10;                     // bits of a compact event index; (plane << IXB) | index is 16 bits, or 17 in a 32-bit entry
+    constexpr unsigned IXM = (1u << IXB) - 1u;
+    typedef typename std::conditional<(NEV > 1024), unsigned int, unsigned short>::type hl_t;
     __shared__ double pl[MAX_PLANES][8];          // center[3], normal[3], mse, pad
     __shared__ unsigned long long adj[MAX_PLANES], simok[MAX_PLANES];
     __shared__ int hkeys[FLOOD_HS], hcnt[FLOOD_HS];
-    __shared__ __attribute__((aligned(8))) unsigned short hlist[FLOOD_HS * FLOOD_HL];
+    __shared__ __attribute__((aligned(16))) hl_t hlist[FLOOD_HS * FLOOD_HL];
     __shared__ uint4 rec[NEV];                    // the round's live events in event order: packed (plane, y, x) of the target pixel, its state word, its dist bits
     __shared__ int wsum[EPL * NW], psum[FLOOD_NP * NW];
     __shared__ int s_nq, s_cx[2];
@@ -1539,7 +1544,7 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                         s = (s + 1) & (FLOOD_HS - 1);
                     }
                     const int pos = atomicAdd(&hcnt[s], 1);
-                    if (pos < FLOOD_HL) hlist[s * FLOOD_HL + pos] = (unsigned short)((ep << 10) | c);
+                    if (pos < FLOOD_HL) hlist[s * FLOOD_HL + pos] = (hl_t)((ep << IXB) | c);
                     hs[p] = s;
                 }
             }
@@ -1555,13 +1560,13 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                 first[p] = true;
                 if (cnt[p] > FLOOD_HL) cx |= 2;
                 else if (cnt[p] > 1) {
-                    const uint2 L = *(const uint2 *)&hlist[hs[p] * FLOOD_HL];
-                    const unsigned me = ((eq[p] >> 26) << 10) | (unsigned)(p * FLOOD_T + tid);
-                    const unsigned l[4] = { L.x & 0xFFFFu, L.x >> 16, L.y & 0xFFFFu, L.y >> 16 };
+                    const unsigned me = ((eq[p] >> 26) << IXB) | (unsigned)(p * FLOOD_T + tid);
+                    const hl_t *hp_ = &hlist[hs[p] * FLOOD_HL];
+                    const unsigned l[4] = { hp_[0], hp_[1], hp_[2], hp_[3] };
 #pragma unroll
                     for (int t = 0; t < 4; t++) if (t < cnt[p]) {
-                        if ((l[t] ^ me) >> 10) multi[p] = true;                    // another plane on the same pixel
-                        if ((l[t] & 1023u) < (me & 1023u)) first[p] = false;       // compact index == event order
+                        if ((l[t] ^ me) >> IXB) multi[p] = true;                   // another plane on the same pixel
+                        if ((l[t] & IXM) < (me & IXM)) first[p] = false;           // compact index == event order
                     }
                     // two planes racing for an unlabelled pixel: ranked replay by the group's first event (below);
                     // on a labelled pixel the passive events of a third plane could matter: serial replay of the round
@@ -1604,15 +1609,15 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
 #pragma unroll
                 for (int p = 0; p < FLOOD_NP; p++) {
                     if (p < npass && first[p] && multi[p]) {
-                        const uint2 L = *(const uint2 *)&hlist[hs[p] * FLOOD_HL];
-                        const unsigned l[4] = { L.x & 0xFFFFu, L.x >> 16, L.y & 0xFFFFu, L.y >> 16 };
+                        const hl_t *hp_ = &hlist[hs[p] * FLOOD_HL];
+                        const unsigned l[4] = { hp_[0], hp_[1], hp_[2], hp_[3] };
                         int trail = FS_LABEL(es[p]); float dist = ed[p];
                         int last = -1;
                         for (int it = 0; it < cnt[p]; it++) {
                             unsigned best = 0; int c = 1 << 20;                     // next event of the group in event order
 #pragma unroll
-                            for (int t = 0; t < 4; t++) { const int ct = (int)(l[t] & 1023u); if (t < cnt[p] && ct > last && ct < c) { c = ct; best = l[t]; } }
-                            const int ep = (int)(best >> 10);
+                            for (int t = 0; t < 4; t++) { const int ct = (int)(l[t] & IXM); if (t < cnt[p] && ct > last && ct < c) { c = ct; best = l[t]; } }
+                            const int ep = (int)(best >> IXB);
                             last = c;
                             const unsigned okcd = rec[c].w;
                             const bool ok = okcd != 0xFFFFFFFFu; const float cd = __uint_as_float(okcd);
@@ -1946,7 +1951,24 @@ int peac_run(hvo_ctx *ctx, int n)
         a.perm = hvo_frame_perm(ctx, (n + (64 / use) - 1) / (64 / use));
         { const char *e4 = getenv("HVO_PEAC_PERM"); if (e4 && atoi(e4) == 0) a.perm = nullptr; }
         a.tq_lds_keys = 0;
-        if (use == 64) {
+        // a handful of frames (the latency case): several queue heads per round, one wave each (peac_heads.inc); HVO_PEAC_HEADS = 0 / 2 / 4
+        int heads = (gl <= 0 && n <= 32 && a.tq_n0 * 16 <= 64 * MH_MAXE) ? 4 : 0;
+        { const char *e6 = getenv("HVO_PEAC_HEADS"); if (e6 && a.tq_n0 * 16 <= 64 * MH_MAXE) heads = atoi(e6); }
+        if (heads == 2 || heads == 4) {
+            ClArgs b = a;
+            { const char *e7 = getenv("HVO_PEAC_POOLCAP"); if (e7 && atoi(e7) >= 7 * a.nblk && atoi(e7) < a.poolcap) b.poolcap = atoi(e7); }   // tests: force the pool's compaction
+            const size_t segpad = (size_t)a.tq_n0 * 256;
+            const size_t lds = segpad * 8 + (size_t)a.tq_n0 * 16 * 12 + segpad / 8 * 4 + 4 * sizeof(MhHead) + 16;
+            static size_t lds_set3 = 0;
+            if (lds > lds_set3) {
+                HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                lds_set3 = lds;
+            }
+            if (heads == 2) hipLaunchKernelGGL(k_peac_cluster_heads<2>, dim3(n), dim3(128), lds, st, b, n);
+            else hipLaunchKernelGGL(k_peac_cluster_heads<4>, dim3(n), dim3(256), lds, st, b, n);
+        }
+        else if (use == 64) {
             size_t lds = lq;
             bool ldsq = n <= 256;                                  // at most one such frame per CU
             { const char *e5 = getenv("HVO_PEAC_LDSQ"); if (e5) ldsq = atoi(e5) != 0; }
@@ -1975,7 +1997,8 @@ int peac_run(hvo_ctx *ctx, int n)
         const char *e = getenv("HVO_FLOOD_T");
         const int flood_t = e ? atoi(e) : -1;
         // measured: 256 threads per frame up to ~4096 resident frames, one wave per frame (less LDS, all frames in flight) beyond
-        const int ft = flood_t > 0 ? flood_t : (n >= 6144 ? 64 : 256);
+        // a lone frame (the latency case) takes 512: the flood's rounds are serial, so its time goes with the events a round retires
+        const int ft = flood_t > 0 ? flood_t : (n >= 6144 ? 64 : n <= 32 ? 512 : 256);
         const char *e2 = getenv("HVO_FLOOD_EPL");          // queue entries per thread and round (one-wave variant only)
         const int fe = e2 ? atoi(e2) : 1;
         r.perm = hvo_frame_perm(ctx, n);                   // one wave per frame for its whole life: frames of a SIMD decorrelated
@@ -1983,6 +2006,7 @@ int peac_run(hvo_ctx *ctx, int n)
         { const char *e3 = getenv("HVO_FLOOD_PERM"); if (e3 && atoi(e3) == 0) r.perm = nullptr; }
         if (ft == 64 && fe == 2) hipLaunchKernelGGL((k_peac_flood<64, 2>), dim3(n), dim3(64), 0, st, r, P->d_adj);
         else if (ft == 64) hipLaunchKernelGGL((k_peac_flood<64, 1>), dim3(n), dim3(64), 0, st, r, P->d_adj);
+        else if (ft == 512) hipLaunchKernelGGL((k_peac_flood<512, 1>), dim3(n), dim3(512), 0, st, r, P->d_adj);
         else if (ft == 256) hipLaunchKernelGGL((k_peac_flood<256, 1>), dim3(n), dim3(256), 0, st, r, P->d_adj);
         else hipLaunchKernelGGL((k_peac_flood<128, 1>), dim3(n), dim3(128), 0, st, r, P->d_adj);
     }

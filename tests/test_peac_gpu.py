@@ -264,3 +264,31 @@ def test_peac_lat_kernel_parity(hvo, orc, synth, monkeypatch):
                 check(lg, pg, lo, po)
         finally:
             ctx.close()
+
+
+@pytest.mark.parametrize("heads,poolcap", [("4", None), ("2", None), ("4", "22000"), ("0", None)])
+def test_peac_queue_heads(hvo, orc, synth, monkeypatch, heads, poolcap):
+    """k_peac_cluster_heads (the AHC of small batches: several queue heads per round, one wave each, the longest conflict-free
+    prefix committed) against the oracle -- at four and two heads, with a list pool small enough to be compacted on the way,
+    and HVO_PEAC_HEADS=0 = the one-wave kernel it replaces for a lone frame.  The scenes: textured rooms, an exact plane (every
+    candidate ties at mse ~ 0: the tie rule and the created ids decide), a three-plane corner, no depth at all."""
+    monkeypatch.setenv("HVO_PEAC_HEADS", heads)
+    if poolcap: monkeypatch.setenv("HVO_PEAC_POOLCAP", poolcap)
+    j = np.arange(640)[None, :]; i = np.arange(480)[:, None]
+    exact = np.rint(2.0 / (0.1 * (j - 320.1) / 535.4 + 0.2 * (i - 247.6) / 539.2 + 1.0) * 5000).astype(np.uint16)
+    depth = [synth.make_depth(s) for s in (0x5EED0002, 0x5EED1000, 0x5EED1003, 77)] + [exact, corner_depth(3, 25, cu=323.0, cv=236.0), np.zeros((480, 640), np.uint16)]
+    depth = np.stack(depth)
+    ctx = hvo.Context(max_batch=len(depth))
+    try:
+        ctx.batch_upload(np.zeros((len(depth), 480, 640), np.uint8), depth)
+        ctx.batch_run(hvo.STAGE_PLANES)
+        res = ctx.batch_download(hvo.STAGE_PLANES)
+        one = ctx.compute_planes(depth[1])                       # the single-frame entry point takes the same kernel
+    finally:
+        ctx.close()
+    for b in range(len(depth)):
+        lo, po = orc.peac(depth[b])
+        assert res[b]["status"] == 0
+        check(res[b]["labels"], res[b]["planes"], lo, po)
+    lo, po = orc.peac(depth[1])
+    check(one[0], one[1], lo, po)
