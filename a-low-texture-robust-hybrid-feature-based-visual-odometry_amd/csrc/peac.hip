@@ -1958,7 +1958,7 @@ int peac_run(hvo_ctx *ctx, int n)
             ClArgs b = a;
             { const char *e7 = getenv("HVO_PEAC_POOLCAP"); if (e7 && atoi(e7) >= 7 * a.nblk && atoi(e7) < a.poolcap) b.poolcap = atoi(e7); }   // tests: force the pool's compaction
             const size_t segpad = (size_t)a.tq_n0 * 256;
-            const size_t lds = segpad * 8 + (size_t)a.tq_n0 * 16 * 12 + segpad / 8 * 4 + 4 * sizeof(MhHead) + 16;
+            const size_t lds = segpad * 8 + (size_t)a.tq_n0 * 16 * 12 + segpad / 8 * 4 + 4 * sizeof(MhHead) + 16 + segpad * 8;
             static size_t lds_set3 = 0;
             if (lds > lds_set3) {
                 HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
