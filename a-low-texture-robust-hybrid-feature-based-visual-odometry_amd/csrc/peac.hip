@@ -574,13 +574,45 @@ template <int STEP> static __device__ __forceinline__ double row_partner(double 
 // ------------------------------------------------------------------------------------------------
 #define TQ_INF 1.7976931348623157e308
 struct TQueue { double *K, *M1k; int *M1i; double *M0k; int *M0i; int n0; };
-// all-reduce of (k, i) under hless over the 16-lane DPP row (every lane ends up with the minimum)
-static __device__ __forceinline__ void row_min16(double &k, int &i)
+// all-reduce of (k, i) under hless, key first: min of the keys through DPP (quad, half row, row, then the rows'
+// last lanes broadcast onwards), then the smallest id among the lanes that hold that key -- 30 instructions against the ~80 of a
+// reduction that carries (key, id) pairs through every step
+static __device__ __forceinline__ double dpp_f64(double v, double old, const int ctrl_sel)
 {
-#define RM_STEP(o) { const double ok = row_partner<o>(k); const int oi = row_partner<o>(i); if (hless(ok, oi, k, i)) { k = ok; i = oi; } }
-    RM_STEP(1) RM_STEP(2) RM_STEP(4) RM_STEP(8)
-#undef RM_STEP
+    int lo, hi;
+    if (ctrl_sel == 0) { lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0xB1, 0xF, 0xF, false); }
+    else if (ctrl_sel == 1) { lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x4E, 0xF, 0xF, false); }
+    else if (ctrl_sel == 2) { lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x141, 0xF, 0xF, false); }
+    else if (ctrl_sel == 3) { lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x140, 0xF, 0xF, false); }
+    else if (ctrl_sel == 4) { lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x142, 0xA, 0xF, false); hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x142, 0xA, 0xF, false); }
+    else { lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x143, 0xC, 0xF, false); hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x143, 0xC, 0xF, false); }
+    return __hiloint2double(hi, lo);
 }
+static __device__ __forceinline__ int dpp_i32(int v, int old, const int ctrl_sel)
+{
+    if (ctrl_sel == 0) return __builtin_amdgcn_update_dpp(old, v, 0xB1, 0xF, 0xF, false);
+    if (ctrl_sel == 1) return __builtin_amdgcn_update_dpp(old, v, 0x4E, 0xF, 0xF, false);
+    if (ctrl_sel == 2) return __builtin_amdgcn_update_dpp(old, v, 0x141, 0xF, 0xF, false);
+    if (ctrl_sel == 3) return __builtin_amdgcn_update_dpp(old, v, 0x140, 0xF, 0xF, false);
+    if (ctrl_sel == 4) return __builtin_amdgcn_update_dpp(old, v, 0x142, 0xA, 0xF, false);
+    return __builtin_amdgcn_update_dpp(old, v, 0x143, 0xC, 0xF, false);
+}
+template <int STEPS>                               // 4: within the 16-lane row (every lane of the row gets the result); 6: the wave (uniform result)
+static __device__ __forceinline__ void min_key_id(double &k, int &i)
+{
+    double g = k;
+#pragma unroll
+    for (int s_ = 0; s_ < STEPS; s_++) { const double t = dpp_f64(g, g, s_); g = t < g ? t : g; }
+    if (STEPS == 6) g = readlane_f64(g, 63);
+    int c = (k == g) ? i : 0x7FFFFFFF;
+#pragma unroll
+    for (int s_ = 0; s_ < STEPS; s_++) { const int t = dpp_i32(c, c, s_); c = min(c, t); }
+    if (STEPS == 6) c = __builtin_amdgcn_readlane(c, 63);
+    k = g; i = c;
+}
+
+// all-reduce of (k, i) under hless over the 16-lane DPP row (every lane ends up with the minimum)
+static __device__ __forceinline__ void row_min16(double &k, int &i) { min_key_id<4>(k, i); }
 static __device__ __forceinline__ int tq_top(const TQueue &Q, int rl)
 {
     double k = TQ_INF; int i = 0x7FFFFFFF;
@@ -1952,7 +1984,8 @@ int peac_run(hvo_ctx *ctx, int n)
         { const char *e4 = getenv("HVO_PEAC_PERM"); if (e4 && atoi(e4) == 0) a.perm = nullptr; }
         a.tq_lds_keys = 0;
         // a handful of frames (the latency case): several queue heads per round, one wave each (peac_heads.inc); HVO_PEAC_HEADS = 0 / 2 / 4
-        int heads = (gl <= 0 && n <= 32 && a.tq_n0 * 16 <= 64 * MH_MAXE) ? 4 : 0;
+        int heads_max = 256; { const char *e8 = getenv("HVO_PEAC_HEADS_MAXN"); if (e8) heads_max = atoi(e8); }
+        int heads = (gl <= 0 && n <= heads_max && a.tq_n0 * 16 <= 64 * MH_MAXE) ? 4 : 0;
         { const char *e6 = getenv("HVO_PEAC_HEADS"); if (e6 && a.tq_n0 * 16 <= 64 * MH_MAXE) heads = atoi(e6); }
         if (heads == 2 || heads == 4) {
             ClArgs b = a;
@@ -1998,7 +2031,7 @@ int peac_run(hvo_ctx *ctx, int n)
         const int flood_t = e ? atoi(e) : -1;
         // measured: 256 threads per frame up to ~4096 resident frames, one wave per frame (less LDS, all frames in flight) beyond
         // a lone frame (the latency case) takes 512: the flood's rounds are serial, so its time goes with the events a round retires
-        const int ft = flood_t > 0 ? flood_t : (n >= 6144 ? 64 : n <= 32 ? 512 : 256);
+        const int ft = flood_t > 0 ? flood_t : (n >= 6144 ? 64 : n <= 8 ? 512 : 256);
         const char *e2 = getenv("HVO_FLOOD_EPL");          // queue entries per thread and round (one-wave variant only)
         const int fe = e2 ? atoi(e2) : 1;
         r.perm = hvo_frame_perm(ctx, n);                   // one wave per frame for its whole life: frames of a SIMD decorrelated

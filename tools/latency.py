@@ -10,9 +10,11 @@ import __graft_entry__ as ge
 def main():
     hvo = ge.package(); synth = importlib.import_module("hvo_amd.synth")
     kind = sys.argv[1] if len(sys.argv) > 1 else "std"
+    W = int(sys.argv[2]) if len(sys.argv) > 3 else 640; H = int(sys.argv[3]) if len(sys.argv) > 3 else 480
+    sizes = tuple(int(x) for x in sys.argv[4].split(",")) if len(sys.argv) > 4 else (1, 4, 32, 64)
     out = {}
-    for B in (1, 4, 32, 64):
-        g, d = synth.make_batch(kind, 0x5EED1000, B, 640, 480)
+    for B in sizes:
+        g, d = synth.make_batch(kind, 0x5EED1000, B, W, H)
         ctx = hvo.Context(max_batch=B)
         ctx.batch_upload(g, d)
         row = {}
@@ -35,7 +37,7 @@ def main():
             row["compute_planes_call_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
         ctx.close()
     orc = ge.oracle(); orb = orc.Orb()
-    g, d = synth.make_batch(kind, 0x5EED1000, 4, 640, 480)
+    g, d = synth.make_batch(kind, 0x5EED1000, 4, W, H)
     cpu = {}
     for name, fn in (("orb", lambda i: orb.extract(g[i])), ("lsd", lambda i: orc.line_extract(g[i])), ("planes", lambda i: orc.peac(d[i]))):
         fn(0); t0 = time.perf_counter()
