@@ -324,7 +324,7 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
             if (s * 7 >= cnt) continue;              // slot has no pending point (uniform)
             if (lane < 63 && k < cnt) {
                 const int idx = i + k;
-                const int pxy = (rs - idx <= LSD_RING) ? S.ring[idx & (LSD_RING - 1)] : S.reg[idx];
+                const int pxy = (rs - idx <= LSD_RING) ? S.ring[idx & (LSD_RING - 1)] : __hip_atomic_load(&S.reg[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int xx = (pxy & 0xFFFF) + jx, yy = (pxy >> 16) + jy;
                 // one bit test rejects both the pixels without a gradient angle and the ones already taken; only
                 // real candidates fetch their record (angle, cos, sin in one 32-byte access)
@@ -413,7 +413,11 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
         S.t_gather += tg1 - tg0; S.t_add += clock64() - tg1; S.n_rounds++;
 #endif
         i += cnt;
-        __syncthreads();
+        // One wave: its LDS operations execute in order, so the latency variant (mask and ring in LDS) needs no barrier here -- and must
+        // not have one: __syncthreads() also waits for the region-list store just issued to be acknowledged by L2 (~500 cycles per
+        // round).  Region points older than the ring are read back from the list with an L1-bypassing load, long after their store
+        // (every round's record fetch is waited for, and vmcnt counts stores and loads in order).
+        if (S.lm) __builtin_amdgcn_wave_barrier(); else __syncthreads();
     }
     reg_size = rs; reg_angle = ra;
 }
