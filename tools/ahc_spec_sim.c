@@ -18,7 +18,7 @@ static void spec_cluster(void *f);
 #include "../oracle/peac.c"
 
 static int g_K = 8;
-static long g_rounds, g_pops, g_hist[65], g_cands, g_passes64, g_passes16;
+static long g_rounds, g_pops, g_hist[65], g_cands, g_passes64, g_passes16, g_stop[3];
 
 typedef struct { int p, nb, merge; double m; int ncand; } head_t;
 
@@ -64,9 +64,10 @@ static void spec_cluster(void *fv)
         for (int j = 0; j < nh; j++) {
             head_t *h = &heads[j];
             int ok = 1;
-            if (minnew < f->seg[h->p].mse) ok = 0;
+            if (minnew < f->seg[h->p].mse) { ok = 0; g_stop[0]++; }
             seg_t *sp = &f->seg[h->p];
-            if (ok && mark[h->p]) ok = 0;
+            if (ok && mark[h->p]) { ok = 0; g_stop[1]++; }
+            else if (ok && h->merge && mark[h->nb]) g_stop[2]++;
             for (int k = 0; ok && k < sp->nnb; k++) if (mark[sp->nbs[k]]) ok = 0;
             if (ok && h->merge) { seg_t *sn = &f->seg[h->nb]; if (mark[h->nb]) ok = 0; for (int k = 0; ok && k < sn->nnb; k++) if (mark[sn->nbs[k]]) ok = 0; }
             if (!ok) break;
@@ -127,6 +128,7 @@ int main(int argc, char **argv)
     long long csum = 0; for (int i = 0; i < w * h; i++) csum = csum * 31 + labels[i];
     printf("K=%d pops=%ld rounds=%ld pops/round=%.2f planes=%d labelsum=%lld cands/round=%.1f eig-passes/round: 64 lanes %.2f, 16 lanes %.2f\n", g_K, g_pops, g_rounds,
            (double)g_pops / g_rounds, np, csum, (double)g_cands / g_rounds, (double)g_passes64 / g_rounds, (double)g_passes16 / g_rounds);
+    printf("prefix stops: a node created this round precedes the head in queue order %ld, head in an earlier footprint %ld, partner in an earlier footprint %ld (the rest: shared neighbours)\n", g_stop[0], g_stop[1], g_stop[2]);
     printf("prefix-length histogram:"); for (int i = 1; i <= g_K; i++) printf(" %d:%ld", i, g_hist[i]); printf("\n");
     return 0;
 }

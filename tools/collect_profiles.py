@@ -79,3 +79,9 @@ shutil.copy(os.path.join(src, "match_rate.txt"), os.path.join(P, tag + "_match_r
 shutil.copy(os.path.join(src, "peac_timing_batch.txt"), os.path.join(P, tag + "_peac_cluster_phases_batch8192.txt"))
 shutil.copy(os.path.join(src, "peac_lat_timing.txt"), os.path.join(P, tag + "_peac_cluster_lat_phases_1frame.txt"))
 print("value", d["value"], "frames/s; under rocprof", u["value"])
+for a, b in (("peac_heads_timing.txt", "_peac_cluster_heads_phases_1frame.txt"), ("lsd_stats.txt", "_lsd_grow_one_frame_stats.txt")):
+    if os.path.exists(os.path.join(src, a)): shutil.copy(os.path.join(src, a), os.path.join(P, tag + b))
+if os.path.exists(os.path.join(src, "latency_1280.json")):
+    json.dump(json.load(open(os.path.join(src, "latency_1280.json"))), open(os.path.join(P, tag + "_latency_1280x960.json"), "w"), indent=1)
+g1 = glob.glob(os.path.join(src, "kt1", "**", "one_kernel_stats.csv"), recursive=True)
+if g1: shutil.copy(g1[0], os.path.join(P, tag + "_one_frame_kernel_stats.csv"))
