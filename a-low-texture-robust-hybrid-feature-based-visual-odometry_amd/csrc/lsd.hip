@@ -395,8 +395,8 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
                     sumdy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_sy), last));
                     ra = readlane_f64(my_ra, last);
                     rs += nC;
-                    // the committed pixels are no candidates any more, in any slot
-                    unsigned long long cc = C;
+                    // the committed pixels are no candidates any more, in any slot (only a walk that resumes looks at them again)
+                    unsigned long long cc = (m < 64 || GROW_SLOTS > 1) ? C : 0ull;
                     while (cc) {
                         const int L = __ffsll((long long)cc) - 1;
                         cc &= cc - 1;
@@ -422,14 +422,18 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
     reg_size = rs; reg_angle = ra;
 }
 
-// ordered fp64 accumulation helpers: the sums of region2rect / get_theta / refine must be added in
-// region order; 64 points are fetched per step, lane 0 accumulates them in order.
-// Sequentially adds the 64 staged terms of three LDS arrays onto three accumulators (lane 0 only).
-// Unused tail terms are staged as +0.0, which leaves a (never negative-zero) running sum unchanged.
-static __device__ __forceinline__ void seq_add3(const double *t0, const double *t1, const double *t2, double &a0, double &a1, double &a2)
+// Ordered fp64 accumulation: the sums of region2rect / get_theta / refine must be added in region order; 64 points are staged in LDS
+// per step.  Three ordered sums with lanes 0..2 owning one accumulator each: ONE instruction stream (a read and an add per term) serves the
+// three chains, a third of what one lane adding all three would issue -- and a lone wave is bound by issue.  n (uniform) =
+// staged terms of this step; the order of additions within each sum is unchanged.
+static __device__ __forceinline__ void seq_add_lanes(const double *mine, int n, double &acc)
 {
+    int q = 0;
+    for (; q + 8 <= n; q += 8) {
 #pragma unroll
-    for (int q = 0; q < 64; q++) { a0 += t0[q]; a1 += t1[q]; a2 += t2[q]; }
+        for (int u = 0; u < 8; u++) acc += mine[q + u];
+    }
+    for (; q < n; q++) acc += mine[q];
 }
 
 static __device__ void region2rect_wave(const GrowState &S, int reg_size, double reg_angle, double prec, Rect &rec,
@@ -437,33 +441,41 @@ static __device__ void region2rect_wave(const GrowState &S, int reg_size, double
 {
     const int lane = threadIdx.x, sw = S.sw;
     // weighted centroid: x += px*w; y += py*w; sum += w   (region order)
-    double x = 0, y = 0, sum = 0;
-    for (int base = 0; base < reg_size; base += 64) {
-        const int i = base + lane;
-        double t0 = 0, t1 = 0, t2 = 0;
-        if (i < reg_size) { const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; const double wgt = S.px4[px + py * sw].w; t0 = (double)px * wgt; t1 = (double)py * wgt; t2 = wgt; }
-        b0[lane] = t0; b1[lane] = t1; b2[lane] = t2;
-        __syncthreads();
-        if (lane == 0) seq_add3(b0, b1, b2, x, y, sum);
-        __syncthreads();
-    }
-    if (lane == 0) { x /= sum; y /= sum; }
-    x = __shfl(x, 0); y = __shfl(y, 0);
-    // get_theta: Ixx += dy*dy*w; Iyy += dx*dx*w; Ixy -= dx*dy*w
-    double Ixx = 0, Iyy = 0, Ixy = 0;
+    const double *mine = lane == 0 ? b0 : lane == 1 ? b1 : b2;
+    int a_first = 0; double w_first = 0;
+    double acc = 0;                                           // lanes 0..2: x, y, sum
     for (int base = 0; base < reg_size; base += 64) {
         const int i = base + lane;
         double t0 = 0, t1 = 0, t2 = 0;
         if (i < reg_size) {
-            const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; const double wgt = S.px4[px + py * sw].w;
+            const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; const double wgt = S.px4[px + py * sw].w; t0 = (double)px * wgt; t1 = (double)py * wgt; t2 = wgt;
+            if (base == 0) { a_first = a; w_first = wgt; }     // the first 64 points stay in registers for the second pass
+        }
+        b0[lane] = t0; b1[lane] = t1; b2[lane] = t2;
+        __syncthreads();
+        if (lane < 3) seq_add_lanes(mine, min(64, reg_size - base), acc);
+        __syncthreads();
+    }
+    double x = __shfl(acc, 0), y = __shfl(acc, 1);
+    { const double sum = __shfl(acc, 2); x /= sum; y /= sum; }
+    // get_theta: Ixx += dy*dy*w; Iyy += dx*dx*w; Ixy -= dx*dy*w
+    acc = 0;                                                  // lanes 0..2: Ixx, Iyy, Ixy
+    for (int base = 0; base < reg_size; base += 64) {
+        const int i = base + lane;
+        double t0 = 0, t1 = 0, t2 = 0;
+        if (i < reg_size) {
+            int a = a_first; double wgt = w_first;
+            if (base != 0) { a = S.reg[i]; wgt = S.px4[(a & 0xFFFF) + (a >> 16) * sw].w; }
+            const int px = a & 0xFFFF, py = a >> 16;
             const double dx = (double)px - x, dy = (double)py - y;
             t0 = dy * dy * wgt; t1 = dx * dx * wgt; t2 = -(dx * dy * wgt);      // a -= b  ==  a += (-b), exactly
         }
         b0[lane] = t0; b1[lane] = t1; b2[lane] = t2;
         __syncthreads();
-        if (lane == 0) seq_add3(b0, b1, b2, Ixx, Iyy, Ixy);
+        if (lane < 3) seq_add_lanes(mine, min(64, reg_size - base), acc);
         __syncthreads();
     }
+    const double Ixx = __shfl(acc, 0), Iyy = __shfl(acc, 1), Ixy = __shfl(acc, 2);
     double theta = 0, dx = 0, dy = 0;
     if (lane == 0) {
         const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
@@ -509,7 +521,8 @@ static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle
     const int a0 = S.reg[0];
     const double xc = (double)(a0 & 0xFFFF), yc = (double)(a0 >> 16);
     const double ang_c = S.px4[(a0 & 0xFFFF) + (a0 >> 16) * sw].x;
-    double sum = 0, s_sum = 0, dummy = 0; int n = 0;
+    const double *mine = lane == 0 ? b0 : b1;
+    double acc = 0; int n = 0;                                // lanes 0, 1: sum, s_sum
     for (int base = 0; base < reg_size; base += 64) {
         const int i = base + lane;
         double t0 = 0, t1 = 0; bool in = false;
@@ -522,13 +535,14 @@ static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle
                 t0 = ang_d; t1 = ang_d * ang_d; in = true;
             }
         }
-        b0[lane] = t0; b1[lane] = t1; b2[lane] = 0;
+        b0[lane] = t0; b1[lane] = t1;
         n += __popcll(__ballot(in));
         __syncthreads();
         if (i < reg_size) used_clr(S, n_addr[lane] & 0xFFFF, n_addr[lane] >> 16);
-        if (lane == 0) seq_add3(b0, b1, b2, sum, s_sum, dummy);
+        if (lane < 2) seq_add_lanes(mine, min(64, reg_size - base), acc);
         __syncthreads();
     }
+    const double sum = __shfl(acc, 0), s_sum = __shfl(acc, 1);
     double tau = 0;
     if (lane == 0) {
         const double mean_angle = sum / (double)n;
