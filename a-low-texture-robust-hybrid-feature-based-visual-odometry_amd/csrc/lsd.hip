@@ -70,14 +70,12 @@ static __device__ __forceinline__ float fatan2_deg(float y, float x)
     const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
     const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
     const float eps = (float)2.2204460492503131e-16;
-    float ax = fabsf(x), ay = fabsf(y), r, c, c2;
-    if (ax >= ay) {
-        c = __fdiv_rn(ay, __fadd_rn(ax, eps)); c2 = __fmul_rn(c, c);
-        r = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
-    } else {
-        c = __fdiv_rn(ax, __fadd_rn(ay, eps)); c2 = __fmul_rn(c, c);
-        r = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
-    }
+    // both branches of the reference are the same arithmetic on (smaller, larger): selected, not branched -- lanes of a wave differ
+    const float ax = fabsf(x), ay = fabsf(y);
+    const bool hi = ax >= ay;
+    const float c = __fdiv_rn(hi ? ay : ax, __fadd_rn(hi ? ax : ay, eps)), c2 = __fmul_rn(c, c);
+    float r = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    if (!hi) r = __fsub_rn(90.f, r);
     if (x < 0) r = __fsub_rn(180.f, r);
     if (y < 0) r = __fsub_rn(360.f, r);
     return r;
@@ -293,10 +291,8 @@ static __device__ __forceinline__ double readlane_f64(double v, int l)
 }
 static __device__ __forceinline__ bool lsd_aligned(double a, double theta, double prec)
 {
-    double n_theta = theta - a;
-    if (n_theta < 0) n_theta = -n_theta;
-    if (n_theta > (3 * LSD_PI) / 2) { n_theta -= 2 * LSD_PI; if (n_theta < 0) n_theta = -n_theta; }
-    return n_theta <= prec;
+    const double t = fabs(theta - a), t2 = fabs(t - 2 * LSD_PI);          // selected, not branched: the lanes of a wave differ
+    return (t > (3 * LSD_PI) / 2 ? t2 : t) <= prec;
 }
 
 static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size, double &reg_angle, double prec)
@@ -328,7 +324,8 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
                 const int xx = (pxy & 0xFFFF) + jx, yy = (pxy >> 16) + jy;
                 // one bit test rejects both the pixels without a gradient angle and the ones already taken; only
                 // real candidates fetch their record (angle, cos, sin in one 32-byte access)
-                if (xx >= 0 && yy >= 0 && xx < sw && yy < sh && !used_get(S, xx, yy)) {
+                const bool inb = (unsigned)xx < (unsigned)sw && (unsigned)yy < (unsigned)sh;
+                if (inb & !used_get(S, inb ? xx : 0, inb ? yy : 0)) {
                     const double4 r = S.px4[xx + yy * sw];
                     c[s] = (yy << 16) | xx; an[s] = r.x; cs[s] = r.y; sn[s] = r.z; valid[s] = true;
                 }
