@@ -377,7 +377,7 @@ class Context:
         m = np.zeros(16, np.int32)
         self._chk(L.hvo_debug_peac_stats(self.h, frame, _p(m)), "peac_stats")
         return {"segments": int(m[0]), "coarse_planes": int(m[2]), "flags": int(m[3]), "planes": int(m[4]), "queue_entries": int(m[5]),
-                "flood_rounds": int(m[8]), "flood_ranked_rounds": int(m[9]), "flood_serial_rounds": int(m[10])}
+                "flood_rounds": int(m[8]), "flood_ranked_rounds": int(m[9]), "flood_serial_rounds": int(m[10]), "ahc_rounds": int(m[11]), "ahc_stops_no_head": int(m[12]), "ahc_stops_conflict": int(m[13]), "ahc_stops_key_order": int(m[14])}
 
     # ---- matching ----
     def hamming_matrix(self, q, t):

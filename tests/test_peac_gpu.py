@@ -283,6 +283,7 @@ def test_peac_queue_heads(hvo, orc, synth, monkeypatch, heads, poolcap):
         ctx.batch_upload(np.zeros((len(depth), 480, 640), np.uint8), depth)
         ctx.batch_run(hvo.STAGE_PLANES)
         res = ctx.batch_download(hvo.STAGE_PLANES)
+        stats = ctx.peac_stats(1)
         one = ctx.compute_planes(depth[1])                       # the single-frame entry point takes the same kernel
     finally:
         ctx.close()
@@ -292,3 +293,8 @@ def test_peac_queue_heads(hvo, orc, synth, monkeypatch, heads, poolcap):
         check(res[b]["labels"], res[b]["planes"], lo, po)
     lo, po = orc.peac(depth[1])
     check(one[0], one[1], lo, po)
+    # the speculation must pay, not only be right: rounds per merge (tools/ahc_spec_sim.c: 0.47 at four heads, 0.64 at two).  Marks that
+    # are never cleared, say, keep every result exact and commit one head per round.
+    merges = stats["segments"] - 3072
+    if heads == "4": assert 0 < stats["ahc_rounds"] < 0.55 * merges, stats
+    if heads == "2": assert 0 < stats["ahc_rounds"] < 0.75 * merges, stats

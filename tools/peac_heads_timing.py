@@ -25,6 +25,7 @@ def main():
     tot = v[:10].sum()
     print("ticks total %.3e; rounds %d, pops %d (%.2f per round), %.0f ticks per round" % (tot, v[10], v[11], v[11] / max(v[10], 1), tot / max(v[10], 1)))
     for i in range(10): print("  %-26s %6.2f %%  %.0f ticks per round" % (NAMES[i], 100 * v[i] / tot, v[i] / max(v[10], 1)))
+    print("queue wave after barrier 2: prefix %.0f, front merge (masks) %.0f, front stores %.0f ticks per round; from a round's start to barrier 1: %.0f (of which deferred updates + extraction %.0f)" % tuple(v[16 + i] / max(v[10], 1) for i in range(5)))
     ctx.close(); shutil.rmtree(tmp, ignore_errors=True)
 
 if __name__ == "__main__":
