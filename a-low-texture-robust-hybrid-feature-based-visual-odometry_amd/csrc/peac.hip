@@ -1987,18 +1987,20 @@ int peac_run(hvo_ctx *ctx, int n)
         int heads_max = 256; { const char *e8 = getenv("HVO_PEAC_HEADS_MAXN"); if (e8) heads_max = atoi(e8); }
         int heads = (gl <= 0 && n <= heads_max && a.tq_n0 * 16 <= 64 * MH_MAXE) ? 4 : 0;
         { const char *e6 = getenv("HVO_PEAC_HEADS"); if (e6 && a.tq_n0 * 16 <= 64 * MH_MAXE) heads = atoi(e6); }
-        if (heads == 2 || heads == 4) {
+        if (heads >= 2 && heads <= 4) {
             ClArgs b = a;
             { const char *e7 = getenv("HVO_PEAC_POOLCAP"); if (e7 && atoi(e7) >= 7 * a.nblk && atoi(e7) < a.poolcap) b.poolcap = atoi(e7); }   // tests: force the pool's compaction
             const size_t segpad = (size_t)a.tq_n0 * 256;
-            const size_t lds = segpad * 8 + (size_t)a.tq_n0 * 16 * 12 + segpad / 8 * 4 + 4 * sizeof(MhHead) + 16 + segpad * 8 + 512;
+            const size_t lds = segpad * 8 + (size_t)a.tq_n0 * 16 * 12 + segpad / 8 * 4 + 4 * sizeof(MhHead) + 32 + segpad * 8 + 512;
             static size_t lds_set3 = 0;
             if (lds > lds_set3) {
                 HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 lds_set3 = lds;
             }
             if (heads == 2) hipLaunchKernelGGL(k_peac_cluster_heads<2>, dim3(n), dim3(192), lds, st, b, n);
+            else if (heads == 3) hipLaunchKernelGGL(k_peac_cluster_heads<3>, dim3(n), dim3(256), lds, st, b, n);
             else hipLaunchKernelGGL(k_peac_cluster_heads<4>, dim3(n), dim3(320), lds, st, b, n);
         }
         else if (use == 64) {

@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge
-NAMES = ["compaction check", "A heads", "B evaluate", "B edit loads + marks", "barrier 1", "C conflicts", "barrier 2", "D commit || E front merge", "-", "barrier 3"]
+NAMES = ["compaction check", "A heads", "B evaluate", "B edit loads + marks", "barrier 1", "decisions + queue masks", "(unused)", "D commit || E front merge", "-", "barrier 3"]
 
 def main():
     tmp = tempfile.mkdtemp(prefix="hvo_timing_")
