@@ -218,6 +218,7 @@ struct ClArgs {
     double *tqK, *tqM1k; int *tqM1i; int tq_n0;      // the grouped kernel's min-MSE queue (TQueue): n0 * 256 keys, n0 * 16 bucket minima per frame
     int tq_lds_keys;                                 // GL = 64, a handful of frames: the keys and bucket minima live in LDS too (54 KB per frame)
     int segcap, poolcap, nblk, Nw, Nh;
+    int edges_done;                                  // k_peac_edges has written eflag (initGraph's edges); the clustering kernels skip their own passes
     double c15, c60;
     double ang_factor, ang_near;   // T_ang(P_INIT): (angle_far - angle_near) / (z_far - z_near), angle_near (AHCParamSet.hpp:113-121)
 };
@@ -1143,6 +1144,63 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_peac_edges: initGraph's edges (AHCPlaneFitter.hpp:894-954) for the clustering kernels.  The two passes are state machines along
+// a row / a column (the reference's loops step back and forth), 48 + 64 independent chains per 640x480 frame whose every step reads
+// three or four block records: inside the clustering kernels (a quarter wave per frame, records in global memory) they were 7.5 % of
+// the AHC's time.  Here a workgroup stages the frame's normals, centre depths and validity in LDS (34 bytes per block) and a thread
+// walks a row, then a column, out of LDS.  Frames whose blocks do not fit (1280x960) keep the in-kernel passes (edges_done = 0).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_peac_edges(ClArgs a, int nframes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ed_lds[];
+    const int frame = blockIdx.x, tid = threadIdx.x, nblk = a.nblk, Nw = a.Nw, Nh = a.Nh;
+    double4 *nz = reinterpret_cast<double4 *>(ed_lds);                   // (normal, centre z) of a block
+    unsigned char *okb = reinterpret_cast<unsigned char *>(nz + nblk), *ef = okb + nblk;
+    const double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
+    const int *segI = a.segI + (size_t)frame * a.segcap * SEG_I;
+    int *eflag = a.eflag + (size_t)frame * nblk;
+    for (int b = tid; b < nblk; b += 512) {
+        const double *sd = segD + (size_t)b * SEG_D;
+        nz[b] = make_double4(sd[12], sd[13], sd[14], sd[11]);
+        okb[b] = segI[(size_t)b * SEG_I + 6] != 0; ef[b] = 0;
+    }
+    __syncthreads();
+#define ENS(P_, Q_) fabs(nz[P_].x * nz[Q_].x + nz[P_].y * nz[Q_].y + nz[P_].z * nz[Q_].z)
+    // rows (896-923).  bits: 1=left 2=right 4=up 8=down
+    for (int i = tid; i < Nh; i += 512) {
+        for (int j = 1; j < Nw; j += 2) {
+            const int c = i * Nw + j;
+            if (!okb[c - 1]) { --j; continue; }
+            if (!okb[c]) continue;
+            if (j < Nw - 1 && !okb[c + 1]) { ++j; continue; }
+            const double th = t_ang_init(a, nz[c].w);
+            if ((j < Nw - 1 && ENS(c - 1, c + 1) >= th) || (j == Nw - 1 && ENS(c, c - 1) >= th)) {
+                ef[c] |= 1; ef[c - 1] |= 2;
+                if (j < Nw - 1) { ef[c] |= 2; ef[c + 1] |= 1; }
+            } else --j;
+        }
+    }
+    __syncthreads();
+    // columns (926-954)
+    for (int j = tid; j < Nw; j += 512) {
+        for (int i = 1; i < Nh; i += 2) {
+            const int c = i * Nw + j;
+            if (!okb[c - Nw]) { --i; continue; }
+            if (!okb[c]) continue;
+            if (i < Nh - 1 && !okb[c + Nw]) { ++i; continue; }
+            const double th = t_ang_init(a, nz[c].w);
+            if ((i < Nh - 1 && ENS(c - Nw, c + Nw) >= th) || (i == Nh - 1 && ENS(c, c - Nw) >= th)) {
+                ef[c] |= 4; ef[c - Nw] |= 8;
+                if (i < Nh - 1) { ef[c] |= 8; ef[c + Nw] |= 4; }
+            } else --i;
+        }
+    }
+#undef ENS
+    __syncthreads();
+    for (int b = tid; b < nblk; b += 512) eflag[b] = ef[b];
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_peac_cluster: initGraph edges + main ahCluster, 64/GL frames per wave
 // ------------------------------------------------------------------------------------------------
 template <int GL>
@@ -1181,12 +1239,12 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
 #ifdef HVO_PEAC_TIMING
     const unsigned long long t_in0 = clock64();
 #endif
-    if (galive) for (int b = gl; b < nblk; b += GL) { parent[b] = b; dsize[b] = 1; eflag[b] = 0; }
+    if (galive) for (int b = gl; b < nblk; b += GL) { parent[b] = b; dsize[b] = 1; if (!a.edges_done) eflag[b] = 0; }
     __syncthreads();
 #define GOK(c) (segI[(size_t)(c) * SEG_I + 6] != 0)
 #define SD(c) (segD + (size_t)(c) * SEG_D)
     // first pass: rows (AHCPlaneFitter.hpp:896-923).  bits: 1=left 2=right 4=up 8=down
-    if (galive) for (int i = gl; i < Nh; i += GL) {
+    if (galive && !a.edges_done) for (int i = gl; i < Nh; i += GL) {
         for (int j = 1; j < Nw; j += 2) {
             const int c = i * Nw + j;
             if (!GOK(c - 1)) { --j; continue; }
@@ -1200,7 +1258,7 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
         }
     }
     __syncthreads();
-    if (galive) for (int j = gl; j < Nw; j += GL) {
+    if (galive && !a.edges_done) for (int j = gl; j < Nw; j += GL) {
         for (int i = 1; i < Nh; i += 2) {
             const int c = i * Nw + j;
             if (!GOK(c - Nw)) { --i; continue; }
@@ -1955,6 +2013,17 @@ int peac_run(hvo_ctx *ctx, int n)
         if (ctx->lsd_pre_recorded) HVO_HIP(hipStreamWaitEvent(st, ctx->ev_lsd_pre, 0));
     }
     id = hvo_prof_begin(ctx, "peac_cluster", st);
+    a.edges_done = 0;
+    {
+        const size_t elds = (size_t)P->nblk * 34 + 16;
+        const char *ee = getenv("HVO_PEAC_EDGES");                 // 0: the passes stay inside the clustering kernels (A/B runs, tests)
+        if (elds <= 150 * 1024 && !(ee && atoi(ee) == 0)) {
+            static size_t elds_set = 0;
+            if (elds > 48 * 1024 && elds > elds_set) { HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_edges), hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds)); elds_set = elds; }
+            hipLaunchKernelGGL(k_peac_edges, dim3(n), dim3(512), elds, st, a, n);
+            a.edges_done = 1;
+        }
+    }
     // k_peac_cluster_lat (one frame per workgroup, queue in LDS, adjacency inline in 256-byte node records): an experiment in
     // trading memory round trips for instructions that did not pay (a lone wave issues one instruction every 5-8 cycles,
     // whatever it waits for); kept behind HVO_PEAC_LAT=1 with its parity tests, see DESIGN.md section 4
