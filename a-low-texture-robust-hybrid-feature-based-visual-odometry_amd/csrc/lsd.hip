@@ -1329,8 +1329,13 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     bool lat = n <= 64 && (size_t)P->nwords * 4 <= 150 * 1024;
     { const char *e = getenv("HVO_LSD_LAT"); if (e) lat = atoi(e) != 0 && (size_t)P->nwords * 4 <= 150 * 1024; }
     if (lat) {
-        const size_t lds = (size_t)P->nwords * 4;
-        if (lds > 48 * 1024) HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lsd_grow_lat), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // The LDS request also keeps this one-wave workgroup off the CUs where a frame's five AHC waves sit (k_peac_cluster_heads takes
+        // 108 KB): both are bound by instruction issue and a shared SIMD slows both (HVO_LSD_LAT_LDS: bytes requested at least [56 K])
+        size_t lds = (size_t)P->nwords * 4, floor_ = 56 * 1024;
+        { const char *e2 = getenv("HVO_LSD_LAT_LDS"); if (e2) floor_ = (size_t)atoi(e2); }
+        if (lds < floor_ && floor_ <= 150 * 1024) lds = floor_;
+        static size_t lat_lds_set = 0;
+        if (lds > 48 * 1024 && lds > lat_lds_set) { HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lsd_grow_lat), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); lat_lds_set = lds; }
         hipLaunchKernelGGL(k_lsd_grow_lat, dim3(n), dim3(64), lds, st, g);
     } else if (dense) hipLaunchKernelGGL(k_lsd_grow_dense, dim3(n), dim3(64), 0, st, g);     // more frames than five waves per SIMD hold
     else hipLaunchKernelGGL(k_lsd_grow, dim3(n), dim3(64), 0, st, g);
