@@ -74,7 +74,7 @@ def test_stress_depth(gpu_ctx, orc, synth):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("env", [{"HVO_SCHED": "5"}, {"HVO_SCHED": "2", "HVO_PRIO": "0,0,0"}, {"HVO_SCHED": "0", "HVO_FRAME_PERM": "0", "HVO_PEAC_PERM": "0"},
+@pytest.mark.parametrize("env", [{"HVO_SCHED": "5"}, {"HVO_SCHED": "2", "HVO_PRIO": "0,0,0"}, {"HVO_SCHED": "0", "HVO_FRAME_PERM": "0", "HVO_PEAC_PERM": "0", "HVO_PEAC_EDGES": "0", "HVO_LSD_LAT_LDS": "0"},
                                  {"HVO_SCHED": "5", "HVO_PEAC_GL": "16", "HVO_FLOOD_T": "64", "HVO_LSD_DENSE": "1", "HVO_ORB_BLUR_LATE": "1"}])
 def test_overlap_policy_and_launch_order_do_not_change_results(hvo, orc, synth, monkeypatch, env):
     """which stream waits for which kernel (HVO_SCHED), the stream priorities and the order in which the serial kernels take their
