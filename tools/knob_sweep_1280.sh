@@ -1,0 +1,5 @@
+#!/bin/bash
+# Kernel-variant knobs at the big1280 bench size (run through gpurun).
+run() { echo -n "$1: "; env $1 timeout -k 10 300 python bench.py --config big1280 --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; }
+run "HVO_NOP=1"
+run "HVO_FLOOD_T=64"; run "HVO_FLOOD_T=128"; run "HVO_LSD_DENSE=1"; run "HVO_PEAC_GL=32"; run "HVO_SCHED=1"; run "HVO_SCHED=7"
