@@ -1347,7 +1347,9 @@ __global__ __launch_bounds__(256) void k_peac_blkmap(const int *__restrict__ par
                                                      const uint16_t *__restrict__ depth_, size_t dframe, int pitch,
                                                      int nblk, int Nw, int Nh, int w, int h, int segcap)
 {
-    const int frame = blockIdx.x, tid = threadIdx.x;
+    // gridDim.y workgroups share a frame's pixels (a handful of frames: one workgroup filling 2.5 MB of states took 0.5 ms of the plane
+    // chain); each of them computes the block map for itself -- the same values, written by all
+    const int frame = blockIdx.x, tid = threadIdx.x, slice = blockIdx.y, nslices = gridDim.y;
     const int *parent = parent_ + (size_t)frame * nblk, *dsize = dsize_ + (size_t)frame * nblk;
     const int *segI = segI_ + (size_t)frame * segcap * SEG_I;
     const int *ext = ext_ + (size_t)frame * 2 * MAX_PLANES;
@@ -1378,7 +1380,7 @@ __global__ __launch_bounds__(256) void k_peac_blkmap(const int *__restrict__ par
     // phase 2: the frame's pixels in state order (tile by tile: coalesced stores, depth read in 8-byte row pieces);
     // pixels outside the block grid get -1, tile padding outside the image is never read
     const int tw = FS_TW(w), nst = tw * FS_TH(h) * 16;
-    for (int i = tid; i < nst; i += 256) {
+    for (int i = slice * 256 + tid; i < nst; i += 256 * nslices) {
         const int t = i >> 4, ty = t / tw, tx = t - ty * tw;
         const int x = tx * 4 + (i & 3), y = ty * 4 + ((i >> 2) & 3);
         if (x >= w || y >= h) continue;
@@ -2091,7 +2093,7 @@ int peac_run(hvo_ctx *ctx, int n)
     }
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "peac_refine", st);
-    hipLaunchKernelGGL(k_peac_blkmap, dim3(n), dim3(256), 0, st, P->d_parent, P->d_dsize, P->d_segI, P->d_extracted, P->d_meta, P->d_blkmap,
+    hipLaunchKernelGGL(k_peac_blkmap, dim3(n, n <= 64 ? 32 : n <= 1024 ? 4 : 1), dim3(256), 0, st, P->d_parent, P->d_dsize, P->d_segI, P->d_extracted, P->d_meta, P->d_blkmap,
                        P->d_isvalid, P->d_state, P->d_depth, dframe, P->pitch, P->nblk, P->Nw, P->Nh, P->w, P->h, P->segcap);
     RfArgs r;
     r.c = a; r.depth = P->d_depth; r.dframe = dframe; r.pitch = P->pitch; r.w = P->w; r.h = P->h;
