@@ -42,7 +42,11 @@ struct LsdPlan {
     int w = 0, h = 0, sw = 0, sh = 0, batch = 0, nfeat = 0, nwords = 0;
     double *d_blur = nullptr;                               // w*h doubles per frame of a chunk
     int chunk = 0;                                          // frames the transient images exist for
-    double4 *d_px = nullptr;           // sw*sh x {angle, cos, sin, modgrad}: one 32-byte record per scaled pixel
+    double4 *d_px = nullptr;           // sw*sh x {angle, cos, sin, modgrad}: one 32-byte record per scaled pixel (compact plans: for a chunk only)
+    // compact plans (large resident batches): only the pixels that have a gradient angle keep their record, in one pool for the batch
+    bool compact = false; double4 *d_pool = nullptr; size_t pool_cap = 0;           // records
+    unsigned *d_defmask = nullptr, *d_wprefix = nullptr;                            // per frame: the defined mask (the availability mask is consumed), records before each mask word
+    long long *d_fbase = nullptr; int *d_fcount = nullptr; unsigned long long *d_pooltop = nullptr;   // per frame: base in the pool (-1: no room), defined pixels; records asked for so far
     unsigned *d_defined = nullptr;                          // bitmask, nwords per frame
     int *d_reg = nullptr;                                   // sw*sh ints
     float *d_segs = nullptr;                                // LSD_MAXSEG x 4
@@ -217,10 +221,69 @@ __global__ __launch_bounds__(256) void k_lsd_resize_grad(const double *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// Compact records (plans of large resident batches): k_lsd_resize_grad writes a chunk's records into the chunk's dense image as ever;
+// k_lsd_prefix keeps the frame's defined mask and the count of records before every mask word, k_lsd_bases gives the chunk's frames their
+// places in the batch's pool, k_lsd_compact moves the records there (raster order).  32 bytes per DEFINED pixel (13-20 % of the pixels)
+// instead of per pixel: 6.3 -> ~1.7 MB per 640x480 frame, 25 -> ~7 MB at 1280x960.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lsd_prefix(const unsigned *__restrict__ defined, unsigned *__restrict__ defmask, unsigned *__restrict__ wprefix,
+                                                    int *__restrict__ fcount, int nwords)
+{
+    __shared__ int wsum[4];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned *D = defined + (size_t)f * nwords; unsigned *M = defmask + (size_t)f * nwords, *W = wprefix + (size_t)f * nwords;
+    int run = 0;
+    for (int base = 0; base < nwords; base += 256) {
+        const int i = base + tid;
+        const unsigned m = i < nwords ? D[i] : 0u;
+        const int c = __popc(m);
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int off = run, tot = 0;
+        for (int k = 0; k < 4; k++) { const int v = wsum[k]; if (k < wv) off += v; tot += v; }
+        if (i < nwords) { M[i] = m; W[i] = (unsigned)(off + incl - c); }
+        run += tot;
+        __syncthreads();
+    }
+    if (tid == 0) fcount[f] = run;
+}
+__global__ __launch_bounds__(512) void k_lsd_bases(const int *__restrict__ fcount, int m, long long *__restrict__ fbase, unsigned long long *__restrict__ pooltop,
+                                                   unsigned long long cap)
+{
+    __shared__ unsigned long long s[512];
+    const int tid = threadIdx.x;
+    const unsigned long long c = tid < m ? (unsigned long long)fcount[tid] : 0ull;
+    s[tid] = c;
+    __syncthreads();
+    for (int o = 1; o < 512; o <<= 1) { const unsigned long long t = tid >= o ? s[tid - o] : 0ull; __syncthreads(); s[tid] += t; __syncthreads(); }
+    const unsigned long long base0 = pooltop[0], b = base0 + s[tid] - c;
+    if (tid < m) fbase[tid] = b + c <= cap ? (long long)b : -1ll;
+    __syncthreads();
+    if (tid == 511) pooltop[0] = base0 + s[511];              // what the batch asks for so far (lsd_run compares it with the pool's size)
+}
+__global__ __launch_bounds__(256) void k_lsd_compact(const double4 *__restrict__ dense, size_t nsp, const unsigned *__restrict__ defmask, const unsigned *__restrict__ wprefix,
+                                                     const long long *__restrict__ fbase, double4 *__restrict__ pool, int nwords, int sw, int wpr)
+{
+    const int f = blockIdx.y;
+    const long long base = fbase[f];
+    if (base < 0) return;
+    const double4 *D = dense + (size_t)f * nsp; double4 *P = pool + base;
+    for (int w = blockIdx.x * 256 + threadIdx.x; w < nwords; w += gridDim.x * 256) {
+        unsigned m = defmask[(size_t)f * nwords + w]; unsigned k = wprefix[(size_t)f * nwords + w];
+        const int y = w / wpr, x0 = (w - y * wpr) * 32;
+        while (m) { const int b = __ffs((int)m) - 1; m &= m - 1; P[k++] = D[(size_t)y * sw + x0 + b]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_lsd_grow: the serial heart of LSD, one wave per frame
 // ------------------------------------------------------------------------------------------------
 struct GrowArgs {
     const double4 *px4; unsigned *avail; int *reg; float *segs; const int *perm;
+    const unsigned *defmask, *wprefix; const long long *fbase;      // compact plans: px4 is the pool
     hvo_keyline *kl_all, *kl; double *fn; int *nkl; int *flags; long long *stats;
     int sw, sh, nwords, w, h, nfeat, kl_cap;
     double rho, prec, p; unsigned min_reg;
@@ -230,6 +293,7 @@ struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy; };
 
 struct GrowState {
     const double4 *px4; int *reg; unsigned *avail; int *ring;     // px4: {angle, cos, sin, modgrad}
+    const unsigned *defmask, *wprefix;                            // compact plans (rec_index)
     int sw, sh, wpr;          // wpr = mask words per row
     bool lm;                  // the mask lives in LDS (lsd_lds_mask)
 #ifdef HVO_LSD_TIMING
@@ -268,6 +332,16 @@ static __device__ __forceinline__ void used_clr(const GrowState &S, int x, int y
     else __hip_atomic_fetch_or(&S.avail[wi], 1u << (x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Where pixel (x, y)'s record is.  Compact plans keep records only for pixels with a gradient angle, in raster order: the index is the
+// count of defined pixels before it = the prefix of its mask word + the bits below it in the word.  Both words are read beside the
+// availability word the caller tests anyway, so the record stays ONE dependent access away (what an index image would not give).
+template <bool CP> static __device__ __forceinline__ size_t rec_index(const GrowState &S, int x, int y)
+{
+    if (!CP) return (size_t)x + (size_t)y * S.sw;
+    const int wi = y * S.wpr + (x >> 5);
+    return (size_t)S.wprefix[wi] + (size_t)__popc(S.defmask[wi] & ((1u << (x & 31)) - 1u));
+}
+
 static __device__ __forceinline__ double angle_diff_signed(double a, double b)
 {
     double diff = a - b;
@@ -299,14 +373,17 @@ static __device__ __forceinline__ bool lsd_aligned(double a, double theta, doubl
     return (t > (3 * LSD_PI) / 2 ? t2 : t) <= prec;
 }
 
+template <bool CP>
 static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size, double &reg_angle, double prec)
 {
     const int lane = threadIdx.x, sw = S.sw, sh = S.sh;
     const int sx0 = seed_xy & 0xFFFF, sy0 = seed_xy >> 16;
-    const double a0 = S.px4[sx0 + sy0 * sw].x;
+    const double a0 = S.px4[rec_index<CP>(S, sx0, sy0)].x;
     double ra = a0;
+    // one argument reduction for both (once per seed, 890 seeds per frame) where registers are free: the lone-frame kernel gains 5 %,
+    // the batch kernels lose a wave per SIMD to sincos' 16 registers
     double s0_, c0_;
-    sincos(a0, &s0_, &c0_);                                   // one argument reduction for both (once per seed: 890 seeds per frame)
+    if (S.lm) sincos(a0, &s0_, &c0_); else { c0_ = cos(a0); s0_ = sin(a0); }
     float sumdx = (float)c0_, sumdy = (float)s0_;
     if (lane == 0) { S.reg[0] = seed_xy; S.ring[0] = seed_xy; used_set(S, sx0, sy0); }
     int rs = 1;
@@ -332,7 +409,7 @@ static __device__ void region_grow_wave(GrowState &S, int seed_xy, int &reg_size
                 // real candidates fetch their record (angle, cos, sin in one 32-byte access)
                 const bool inb = (unsigned)xx < (unsigned)sw && (unsigned)yy < (unsigned)sh;
                 if (inb & !used_get(S, inb ? xx : 0, inb ? yy : 0)) {
-                    const double4 r = S.px4[xx + yy * sw];
+                    const double4 r = S.px4[rec_index<CP>(S, xx, yy)];
                     c[s] = (yy << 16) | xx; an[s] = r.x; cs[s] = r.y; sn[s] = r.z; valid[s] = true;
                 }
             }
@@ -439,10 +516,11 @@ static __device__ __forceinline__ void seq_add_lanes(const double *mine, int n, 
     for (; q < n; q++) acc += mine[q];
 }
 
+template <bool CP>
 static __device__ void region2rect_wave(const GrowState &S, int reg_size, double reg_angle, double prec, Rect &rec,
                                         double *b0, double *b1, double *b2)
 {
-    const int lane = threadIdx.x, sw = S.sw;
+    const int lane = threadIdx.x;
     // weighted centroid: x += px*w; y += py*w; sum += w   (region order)
     const double *mine = lane == 0 ? b0 : lane == 1 ? b1 : b2;
     int a_first = 0; double w_first = 0;
@@ -451,7 +529,7 @@ static __device__ void region2rect_wave(const GrowState &S, int reg_size, double
         const int i = base + lane;
         double t0 = 0, t1 = 0, t2 = 0;
         if (i < reg_size) {
-            const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; const double wgt = S.px4[px + py * sw].w; t0 = (double)px * wgt; t1 = (double)py * wgt; t2 = wgt;
+            const int a = S.reg[i]; const int px = a & 0xFFFF, py = a >> 16; const double wgt = S.px4[rec_index<CP>(S, px, py)].w; t0 = (double)px * wgt; t1 = (double)py * wgt; t2 = wgt;
             if (base == 0) { a_first = a; w_first = wgt; }     // the first 64 points stay in registers for the second pass
         }
         b0[lane] = t0; b1[lane] = t1; b2[lane] = t2;
@@ -468,7 +546,7 @@ static __device__ void region2rect_wave(const GrowState &S, int reg_size, double
         double t0 = 0, t1 = 0, t2 = 0;
         if (i < reg_size) {
             int a = a_first; double wgt = w_first;
-            if (base != 0) { a = S.reg[i]; wgt = S.px4[(a & 0xFFFF) + (a >> 16) * sw].w; }
+            if (base != 0) { a = S.reg[i]; wgt = S.px4[rec_index<CP>(S, a & 0xFFFF, a >> 16)].w; }
             const int px = a & 0xFFFF, py = a >> 16;
             const double dx = (double)px - x, dy = (double)py - y;
             t0 = dy * dy * wgt; t1 = dx * dx * wgt; t2 = -(dx * dy * wgt);      // a -= b  ==  a += (-b), exactly
@@ -515,15 +593,16 @@ static __device__ __forceinline__ double rect_density(const Rect &r, int reg_siz
 }
 
 // refine + reduce_region_radius (LSD_REFINE_STD).  Returns false when the region is rejected.
+template <bool CP>
 static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle, double prec, Rect &rec, double density_th,
                                    double *b0, double *b1, double *b2, int *n_addr)
 {
-    const int lane = threadIdx.x, sw = S.sw;
+    const int lane = threadIdx.x;
     double density = rect_density(rec, reg_size);
     if (density >= density_th) return true;
     const int a0 = S.reg[0];
     const double xc = (double)(a0 & 0xFFFF), yc = (double)(a0 >> 16);
-    const double ang_c = S.px4[(a0 & 0xFFFF) + (a0 >> 16) * sw].x;
+    const double ang_c = S.px4[rec_index<CP>(S, a0 & 0xFFFF, a0 >> 16)].x;
     const double *mine = lane == 0 ? b0 : b1;
     double acc = 0; int n = 0;                                // lanes 0, 1: sum, s_sum
     for (int base = 0; base < reg_size; base += 64) {
@@ -534,7 +613,7 @@ static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle
             n_addr[lane] = a;
             const double ddx = (double)px - xc, ddy = (double)py - yc;
             if (sqrt(ddx * ddx + ddy * ddy) < rec.width) {
-                const double ang_d = angle_diff_signed(S.px4[px + py * sw].x, ang_c);
+                const double ang_d = angle_diff_signed(S.px4[rec_index<CP>(S, px, py)].x, ang_c);
                 t0 = ang_d; t1 = ang_d * ang_d; in = true;
             }
         }
@@ -552,9 +631,9 @@ static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle
         tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
     }
     tau = __shfl(tau, 0);
-    region_grow_wave(S, a0, reg_size, reg_angle, tau);
+    region_grow_wave<CP>(S, a0, reg_size, reg_angle, tau);
     if (reg_size < 2) return false;
-    region2rect_wave(S, reg_size, reg_angle, prec, rec, b0, b1, b2);
+    region2rect_wave<CP>(S, reg_size, reg_angle, prec, rec, b0, b1, b2);
     density = rect_density(rec, reg_size);
     if (density >= density_th) return true;
     // reduce_region_radius
@@ -582,7 +661,7 @@ static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle
         reg_size = __shfl(reg_size, 0);
         __syncthreads();
         if (reg_size < 2) return false;
-        region2rect_wave(S, reg_size, reg_angle, prec, rec, b0, b1, b2);
+        region2rect_wave<CP>(S, reg_size, reg_angle, prec, rec, b0, b1, b2);
         density = rect_density(rec, reg_size);
     }
     return true;
@@ -616,7 +695,7 @@ static __device__ int cull_line_count(int w, int h, float fx1, float fy1, float 
 }
 
 // The kernel body; two kernels wrap it (below).
-template <bool LM>
+template <bool LM, bool CP>
 static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
 {
     __shared__ double b0[64], b1[64], b2[64];
@@ -626,7 +705,11 @@ static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
     const int sw = g.sw, sh = g.sh, wpr = (sw + 31) / 32, nwords = g.nwords;
     const size_t np = (size_t)sw * sh;
     GrowState S;
-    S.px4 = g.px4 + f * np;
+    S.px4 = g.px4 + f * np; S.defmask = nullptr; S.wprefix = nullptr;
+    if (CP) {                                                  // (a frame whose records found no room: lsd_run has grown the pool and come again before this kernel runs)
+        const long long fb = g.fbase[f];
+        S.px4 = g.px4 + (fb < 0 ? 0 : fb); S.defmask = g.defmask + (size_t)f * nwords; S.wprefix = g.wprefix + (size_t)f * nwords;
+    }
     S.reg = g.reg + f * np; S.avail = g.avail + (size_t)f * nwords; S.ring = ring; S.sw = sw; S.sh = sh; S.wpr = wpr; S.lm = LM;
     if (LM) {
         for (int i = lane; i < nwords; i += 64) lsd_lds_mask[i] = S.avail[i];
@@ -655,14 +738,14 @@ static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
             const int seed = (sy << 16) | sx;
             int reg_size; double reg_angle = 0;
             long long t0 = wall_clock64();
-            region_grow_wave(S, seed, reg_size, reg_angle, g.prec);
+            region_grow_wave<CP>(S, seed, reg_size, reg_angle, g.prec);
             long long t1 = wall_clock64(); st_tg += t1 - t0; st_seeds++; st_pts += reg_size;
             if ((unsigned)reg_size < g.min_reg) continue;
             st_big++;
             Rect rec;
-            region2rect_wave(S, reg_size, reg_angle, g.prec, rec, b0, b1, b2);
+            region2rect_wave<CP>(S, reg_size, reg_angle, g.prec, rec, b0, b1, b2);
             long long t2 = wall_clock64(); st_tr += t2 - t1;
-            const bool okr = refine_wave(S, reg_size, reg_angle, g.prec, rec, 0.7, b0, b1, b2, n_addr);
+            const bool okr = refine_wave<CP>(S, reg_size, reg_angle, g.prec, rec, 0.7, b0, b1, b2, n_addr);
             st_tf += wall_clock64() - t2;
             if (!okr) continue;
             if (nseg < LSD_MAXSEG) {
@@ -739,13 +822,16 @@ static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
 // k_lsd_grow_dense: eight waves per SIMD (64 VGPRs, some spills): the kernel is one dependent chain per frame, so frames in
 // flight are its only source of throughput once a batch fills the wave slots; measured 69 -> 58 ms per 8192 frames, but
 // 12 -> 18 ms for a lone frame -- hence two kernels and a choice by batch size (lsd_run).
-__global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g) { lsd_grow_body<false>(g); }
-__global__ __launch_bounds__(64) void k_lsd_grow_lat(GrowArgs g) { lsd_grow_body<true>(g); }
+__global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g) { lsd_grow_body<false, false>(g); }
+__global__ __launch_bounds__(64) void k_lsd_grow_lat(GrowArgs g) { lsd_grow_body<true, false>(g); }
+__global__ __launch_bounds__(64) void k_lsd_grow_c(GrowArgs g) { lsd_grow_body<false, true>(g); }       // compact records
 #ifndef HVO_WPE_GROW
 #define HVO_WPE_GROW 8
 #endif
 __attribute__((amdgpu_waves_per_eu(HVO_WPE_GROW)))
-__global__ __launch_bounds__(64) void k_lsd_grow_dense(GrowArgs g) { lsd_grow_body<false>(g); }
+__global__ __launch_bounds__(64) void k_lsd_grow_dense(GrowArgs g) { lsd_grow_body<false, false>(g); }
+__attribute__((amdgpu_waves_per_eu(HVO_WPE_GROW)))
+__global__ __launch_bounds__(64) void k_lsd_grow_dense_c(GrowArgs g) { lsd_grow_body<false, true>(g); }
 
 // ------------------------------------------------------------------------------------------------
 // LBD: blur 5x5 (u8 fixed point, same rounding rules as the ORB blur), Sobel, descriptor
@@ -1185,7 +1271,8 @@ void lsd_free(hvo_ctx *ctx)
     LsdPlan *P = plan_of(ctx);
     if (!P) return;
     void *ptrs[] = { P->d_kl2, P->d_desc2, P->d_fn2, P->d_nkl2, P->d_blur, P->d_px, P->d_defined, P->d_reg, P->d_segs, P->d_kl_all, P->d_kl,
-                     P->d_desc, P->d_fn, P->d_nkl, P->d_flags, P->d_b5, P->d_dxy, P->d_xofs, P->d_yofs, P->d_xa, P->d_yb, P->d_gL, P->d_gG, P->d_stats };
+                     P->d_desc, P->d_fn, P->d_nkl, P->d_flags, P->d_b5, P->d_dxy, P->d_xofs, P->d_yofs, P->d_xa, P->d_yb, P->d_gL, P->d_gG, P->d_stats,
+                     P->d_pool, P->d_defmask, P->d_wprefix, P->d_fbase, P->d_fcount, P->d_pooltop };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
     ctx->lsd = nullptr;
@@ -1258,9 +1345,29 @@ static int lsd_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     // k_lbd_desc) exist for a CHUNK of the batch only: lsd_run walks the batch chunk by chunk through those kernels (3.7 MB per frame saved)
     P->chunk = (int)std::min<size_t>(B, 512);
     { const char *e = getenv("HVO_LSD_CHUNK"); if (e && atoi(e) > 0) P->chunk = (int)std::min<size_t>(B, (size_t)atoi(e)); }
+    // compact records (HVO_LSD_COMPACT): the dense record image exists for a chunk only
+    // (at most ~3.3 GB of it), the batch keeps a pool sized for HVO_LSD_COMPACT_FRAC of the pixels (lsd_run grows it when a batch asks for more)
+    // Opt-in (HVO_LSD_COMPACT=1): it buys memory, not time.  Measured: 22.1 -> 18.0 MB per 640x480 frame for 5 % of the step (the compaction
+    // pass and the longer index arithmetic of an issue-bound kernel); 1280x960: 78 -> ~60 MB, 4096 frames resident instead of 3072, but
+    // 8.5 k frames/s at 4096 against 8.95 k at 3072 with one record per pixel -- the wave slots are full by then.
+    P->compact = false;
+    { const char *e = getenv("HVO_LSD_COMPACT"); if (e) P->compact = atoi(e) != 0; }
+    double frac = 0.27;
+    { const char *e = getenv("HVO_LSD_COMPACT_FRAC"); if (e && atof(e) > 0) frac = std::min(1.0, atof(e)); }
+    if (P->compact) {
+        const size_t fit = std::max<size_t>(64, (size_t)(3.3e9 / (double)(nsp * sizeof(double4))) / 64 * 64);
+        P->chunk = (int)std::min<size_t>((size_t)P->chunk, std::min<size_t>(fit, 512));
+    }
     const size_t CB = (size_t)P->chunk;
     PA(P->d_blur, CB * npix * 8);
-    PA(P->d_px, B * nsp * sizeof(double4));
+    if (P->compact) {
+        PA(P->d_px, CB * nsp * sizeof(double4));
+        P->pool_cap = std::max<size_t>((size_t)((double)(B * nsp) * frac), 4096);
+        PA(P->d_pool, P->pool_cap * sizeof(double4));
+        PA(P->d_defmask, B * P->nwords * 4); PA(P->d_wprefix, B * P->nwords * 4);
+        PA(P->d_fbase, B * 8); PA(P->d_fcount, B * 4); PA(P->d_pooltop, 16);
+    } else
+        PA(P->d_px, B * nsp * sizeof(double4));
     PA(P->d_defined, B * P->nwords * 4); PA(P->d_reg, B * nsp * 4);
     PA(P->d_segs, B * LSD_MAXSEG * 16); PA(P->d_kl_all, B * LSD_MAXSEG * sizeof(hvo_keyline));
     PA(P->d_kl, B * P->nfeat * sizeof(hvo_keyline)); PA(P->d_desc, B * P->nfeat * 32); PA(P->d_fn, B * P->nfeat * 24);
@@ -1310,30 +1417,52 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     int id;
     const size_t nsp = (size_t)sw * sh;
     const int gx = (((sw + 31) & ~31) + 255) / 256;
-    for (int c0 = 0; c0 < n; c0 += P->chunk) {
-        const int m = std::min(P->chunk, n - c0);
-        id = hvo_prof_begin(ctx, "lsd_blur_scale", st);
-        hipLaunchKernelGGL(k_lsd_blur, dim3((w + 255) / 256, (h + LSD_BLUR_ROWS - 1) / LSD_BLUR_ROWS, m), dim3(256), 0, st, gray + (size_t)c0 * O.pyr_bytes, O.pyr_bytes, gpitch, P->d_blur, w, h,
-                           P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
-        hvo_prof_end(ctx, id);
-        id = hvo_prof_begin(ctx, "lsd_gradient", st);
-        hipLaunchKernelGGL(k_lsd_resize_grad, dim3(gx, (sh + GRAD_ROWS - 1) / GRAD_ROWS, m), dim3(256), 0, st, P->d_blur, w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb,
-                           P->d_px + (size_t)c0 * nsp, P->d_defined + (size_t)c0 * P->nwords, P->nwords, P->rho);
-        hvo_prof_end(ctx, id);
+    for (int attempt = 0; attempt < 3; attempt++) {
+        if (P->compact) HVO_HIP(hipMemsetAsync(P->d_pooltop, 0, 16, st));
+        for (int c0 = 0; c0 < n; c0 += P->chunk) {
+            const int m = std::min(P->chunk, n - c0);
+            id = hvo_prof_begin(ctx, "lsd_blur_scale", st);
+            hipLaunchKernelGGL(k_lsd_blur, dim3((w + 255) / 256, (h + LSD_BLUR_ROWS - 1) / LSD_BLUR_ROWS, m), dim3(256), 0, st, gray + (size_t)c0 * O.pyr_bytes, O.pyr_bytes, gpitch, P->d_blur, w, h,
+                               P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
+            hvo_prof_end(ctx, id);
+            id = hvo_prof_begin(ctx, "lsd_gradient", st);
+            hipLaunchKernelGGL(k_lsd_resize_grad, dim3(gx, (sh + GRAD_ROWS - 1) / GRAD_ROWS, m), dim3(256), 0, st, P->d_blur, w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb,
+                               P->d_px + (P->compact ? 0 : (size_t)c0 * nsp), P->d_defined + (size_t)c0 * P->nwords, P->nwords, P->rho);
+            if (P->compact) {
+                hipLaunchKernelGGL(k_lsd_prefix, dim3(m), dim3(256), 0, st, P->d_defined + (size_t)c0 * P->nwords, P->d_defmask + (size_t)c0 * P->nwords,
+                                   P->d_wprefix + (size_t)c0 * P->nwords, P->d_fcount + c0, P->nwords);
+                hipLaunchKernelGGL(k_lsd_bases, dim3(1), dim3(512), 0, st, P->d_fcount + c0, m, P->d_fbase + c0, P->d_pooltop, (unsigned long long)P->pool_cap);
+                hipLaunchKernelGGL(k_lsd_compact, dim3(std::min((P->nwords + 255) / 256, 16), m), dim3(256), 0, st, P->d_px, nsp, P->d_defmask + (size_t)c0 * P->nwords,
+                                   P->d_wprefix + (size_t)c0 * P->nwords, P->d_fbase + c0, P->d_pool, P->nwords, sw, (sw + 31) / 32);
+            }
+            hvo_prof_end(ctx, id);
+        }
+        if (!P->compact) break;
+        // Does the pool hold what the batch asked for?  One host wait on this stream (the other stages are enqueued and running; the growing
+        // kernel waits for FAST under the large-batch policies anyway).  If not: a larger pool, and the preamble once more.
+        unsigned long long need = 0;
+        HVO_HIP(hipMemcpyAsync(&need, P->d_pooltop, 8, hipMemcpyDeviceToHost, st));
+        HVO_HIP(hipStreamSynchronize(st));
+        if (need <= P->pool_cap) break;
+        if (attempt == 2) return HVO_ERR_CAPACITY;
+        HVO_HIP(hipFree(P->d_pool)); P->d_pool = nullptr;
+        P->pool_cap = (size_t)((double)need * 1.1) + 4096;
+        HVO_HIP(hipMalloc((void **)&P->d_pool, P->pool_cap * sizeof(double4)));
     }
     if (ctx->ev_lsd_pre && !ctx->serialize) { HVO_HIP(hipEventRecord(ctx->ev_lsd_pre, st)); ctx->lsd_pre_recorded = true; }
     if ((ctx->sched == 2 || ctx->sched == 5 || ctx->sched == 6) && ctx->fast_recorded && !ctx->serialize) HVO_HIP(hipStreamWaitEvent(st, ctx->ev_fast, 0));
     id = hvo_prof_begin(ctx, "lsd_grow", st);
     GrowArgs g;
-    g.px4 = P->d_px; g.avail = P->d_defined; g.reg = P->d_reg; g.segs = P->d_segs; g.perm = hvo_frame_perm(ctx, n);
+    g.px4 = P->compact ? P->d_pool : P->d_px; g.avail = P->d_defined; g.reg = P->d_reg; g.segs = P->d_segs; g.perm = hvo_frame_perm(ctx, n);
+    g.defmask = P->d_defmask; g.wprefix = P->d_wprefix; g.fbase = P->d_fbase;
     g.stats = P->d_stats; g.kl_all = P->d_kl_all; g.kl = P->d_kl; g.fn = P->d_fn; g.nkl = P->d_nkl; g.flags = P->d_flags;
     g.sw = sw; g.sh = sh; g.nwords = P->nwords; g.w = w; g.h = h; g.nfeat = P->nfeat; g.kl_cap = P->nfeat;
     g.rho = P->rho; g.prec = P->prec; g.p = P->p; g.min_reg = P->min_reg;
     bool dense = n > 5 * 1024;
     { const char *e = getenv("HVO_LSD_DENSE"); if (e) dense = atoi(e) != 0; }              // tests force either kernel on small batches
     // a handful of frames (the streamed mode, a tracker's small batches): the latency variant with the mask in LDS
-    bool lat = n <= 64 && (size_t)P->nwords * 4 <= 150 * 1024;
-    { const char *e = getenv("HVO_LSD_LAT"); if (e) lat = atoi(e) != 0 && (size_t)P->nwords * 4 <= 150 * 1024; }
+    bool lat = n <= 64 && (size_t)P->nwords * 4 <= 150 * 1024 && !P->compact;
+    { const char *e = getenv("HVO_LSD_LAT"); if (e) lat = atoi(e) != 0 && (size_t)P->nwords * 4 <= 150 * 1024 && !P->compact; }
     if (lat) {
         // The LDS request also keeps this one-wave workgroup off the CUs where a frame's five AHC waves sit (k_peac_cluster_heads takes
         // 108 KB): both are bound by instruction issue and a shared SIMD slows both (HVO_LSD_LAT_LDS: bytes requested at least [56 K])
@@ -1343,6 +1472,9 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
         static size_t lat_lds_set = 0;
         if (lds > 48 * 1024 && lds > lat_lds_set) { HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lsd_grow_lat), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); lat_lds_set = lds; }
         hipLaunchKernelGGL(k_lsd_grow_lat, dim3(n), dim3(64), lds, st, g);
+    } else if (P->compact) {
+        if (dense) hipLaunchKernelGGL(k_lsd_grow_dense_c, dim3(n), dim3(64), 0, st, g);
+        else hipLaunchKernelGGL(k_lsd_grow_c, dim3(n), dim3(64), 0, st, g);
     } else if (dense) hipLaunchKernelGGL(k_lsd_grow_dense, dim3(n), dim3(64), 0, st, g);     // more frames than five waves per SIMD hold
     else hipLaunchKernelGGL(k_lsd_grow, dim3(n), dim3(64), 0, st, g);
     hvo_prof_end(ctx, id);

@@ -46,6 +46,32 @@ def test_lines_both_grow_kernels(hvo, orc, synth, monkeypatch, dense):
         check(res[b]["kl"], res[b]["ldesc"], res[b]["linefn"], kl_o, d_o, fn_o)
 
 
+@pytest.mark.parametrize("dense,frac,chunk", [("0", None, None), ("1", None, "2"), ("0", "0.01", None)])
+def test_lines_compact_records(hvo, orc, synth, monkeypatch, dense, frac, chunk):
+    """Plans of large resident batches keep a 32-byte record only for the pixels that have a gradient angle (k_lsd_prefix / _bases / _compact;
+    the growing kernels reach them through the defined mask's prefix counts).  HVO_LSD_COMPACT forces the layout on a small batch: both growing
+    kernels, chunks smaller than the batch, an odd geometry, and a pool far too small (HVO_LSD_COMPACT_FRAC: lsd_run must grow it and come again)."""
+    monkeypatch.setenv("HVO_LSD_COMPACT", "1")
+    monkeypatch.setenv("HVO_LSD_DENSE", dense)
+    if frac: monkeypatch.setenv("HVO_LSD_COMPACT_FRAC", frac)
+    if chunk: monkeypatch.setenv("HVO_LSD_CHUNK", chunk)
+    for hh, ww in ((480, 640), (397, 501)):
+        g = np.stack([synth.make_gray(k, s)[:hh, :ww] for k, s in (("std", 0x5EED0002), ("lowtex", 0x5EED0001), ("std", 0x5EED1003), ("std", 9), ("std", 0x5EED1001))])
+        g = np.ascontiguousarray(g)
+        ctx = hvo.Context(max_batch=5)
+        try:
+            ctx.batch_upload(g, np.zeros((5, hh, ww), np.uint16))
+            for _ in range(2):                                    # the second run starts from the pool the first one left
+                ctx.batch_run(hvo.STAGE_LSD)
+                res = ctx.batch_download(hvo.STAGE_LSD)
+                for b in range(5):
+                    kl_o, d_o, fn_o = orc.line_extract(g[b])
+                    assert res[b]["status"] == 0
+                    check(res[b]["kl"], res[b]["ldesc"], res[b]["linefn"], kl_o, d_o, fn_o)
+        finally:
+            ctx.close()
+
+
 @pytest.mark.parametrize("hh,ww", [(397, 501), (479, 638), (400, 642)])
 def test_lines_odd_geometry(hvo, orc, synth, hh, ww):
     """widths that are not a multiple of 4 (scalar tails of the LBD blur / Sobel strips, unaligned Sobel rows) and lines
