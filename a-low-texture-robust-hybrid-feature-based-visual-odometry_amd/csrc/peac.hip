@@ -1483,31 +1483,59 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
         }
         simok[tid] = m;
     }
-    // ---- seeds in block raster order: count, scan, write (wave 0) ----
-    if (wv == 0) {
-        int nq = 0;
-        for (int base = 0; base < nblk; base += 64) {
-            const int b = base + lane;
-            int cnt = 0, m = -2, up = -2, lf = -2, i = 0, j = 0;
-            if (b < nblk) {
-                i = b / Nw; j = b - i * Nw; m = blkmap[b];
-                up = i > 0 ? blkmap[b - Nw] : -2; lf = j > 0 ? blkmap[b - 1] : -2;
-                if (m < 0) { if (i > 0 && up >= 0) cnt += WIN - 1; if (j > 0 && lf >= 0) cnt += WIN - 1; }
-                else { if (i > 0 && up != m) cnt += WIN - 1; if (j > 0 && lf != m) cnt += WIN - 1; }
+    // ---- seeds in block raster order: count, scan, write.  One wave per frame walks the blocks 64 at a time; a workgroup of several waves
+    //      (small batches) deals the groups of 64 out, counts first, and every wave places its groups behind the totals of the groups before ----
+    constexpr int SEED_MAXG = 256;                           // groups of 64 blocks the parallel form holds (16384 blocks)
+    __shared__ int gtot[NW > 1 ? SEED_MAXG : 1];
+    auto seed_count = [&](int b, int &m, int &up, int &lf, int &i, int &j) {
+        int cnt = 0; m = -2; up = -2; lf = -2; i = 0; j = 0;
+        if (b < nblk) {
+            i = b / Nw; j = b - i * Nw; m = blkmap[b];
+            up = i > 0 ? blkmap[b - Nw] : -2; lf = j > 0 ? blkmap[b - 1] : -2;
+            if (m < 0) { if (i > 0 && up >= 0) cnt += WIN - 1; if (j > 0 && lf >= 0) cnt += WIN - 1; }
+            else { if (i > 0 && up != m) cnt += WIN - 1; if (j > 0 && lf != m) cnt += WIN - 1; }
+        }
+        return cnt;
+    };
+    auto seed_write = [&](int pos, int cnt, int m, int up, int lf, int i, int j) {
+        if (cnt && pos + cnt <= r.qcap) {
+            const int x0 = j * WIN, y0 = i * WIN;
+            if (m < 0) {
+                if (i > 0 && up >= 0) for (int k = 1; k < WIN; ++k) queue[pos++] = FQ_PACK(x0 + k, y0 - 1, up);
+                if (j > 0 && lf >= 0) for (int k = 0; k < WIN - 1; ++k) queue[pos++] = FQ_PACK(x0 - 1, y0 + k, lf);
+            } else {
+                if (i > 0 && up != m) for (int k = 0; k < WIN - 1; ++k) queue[pos++] = FQ_PACK(x0 + k, y0, m);
+                if (j > 0 && lf != m) for (int k = 1; k < WIN; ++k) queue[pos++] = FQ_PACK(x0, y0 + k, m);
             }
+        }
+    };
+    const int ngrp = (nblk + 63) / 64;
+    if (NW > 1 && ngrp <= SEED_MAXG) {
+        for (int g = wv; g < ngrp; g += NW) {
+            int m, up, lf, i, j;
+            int incl = seed_count(g * 64 + lane, m, up, lf, i, j);
+            for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            if (lane == 63) gtot[g] = incl;
+        }
+        __syncthreads();
+        int before = 0, gdone = 0;                           // records of the groups before g (this wave's groups come in ascending order)
+        for (int g = wv; g < ngrp; g += NW) {
+            for (; gdone < g; gdone++) before += gtot[gdone];
+            int m, up, lf, i, j;
+            const int cnt = seed_count(g * 64 + lane, m, up, lf, i, j);
             int incl = cnt;
             for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-            int pos = nq + incl - cnt;
-            if (cnt && pos + cnt <= r.qcap) {
-                const int x0 = j * WIN, y0 = i * WIN;
-                if (m < 0) {
-                    if (i > 0 && up >= 0) for (int k = 1; k < WIN; ++k) queue[pos++] = FQ_PACK(x0 + k, y0 - 1, up);
-                    if (j > 0 && lf >= 0) for (int k = 0; k < WIN - 1; ++k) queue[pos++] = FQ_PACK(x0 - 1, y0 + k, lf);
-                } else {
-                    if (i > 0 && up != m) for (int k = 0; k < WIN - 1; ++k) queue[pos++] = FQ_PACK(x0 + k, y0, m);
-                    if (j > 0 && lf != m) for (int k = 1; k < WIN; ++k) queue[pos++] = FQ_PACK(x0, y0 + k, m);
-                }
-            }
+            seed_write(before + incl - cnt, cnt, m, up, lf, i, j);
+        }
+        if (tid == 0) { int t = 0; for (int g = 0; g < ngrp; g++) t += gtot[g]; s_nq = t; }
+    } else if (wv == 0) {
+        int nq = 0;
+        for (int base = 0; base < nblk; base += 64) {
+            int m, up, lf, i, j;
+            const int cnt = seed_count(base + lane, m, up, lf, i, j);
+            int incl = cnt;
+            for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            seed_write(nq + incl - cnt, cnt, m, up, lf, i, j);
             nq += __shfl(incl, 63);
         }
         if (lane == 0) s_nq = nq;
