@@ -61,6 +61,8 @@ struct LsdPlan {
     float *d_gL = nullptr, *d_gG = nullptr;
     double rho = 0, prec = 0, p = 0; unsigned min_reg = 0;
     long long *d_stats = nullptr;      // per frame 8 counters (diagnostics: hvo_debug_lsd_stats)
+    // k_lsd_grow_async (lsd_async.inc), allocated at its first launch for the first `async_b` frames of the plan
+    int async_b = 0; unsigned *d_atags = nullptr; void *d_actl = nullptr; int *d_alists = nullptr, *d_ablk = nullptr, *d_afreg = nullptr;
 };
 static LsdPlan *plan_of(hvo_ctx *ctx) { return (LsdPlan *)ctx->lsd; }
 
@@ -694,6 +696,61 @@ static __device__ int cull_line_count(int w, int h, float fx1, float fy1, float 
     return (int)((dx > dy ? dx : dy) + 1);
 }
 
+// The end of a frame's detection, by ONE wave: KeyLines of the segments (detection order), the nfeat strongest, the line functions.
+// Returns the number of key lines kept.
+static __device__ __forceinline__ int lsd_emit_keylines(const GrowArgs &g, int f, const float *segs, int nseg, int &flags)
+{
+    const int lane = threadIdx.x & 63;
+    __syncthreads();
+    // ---- KeyLines (LSDDetector_custom.cpp:161-196) ----
+    hvo_keyline *all = g.kl_all + (size_t)f * LSD_MAXSEG;
+    const int w = g.w, h = g.h;
+    for (int i = lane; i < nseg; i += 64) {
+        float e0 = segs[4 * i], e1 = segs[4 * i + 1], e2 = segs[4 * i + 2], e3 = segs[4 * i + 3];
+        if (e0 < 0) e0 = 0; if (e0 >= w) e0 = (float)w - 1.0f;
+        if (e2 < 0) e2 = 0; if (e2 >= w) e2 = (float)w - 1.0f;
+        if (e1 < 0) e1 = 0; if (e1 >= h) e1 = (float)h - 1.0f;
+        if (e3 < 0) e3 = 0; if (e3 >= h) e3 = (float)h - 1.0f;
+        hvo_keyline kl;
+        kl.sx = e0; kl.sy = e1; kl.ex = e2; kl.ey = e3; kl.sox = e0; kl.soy = e1; kl.eox = e2; kl.eoy = e3;
+        const double ddx = (double)__fsub_rn(e0, e2), ddy = (double)__fsub_rn(e1, e3);
+        kl.length = (float)sqrt(ddx * ddx + ddy * ddy);
+        kl.num_pixels = cull_line_count(g.w, g.h, e0, e1, e2, e3);
+        kl.angle = (float)atan2((double)__fsub_rn(kl.ey, kl.sy), (double)__fsub_rn(kl.ex, kl.sx));
+        kl.class_id = i; kl.octave = 0;
+        kl.size = __fmul_rn(__fsub_rn(kl.ex, kl.sx), __fsub_rn(kl.ey, kl.sy));
+        kl.response = __fdiv_rn(kl.length, (float)(w > h ? w : h));
+        kl.pt_x = __fdiv_rn(__fadd_rn(kl.ex, kl.sx), 2.f); kl.pt_y = __fdiv_rn(__fadd_rn(kl.ey, kl.sy), 2.f);
+        all[i] = kl;
+    }
+    __syncthreads();
+    // ---- keep the nfeat strongest (stable by response desc), class_id = rank ----
+    hvo_keyline *out = g.kl + (size_t)f * g.kl_cap;
+    int n = nseg;
+    if (nseg > g.nfeat) {
+        n = g.nfeat;
+        for (int i = lane; i < nseg; i += 64) {
+            const float r = all[i].response;
+            int rank = 0;
+            for (int q = 0; q < nseg; q++) { const float rq = all[q].response; rank += (rq > r) || (rq == r && q < i); }
+            if (rank < n && rank < g.kl_cap) { hvo_keyline kl = all[i]; kl.class_id = rank; out[rank] = kl; }
+        }
+    } else {
+        for (int i = lane; i < nseg; i += 64) if (i < g.kl_cap) out[i] = all[i];
+    }
+    if (n > g.kl_cap) { n = g.kl_cap; flags |= 2; }
+    __syncthreads();
+    // ---- 2-D line functions (LineExtractor.cpp:367-377) ----
+    double *fn = g.fn + (size_t)f * g.kl_cap * 3;
+    for (int i = lane; i < n; i += 64) {
+        const double sx = out[i].sx, sy = out[i].sy, ex = out[i].ex, ey = out[i].ey;
+        const double l0 = sy * 1.0 - 1.0 * ey, l1 = 1.0 * ex - sx * 1.0, l2 = sx * ey - sy * ex;
+        const double nrm = sqrt(l0 * l0 + l1 * l1);
+        fn[3 * i] = l0 / nrm; fn[3 * i + 1] = l1 / nrm; fn[3 * i + 2] = l2 / nrm;
+    }
+    return n;
+}
+
 // The kernel body; two kernels wrap it (below).
 template <bool LM, bool CP>
 static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
@@ -758,53 +815,7 @@ static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
             } else flags |= 1;
         }
     }
-    __syncthreads();
-    // ---- KeyLines (LSDDetector_custom.cpp:161-196) ----
-    hvo_keyline *all = g.kl_all + (size_t)f * LSD_MAXSEG;
-    const int w = g.w, h = g.h;
-    for (int i = lane; i < nseg; i += 64) {
-        float e0 = segs[4 * i], e1 = segs[4 * i + 1], e2 = segs[4 * i + 2], e3 = segs[4 * i + 3];
-        if (e0 < 0) e0 = 0; if (e0 >= w) e0 = (float)w - 1.0f;
-        if (e2 < 0) e2 = 0; if (e2 >= w) e2 = (float)w - 1.0f;
-        if (e1 < 0) e1 = 0; if (e1 >= h) e1 = (float)h - 1.0f;
-        if (e3 < 0) e3 = 0; if (e3 >= h) e3 = (float)h - 1.0f;
-        hvo_keyline kl;
-        kl.sx = e0; kl.sy = e1; kl.ex = e2; kl.ey = e3; kl.sox = e0; kl.soy = e1; kl.eox = e2; kl.eoy = e3;
-        const double ddx = (double)__fsub_rn(e0, e2), ddy = (double)__fsub_rn(e1, e3);
-        kl.length = (float)sqrt(ddx * ddx + ddy * ddy);
-        kl.num_pixels = cull_line_count(g.w, g.h, e0, e1, e2, e3);
-        kl.angle = (float)atan2((double)__fsub_rn(kl.ey, kl.sy), (double)__fsub_rn(kl.ex, kl.sx));
-        kl.class_id = i; kl.octave = 0;
-        kl.size = __fmul_rn(__fsub_rn(kl.ex, kl.sx), __fsub_rn(kl.ey, kl.sy));
-        kl.response = __fdiv_rn(kl.length, (float)(w > h ? w : h));
-        kl.pt_x = __fdiv_rn(__fadd_rn(kl.ex, kl.sx), 2.f); kl.pt_y = __fdiv_rn(__fadd_rn(kl.ey, kl.sy), 2.f);
-        all[i] = kl;
-    }
-    __syncthreads();
-    // ---- keep the nfeat strongest (stable by response desc), class_id = rank ----
-    hvo_keyline *out = g.kl + (size_t)f * g.kl_cap;
-    int n = nseg;
-    if (nseg > g.nfeat) {
-        n = g.nfeat;
-        for (int i = lane; i < nseg; i += 64) {
-            const float r = all[i].response;
-            int rank = 0;
-            for (int q = 0; q < nseg; q++) { const float rq = all[q].response; rank += (rq > r) || (rq == r && q < i); }
-            if (rank < n && rank < g.kl_cap) { hvo_keyline kl = all[i]; kl.class_id = rank; out[rank] = kl; }
-        }
-    } else {
-        for (int i = lane; i < nseg; i += 64) if (i < g.kl_cap) out[i] = all[i];
-    }
-    if (n > g.kl_cap) { n = g.kl_cap; flags |= 2; }
-    __syncthreads();
-    // ---- 2-D line functions (LineExtractor.cpp:367-377) ----
-    double *fn = g.fn + (size_t)f * g.kl_cap * 3;
-    for (int i = lane; i < n; i += 64) {
-        const double sx = out[i].sx, sy = out[i].sy, ex = out[i].ex, ey = out[i].ey;
-        const double l0 = sy * 1.0 - 1.0 * ey, l1 = 1.0 * ex - sx * 1.0, l2 = sx * ey - sy * ex;
-        const double nrm = sqrt(l0 * l0 + l1 * l1);
-        fn[3 * i] = l0 / nrm; fn[3 * i + 1] = l1 / nrm; fn[3 * i + 2] = l2 / nrm;
-    }
+    const int n = lsd_emit_keylines(g, f, segs, nseg, flags);
     if (lane == 0) {
         g.nkl[f] = n; g.flags[f] = flags;
         long long *st = g.stats + (size_t)f * 8;
@@ -832,6 +843,8 @@ __attribute__((amdgpu_waves_per_eu(HVO_WPE_GROW)))
 __global__ __launch_bounds__(64) void k_lsd_grow_dense(GrowArgs g) { lsd_grow_body<false, false>(g); }
 __attribute__((amdgpu_waves_per_eu(HVO_WPE_GROW)))
 __global__ __launch_bounds__(64) void k_lsd_grow_dense_c(GrowArgs g) { lsd_grow_body<false, true>(g); }
+
+#include "lsd_async.inc"
 
 // ------------------------------------------------------------------------------------------------
 // LBD: blur 5x5 (u8 fixed point, same rounding rules as the ORB blur), Sobel, descriptor
@@ -1272,7 +1285,7 @@ void lsd_free(hvo_ctx *ctx)
     if (!P) return;
     void *ptrs[] = { P->d_kl2, P->d_desc2, P->d_fn2, P->d_nkl2, P->d_blur, P->d_px, P->d_defined, P->d_reg, P->d_segs, P->d_kl_all, P->d_kl,
                      P->d_desc, P->d_fn, P->d_nkl, P->d_flags, P->d_b5, P->d_dxy, P->d_xofs, P->d_yofs, P->d_xa, P->d_yb, P->d_gL, P->d_gG, P->d_stats,
-                     P->d_pool, P->d_defmask, P->d_wprefix, P->d_fbase, P->d_fcount, P->d_pooltop };
+                     P->d_pool, P->d_defmask, P->d_wprefix, P->d_fbase, P->d_fcount, P->d_pooltop, P->d_atags, P->d_actl, P->d_alists, P->d_ablk, P->d_afreg };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
     ctx->lsd = nullptr;
@@ -1463,7 +1476,29 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     // a handful of frames (the streamed mode, a tracker's small batches): the latency variant with the mask in LDS
     bool lat = n <= 64 && (size_t)P->nwords * 4 <= 150 * 1024 && !P->compact;
     { const char *e = getenv("HVO_LSD_LAT"); if (e) lat = atoi(e) != 0 && (size_t)P->nwords * 4 <= 150 * 1024 && !P->compact; }
-    if (lat) {
+    // a handful of frames: W waves per frame grow regions side by side and commit them in seed order (lsd_async.inc); HVO_LSD_ASYNC = W, 0: off
+    int aw = 0;
+    { const char *e = getenv("HVO_LSD_ASYNC"); if (e) aw = std::min(std::max(atoi(e), 0), LA_MAXW); }
+    if (aw > 0 && n <= 64 && !P->compact) {
+        if (!P->d_atags) {
+            const size_t AB = (size_t)std::min(P->batch, 64);
+            HVO_HIP(hipMalloc((void **)&P->d_atags, AB * P->nwords * 32 * 4)); HVO_HIP(hipMalloc((void **)&P->d_actl, AB * sizeof(LaCtl)));
+            HVO_HIP(hipMalloc((void **)&P->d_alists, AB * LA_MAXW * LA_CAP * 4)); HVO_HIP(hipMalloc((void **)&P->d_ablk, AB * LA_MAXW * 2 * LA_BCAP * 4));
+            HVO_HIP(hipMalloc((void **)&P->d_afreg, AB * 2 * nsp * 4));
+            HVO_HIP(hipMemsetAsync(P->d_atags, 0xFF, AB * P->nwords * 32 * 4, st));      // every region releases its tags: all free between launches
+            P->async_b = (int)AB;
+        }
+        if (n <= P->async_b) {
+            HVO_HIP(hipMemsetAsync(P->d_actl, 0, (size_t)n * sizeof(LaCtl), st));
+            LaArgs a; a.g = g; a.tags = P->d_atags; a.ctl = (LaCtl *)P->d_actl; a.lists = P->d_alists; a.blocked = P->d_ablk; a.freg = P->d_afreg; a.W = aw; a.n = n;
+            bool local = true;                              // a frame's workers on one XCD, L2-local atomics (lsd_async.inc)
+            { const char *e = getenv("HVO_LSD_ASYNC_LOCAL"); if (e) local = atoi(e) != 0; }
+            if (local) hipLaunchKernelGGL(k_lsd_grow_async_xcd, dim3(((n + 7) / 8) * 8 * aw), dim3(64), 0, st, a);
+            else hipLaunchKernelGGL(k_lsd_grow_async, dim3(n * aw), dim3(64), 0, st, a);
+        } else aw = 0;
+    } else aw = 0;
+    if (aw > 0) {
+    } else if (lat) {
         // The LDS request also keeps this one-wave workgroup off the CUs where a frame's five AHC waves sit (k_peac_cluster_heads takes
         // 108 KB): both are bound by instruction issue and a shared SIMD slows both (HVO_LSD_LAT_LDS: bytes requested at least [56 K])
         size_t lds = (size_t)P->nwords * 4, floor_ = 56 * 1024;
@@ -1603,5 +1638,15 @@ extern "C" int hvo_debug_lsd_stats(hvo_ctx *ctx, int frame, long long *out8)
     LsdPlan *P = ctx ? plan_of(ctx) : nullptr;
     if (!P || frame < 0 || frame >= P->batch) return HVO_ERR_INVALID_ARG;
     HVO_HIP(hipMemcpy(out8, P->d_stats + (size_t)frame * 8, 64, hipMemcpyDeviceToHost));
+    return HVO_OK;
+}
+
+// diagnostics (not part of include/hvo.h): the control block k_lsd_grow_async left for `frame` (64 words, struct LaCtl): counters and the
+// workers' summed ticks in dispatch / growing / waiting for the turn / head work / the tail
+extern "C" int hvo_debug_lsd_async(hvo_ctx *ctx, int frame, unsigned *out64)
+{
+    LsdPlan *P = ctx ? plan_of(ctx) : nullptr;
+    if (!P || !P->d_actl || frame < 0 || frame >= P->async_b) return HVO_ERR_INVALID_ARG;
+    HVO_HIP(hipMemcpy(out64, (const char *)P->d_actl + (size_t)frame * sizeof(LaCtl), sizeof(LaCtl), hipMemcpyDeviceToHost));
     return HVO_OK;
 }
