@@ -1477,7 +1477,8 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     bool lat = n <= 64 && (size_t)P->nwords * 4 <= 150 * 1024 && !P->compact;
     { const char *e = getenv("HVO_LSD_LAT"); if (e) lat = atoi(e) != 0 && (size_t)P->nwords * 4 <= 150 * 1024 && !P->compact; }
     // a handful of frames: W waves per frame grow regions side by side and commit them in seed order (lsd_async.inc); HVO_LSD_ASYNC = W, 0: off
-    int aw = 0;
+    // (default: up to 16 frames; at 32 frames the one-wave kernel beside the plane chain is the faster whole, tools/latency.py)
+    int aw = n <= 8 ? 32 : n <= 16 ? 16 : 0;
     { const char *e = getenv("HVO_LSD_ASYNC"); if (e) aw = std::min(std::max(atoi(e), 0), LA_MAXW); }
     if (aw > 0 && n <= 64 && !P->compact) {
         if (!P->d_atags) {
@@ -1490,11 +1491,9 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
         }
         if (n <= P->async_b) {
             HVO_HIP(hipMemsetAsync(P->d_actl, 0, (size_t)n * sizeof(LaCtl), st));
-            LaArgs a; a.g = g; a.tags = P->d_atags; a.ctl = (LaCtl *)P->d_actl; a.lists = P->d_alists; a.blocked = P->d_ablk; a.freg = P->d_afreg; a.W = aw; a.n = n;
-            bool local = true;                              // a frame's workers on one XCD, L2-local atomics (lsd_async.inc)
-            { const char *e = getenv("HVO_LSD_ASYNC_LOCAL"); if (e) local = atoi(e) != 0; }
-            if (local) hipLaunchKernelGGL(k_lsd_grow_async_xcd, dim3(((n + 7) / 8) * 8 * aw), dim3(64), 0, st, a);
-            else hipLaunchKernelGGL(k_lsd_grow_async, dim3(n * aw), dim3(64), 0, st, a);
+            LaArgs a; a.g = g; a.tags = P->d_atags; a.ctl = (LaCtl *)P->d_actl; a.lists = P->d_alists; a.blocked = P->d_ablk; a.freg = P->d_afreg; a.W = aw; a.n = n; a.early = 1;
+            { const char *e = getenv("HVO_LSD_ASYNC_EARLY"); if (e) a.early = atoi(e); }
+            hipLaunchKernelGGL(k_lsd_grow_async, dim3(((n + 7) / 8) * 8 * aw), dim3(64), 0, st, a);      // workgroups b, b + 8, ... of a frame: one XCD
         } else aw = 0;
     } else aw = 0;
     if (aw > 0) {

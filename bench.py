@@ -34,6 +34,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 TRAFFIC_PROFILE = "profiles/r03_hbm_traffic.json"
 SQ_PROFILE = "profiles/r03_sq_utilisation.json"
+VALU_ISSUE_PROFILE = "profiles/r04_valu_issue.txt"
+VALU_ISSUE_NS = 1.77           # ns per wave64 instruction per SIMD, the integer / fp64 classes at 8 waves per SIMD (that profile)
 BYTES_PER_FRAME_640 = 23.0e6      # resident footprint of one 640x480 frame incl. its share of the chunk scratch (profiles/r03_hbm_footprint.txt)
 BYTES_PER_FRAME_1280 = 80.0e6     # 1280x960, 2000 ORB: 63 MB per frame + 32 GB of chunk scratch
 
@@ -137,8 +139,12 @@ def sq_utilisation(frames_per_s):
     try:
         tot = t["per_frame_total"]
         cap = t["simds"] * t["clock_hz"] / 4.0                     # SIMD quad-cycles per second
-        return {"valu_issue_frac": round(tot["sq_active_inst_valu"] * frames_per_s / cap, 4),      # VALU wave-instructions x 4 cycles / SIMD-cycles of the step
-                "valu_busy_frac": round(tot["sq_active_inst_valu"] * frames_per_s / cap, 4),
+        # MEASURED issue cost (tools/microbench/valu_issue.hip -> VALU_ISSUE_PROFILE): at 2-8 waves per SIMD a SIMD issues one wave64
+        # instruction per 1.77-1.9 ns for everything this front-end is made of (v_dot4 / v_perm / v_min3 / SDWA / DPP / v_pk_*_u16 /
+        # v_mad / fp64: 4.2 cycles at 2.4 GHz) and per 1.0 ns for VOP2 add / logic / shift and fp32 add / fma only; the fraction below
+        # prices every VALU instruction of the step at the former (an upper bound by the share of the latter, < 15 % of these kernels)
+        return {"valu_issue_frac": round(tot["sq_insts_valu"] * frames_per_s * VALU_ISSUE_NS * 1e-9 / t["simds"], 4),
+                "valu_issue_ns_per_wave_instruction": VALU_ISSUE_NS, "valu_issue_source": VALU_ISSUE_PROFILE,
                 "resident_waves_per_simd": round(tot["sq_wave_cycles"] * frames_per_s / cap, 3),
                 "wave_time_with_inst_active": round(tot["sq_active_inst_any"] / tot["sq_wave_cycles"], 4),
                 "counters_source": SQ_PROFILE + " (replayed: PMC counters cannot be read in-process)"}
@@ -560,7 +566,7 @@ def main():
             if vif is not None:
                 # what limits the STEP (all kernels overlapped): the vector ALUs' issue slots once they are more than half taken; the dominant
                 # KERNEL alone is a dependent chain (its own HBM fraction is `frac`)
-                roof["step_limiter"] = ("valu-issue: %.0f %% of the SIMDs' issue cycles carry a VALU instruction (integer VALU, 4 cycles per wave instruction)" % (100 * vif)) if vif >= 0.5 \
+                roof["step_limiter"] = ("valu-issue: %.0f %% of the SIMDs' issue cycles carry a VALU instruction (%.2f ns per wave instruction per SIMD, measured)" % (100 * vif, VALU_ISSUE_NS)) if vif >= 0.5 \
                     else "latency: the serial-semantics kernels wait on dependent memory round trips (VALU issue %.0f %%)" % (100 * vif)
             orb_ms = sum(v for k, v in groups.items() if k in ("orb_pyramid", "orb_fast_cells", "orb_blur", "orb_levels", "orb_brief", "orb_orient", "orb_describe"))
             if orb_ms > 0:

@@ -208,3 +208,48 @@ def test_all_stages_soak(hvo, orc, synth):
         if not ok:
             bad.append(b)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("workers,early", [("4", "1"), ("16", "0"), ("32", "1"), ("7", "0")])
+def test_lines_async_growing(hvo, orc, synth, monkeypatch, workers, early):
+    """k_lsd_grow_async (lsd_async.inc): W waves per frame grow regions side by side and commit them in seed order after validation --
+    the committed sequence must be the sequential run's.  Forced onto a ragged 5-frame batch (odd geometry, a low-texture frame), with
+    and without the early drop of void results, and checked to have speculated at all and to have kept a frame's workers on one XCD
+    (frame 0's control block)."""
+    import ctypes
+    monkeypatch.setenv("HVO_LSD_ASYNC", workers); monkeypatch.setenv("HVO_LSD_ASYNC_EARLY", early)
+    for hh, ww in ((480, 640), (397, 501)):
+        g = np.ascontiguousarray(np.stack([synth.make_gray(k, s)[:hh, :ww] for k, s in (("std", 0x5EED0002), ("lowtex", 0x5EED0001), ("std", 0x5EED1003), ("std", 9), ("std", 0x5EED1001))]))
+        ctx = hvo.Context(max_batch=5)
+        try:
+            ctx.batch_upload(g, np.zeros((5, hh, ww), np.uint16))
+            for _ in range(2):                                    # the second run starts from the tags and lists the first one left
+                ctx.batch_run(hvo.STAGE_LSD)
+                res = ctx.batch_download(hvo.STAGE_LSD)
+                for b in range(5):
+                    kl_o, d_o, fn_o = orc.line_extract(g[b])
+                    assert res[b]["status"] == 0
+                    check(res[b]["kl"], res[b]["ldesc"], res[b]["linefn"], kl_o, d_o, fn_o)
+            L = hvo.lib(); L.hvo_debug_lsd_async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+            ac = (ctypes.c_uint * 128)()
+            assert L.hvo_debug_lsd_async(ctx.h, 0, ac) == 0
+            ctl = list(ac)
+            assert ctl[3] == 1 and ctl[6] == 0                      # done, not aborted
+            regions, spec, valid = ctl[8], ctl[9], ctl[10]
+            assert regions > 100 and valid > regions // 2 and spec >= valid, (regions, spec, valid)      # most regions were committed from a speculative growth
+            assert ctl[64] != 0 and ctl[65] == 0                    # one XCD, nobody elsewhere
+        finally:
+            ctx.close()
+
+
+def test_lines_async_1280(hvo, orc, synth, monkeypatch):
+    """the async growing at 1280x960 (5.4 k seeds, regions of up to thousands of points: private lists that overflow go to the frontier)"""
+    monkeypatch.setenv("HVO_LSD_ASYNC", "32")
+    g = synth.make_gray("std", 0x5EED0003, 1280, 960)
+    kl_o, d_o, fn_o = orc.line_extract(g)
+    ctx = hvo.Context()
+    try:
+        kl_g, d_g, fn_g = ctx.extract_lsd(g)
+    finally:
+        ctx.close()
+    check(kl_g, d_g, fn_g, kl_o, d_o, fn_o)
