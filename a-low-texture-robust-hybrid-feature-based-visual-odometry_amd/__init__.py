@@ -69,7 +69,7 @@ EXPORTS = [
     "hvo_profile_last", "hvo_profile_enable", "hvo_pin_host", "hvo_unpin_host",
     "hvo_stream_create", "hvo_stream_destroy", "hvo_stream_last_error", "hvo_stream_capacity", "hvo_stream_image_bounds",
     "hvo_stream_submit", "hvo_stream_poll", "hvo_stream_collect", "hvo_stream_stage_ms",
-    "hvo_stream_search_by_projection", "hvo_stream_match_lines",
+    "hvo_stream_search_by_projection", "hvo_stream_match_lines", "hvo_stream_project_last", "hvo_search_by_projection_tracked",
     "hvo_tail_capacity", "hvo_set_tail_params", "hvo_batch_download_tail", "hvo_stream_collect_tail", "hvo_normals_lpvo",
 ]
 
@@ -440,6 +440,25 @@ class Context:
                   "search_by_projection_map")
         return n.value, mi, md
 
+    def search_by_projection_tracked(self, q_desc, proj_x, proj_y, proj_xr, level, view_cos, q_blocks, th,
+                                     t_kp, t_uright, t_occupied, t_desc, bounds, th_high=100, nn_ratio=0.8):
+        """ORBmatcher::SearchByProjection(F, vpMapPoints, th) from mTrackProjX/Y/XR, mnTrackScaleLevel, mTrackViewCos: the window
+        prologue (src/ORBmatcher.cc:55-70, 134-140) runs on the device -> (nmatches, match_idx, match_dist)"""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        q_desc = np.ascontiguousarray(q_desc, np.uint8); t_desc = np.ascontiguousarray(t_desc, np.uint8)
+        nq, nt = len(q_desc), len(t_desc)
+        proj_x, proj_y, view_cos = map(f32, (proj_x, proj_y, view_cos)); proj_xr = f32(proj_xr) if proj_xr is not None else None
+        level = np.ascontiguousarray(level, np.int32)
+        q_blocks = np.ascontiguousarray(q_blocks, np.uint8); t_occupied = np.ascontiguousarray(t_occupied, np.uint8)
+        t_kp = np.ascontiguousarray(t_kp); t_uright = f32(t_uright)
+        mi = np.zeros(nq, np.int32); md = np.zeros(nq, np.int32); n = C.c_int(0)
+        fn = lib().hvo_search_by_projection_tracked
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 4 + [C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_float] + [C.c_void_p] * 3
+        self._chk(fn(self.h, _p(q_desc), nq, _p(proj_x), _p(proj_y), _p(proj_xr) if proj_xr is not None else None, _p(level), _p(view_cos), _p(q_blocks), float(th),
+                     _p(t_kp), _p(t_uright), _p(t_occupied), _p(t_desc), nt, bounds[0], bounds[1], bounds[2], bounds[3], th_high, nn_ratio,
+                     _p(mi), _p(md), C.byref(n)), "search_by_projection_tracked")
+        return n.value, mi, md
+
     def stereo_from_rgbd(self, kp, kp_un, depth, bf):
         """Frame::ComputeStereoFromRGBD (src/Frame.cc:1940-1961) -> (mvuRight, mvDepth)"""
         kp = np.ascontiguousarray(kp); kp_un = np.ascontiguousarray(kp_un); depth = np.ascontiguousarray(depth, np.uint16)
@@ -716,6 +735,29 @@ class Stream:
         ms = np.zeros(3, np.float32)
         self._chk(lib().hvo_stream_stage_ms(self.h, ticket, _p(ms)), "stream_stage_ms")
         return {"orb": float(ms[0]), "lsd": float(ms[1]), "planes": float(ms[2])}
+
+    def project_last(self, cur, last, cam, Tcw, Tlw, q_index, x3Dw, q_blocks, th, mono=False, t_occupied=None, q_desc=None,
+                     th_high=100, check_orientation=True, want_uv=False):
+        """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) whole between two resident frames: projection prologue
+        (src/ORBmatcher.cc:1364-1405) + search core on the device.  cam = (fx, fy, cx, cy, mbf, mb); Tcw / Tlw: 3 x 4 row-major.
+        -> (nmatches, idx, dist[, uv])"""
+        class Cam(C.Structure):
+            _fields_ = [(k, C.c_float) for k in ("fx", "fy", "cx", "cy", "bf", "b")]
+        q_index = np.ascontiguousarray(q_index, np.int32); nq = len(q_index)
+        x3Dw = np.ascontiguousarray(x3Dw, np.float32).reshape(-1, 3); assert len(x3Dw) == nq
+        Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(12); Tlw = np.ascontiguousarray(Tlw, np.float32).reshape(12)
+        q_blocks = np.ascontiguousarray(q_blocks, np.uint8)
+        t_occupied = np.ascontiguousarray(t_occupied, np.uint8) if t_occupied is not None else None
+        q_desc = np.ascontiguousarray(q_desc, np.uint8) if q_desc is not None else None
+        mi = np.zeros(max(nq, 1), np.int32); md = np.zeros(max(nq, 1), np.int32); n = C.c_int(0)
+        uv = np.zeros((max(nq, 1), 2), np.float32) if want_uv else None
+        pp = lambda a: _p(a) if a is not None else None
+        c = Cam(*[float(v) for v in cam])
+        fn = lib().hvo_stream_project_last
+        fn.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
+        self._chk(fn(self.h, cur, last, C.byref(c), _p(Tcw), _p(Tlw), nq, _p(q_index), _p(x3Dw), _p(q_blocks), pp(q_desc), pp(t_occupied),
+                     float(th), 1 if mono else 0, th_high, 1 if check_orientation else 0, _p(mi), _p(md), C.byref(n), pp(uv)), "stream_project_last")
+        return (n.value, mi[:nq], md[:nq], uv[:nq]) if want_uv else (n.value, mi[:nq], md[:nq])
 
     def search_by_projection(self, cur, last, q_index, q_u, q_v, q_radius, q_min_level, q_max_level, q_ur, q_blocks,
                              t_occupied=None, q_desc=None, th_high=100, check_orientation=True):

@@ -481,6 +481,25 @@ int hvo_search_by_projection(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const 
 
 // ORBmatcher::SearchByProjection(F, vpMapPoints, th) core (ORBmatcher.cc:45-132): same ranked candidates, best and second best
 // still-free candidate per query, same-octave ratio test
+int hvo_search_by_projection_tracked(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const float *proj_x, const float *proj_y, const float *proj_xr,
+                                     const int32_t *level, const float *view_cos, const uint8_t *q_blocks, float th,
+                                     const hvo_keypoint *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
+                                     float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, int th_high, float nn_ratio,
+                                     int32_t *match_idx, int32_t *match_dist, int *n_matches)
+{
+    if (!ctx || !n_matches || nq < 0 || nt < 0) return HVO_ERR_INVALID_ARG;
+    *n_matches = 0;
+    if (nq == 0) return HVO_OK;
+    if (!q_desc || !proj_x || !proj_y || !level || !view_cos || !q_blocks || !match_idx || !match_dist) return HVO_ERR_INVALID_ARG;
+    for (int i = 0; i < nq; i++) if (level[i] < 0 || level[i] >= ctx->p.orb_nlevels) return HVO_ERR_INVALID_ARG;      // mvScaleFactors[level] on the device
+    for (int i = 0; i < nq; i++) { match_idx[i] = -1; match_dist[i] = 256; }
+    if (nt == 0) return HVO_OK;
+    if (!t_kp || !t_desc || nt > 65535 || !(mnMaxX > mnMinX) || !(mnMaxY > mnMinY)) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    return match_search_by_projection_tracked(ctx, q_desc, nq, proj_x, proj_y, proj_xr, level, view_cos, q_blocks, th, t_kp, t_uright, t_occupied,
+                                              t_desc, nt, mnMinX, mnMinY, mnMaxX, mnMaxY, th_high, nn_ratio, match_idx, match_dist, n_matches);
+}
+
 int hvo_search_by_projection_map(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
                                  const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur, const uint8_t *q_blocks,
                                  const hvo_keypoint *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,

@@ -225,6 +225,16 @@ struct SbpDev {
     unsigned long long *keys; int *cnt;                        // scratch (match_sbp_enqueue carves them)
     int32_t *match_idx, *match_dist; int *n_matches;          // results
 };
+// the projection prologue of SearchByProjection(Cur, Last) (match.hip k_project_last); sf = mvScaleFactors
+struct ProjDev { float Rcw[9], tcw[3]; int fwd, bwd; float fx, fy, cx, cy, mbf, th; float sf[HVO_MAX_LEVELS]; float mnMinX, mnMinY, mnMaxX, mnMaxY; };
+void match_project_setup(ProjDev &P, const float *Tcw, const float *Tlw, float mb, int mono);
+int match_project_last_enqueue(hipStream_t st, const ProjDev &P, int n, const float *d_x3Dw, const int *d_qidx, const hvo_keypoint *d_last_kp,
+                               float *q_u, float *q_v, float *q_radius, int *q_min, int *q_max, float *q_ur);
+int match_search_by_projection_tracked(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const float *proj_x, const float *proj_y, const float *proj_xr,
+                                       const int32_t *level, const float *view_cos, const uint8_t *q_blocks, float th,
+                                       const hvo_keypoint *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
+                                       float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, int th_high, float nn_ratio,
+                                       int32_t *match_idx, int32_t *match_dist, int *n_matches);
 int match_matrix(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, uint16_t *d);
 int match_knn2(hvo_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx2, int32_t *dist2);
 int match_knn2_enqueue(hipStream_t st, const uint8_t *dq, int nq, const uint8_t *dt, int nt, int32_t *d_idx2, int32_t *d_dist2);

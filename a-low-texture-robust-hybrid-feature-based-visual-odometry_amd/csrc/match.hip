@@ -541,6 +541,105 @@ int match_sbp_enqueue(hipStream_t st, SbpDev a, void *scratch)
 }
 
 // host-array form (hvo_search_by_projection / hvo_search_by_projection_map): stage, run, fetch
+// ------------------------------------------------------------------------------------------------
+// The projection prologues of the two guided searches, on the device: what used to cross PCIe per frame as six query arrays is
+// computed where the search reads it.
+//   k_project_last   ORBmatcher::SearchByProjection(Cur, Last): x3Dc = Rcw x3Dw + tcw, u, v, the bounds tests, radius, octave band, ur
+//                    (src/ORBmatcher.cc:1381-1405; cv::Mat arithmetic as oracle/match.c orc_project_last states it)
+//   k_track_windows  SearchByProjection(F, vpMapPoints, th): RadiusByViewingCos, th, scale[level], band [level - 1, level] (55-70, 134-140)
+// ------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ float gemm3_row(const float *a, float b0, float b1, float b2, float c)
+{
+    float t = __fmul_rn(a[0], b0); t = __fadd_rn(t, __fmul_rn(a[1], b1)); t = __fadd_rn(t, __fmul_rn(a[2], b2));
+    return (float)((double)t * 1.0 + (double)c * 1.0);
+}
+__global__ __launch_bounds__(256) void k_project_last(ProjDev P, int n, const float *__restrict__ x3Dw, const int *__restrict__ q_index,
+                                                      const hvo_keypoint *__restrict__ last_kp, float *__restrict__ q_u, float *__restrict__ q_v,
+                                                      float *__restrict__ q_radius, int *__restrict__ q_min, int *__restrict__ q_max, float *__restrict__ q_ur)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float u = 1e30f, v = 1e30f, radius = 0.f, ur = 0.f; int lo = 0, hi = -1;       // a point that fails a test: no grid cell, never searched
+    const float X = x3Dw[3 * i], Y = x3Dw[3 * i + 1], Z = x3Dw[3 * i + 2];
+    const float xc = gemm3_row(P.Rcw, X, Y, Z, P.tcw[0]), yc = gemm3_row(P.Rcw + 3, X, Y, Z, P.tcw[1]), zc = gemm3_row(P.Rcw + 6, X, Y, Z, P.tcw[2]);
+    const float invzc = (float)(1.0 / (double)zc);
+    if (!(invzc < 0)) {
+        const float uu = __fadd_rn(__fmul_rn(__fmul_rn(P.fx, xc), invzc), P.cx), vv = __fadd_rn(__fmul_rn(__fmul_rn(P.fy, yc), invzc), P.cy);
+        if (!(uu < P.mnMinX || uu > P.mnMaxX) && !(vv < P.mnMinY || vv > P.mnMaxY)) {
+            const int oct = last_kp[q_index[i]].octave;
+            u = uu; v = vv; radius = __fmul_rn(P.th, P.sf[oct]);
+            if (P.fwd) { lo = oct; hi = -1; } else if (P.bwd) { lo = 0; hi = oct; } else { lo = oct - 1; hi = oct + 1; }
+            ur = __fsub_rn(uu, __fmul_rn(P.mbf, invzc));
+        }
+    }
+    q_u[i] = u; q_v[i] = v; q_radius[i] = radius; q_min[i] = lo; q_max[i] = hi; q_ur[i] = ur;
+}
+void match_project_setup(ProjDev &P, const float *Tcw, const float *Tlw, float mb, int mono)
+{
+    // twc = -Rcw.t() * tcw (double sums: the transposed product takes the generic gemm), tlc = Rlw * twc + tlw (the small-matrix path)
+    const float Rcw[9] = { Tcw[0], Tcw[1], Tcw[2], Tcw[4], Tcw[5], Tcw[6], Tcw[8], Tcw[9], Tcw[10] }, tcw[3] = { Tcw[3], Tcw[7], Tcw[11] };
+    const float Rlw[9] = { Tlw[0], Tlw[1], Tlw[2], Tlw[4], Tlw[5], Tlw[6], Tlw[8], Tlw[9], Tlw[10] }, tlw[3] = { Tlw[3], Tlw[7], Tlw[11] };
+    float twc[3], tlc[3];
+    for (int r = 0; r < 3; r++) { double s0 = 0; for (int k = 0; k < 3; k++) s0 += (double)Rcw[3 * k + r] * (double)tcw[k]; twc[r] = (float)(s0 * -1.0); }
+    for (int r = 0; r < 3; r++) { float t = Rlw[3 * r] * twc[0]; t += Rlw[3 * r + 1] * twc[1]; t += Rlw[3 * r + 2] * twc[2]; tlc[r] = (float)((double)t * 1.0 + (double)tlw[r] * 1.0); }
+    for (int q = 0; q < 9; q++) P.Rcw[q] = Rcw[q];
+    for (int q = 0; q < 3; q++) P.tcw[q] = tcw[q];
+    P.fwd = (tlc[2] > mb && !mono) ? 1 : 0; P.bwd = (-tlc[2] > mb && !mono) ? 1 : 0;
+}
+int match_project_last_enqueue(hipStream_t st, const ProjDev &P, int n, const float *d_x3Dw, const int *d_qidx, const hvo_keypoint *d_last_kp,
+                               float *q_u, float *q_v, float *q_radius, int *q_min, int *q_max, float *q_ur)
+{
+    if (n < 1) return HVO_OK;
+    hipLaunchKernelGGL(k_project_last, dim3((n + 255) / 256), dim3(256), 0, st, P, n, d_x3Dw, d_qidx, d_last_kp, q_u, q_v, q_radius, q_min, q_max, q_ur);
+    return hipGetLastError() == hipSuccess ? HVO_OK : HVO_ERR_HIP;
+}
+__global__ __launch_bounds__(256) void k_track_windows(int n, const int *__restrict__ level, const float *__restrict__ view_cos, float th, int bfactor, ProjDev P,
+                                                       float *__restrict__ q_radius, int *__restrict__ q_min, int *__restrict__ q_max)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float r = (double)view_cos[i] > 0.998 ? 2.5f : 4.0f;
+    if (bfactor) r = __fmul_rn(r, th);
+    const int l = level[i];
+    q_radius[i] = __fmul_rn(r, P.sf[l]); q_min[i] = l - 1; q_max[i] = l;
+}
+
+// SearchByProjection(F, vpMapPoints, th) from the tracker's own per-point fields (mTrackProjX / Y / XR, mnTrackScaleLevel, mTrackViewCos)
+int match_search_by_projection_tracked(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const float *proj_x, const float *proj_y, const float *proj_xr,
+                                       const int32_t *level, const float *view_cos, const uint8_t *q_blocks, float th,
+                                       const hvo_keypoint *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
+                                       float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, int th_high, float nn_ratio,
+                                       int32_t *match_idx, int32_t *match_dist, int *n_matches)
+{
+    if (nq > SBP_MAXQ || nt > 65535) return HVO_ERR_UNSUPPORTED;
+    const size_t in_bytes = AL(nq * 32, char) + 9 * AL(nq, float) + AL(nq, char) + AL(nt, hvo_keypoint) + AL(nt, float) + AL(nt, char) + AL(nt * 32, char);
+    const size_t out_bytes = AL(2 * (size_t)nq + 1, int32_t);
+    int rc = arena_begin(ctx, in_bytes + out_bytes + match_sbp_scratch_bytes(nq) + 1024, in_bytes + out_bytes + 1024);
+    if (rc) return rc;
+    SbpDev a; memset(&a, 0, sizeof(a));
+    a.q_desc = arena_up(ctx, q_desc, (size_t)nq * 32); a.q_desc_index = nullptr;
+    a.q_u = arena_up(ctx, proj_x, (size_t)nq); a.q_v = arena_up(ctx, proj_y, (size_t)nq); a.q_ur = arena_up(ctx, proj_xr, (size_t)nq);
+    const int *d_level = arena_up(ctx, level, (size_t)nq); const float *d_vc = arena_up(ctx, view_cos, (size_t)nq);
+    float *d_radius = arena_dev<float>(ctx, nq); int *d_min = arena_dev<int>(ctx, nq), *d_max = arena_dev<int>(ctx, nq);
+    ProjDev P; memset(&P, 0, sizeof(P));
+    for (int l = 0; l < HVO_MAX_LEVELS; l++) P.sf[l] = ctx->scale[l];
+    hipLaunchKernelGGL(k_track_windows, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, nq, d_level, d_vc, th, th != 1.0f ? 1 : 0, P, d_radius, d_min, d_max);
+    a.q_radius = d_radius; a.q_min_level = d_min; a.q_max_level = d_max; a.q_angle = nullptr; a.q_blocks = arena_up(ctx, q_blocks, (size_t)nq);
+    a.t_kp = arena_up(ctx, t_kp, (size_t)nt); a.t_uright = arena_up(ctx, t_uright, (size_t)nt); a.t_occ = arena_up(ctx, t_occupied, (size_t)nt);
+    a.t_desc = arena_up(ctx, t_desc, (size_t)nt * 32);
+    a.nq = nq; a.nt = nt; a.mnMinX = mnMinX; a.mnMinY = mnMinY; a.mnMaxX = mnMaxX; a.mnMaxY = mnMaxY;
+    a.th_high = th_high; a.check_orientation = 0; a.map_mode = 1; a.nn_ratio = nn_ratio;
+    int32_t *dout = arena_dev<int32_t>(ctx, 2 * (size_t)nq + 1), *hout = arena_host<int32_t>(ctx, 2 * (size_t)nq + 1);
+    a.match_idx = dout; a.match_dist = dout + nq; a.n_matches = dout + 2 * nq;
+    void *scratch = arena_dev<char>(ctx, match_sbp_scratch_bytes(nq));
+    if ((rc = match_sbp_enqueue(ctx->stream, a, scratch))) { ctx->last_error = "guided search launch"; return rc; }
+    HVO_HIP(hipMemcpyAsync(hout, dout, (2 * (size_t)nq + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(match_idx, hout, (size_t)nq * sizeof(int32_t)); memcpy(match_dist, hout + nq, (size_t)nq * sizeof(int32_t));
+    *n_matches = hout[2 * nq];
+    return HVO_OK;
+}
+
 int match_search_by_projection(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const float *q_u, const float *q_v, const float *q_radius,
                                const int32_t *q_min_level, const int32_t *q_max_level, const float *q_ur, const float *q_angle, const uint8_t *q_blocks,
                                const hvo_keypoint *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,

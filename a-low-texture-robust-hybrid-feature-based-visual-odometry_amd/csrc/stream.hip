@@ -164,7 +164,7 @@ int hvo_stream_create(const hvo_params *p, const hvo_stream_params *sp, hvo_stre
     }
     if (!rc) {
         const int nq = s->kp_cap;
-        s->ms_bytes = al64((size_t)nq * 32) + 8 * al64((size_t)nq * 4) + 2 * al64((size_t)nq) + al64((size_t)s->kp_cap) + 3 * al64((size_t)nq * 4 + 64) +
+        s->ms_bytes = al64((size_t)nq * 32) + 13 * al64((size_t)nq * 4) + 2 * al64((size_t)nq) + al64((size_t)s->kp_cap) + 3 * al64((size_t)nq * 4 + 64) +
                       match_sbp_scratch_bytes(nq) + match_lines_scratch_bytes(s->nfeat, s->nfeat) + al64((size_t)s->nfeat * 4 + 64) + 4096;
         if (hipMalloc((void **)&s->d_ms, s->ms_bytes) != hipSuccess || hipHostMalloc((void **)&s->h_ms, s->ms_bytes, hipHostMallocDefault) != hipSuccess ||
             hipStreamCreateWithPriority(&s->s_match, hipStreamNonBlocking, -1) != hipSuccess) rc = HVO_ERR_HIP;
@@ -492,6 +492,77 @@ int hvo_stream_search_by_projection(hvo_stream *s, int64_t cur, int64_t last, in
     ST_HIP(hipStreamSynchronize(st));
     memcpy(match_idx, hout, (size_t)nq * 4); memcpy(match_dist, hout + nq, (size_t)nq * 4);
     *n_matches = hout[2 * nq];
+    return HVO_OK;
+}
+
+int hvo_stream_project_last(hvo_stream *s, int64_t cur, int64_t last, const hvo_camera *cam, const float Tcw[12], const float Tlw[12],
+                            int nq, const int32_t *q_index, const float *x3Dw, const uint8_t *q_blocks, const uint8_t *q_desc,
+                            const uint8_t *t_occupied, float th, int mono, int th_high, int check_orientation,
+                            int32_t *match_idx, int32_t *match_dist, int *n_matches, float *q_uv)
+{
+    if (!s || !n_matches || nq < 0) return HVO_ERR_INVALID_ARG;
+    *n_matches = 0;
+    if (nq == 0) return HVO_OK;
+    if (nq > s->kp_cap || !cam || !Tcw || !Tlw || !q_index || !x3Dw || !q_blocks || !match_idx || !match_dist) return HVO_ERR_INVALID_ARG;
+    if (!(s->sp.stages & HVO_STAGE_ORB)) return HVO_ERR_INVALID_ARG;
+    StreamSlot *C = slot_of(s, cur), *Lz = slot_of(s, last);
+    if (!C || !Lz || C == Lz) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(s->p.device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    hipStream_t st = s->s_match;
+    ST_HIP(hipStreamWaitEvent(st, Lz->ev_orb, 0));
+    ST_HIP(hipStreamWaitEvent(st, C->ev_orb, 0));
+    ST_HIP(hipEventSynchronize(C->ev_orb));
+    const int nt = ((const int *)(C->h_out + s->lay.counts))[0];
+    ST_HIP(hipEventSynchronize(Lz->ev_orb));
+    const int n_last = ((const int *)(Lz->h_out + s->lay.counts))[0];
+    for (int i = 0; i < nq; i++) if (q_index[i] < 0 || q_index[i] >= n_last) return HVO_ERR_INVALID_ARG;     // (a gather out of bounds on the device otherwise)
+    for (int i = 0; i < nq; i++) { match_idx[i] = -1; match_dist[i] = 256; }
+    if (q_uv) for (int i = 0; i < 2 * nq; i++) q_uv[i] = 1e30f;
+    if (nt <= 0) return HVO_OK;
+    char *d = s->d_ms, *hh = s->h_ms; size_t off = 0;
+    auto up = [&](const void *src, size_t bytes) -> void * {
+        if (!src) return nullptr;
+        void *dp = d + off; memcpy(hh + off, src, bytes);
+        (void)hipMemcpyAsync(dp, hh + off, bytes, hipMemcpyHostToDevice, st);
+        off += al64(bytes);
+        return dp;
+    };
+    auto dev = [&](size_t bytes) -> void * { void *dp = d + off; off += al64(bytes); return dp; };
+    SbpDev a; memset(&a, 0, sizeof(a));
+    const int *d_qidx = (const int *)up(q_index, (size_t)nq * 4);
+    if (q_desc) { a.q_desc = (const uint8_t *)up(q_desc, (size_t)nq * 32); a.q_desc_index = nullptr; }
+    else { a.q_desc = Lz->ctx->orb.d_desc; a.q_desc_index = d_qidx; }
+    const float *d_x = (const float *)up(x3Dw, (size_t)nq * 12);
+    a.q_blocks = (const uint8_t *)up(q_blocks, (size_t)nq);
+    a.t_occ = (const uint8_t *)up(t_occupied, (size_t)nt);
+    float *d_u = (float *)dev((size_t)nq * 8), *d_v = d_u + nq;                              // u then v: one copy back for q_uv
+    float *d_radius = (float *)dev((size_t)nq * 4), *d_ur = (float *)dev((size_t)nq * 4);
+    int *d_min = (int *)dev((size_t)nq * 4), *d_max = (int *)dev((size_t)nq * 4);
+    float *d_angle = (float *)dev((size_t)nq * 4);
+    ProjDev P; memset(&P, 0, sizeof(P));
+    match_project_setup(P, Tcw, Tlw, cam->b, mono);
+    P.fx = cam->fx; P.fy = cam->fy; P.cx = cam->cx; P.cy = cam->cy; P.mbf = cam->bf; P.th = th;
+    for (int l = 0; l < HVO_MAX_LEVELS; l++) P.sf[l] = C->ctx->scale[l];
+    P.mnMinX = s->bounds[0]; P.mnMaxX = s->bounds[1]; P.mnMinY = s->bounds[2]; P.mnMaxY = s->bounds[3];
+    int32_t *dout = (int32_t *)dev((2 * (size_t)nq + 1) * 4); int32_t *hout = (int32_t *)(hh + ((char *)dout - d));
+    float *huv = (float *)(hh + ((char *)d_u - d));
+    void *scratch = d + off; off += match_sbp_scratch_bytes(nq);
+    if (off > s->ms_bytes) { s->last_error = "matching scratch too small"; return HVO_ERR_CAPACITY; }
+    int rc = match_project_last_enqueue(st, P, nq, d_x, d_qidx, Lz->d_kp_un, d_u, d_v, d_radius, d_min, d_max, d_ur);
+    if (rc) return rc;
+    frame_gather_angles_enqueue(st, Lz->d_kp_un, d_qidx, nq, d_angle);
+    a.q_u = d_u; a.q_v = d_v; a.q_radius = d_radius; a.q_min_level = d_min; a.q_max_level = d_max; a.q_ur = d_ur; a.q_angle = d_angle;
+    a.t_kp = C->d_kp_un; a.t_uright = (C->had_depth && s->sp.bf > 0) ? C->d_uright : nullptr; a.t_desc = C->ctx->orb.d_desc;
+    a.nq = nq; a.nt = nt; a.mnMinX = s->bounds[0]; a.mnMaxX = s->bounds[1]; a.mnMinY = s->bounds[2]; a.mnMaxY = s->bounds[3];
+    a.th_high = th_high; a.check_orientation = check_orientation; a.map_mode = 0; a.nn_ratio = 0.f;
+    a.match_idx = dout; a.match_dist = dout + nq; a.n_matches = dout + 2 * nq;
+    if ((rc = match_sbp_enqueue(st, a, scratch))) return rc;
+    ST_HIP(hipMemcpyAsync(hout, dout, (2 * (size_t)nq + 1) * 4, hipMemcpyDeviceToHost, st));
+    if (q_uv) ST_HIP(hipMemcpyAsync(huv, d_u, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
+    ST_HIP(hipStreamSynchronize(st));
+    memcpy(match_idx, hout, (size_t)nq * 4); memcpy(match_dist, hout + nq, (size_t)nq * 4);
+    *n_matches = hout[2 * nq];
+    if (q_uv) for (int i = 0; i < nq; i++) { q_uv[2 * i] = huv[i]; q_uv[2 * i + 1] = huv[nq + i]; }
     return HVO_OK;
 }
 

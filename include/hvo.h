@@ -268,6 +268,16 @@ int hvo_search_by_projection_map(hvo_ctx *ctx, const uint8_t *q_desc, int nq, co
                                  float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, int th_high, float nn_ratio,
                                  int32_t *match_idx, int32_t *match_dist, int *n_matches);
 
+/* The same search from the tracker's own per-point fields, its prologue (src/ORBmatcher.cc:55-70, RadiusByViewingCos 134-140) on the
+ * device: one query per map point in view (mbTrackInView, not bad) with mTrackProjX / mTrackProjY / mTrackProjXR (may be NULL),
+ * mnTrackScaleLevel and mTrackViewCos; radius = (viewCos > 0.998 ? 2.5 : 4.0) [* th when th != 1] * scale[level], levels
+ * [level - 1, level].  Everything else as hvo_search_by_projection_map. */
+int hvo_search_by_projection_tracked(hvo_ctx *ctx, const uint8_t *q_desc, int nq, const float *proj_x, const float *proj_y, const float *proj_xr,
+                                     const int32_t *level, const float *view_cos, const uint8_t *q_blocks, float th,
+                                     const hvo_keypoint *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
+                                     float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, int th_high, float nn_ratio,
+                                     int32_t *match_idx, int32_t *match_dist, int *n_matches);
+
 /* Frame::ComputeStereoFromRGBD (reference src/Frame.cc:1940-1961): uright[i] = kp_un[i].x - bf/d and zdepth[i] = d
  * where d = depth(v,u) * depth_map_factor at the truncated key-point position, if 0 < d < 7; else -1. */
 int hvo_stereo_from_rgbd(hvo_ctx *ctx, const hvo_keypoint *kp, const hvo_keypoint *kp_un, int n,
@@ -389,6 +399,18 @@ int  hvo_stream_search_by_projection(hvo_stream *s, int64_t cur, int64_t last, i
                                      const float *q_u, const float *q_v, const float *q_radius, const int32_t *q_min_level, const int32_t *q_max_level,
                                      const float *q_ur, const uint8_t *q_blocks, const uint8_t *t_occupied, int th_high, int check_orientation,
                                      int32_t *match_idx, int32_t *match_dist, int *n_matches);
+/* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) WHOLE, between two resident frames (src/ORBmatcher.cc:1353-1497):
+ * the projection prologue (1364-1405) runs on the device too -- x3Dc = Rcw x3Dw + tcw, invzc, (u, v), the image-bounds tests,
+ * bForward / bBackward from tlc = Rlw twc + tlw against mb, radius = th * mvScaleFactors[octave of the last frame's feature], the octave
+ * band and ur = u - mbf invzc -- and feeds the search core where it stands: per query only the map point's world position crosses PCIe.
+ * Tcw / Tlw: rows 0..2 of CurrentFrame.mTcw / LastFrame.mTcw, row-major 3 x 4.  Query i = last-frame feature q_index[i] whose map point
+ * (not an outlier) has world position x3Dw[3 i ..]; q_blocks / q_desc / t_occupied as in hvo_stream_search_by_projection.  A point that
+ * fails a projection test is never searched (match_idx -1).  q_uv (may be NULL, nq x 2): the projections, 1e30 where none was searched. */
+typedef struct { float fx, fy, cx, cy, bf, b; } hvo_camera;      /* Frame::fx fy cx cy mbf mb */
+int  hvo_stream_project_last(hvo_stream *s, int64_t cur, int64_t last, const hvo_camera *cam, const float Tcw[12], const float Tlw[12],
+                             int nq, const int32_t *q_index, const float *x3Dw, const uint8_t *q_blocks, const uint8_t *q_desc,
+                             const uint8_t *t_occupied, float th, int mono, int th_high, int check_orientation,
+                             int32_t *match_idx, int32_t *match_dist, int *n_matches, float *q_uv);
 /* line matching between two resident frames: query = lines of `from`, train = lines of `to`; matches12 needs kl_cap entries,
  * *n_from receives n_kl(from) */
 int  hvo_stream_match_lines(hvo_stream *s, int64_t from, int64_t to, int mode, float th, float nnratio, int32_t *matches12, int *n_from, int *n_matches);

@@ -292,3 +292,64 @@ int orc_search_double(const uint8_t *d1, int n1, const uint8_t *d2, int n2, floa
     return m;
 }
 
+
+
+/* ---- the projection prologue of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono), src/ORBmatcher.cc:1364-1405 ----
+ * cv::Mat arithmetic of OpenCV 3.2.0 (not vendored; ASSUMED, modules/core/src/matmul.cpp gemm): a plain CV_32F product A(3x3) * b(3x1)
+ * [+ c] takes the small-matrix path: t = a0*b0 + a1*b1 + a2*b2 in FLOAT, left to right, then float(t * 1.0 + c * 1.0) in double =
+ * float(t + c); a product with a transposed operand (-Rcw.t() * tcw) takes GEMMSingleMul<float, double>: the sum in DOUBLE,
+ * float(sum * alpha).  `invzc = 1.0 / z` divides in double and rounds to float; u, v, radius and ur are float expressions. */
+static float gemm3_row(const float *a, const float *b, float c) { float t = a[0] * b[0]; t += a[1] * b[1]; t += a[2] * b[2]; return (float)((double)t * 1.0 + (double)c * 1.0); }
+
+/* T = rows 0..2 of mTcw, row-major 3 x 4.  Per query i (a last-frame feature with a map point that is no outlier): world position
+ * x3Dw[3 i ..], the feature's octave.  Out: u, v, radius, level band, ur; a point that fails a test (:1385, :1391-1394) gets
+ * u = v = 1e30, radius 0 (no grid cell: never searched). */
+void orc_project_last(const float *Tcw, const float *Tlw, int n, const float *x3Dw, const int32_t *octave,
+                      float fx, float fy, float cx, float cy, float mbf, float mb, int mono, float th, const float *scale_factors,
+                      float mnMinX, float mnMinY, float mnMaxX, float mnMaxY,
+                      float *q_u, float *q_v, float *q_radius, int32_t *q_min_level, int32_t *q_max_level, float *q_ur, int32_t *fwd_bwd)
+{
+    const float Rcw[9] = { Tcw[0], Tcw[1], Tcw[2], Tcw[4], Tcw[5], Tcw[6], Tcw[8], Tcw[9], Tcw[10] }, tcw[3] = { Tcw[3], Tcw[7], Tcw[11] };
+    const float Rlw[9] = { Tlw[0], Tlw[1], Tlw[2], Tlw[4], Tlw[5], Tlw[6], Tlw[8], Tlw[9], Tlw[10] }, tlw[3] = { Tlw[3], Tlw[7], Tlw[11] };
+    float twc[3], tlc[3];
+    for (int r = 0; r < 3; r++) {                     /* twc = -Rcw.t() * tcw */
+        double s0 = 0;
+        for (int k = 0; k < 3; k++) s0 += (double)Rcw[3 * k + r] * (double)tcw[k];
+        twc[r] = (float)(s0 * -1.0);
+    }
+    for (int r = 0; r < 3; r++) tlc[r] = gemm3_row(Rlw + 3 * r, twc, tlw[r]);
+    const int bForward = tlc[2] > mb && !mono, bBackward = -tlc[2] > mb && !mono;
+    if (fwd_bwd) { fwd_bwd[0] = bForward; fwd_bwd[1] = bBackward; }
+    for (int i = 0; i < n; i++) {
+        q_u[i] = q_v[i] = 1e30f; q_radius[i] = 0.f; q_min_level[i] = 0; q_max_level[i] = -1; q_ur[i] = 0.f;
+        float x3Dc[3];
+        for (int r = 0; r < 3; r++) x3Dc[r] = gemm3_row(Rcw + 3 * r, x3Dw + 3 * i, tcw[r]);
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = (float)(1.0 / (double)x3Dc[2]);
+        if (invzc < 0) continue;
+        const float u = fx * xc * invzc + cx, v = fy * yc * invzc + cy;
+        if (u < mnMinX || u > mnMaxX) continue;
+        if (v < mnMinY || v > mnMaxY) continue;
+        const int oct = octave[i];
+        q_u[i] = u; q_v[i] = v; q_radius[i] = th * scale_factors[oct];
+        if (bForward) { q_min_level[i] = oct; q_max_level[i] = -1; }
+        else if (bBackward) { q_min_level[i] = 0; q_max_level[i] = oct; }
+        else { q_min_level[i] = oct - 1; q_max_level[i] = oct + 1; }
+        q_ur[i] = u - mbf * invzc;
+    }
+}
+
+/* the prologue of SearchByProjection(F, vpMapPoints, th), src/ORBmatcher.cc:55-70 + RadiusByViewingCos (134-140): per map point in view
+ * (mbTrackInView, not bad) the window radius r * scale[level] with r = 2.5 (viewCos > 0.998) or 4.0, times th when th != 1.0; levels
+ * [level - 1, level] */
+void orc_track_windows(int n, const int32_t *level, const float *view_cos, float th, const float *scale_factors,
+                       float *q_radius, int32_t *q_min_level, int32_t *q_max_level)
+{
+    const int bFactor = th != 1.0;
+    for (int i = 0; i < n; i++) {
+        float r = (double)view_cos[i] > 0.998 ? 2.5f : 4.0f;
+        if (bFactor) r *= th;
+        q_radius[i] = r * scale_factors[level[i]];
+        q_min_level[i] = level[i] - 1; q_max_level[i] = level[i];
+    }
+}

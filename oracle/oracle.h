@@ -160,6 +160,13 @@ int  orc_search_by_projection_map(const uint8_t *q_desc, int nq, const float *q_
                                   const void *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
                                   float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, int th_high, float nn_ratio,
                                   int32_t *match_idx, int32_t *match_dist);
+/* the projection prologues of the two guided searches (src/ORBmatcher.cc:1364-1405; 55-70 + 134-140) */
+void orc_project_last(const float *Tcw, const float *Tlw, int n, const float *x3Dw, const int32_t *octave,
+                      float fx, float fy, float cx, float cy, float mbf, float mb, int mono, float th, const float *scale_factors,
+                      float mnMinX, float mnMinY, float mnMaxX, float mnMaxY,
+                      float *q_u, float *q_v, float *q_radius, int32_t *q_min_level, int32_t *q_max_level, float *q_ur, int32_t *fwd_bwd);
+void orc_track_windows(int n, const int32_t *level, const float *view_cos, float th, const float *scale_factors,
+                       float *q_radius, int32_t *q_min_level, int32_t *q_max_level);
 /* Frame::ComputeStereoFromRGBD (src/Frame.cc:1940-1961) */
 void orc_stereo_from_rgbd(const void *kp, const void *kp_un, int n, const uint16_t *depth, int w, int h, int stride_bytes,
                           float depth_factor, float bf, float *uright, float *zdepth);

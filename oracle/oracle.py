@@ -419,6 +419,31 @@ def search_by_projection(q_desc, q_u, q_v, q_radius, q_min_level, q_max_level, q
     return n, mi, md
 
 
+def project_last(Tcw, Tlw, x3Dw, octave, cam, mono, th, scale_factors, bounds):
+    """prologue of ORBmatcher::SearchByProjection(Cur, Last) (src/ORBmatcher.cc:1364-1405) -> dict of query arrays; cam = (fx, fy, cx, cy, mbf, mb)"""
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    Tcw = f32(Tcw).reshape(12); Tlw = f32(Tlw).reshape(12); x3Dw = f32(x3Dw); octave = np.ascontiguousarray(octave, np.int32); sf = f32(scale_factors)
+    n = len(octave)
+    out = dict(u=np.zeros(n, np.float32), v=np.zeros(n, np.float32), radius=np.zeros(n, np.float32), min_level=np.zeros(n, np.int32),
+               max_level=np.zeros(n, np.int32), ur=np.zeros(n, np.float32), fwd_bwd=np.zeros(2, np.int32))
+    L = lib(); L.orc_project_last.restype = None
+    L.orc_project_last.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_float] * 6 + [C.c_int, C.c_float, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p] * 7
+    L.orc_project_last(_p(Tcw), _p(Tlw), n, _p(x3Dw), _p(octave), *[float(c) for c in cam], 1 if mono else 0, float(th), _p(sf),
+                       bounds[0], bounds[1], bounds[2], bounds[3], _p(out["u"]), _p(out["v"]), _p(out["radius"]), _p(out["min_level"]), _p(out["max_level"]),
+                       _p(out["ur"]), _p(out["fwd_bwd"]))
+    return out
+
+
+def track_windows(level, view_cos, th, scale_factors):
+    """prologue of SearchByProjection(F, vpMapPoints, th) (src/ORBmatcher.cc:55-70, 134-140) -> (radius, min_level, max_level)"""
+    level = np.ascontiguousarray(level, np.int32); vc = np.ascontiguousarray(view_cos, np.float32); sf = np.ascontiguousarray(scale_factors, np.float32)
+    n = len(level); r = np.zeros(n, np.float32); lo = np.zeros(n, np.int32); hi = np.zeros(n, np.int32)
+    L = lib(); L.orc_track_windows.restype = None
+    L.orc_track_windows.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_track_windows(n, _p(level), _p(vc), float(th), _p(sf), _p(r), _p(lo), _p(hi))
+    return r, lo, hi
+
+
 def stereo_from_rgbd(kp, kp_un, depth, depth_factor, bf):
     kp = np.ascontiguousarray(kp); kp_un = np.ascontiguousarray(kp_un); depth = np.ascontiguousarray(depth, np.uint16)
     h, w = depth.shape

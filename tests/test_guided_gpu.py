@@ -89,3 +89,25 @@ def test_search_by_projection_map_parity(gpu_ctx, orc, synth, th, occupied_frac,
     # the ratio test must have rejected something the plain best-match rule accepts
     n_plain, _, _ = orc.search_by_projection_map(*args, th_high=100, nn_ratio=10.0)
     assert n_plain >= no
+
+
+@pytest.mark.parametrize("th", [1.0, 3.0])
+def test_search_by_projection_tracked(gpu_ctx, orc, synth, th):
+    """SearchByProjection(F, vpMapPoints, th) from the tracker's own fields: RadiusByViewingCos, th and the level band are applied on the
+    device (src/ORBmatcher.cc:55-70, 134-140); against the oracle's prologue + search core"""
+    kp1, d1, kp2, d2 = _scene(orc, synth)
+    rng = np.random.default_rng(11)
+    n1 = len(kp1)
+    sf = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2), np.float32)])).astype(np.float32)
+    px = (kp1["x"] + 3 + rng.normal(0, 1.0, n1)).astype(np.float32); py = (kp1["y"] + 2 + rng.normal(0, 1.0, n1)).astype(np.float32)
+    pxr = (px - 40.0 / rng.uniform(1, 4, n1)).astype(np.float32)
+    level = np.clip(kp1["octave"] + rng.integers(0, 2, n1), 0, 7).astype(np.int32)
+    vcos = np.where(rng.uniform(size=n1) < 0.5, 0.9995, 0.99).astype(np.float32)      # both sides of RadiusByViewingCos' 0.998
+    blocks = np.ones(n1, np.uint8)
+    t_uright = np.where(rng.uniform(size=len(kp2)) < 0.7, kp2["x"] - 40.0 / rng.uniform(1, 4, len(kp2)), -1).astype(np.float32)
+    t_occ = (rng.uniform(size=len(kp2)) < 0.1).astype(np.uint8)
+    rad, lo, hi = orc.track_windows(level, vcos, th, sf)
+    assert set(np.unique(np.round(rad / sf[level] / np.float32(th if th != 1.0 else 1.0), 3))) == {2.5, 4.0}
+    no, io, do = orc.search_by_projection_map(d1, px, py, rad, lo, hi, pxr, blocks, kp2, t_uright, t_occ, d2, BOUNDS, th_high=100, nn_ratio=0.8)
+    ng, ig, dg = gpu_ctx.search_by_projection_tracked(d1, px, py, pxr, level, vcos, blocks, th, kp2, t_uright, t_occ, d2, BOUNDS, th_high=100, nn_ratio=0.8)
+    assert no > 50 and ng == no and np.array_equal(ig, io) and np.array_equal(dg[ig >= 0], do[io >= 0])

@@ -122,3 +122,42 @@ def test_stream_lines_bf_and_double(hvo, orc, synth):
             assert n2 == no and np.array_equal(m2, mo)
     finally:
         st.close()
+
+
+@pytest.mark.parametrize("tz,mono", [(0.0, False), (0.25, False), (-0.25, False), (0.25, True)])
+def test_stream_project_last(hvo, orc, synth, tz, mono):
+    """ORBmatcher::SearchByProjection(Cur, Last) WHOLE on the device: the projection prologue (src/ORBmatcher.cc:1364-1405: x3Dc, invzc, u, v,
+    bounds, bForward / bBackward, radius, octave band, ur) + the search core, against the oracle's prologue feeding the oracle's core.
+    The map points are the last frame's features back-projected with their depth; the current pose is a small rotation + translation
+    (tz beyond mb = 0.08 switches the octave band: forward, backward, none; mono switches it off)."""
+    g, d, off = synth.make_sequence("std", 0x5EED2100, 3)
+    cam = (535.4, 539.2, 320.1, 247.6, 40.0, 40.0 / 535.4)                  # TUM3 fx fy cx cy, mbf, mb = mbf / fx
+    st = hvo.Stream(depth=3, stages=hvo.STAGE_ORB | hvo.STAGE_PLANES, bf=cam[4])
+    sf = np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2), np.float32)])).astype(np.float32)
+    try:
+        t0, t1 = st.submit(g[0], d[0]), st.submit(g[1], d[1])
+        last, cur = st.collect(t0), st.collect(t1)
+        z = last["zdepth"]; sel = np.flatnonzero(z > 0).astype(np.int32)
+        assert len(sel) > 300
+        kpl = last["kp_un"][sel]
+        X = np.stack([(kpl["x"] - np.float32(cam[2])) * z[sel] / np.float32(cam[0]), (kpl["y"] - np.float32(cam[3])) * z[sel] / np.float32(cam[1]), z[sel]], axis=1).astype(np.float32)
+        X[::17, 2] *= -1                                                     # a few points behind the camera (invzc < 0)
+        a = np.float32(0.01)
+        Rcw = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+        Tcw = np.concatenate([Rcw, np.array([[0.01], [-0.005], [tz]], np.float32)], axis=1).astype(np.float32)
+        Tlw = np.concatenate([np.eye(3, dtype=np.float32), np.zeros((3, 1), np.float32)], axis=1)
+        blocks = np.ones(len(sel), np.uint8)
+        th = 15.0
+        q = orc.project_last(Tcw, Tlw, X, last["kp_un"]["octave"][sel], cam, mono, th, sf, (0.0, 0.0, 640.0, 480.0))
+        assert tuple(q["fwd_bwd"]) == ((1, 0) if (tz < -0.08 and not mono) else (0, 1) if (tz > 0.08 and not mono) else (0, 0))   # tlc = -Rcw^T tcw
+        searched = q["radius"] > 0
+        assert 100 < searched.sum() < len(sel)                               # some fail the tests (behind the camera, out of bounds)
+        no, mio, mdo = orc.search_by_projection(last["desc"][sel], q["u"], q["v"], q["radius"], q["min_level"], q["max_level"], q["ur"],
+                                                last["kp_un"]["angle"][sel], blocks, cur["kp_un"], cur["uright"], np.zeros(len(cur["kp"]), np.uint8),
+                                                cur["desc"], (0.0, 0.0, 640.0, 480.0))
+        ng, mi, md, uv = st.project_last(t1, t0, cam, Tcw, Tlw, sel, X, blocks, th, mono=mono, want_uv=True)
+        assert np.array_equal(uv[:, 0], q["u"]) and np.array_equal(uv[:, 1], q["v"])         # the projections bit for bit
+        assert ng == no and np.array_equal(mi, mio) and np.array_equal(md[mi >= 0], mdo[mio >= 0])
+        assert no > 50
+    finally:
+        st.close()
