@@ -58,6 +58,7 @@ struct OrbPlan {
     size_t lvl_bytes = 0, blur_bytes = 0;  // strides of d_lvl (levels >= 1) and d_blur (all levels): scratch, one per frame of a CHUNK
     int chunk = 0;                      // frames the scratch slabs exist for: orb_run walks the batch chunk by chunk
     bool resize_dw[HVO_MAX_LEVELS] = {};  // level is produced by k_resize_dw (dword loads) instead of k_resize
+    int last_chunks = 0;                  // chunks the last orb_run walked (hvo_debug_orb_plan)
     bool fused = false;                 // the fused per-level pass (orb_level.hip) serves this geometry
     int lt_off[HVO_MAX_LEVELS] = {}, lt_cnt[HVO_MAX_LEVELS] = {}, lt_tpw = 4;
     OrbTile *d_ltiles = nullptr;

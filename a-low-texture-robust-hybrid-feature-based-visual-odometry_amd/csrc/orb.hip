@@ -971,6 +971,7 @@ int orb_run(hvo_ctx *ctx, int n)
     }
     int id;
     // the batch, chunk by chunk: frames [c0, c0 + m) use the scratch slabs as their frames 0 .. m-1
+    P.last_chunks = (n + P.chunk - 1) / P.chunk;
     for (int c0 = 0; c0 < n; c0 += P.chunk) {
     const int m = std::min(P.chunk, n - c0);
     const bool last = c0 + m >= n;
@@ -1057,5 +1058,14 @@ int orb_download(hvo_ctx *ctx, int n, hvo_frame_out *out)
     if (rc) return rc;
     if ((rc = hvo_staged_d2h(ctx, cs, P.d_desc, (size_t)P.kp_cap * 32, n, dd.data(), bd.data()))) return rc;
     HVO_HIP(hipStreamSynchronize(cs));
+    return HVO_OK;
+}
+
+// diagnostics (not part of include/hvo.h): which ORB path the current plan runs and how it walks a batch -- out4 = { fused per-level pass
+// (orb_level.hip) 1 / the separate kernels 0, frames per chunk, frames the plan holds, chunks the last orb_run walked }
+extern "C" int hvo_debug_orb_plan(hvo_ctx *ctx, int *out4)
+{
+    if (!ctx || !out4 || ctx->orb.w <= 0) return HVO_ERR_INVALID_ARG;
+    out4[0] = ctx->orb.fused ? 1 : 0; out4[1] = ctx->orb.chunk; out4[2] = ctx->orb.batch; out4[3] = ctx->orb.last_chunks;
     return HVO_OK;
 }

@@ -56,6 +56,67 @@ def test_orb_odd_geometry_and_stride(gpu_ctx, orc, synth):
     check_orb(kp_g, d_g, kp_o, d_o)
 
 
+def _orb_plan(hvo, ctx):
+    import ctypes
+    out = (ctypes.c_int * 4)()
+    L = hvo.lib(); L.hvo_debug_orb_plan.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    assert L.hvo_debug_orb_plan(ctx.h, out) == 0
+    return list(out)
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("hh,ww", [(480, 640), (397, 501), (479, 638), (240, 322), (200, 270)])
+def test_orb_both_paths_every_geometry(hvo, orc, synth, monkeypatch, fused, hh, ww):
+    """The fused per-level pass (orb_level.hip) and the separate resize / FAST / blur kernels are two formulations of the same levels:
+    both are forced (HVO_ORB_FUSED) onto even, odd and small geometries, and WHICH one ran is asserted -- the separate kernels are the
+    fallback for a geometry whose FAST cells do not fit the LDS tile, and must not rot behind a path that always wins."""
+    monkeypatch.setenv("HVO_ORB_FUSED", fused)
+    big = synth.make_gray("std", 11, 704, 480)
+    g = np.ascontiguousarray(big[:hh, :ww])
+    kp_o, d_o = orc.Orb().extract(g)
+    ctx = hvo.Context()
+    try:
+        kp_g, d_g = ctx.extract_orb(g)
+        plan = _orb_plan(hvo, ctx)
+    finally:
+        ctx.close()
+    check_orb(kp_g, d_g, kp_o, d_o)
+    # the camera geometries take the fused pass; the two small ones have FAST cells that do not fit the LDS tile and fall back (exactly)
+    if fused == "0" or (hh, ww) in ((480, 640), (397, 501), (479, 638)): assert plan[0] == int(fused), plan
+    else: assert plan[0] == 0, plan
+    assert len(kp_o) > 20
+
+
+@pytest.mark.parametrize("fused,sched", [("1", None), ("0", None), ("1", "5"), ("1", "7")])
+def test_orb_chunked_batch(hvo, orc, synth, monkeypatch, fused, sched):
+    """orb_run walks a batch chunk by chunk through scratch slabs that exist for one chunk (HVO_ORB_CHUNK = 3 of 8 frames: chunks of
+    3, 3, 2): every frame of every chunk against the oracle, both ORB paths, and under the overlap policies that make the other stages
+    wait for the LAST chunk's FAST (ev_fast is recorded there)."""
+    monkeypatch.setenv("HVO_ORB_CHUNK", "3"); monkeypatch.setenv("HVO_ORB_FUSED", fused)
+    if sched: monkeypatch.setenv("HVO_SCHED", sched)
+    gray, depth = synth.make_batch("std", 0x5EED3000, 8)
+    gray[5] = synth.make_gray("lowtex", 0x5EED0001)
+    ctx = hvo.Context(max_batch=8)
+    try:
+        ctx.batch_upload(gray, depth)
+        stages = hvo.STAGE_ALL if sched else hvo.STAGE_ORB
+        for _ in range(2):
+            ctx.batch_run(stages)
+            res = ctx.batch_download(stages)
+            plan = _orb_plan(hvo, ctx)
+            assert plan[0] == int(fused) and plan[1] == 3 and plan[3] == 3, plan
+            o = orc.Orb()
+            for b in range(8):
+                kp_o, d_o = o.extract(gray[b])
+                assert res[b]["status"] == 0
+                check_orb(res[b]["kp"], res[b]["desc"], kp_o, d_o)
+            if sched:                                              # the stages that waited for FAST
+                lo, po = orc.peac(depth[7]); assert np.array_equal(res[7]["labels"], lo)
+                kl_o, dl_o, _ = orc.line_extract(gray[7]); assert np.array_equal(res[7]["ldesc"], dl_o)
+    finally:
+        ctx.close()
+
+
 def test_orb_flat_image_gives_nothing(gpu_ctx):
     kp, d = gpu_ctx.extract_orb(np.full((480, 640), 128, np.uint8))
     assert len(kp) == 0 and d.shape == (0, 32)
