@@ -33,6 +33,7 @@ _LOADED_BEFORE_TORCH = False
 
 HVO_OK = 0
 STAGE_ORB, STAGE_LSD, STAGE_PLANES, STAGE_ALL = 1, 2, 4, 7
+SLAB_LABELS = 1            # hvo_batch_pack_results_ex: the int8 label image at the end of every slab
 STAGE_LSD_CULL = 8        # STAGE_LSD followed by Frame::cullingLine (merged lines replace the extractor's)
 # the rest of the Frame constructor as pipeline stages (include/hvo.h): isLineGood, vanishing points, ComputePlanes' tail, the two grids
 STAGE_LINES3D, STAGE_VP, STAGE_PLANE_TAIL, STAGE_GRIDS = 16, 32, 64, 128
@@ -65,7 +66,7 @@ EXPORTS = [
     "hvo_hamming_matrix", "hvo_hamming_knn2", "hvo_match_nnr", "hvo_search_by_projection", "hvo_stereo_from_rgbd",
     "hvo_undistort_keypoints", "hvo_image_bounds", "hvo_assign_features_to_grid", "hvo_assign_lines_to_grid",
     "hvo_extract_lsd_culled", "hvo_set_line_culling", "hvo_lines_3d", "hvo_vanishing_points", "hvo_plane_clouds", "hvo_surface_normals", "hvo_search_by_projection_map", "hvo_frame_bf_match", "hvo_search_double",
-    "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch", "hvo_batch_slab_layout", "hvo_batch_pack_results",
+    "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch", "hvo_batch_slab_layout", "hvo_batch_pack_results", "hvo_batch_slab_layout_ex", "hvo_batch_pack_results_ex",
     "hvo_profile_last", "hvo_profile_enable", "hvo_pin_host", "hvo_unpin_host",
     "hvo_stream_create", "hvo_stream_destroy", "hvo_stream_last_error", "hvo_stream_capacity", "hvo_stream_image_bounds",
     "hvo_stream_submit", "hvo_stream_poll", "hvo_stream_collect", "hvo_stream_stage_ms",
@@ -589,15 +590,20 @@ class Context:
                 r["planes"] = r["planes"][: fo[b].n_planes]
         return res
 
-    def slab_layout(self):
-        """(kp_cap, kl_cap, pl_cap, slab_bytes) of the resident batch's device result slabs"""
-        a, b, c, d = C.c_int(0), C.c_int(0), C.c_int(0), C.c_size_t(0)
-        self._chk(lib().hvo_batch_slab_layout(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "batch_slab_layout")
-        return a.value, b.value, c.value, d.value
+    def slab_layout(self, labels=False):
+        """(kp_cap, kl_cap, pl_cap, slab_bytes) of the resident batch's device result slabs; labels=True: with the int8 label image at
+        the end of every slab (HVO_SLAB_LABELS) -> (kp_cap, kl_cap, pl_cap, slab_bytes, labels_off)"""
+        a, b, c, d, e = C.c_int(0), C.c_int(0), C.c_int(0), C.c_size_t(0), C.c_size_t(0)
+        fn = lib().hvo_batch_slab_layout_ex
+        fn.argtypes = [C.c_void_p, C.c_uint] + [C.c_void_p] * 5
+        self._chk(fn(self.h, SLAB_LABELS if labels else 0, C.byref(a), C.byref(b), C.byref(c), C.byref(e), C.byref(d)), "batch_slab_layout")
+        return (a.value, b.value, c.value, d.value, e.value) if labels else (a.value, b.value, c.value, d.value)
 
-    def pack_results(self, n, device_ptr):
+    def pack_results(self, n, device_ptr, labels=False):
         """write the first n frames' result slabs to device memory at `device_ptr` (n * slab_bytes bytes)"""
-        self._chk(lib().hvo_batch_pack_results(self.h, n, C.c_void_p(device_ptr)), "batch_pack_results")
+        fn = lib().hvo_batch_pack_results_ex
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint]
+        self._chk(fn(self.h, n, C.c_void_p(device_ptr), SLAB_LABELS if labels else 0), "batch_pack_results")
 
     def profile_enable(self, mode=1):
         """0 off, 1 hipEvents around each kernel group, 2 events + stages serialised on one stream"""

@@ -279,23 +279,30 @@ static __global__ void k_pack_header(const int *__restrict__ nkp, const int *__r
     h[0] = a; h[1] = b; h[2] = c; h[3] = st;
 }
 
-int hvo_batch_slab_layout(hvo_ctx *ctx, int *kp_cap, int *kl_cap, int *pl_cap, size_t *slab_bytes)
+int hvo_batch_slab_layout_ex(hvo_ctx *ctx, unsigned flags, int *kp_cap, int *kl_cap, int *pl_cap, size_t *labels_off, size_t *slab_bytes)
 {
-    if (!ctx || ctx->batch_n < 1 || ctx->orb.kp_cap <= 0) return HVO_ERR_INVALID_ARG;
+    if (!ctx || ctx->batch_n < 1 || ctx->orb.kp_cap <= 0 || (flags & ~HVO_SLAB_LABELS)) return HVO_ERR_INVALID_ARG;
     const int kc = ctx->orb.kp_cap, lc = std::max(ctx->p.lsd_nfeatures, 1), pc = 64;
     if (kp_cap) *kp_cap = kc;
     if (kl_cap) *kl_cap = lc;
     if (pl_cap) *pl_cap = pc;
-    if (slab_bytes) *slab_bytes = 16 + (size_t)kc * (sizeof(hvo_keypoint) + 32) + (size_t)lc * (sizeof(hvo_keyline) + 32 + 24) + (size_t)pc * sizeof(hvo_plane);
+    size_t sb = 16 + (size_t)kc * (sizeof(hvo_keypoint) + 32) + (size_t)lc * (sizeof(hvo_keyline) + 32 + 24) + (size_t)pc * sizeof(hvo_plane);
+    if (labels_off) *labels_off = (flags & HVO_SLAB_LABELS) ? sb : 0;
+    if (flags & HVO_SLAB_LABELS) sb += ((size_t)ctx->batch_w * ctx->batch_h + 15) & ~(size_t)15;
+    if (slab_bytes) *slab_bytes = sb;
     return HVO_OK;
 }
+int hvo_batch_slab_layout(hvo_ctx *ctx, int *kp_cap, int *kl_cap, int *pl_cap, size_t *slab_bytes)
+{
+    return hvo_batch_slab_layout_ex(ctx, 0, kp_cap, kl_cap, pl_cap, nullptr, slab_bytes);
+}
 
-int hvo_batch_pack_results(hvo_ctx *ctx, int n, void *d_slabs)
+int hvo_batch_pack_results_ex(hvo_ctx *ctx, int n, void *d_slabs, unsigned flags)
 {
     if (!ctx || !d_slabs || n < 1 || n > ctx->batch_n) return HVO_ERR_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
-    int kc, lc, pc; size_t sb;
-    int rc = hvo_batch_slab_layout(ctx, &kc, &lc, &pc, &sb);
+    int kc, lc, pc; size_t sb, lab_off;
+    int rc = hvo_batch_slab_layout_ex(ctx, flags, &kc, &lc, &pc, &lab_off, &sb);
     if (rc) return rc;
     const unsigned done = ctx->last_stages;
     OrbPlan &O = ctx->orb;
@@ -305,7 +312,8 @@ int hvo_batch_pack_results(hvo_ctx *ctx, int n, void *d_slabs)
     if (done & HVO_STAGE_PLANES) { if ((rc = peac_prepare(ctx, ctx->batch_w, ctx->batch_h, ctx->batch_n, &pv))) return rc; }
     hipStream_t st = ctx->stream;
     char *S = (char *)d_slabs;
-    HVO_HIP(hipMemsetAsync(S, 0, (size_t)n * sb, st));
+    // the records' part of every slab is zeroed (unused capacity must not carry stale bytes into the collective); the labels are whole
+    HVO_HIP(hipMemset2DAsync(S, sb, 0, (flags & HVO_SLAB_LABELS) ? lab_off : sb, (size_t)n, st));
     hipLaunchKernelGGL(k_pack_header, dim3((n + 255) / 256), dim3(256), 0, st, (done & HVO_STAGE_ORB) ? O.d_nkp : nullptr, (done & HVO_STAGE_ORB) ? O.d_flags : nullptr,
                        lv.d_nkl, lv.d_flags, pv.d_meta, n, kc, lc, pc, S, sb);
     size_t off = 16;
@@ -321,9 +329,17 @@ int hvo_batch_pack_results(hvo_ctx *ctx, int n, void *d_slabs)
     HVO_HIP(field(lv.d_desc, (size_t)lc * 32, (size_t)lc * 32, lv.d_kl != nullptr));
     HVO_HIP(field(lv.d_fn, (size_t)lc * 24, (size_t)lc * 24, lv.d_kl != nullptr));
     HVO_HIP(field(pv.d_planes, (size_t)pc * sizeof(hvo_plane), (size_t)pc * sizeof(hvo_plane), pv.d_planes != nullptr));
+    if (flags & HVO_SLAB_LABELS) {
+        const size_t lb = (size_t)ctx->batch_w * ctx->batch_h, lbp = (lb + 15) & ~(size_t)15;
+        if (pv.d_labels8) HVO_HIP(hipMemcpy2DAsync(S + lab_off, sb, pv.d_labels8, (size_t)pv.npix, lb, (size_t)n, hipMemcpyDeviceToDevice, st));
+        else HVO_HIP(hipMemset2DAsync(S + lab_off, sb, 0xFF, lb, (size_t)n, st));          // no plane stage ran: every pixel "no plane"
+        if (lbp > lb) HVO_HIP(hipMemset2DAsync(S + lab_off + lb, sb, 0, lbp - lb, (size_t)n, st));
+    }
     HVO_HIP(hipStreamSynchronize(st));
     return HVO_OK;
 }
+
+int hvo_batch_pack_results(hvo_ctx *ctx, int n, void *d_slabs) { return hvo_batch_pack_results_ex(ctx, n, d_slabs, 0); }
 
 int hvo_extract_batch(hvo_ctx *ctx, int n, const hvo_frame_in *in, hvo_frame_out *out, int w, int h, unsigned stages)
 {

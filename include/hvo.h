@@ -344,6 +344,12 @@ int hvo_batch_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
  * ncclAllGather); stages that did not run report zero counts. */
 int hvo_batch_slab_layout(hvo_ctx *ctx, int *kp_cap, int *kl_cap, int *pl_cap, size_t *slab_bytes);
 int hvo_batch_pack_results(hvo_ctx *ctx, int n, void *d_slabs);
+/* The same with options: HVO_SLAB_LABELS appends the frame's label image (membershipImg as int8, -1 = no plane; w * h bytes rounded up
+ * to 16) to every slab, so that the one collective of a multi-GPU caller also carries the plane labels -- 307 200 B per 640x480 frame on
+ * top of the 93.7 KB of the records (a 256-frame gather over xGMI grows from 24 MB to 103 MB: ~0.7 ms per GPU at 153 GB/s per link). */
+#define HVO_SLAB_LABELS 1u
+int hvo_batch_slab_layout_ex(hvo_ctx *ctx, unsigned flags, int *kp_cap, int *kl_cap, int *pl_cap, size_t *labels_off, size_t *slab_bytes);
+int hvo_batch_pack_results_ex(hvo_ctx *ctx, int n, void *d_slabs, unsigned flags);
 /* upload + run + download */
 int hvo_extract_batch(hvo_ctx *ctx, int n, const hvo_frame_in *in, hvo_frame_out *out, int w, int h,
                       unsigned stages);

@@ -35,7 +35,7 @@ def _oracle_results(orc, gray, depth):
         kp, desc = o.extract(g)
         kl, ld, fn = orc.line_extract(g)
         lab, pl = orc.peac(d)
-        res.append({"kp": kp, "desc": desc, "kl": kl, "ldesc": ld, "linefn": fn, "planes": pl, "status": 0})
+        res.append({"kp": kp, "desc": desc, "kl": kl, "ldesc": ld, "linefn": fn, "planes": pl, "labels": lab, "status": 0})
     return res
 
 
@@ -51,12 +51,14 @@ def _worker(rank, world, port, n_frames, q):
     lo, hi = hd.shard_range(n_frames, world, rank)
     local = _oracle_results(orc, gray[lo:hi], depth[lo:hi])
     allres = hd.gather_results(pkg, local, n_frames, kp_cap=1100, kl_cap=200)
+    withlab = hd.gather_results(pkg, local, n_frames, kp_cap=1100, kl_cap=200, label_shape=(240, 320))      # the slab that also carries membershipImg
     if rank == 0:
         ref = _oracle_results(orc, gray, depth)
-        ok = len(allres) == n_frames
-        for a, b in zip(allres, ref):
+        ok = len(allres) == n_frames and len(withlab) == n_frames
+        for a, a2, b in zip(allres, withlab, ref):
             for k in ("kp", "desc", "kl", "ldesc", "linefn", "planes"):
-                ok = ok and np.array_equal(a[k], b[k])
+                ok = ok and np.array_equal(a[k], b[k]) and np.array_equal(a2[k], b[k])
+            ok = ok and "labels" not in a and np.array_equal(a2["labels"], b["labels"]) and (b["labels"] >= 0).any()
         q.put(bool(ok))
     dist.barrier()
     dist.destroy_process_group()

@@ -186,6 +186,16 @@ for a, b in zip(back, res):
     for k in ("kp", "desc", "kl", "ldesc", "linefn", "planes"):
         assert np.array_equal(a[k], b[k]), k
     assert len(a["kp"]) > 500 and len(a["kl"]) > 20 and len(a["planes"]) >= 3
+# the slab that also carries the label image (HVO_SLAB_LABELS): same records, plus membershipImg bit for bit
+kc2, lc2, pc2, sb2, lo2 = ctx.slab_layout(labels=True)
+L2 = hd.slab_layout(hvo, kc2, lc2, pc2, label_shape=(480, 640))
+assert sb2 == L2["size"] and lo2 == L2["labels"][0] == sb and sb2 == sb + 480 * 640
+slabs2 = hd.device_slabs(ctx, 3, labels=True)
+back2 = hd.unpack_results(hvo, slabs2.cpu().numpy(), kc2, lc2, pc2, label_shape=(480, 640))
+for a, b in zip(back2, res):
+    for k in ("kp", "desc", "kl", "ldesc", "linefn", "planes", "labels"):
+        assert np.array_equal(a[k], b[k]), k
+    assert (a["labels"] >= 0).mean() > 0.3
 ctx.close()
 print("slabs ok")
 """
@@ -216,6 +226,8 @@ ctx = hvo.Context(max_batch=2)
 ctx.batch_upload(g, d); ctx.batch_run(hvo.STAGE_ALL)
 seen, sb = hd.gather_device_slabs(ctx, 2)               # device tensor -> all_gather_into_tensor (RCCL), world size 1
 assert seen == 1 and sb == ctx.slab_layout()[3], (seen, sb)
+seen, sb = hd.gather_device_slabs(ctx, 2, labels=True)  # the slabs that carry the label image too
+assert seen == 1 and sb == ctx.slab_layout(labels=True)[3] == ctx.slab_layout()[3] + 480 * 640, (seen, sb)
 ctx.close()
 dist.destroy_process_group()
 print("nccl gather ok")
