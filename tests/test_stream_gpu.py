@@ -161,3 +161,51 @@ def test_stream_project_last(hvo, orc, synth, tz, mono):
         assert no > 50
     finally:
         st.close()
+
+
+def _write_png(path, arr):
+    """8-bit RGB or 16-bit grey PNG, filter 0 rows (the loader's decoder is exercised filter by filter in test_tum_loader.py)"""
+    import struct, zlib
+    h, w = arr.shape[:2]
+    if arr.dtype == np.uint16:
+        raw = arr.astype(">u2").tobytes(); row = w * 2; depth, ctype = 16, 0
+    else:
+        raw = arr.tobytes(); row = w * 3; depth, ctype = 8, 2
+    body = b"".join(b"\x00" + raw[y * row:(y + 1) * row] for y in range(h))
+    def chunk(t, b): return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(body, 1)) + chunk(b"IEND", b""))
+
+
+def test_tum_directory_through_the_stream_bench(hvo, orc, synth, tmp_path):
+    """BASELINE configs[4] end to end on a TUM-format directory (generated: rgb/*.png, depth/*.png, an association file in the format of
+    Examples/RGB-D/associations/fr1_desk.txt): the loader's frames equal the generated ones, `bench.py --mode stream` with HVO_TUM_DIR
+    runs the whole constructor + matching on them, and two of its frames through hvo_stream_* equal the oracle."""
+    import importlib, json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = 6
+    g, d, off = synth.make_sequence("std", 0x5EED2200, n)
+    os.makedirs(tmp_path / "rgb"); os.makedirs(tmp_path / "depth")
+    lines = ["# color images and depth maps", "# timestamp filename timestamp filename"]
+    for k in range(n):
+        t = 1305031453.359684 + k / 30.0
+        _write_png(tmp_path / "rgb" / ("%.6f.png" % t), np.repeat(g[k][:, :, None], 3, axis=2))     # R = G = B: the grey conversion's weights sum to 1
+        _write_png(tmp_path / "depth" / ("%.6f.png" % (t + 0.01)), d[k])
+        lines.append("%.6f rgb/%.6f.png %.6f depth/%.6f.png" % (t, t, t + 0.01, t + 0.01))
+    (tmp_path / "associations.txt").write_text("\n".join(lines) + "\n")
+    tum = importlib.import_module("hvo_amd.tum")
+    lg, ld = tum.load_sequence(str(tmp_path))
+    assert np.array_equal(lg, g) and np.array_equal(ld, d)
+    env = dict(os.environ, HVO_TUM_DIR=str(tmp_path))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "stream", "--steps", "4", "--warmup", "2"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert "TUM RGB-D sequence" in line["data"] and line["value"] > 0 and line["config"]["workload"]
+    st = hvo.Stream(depth=2, stages=hvo.STAGE_ALL, bf=BF)
+    try:
+        orb = orc.Orb()
+        for k in (0, 5):
+            r = st.collect(st.submit(lg[k], ld[k]))
+            check_frame(r, g[k], d[k], orc, orb)
+    finally:
+        st.close()

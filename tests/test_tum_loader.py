@@ -64,3 +64,30 @@ def test_png_decoder_all_filters_and_sequence(tmp_path):
     (tmp_path / "depth.txt").write_text("".join("%d.015 depth/%d.png\n" % (k, k) for k in range(3)))
     g2, d2 = tum.load_sequence(str(tmp_path), limit=2)
     assert len(g2) == 2 and np.array_equal(d2[1], d[1])
+
+
+def test_png_photograph_filters_mixed_rows_and_alpha(tmp_path):
+    """every row its own filter (what an encoder does on a photograph), a frame-sized image, grey + alpha, and time-stamp association"""
+    load_pkg()
+    tum = importlib.import_module("hvo_amd.tum")
+    rng = np.random.default_rng(7)
+    rgb = rng.integers(0, 256, (9, 23, 3), dtype=np.uint8)
+    # rows with filters 0..4 in turn: built row by row with the reference encoder of this file
+    h, w = rgb.shape[:2]
+    rows = b""
+    import zlib as _z
+    for y in range(h):
+        one = _png(rgb[:y + 1], y % 5)                     # encode rows 0..y with filter y % 5, take the last row's bytes
+        body = _z.decompress(one[one.index(b"IDAT") + 4: one.index(b"IEND") - 8])
+        rows += body[-(w * 3 + 1):]
+    def chunk(t, b): return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xffffffff)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(rows)) + chunk(b"IEND", b"")
+    assert np.array_equal(tum.decode_png(png), rgb)
+    ga = rng.integers(0, 256, (5, 7, 2), dtype=np.uint8)
+    raw = b"".join(b"\x00" + ga[y].tobytes() for y in range(5))
+    png4 = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 7, 5, 8, 4, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+    assert np.array_equal(tum.to_gray(tum.decode_png(png4)), ga[..., 0])
+    # associate(): the closest pair wins even when an earlier colour stamp is nearer to the same depth stamp than its own
+    (tmp_path / "rgb.txt").write_text("# t file\n1.000 rgb/a.png\n1.030 rgb/b.png\n1.060 rgb/c.png\n")
+    (tmp_path / "depth.txt").write_text("1.019 depth/x.png\n1.061 depth/y.png\n")
+    assert tum.associate(str(tmp_path)) == [("rgb/b.png", "depth/x.png"), ("rgb/c.png", "depth/y.png")]
