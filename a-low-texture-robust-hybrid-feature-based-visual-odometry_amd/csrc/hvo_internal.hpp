@@ -61,6 +61,7 @@ struct OrbPlan {
     int last_chunks = 0;                  // chunks the last orb_run walked (hvo_debug_orb_plan)
     bool fused = false;                 // the fused per-level pass (orb_level.hip) serves this geometry
     int lt_off[HVO_MAX_LEVELS] = {}, lt_cnt[HVO_MAX_LEVELS] = {}, lt_tpw = 4;
+    int lt_nw = 4;                        // waves per workgroup of k_orb_level (HVO_ORB_NW, read when the plan is built)
     OrbTile *d_ltiles = nullptr;
     int2 *d_kpchunks = nullptr; int n_kpchunks = 0;     // (level, first slot) of every 32-slot chunk of the per-level key-point slabs (orb_describe.hip)
     int kp_cap = 0;                     // output capacity per frame

@@ -1458,9 +1458,13 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
         HVO_HIP(hipStreamSynchronize(st));
         if (need <= P->pool_cap) break;
         if (attempt == 2) return HVO_ERR_CAPACITY;
-        HVO_HIP(hipFree(P->d_pool)); P->d_pool = nullptr;
-        P->pool_cap = (size_t)((double)need * 1.1) + 4096;
-        HVO_HIP(hipMalloc((void **)&P->d_pool, P->pool_cap * sizeof(double4)));
+        // the larger pool first: a failed allocation must not leave a null pool behind an enlarged capacity (the next run would pass the
+        // capacity test and the kernels would dereference it)
+        const size_t new_cap = (size_t)((double)need * 1.1) + 4096;
+        double4 *np_ = nullptr;
+        if (hipMalloc((void **)&np_, new_cap * sizeof(double4)) != hipSuccess) { (void)hipGetLastError(); ctx->last_error = "LSD record pool: out of device memory"; return HVO_ERR_HIP; }
+        HVO_HIP(hipFree(P->d_pool));
+        P->d_pool = np_; P->pool_cap = new_cap;
     }
     if (ctx->ev_lsd_pre && !ctx->serialize) { HVO_HIP(hipEventRecord(ctx->ev_lsd_pre, st)); ctx->lsd_pre_recorded = true; }
     if ((ctx->sched == 2 || ctx->sched == 5 || ctx->sched == 6) && ctx->fast_recorded && !ctx->serialize) HVO_HIP(hipStreamWaitEvent(st, ctx->ev_fast, 0));

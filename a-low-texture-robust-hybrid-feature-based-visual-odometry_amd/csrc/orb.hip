@@ -890,6 +890,7 @@ static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch)
         const bool want = !(getenv("HVO_ORB_FUSED") && atoi(getenv("HVO_ORB_FUSED")) == 0);
         P.fused = want && orb_level_build(P, cells, xofs, yofs, lt);
         if (getenv("HVO_ORB_TPW")) P.lt_tpw = std::max(1, atoi(getenv("HVO_ORB_TPW")));
+        if (getenv("HVO_ORB_NW")) { const int nw = atoi(getenv("HVO_ORB_NW")); P.lt_nw = nw == 1 || nw == 2 ? nw : 4; }
         if (P.fused && (rc = dev_upload(ctx, &P.d_ltiles, lt))) return rc;
     }
     if ((rc = orb_describe_build(ctx))) return rc;

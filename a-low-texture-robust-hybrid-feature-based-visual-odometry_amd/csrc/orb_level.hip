@@ -563,12 +563,16 @@ int orb_level_run(hvo_ctx *ctx, int c0, int n, hipStream_t st, int k0, int k1, i
         A.wr = P.d_lvl + A.D.lvl_off; A.wr_stride = P.lvl_bytes;
         A.blur = P.d_blur + A.L.img_off; A.blur_stride = P.blur_bytes;
         A.tiles = P.d_ltiles + P.lt_off[l]; A.ntiles = P.lt_cnt[l];
-        const int nw = getenv("HVO_ORB_NW") ? atoi(getenv("HVO_ORB_NW")) : 4;
+        const int nw = P.lt_nw;                            // waves per workgroup: read once when the plan was built (HVO_ORB_NW)
         A.tpw = P.lt_tpw; A.groups = (A.ntiles + nw * A.tpw - 1) / (nw * A.tpw); A.nframes = n;
         A.xofs = P.d_rs_xofs + A.D.rs_off; A.xalpha = P.d_rs_xalpha + A.D.rs_off; A.yofs = P.d_rs_yofs + A.D.ry_off; A.ybeta = P.d_rs_ybeta + A.D.ry_off;
         A.cell_kp = P.d_cell_kp; A.cell_cnt = P.d_cell_cnt; A.ncells = P.ncells; A.iniTh = ctx->p.orb_ini_th_fast; A.minTh = ctx->p.orb_min_th_fast;
         A.res_dw = A.has_next && P.resize_dw[l + 1];
-        A.skip = getenv("HVO_LT_SKIP") ? atoi(getenv("HVO_LT_SKIP")) : 0;
+#ifdef HVO_TIMING_KNOBS
+        A.skip = getenv("HVO_LT_SKIP") ? atoi(getenv("HVO_LT_SKIP")) : 0;      // phases skipped for timing (tools/orb_phase_sweep.py): results are NOT valid outputs
+#else
+        A.skip = 0;                                        // (the phase-skip mask exists in -DHVO_TIMING_KNOBS builds only: a stray variable must not corrupt ORB output)
+#endif
         A.flags = P.d_flags + c0; A.k0 = k0; A.k1 = k1; A.k2 = k2; A.k3 = k3;
         if (A.ntiles < 1) continue;
         const int n8 = (n + 7) / 8 * 8;

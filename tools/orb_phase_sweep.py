@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ms per 8192-frame launch group of the ORB stage under HVO_LT_SKIP / HVO_ORB_TPW settings (timing experiments for orb_level.hip;
+"""(needs a timing build: make -C .../csrc DEFS=-DHVO_TIMING_KNOBS -- the phase-skip mask is compiled out of the product library) ms per 8192-frame launch group of the ORB stage under HVO_LT_SKIP / HVO_ORB_TPW settings (timing experiments for orb_level.hip;
 results with a skip mask are not valid outputs).  usage: python tools/orb_phase_sweep.py [batch]"""
 import importlib, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

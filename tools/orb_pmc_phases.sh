@@ -1,5 +1,5 @@
 #!/bin/bash
-# instruction counts of k_orb_level per phase: SQ counters with HVO_LT_SKIP masks (timing experiment knob of orb_level.hip)
+# instruction counts of k_orb_level per phase: SQ counters with HVO_LT_SKIP masks (timing experiment knob of orb_level.hip) -- needs a -DHVO_TIMING_KNOBS build of libhvo.so
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 B=${1:-1024}
 O=$R/gpurun_out/prof/orb_pmc_ph
