@@ -62,6 +62,7 @@ struct LsdPlan {
     double rho = 0, prec = 0, p = 0; unsigned min_reg = 0;
     long long *d_stats = nullptr;      // per frame 8 counters (diagnostics: hvo_debug_lsd_stats)
     // k_lsd_grow_async (lsd_async.inc), allocated at its first launch for the first `async_b` frames of the plan
+    bool pre_fused = true;             // k_lsd_pre instead of k_lsd_blur + k_lsd_resize_grad (HVO_LSD_PRE_SPLIT=1: the pair, with its fp64 image)
     int async_b = 0; unsigned *d_atags = nullptr; void *d_actl = nullptr; int *d_alists = nullptr, *d_ablk = nullptr, *d_afreg = nullptr;
 };
 static LsdPlan *plan_of(hvo_ctx *ctx) { return (LsdPlan *)ctx->lsd; }
@@ -218,6 +219,130 @@ __global__ __launch_bounds__(256) void k_lsd_resize_grad(const double *__restric
             __syncthreads();
         }
         vprev = vcur; vprev_r = vcur_r;
+    }
+    if (tid < npend) emit(tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_lsd_pre: the whole preamble in one kernel -- the u8 image in, the 32-byte gradient records and the defined mask out.  The CV_64F
+// blurred image (2.46 MB per 640x480 frame written by k_lsd_blur and read back by k_lsd_resize_grad: 5.6 x the algorithmic bytes of
+// that pair) is never written.  A workgroup owns a band of PRE_TW scaled columns over PRE_SEG scaled rows and STREAMS down the source
+// rows it needs: a thread owns a source column, forms the row-pass value of the next source row (seven cached byte loads, RowFilter's
+// order), keeps the last seven in registers, and emits one blurred value per step (SymmColumnFilter's order) into a four-row LDS ring;
+// as soon as the two source rows a scaled row interpolates from are in the ring the scaled row is formed (scaled_at's expression) and,
+// with the previous scaled row, the gradients of that row (ll_angle as in k_lsd_resize_grad: defined-mask words by ballot, the ~15 % of
+// the pixels that have an angle queued for the double cos / sin on full workgroups).  No vertical halo but the seven-row start of a
+// segment (7 %), no horizontal one at all: every arithmetic step is the unfused pair's, in its order.
+// ------------------------------------------------------------------------------------------------
+#define PRE_TW 192                                    // scaled columns of a band: six mask words
+#define PRE_SEG 96                                    // scaled rows a workgroup walks
+__global__ __launch_bounds__(256) void k_lsd_pre(const uint8_t *__restrict__ gray, size_t gframe, int gpitch, int w, int h, int sw, int sh,
+                                                 const int *__restrict__ xofs, const float *__restrict__ xa, const int *__restrict__ yofs, const float *__restrict__ yb,
+                                                 double4 *__restrict__ px4, unsigned *__restrict__ defined, int nwords, double rho,
+                                                 double k0, double k1, double k2, double k3)
+{
+    __shared__ double bl[4][256];                     // ring of blurred source rows (row & 3), one value per thread's column
+    __shared__ double sc[2][PRE_TW + 1];              // the last two scaled rows
+    __shared__ double la[512], lm[512]; __shared__ int lpos[512];
+    __shared__ int wcnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x0 = blockIdx.x * PRE_TW, y0 = blockIdx.y * PRE_SEG, f = blockIdx.z;
+    const uint8_t *G = gray + (size_t)f * gframe;
+    double4 *PX = px4 + (size_t)f * sh * sw;
+    const int xe = min(x0 + PRE_TW, sw - 1), ye = min(y0 + PRE_SEG, sh - 1);          // last scaled column / row the band reads
+    const int nsc = xe - x0 + 1;                                                       // scaled values per row (the gradient's right neighbour included)
+    const int cA = xofs[x0], cB = min(xofs[xe] + 1, w - 1), ncols = cB - cA + 1;      // source columns (host-checked: <= 256)
+    const int sya = yofs[y0] & 0xFFFF, syb = yofs[ye] >> 16;
+    const bool colt = tid < ncols;
+    const int x = min(cA + tid, w - 1);
+    const int xm3 = refl(x - 3, w), xm2 = refl(x - 2, w), xm1 = refl(x - 1, w), xp1 = refl(x + 1, w), xp2 = refl(x + 2, w), xp3 = refl(x + 3, w);
+    // my scaled column's taps (threads < nsc) -- fixed over the rows
+    const int sxq = x0 + min(tid, nsc - 1);
+    const int tx0 = xofs[sxq] - cA, tx1 = min(xofs[sxq] + 1, w - 1) - cA;
+    const double a0 = (double)xa[2 * sxq], a1 = (double)xa[2 * sxq + 1];
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0;
+    int ys = y0;                                        // next scaled row to form
+    int npend = 0;
+    auto emit = [&](int i) {
+        // region_grow accumulates cos(float(angle)) / sin(float(angle)) evaluated in double
+        const double aa = la[i], af = (double)(float)aa;
+        double sn, cs; sincos(af, &sn, &cs);
+        PX[lpos[i]] = make_double4(aa, cs, sn, lm[i]);
+    };
+    for (int j = sya - 3; j <= syb + 3; j++) {
+        // ---- row pass of source row j (reflected), the window of seven, the column pass of row j - 3 ----
+        {
+            const uint8_t *S = G + (size_t)refl(min(j, h + 2), h) * gpitch;
+            double s = k0 * (double)S[xm3];
+            s += k1 * (double)S[xm2];
+            s += k2 * (double)S[xm1];
+            s += k3 * (double)S[x];
+            s += k2 * (double)S[xp1];
+            s += k1 * (double)S[xp2];
+            s += k0 * (double)S[xp3];
+            v0 = v1; v1 = v2; v2 = v3; v3 = v4; v4 = v5; v5 = v6; v6 = s;
+        }
+        const int rb = j - 3;                           // the blurred row that is complete now
+        if (rb < sya) continue;                         // (uniform) the window is filling
+        {
+            double s = k3 * v3;
+            s += k2 * (v4 + v2);
+            s += k1 * (v5 + v1);
+            s += k0 * (v6 + v0);
+            if (colt) bl[rb & 3][tid] = s;
+        }
+        __syncthreads();
+        // ---- every scaled row whose lower source row is rb (0, 1 or 2 of them) ----
+        while (ys <= ye && (yofs[ys] >> 16) <= rb) {     // uniform
+            const int yo = yofs[ys];
+            const int sy0 = yo & 0xFFFF, sy1 = yo >> 16;
+            if (tid < nsc) {
+                const double b0 = (double)yb[2 * ys], b1 = (double)yb[2 * ys + 1];
+                const double *S0 = bl[sy0 & 3], *S1 = bl[sy1 & 3];
+                const double t0 = S0[tx0] * a0 + S0[tx1] * a1;
+                const double t1 = S1[tx0] * a0 + S1[tx1] * a1;
+                sc[ys & 1][tid] = t0 * b0 + t1 * b1;
+            }
+            __syncthreads();
+            if (ys > y0) {
+                // ---- ll_angle of scaled row ys - 1 (its lower neighbours are row ys) ----
+                const int y = ys - 1, xg = x0 + tid;
+                bool def = false;
+                double a = LSD_NOTDEF, m = 0;
+                if (tid < PRE_TW && xg < sw - 1 && y < sh - 1) {
+                    const double vprev = sc[y & 1][tid], vprev_r = sc[y & 1][tid + 1], vcur = sc[ys & 1][tid], vcur_r = sc[ys & 1][tid + 1];
+                    const double DA = vcur_r - vprev, BC = vprev_r - vcur;
+                    const double gx = DA + BC, gy = DA - BC;
+                    m = sqrt((gx * gx + gy * gy) / 4);
+                    if (!(m <= rho)) { a = (double)fatan2_deg((float)gx, (float)-gy) * (LSD_PI / 180); def = true; }
+                }
+                const unsigned long long bal = __ballot(def);
+                if (tid < PRE_TW && xg < ((sw + 31) & ~31)) {
+                    const int word = (y * ((sw + 31) / 32)) + (xg >> 5);
+                    if ((lane & 31) == 0) defined[(size_t)f * nwords + word] = (unsigned)(bal >> (lane & 32));
+                }
+                // the ~15 % of the pixels that have an angle are queued; the double cos / sin run on full workgroups (all four waves at once:
+                // a per-wave queue was tried -- the waves are tied by the barriers of the row loop and wait for whichever one is emitting)
+                if (lane == 0) wcnt[wv] = __popcll(bal);
+                __syncthreads();
+                int base = 0, total = 0;
+                for (int i = 0; i < 4; i++) { const int cn = wcnt[i]; if (i < wv) base += cn; total += cn; }
+                if (def) { const int p = npend + base + __popcll(bal & ((1ull << lane) - 1)); la[p] = a; lm[p] = m; lpos[p] = y * sw + xg; }
+                npend += total;
+                __syncthreads();
+                if (npend >= 256) {                       // a full workgroup of queued pixels
+                    emit(tid);
+                    const int rem = npend - 256;
+                    double ta = 0, tm = 0; int tp = 0;
+                    if (tid < rem) { ta = la[256 + tid]; tm = lm[256 + tid]; tp = lpos[256 + tid]; }
+                    __syncthreads();
+                    if (tid < rem) { la[tid] = ta; lm[tid] = tm; lpos[tid] = tp; }
+                    npend = rem;
+                }
+            }
+            __syncthreads();                              // the scaled row before this one (and the queue) may be written again
+            ys++;
+        }
     }
     if (tid < npend) emit(tid);
 }
@@ -1372,7 +1497,9 @@ static int lsd_build_plan(hvo_ctx *ctx, int w, int h, int batch)
         P->chunk = (int)std::min<size_t>((size_t)P->chunk, std::min<size_t>(fit, 512));
     }
     const size_t CB = (size_t)P->chunk;
-    PA(P->d_blur, CB * npix * 8);
+    { const char *e = getenv("HVO_LSD_PRE_SPLIT"); P->pre_fused = !(e && atoi(e) != 0); }
+    // the tile of k_lsd_pre holds the source rectangle of PRE_TW x PRE_TR scaled pixels: true for the 0.8 scale of every geometry (asserted here)
+    if (!P->pre_fused) PA(P->d_blur, CB * npix * 8);
     if (P->compact) {
         PA(P->d_px, CB * nsp * sizeof(double4));
         P->pool_cap = std::max<size_t>((size_t)((double)(B * nsp) * frac), 4096);
@@ -1390,6 +1517,12 @@ static int lsd_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_dxy, CB * npix * sizeof(short2));
     PA(P->d_xofs, P->sw * 4); PA(P->d_yofs, P->sh * 4); PA(P->d_xa, P->sw * 8); PA(P->d_yb, P->sh * 8);
     PA(P->d_gL, 21 * 4); PA(P->d_gG, 63 * 4); PA(P->d_stats, B * 64);
+    if (P->pre_fused) {
+        // a band's source columns must fit the workgroup's 256 threads (true for the 0.8x scale: 192 / 0.8 + 2; checked, not assumed)
+        int maxc = 0;
+        for (int x0 = 0; x0 < P->sw; x0 += PRE_TW) { const int xe = std::min(x0 + PRE_TW, P->sw - 1); maxc = std::max(maxc, std::min(xofs[xe] + 1, w - 1) - xofs[x0] + 1); }
+        if (maxc > 256) { P->pre_fused = false; PA(P->d_blur, CB * npix * 8); }
+    }
 #undef PA
     HVO_HIP(hipMemcpy(P->d_xofs, xofs.data(), P->sw * 4, hipMemcpyHostToDevice));
     HVO_HIP(hipMemcpy(P->d_yofs, yofs.data(), P->sh * 4, hipMemcpyHostToDevice));
@@ -1434,6 +1567,13 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
         if (P->compact) HVO_HIP(hipMemsetAsync(P->d_pooltop, 0, 16, st));
         for (int c0 = 0; c0 < n; c0 += P->chunk) {
             const int m = std::min(P->chunk, n - c0);
+            if (P->pre_fused) {
+                // one kernel from the u8 image to the records (k_lsd_pre); the fp64 blurred image is never written
+                id = hvo_prof_begin(ctx, "lsd_gradient", st);
+                hipLaunchKernelGGL(k_lsd_pre, dim3((sw + PRE_TW - 1) / PRE_TW, (sh - 1 + PRE_SEG - 1) / PRE_SEG, m), dim3(256), 0, st, gray + (size_t)c0 * O.pyr_bytes, O.pyr_bytes, gpitch,
+                                   w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb, P->d_px + (P->compact ? 0 : (size_t)c0 * nsp),
+                                   P->d_defined + (size_t)c0 * P->nwords, P->nwords, P->rho, P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
+            } else {
             id = hvo_prof_begin(ctx, "lsd_blur_scale", st);
             hipLaunchKernelGGL(k_lsd_blur, dim3((w + 255) / 256, (h + LSD_BLUR_ROWS - 1) / LSD_BLUR_ROWS, m), dim3(256), 0, st, gray + (size_t)c0 * O.pyr_bytes, O.pyr_bytes, gpitch, P->d_blur, w, h,
                                P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
@@ -1441,6 +1581,7 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
             id = hvo_prof_begin(ctx, "lsd_gradient", st);
             hipLaunchKernelGGL(k_lsd_resize_grad, dim3(gx, (sh + GRAD_ROWS - 1) / GRAD_ROWS, m), dim3(256), 0, st, P->d_blur, w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb,
                                P->d_px + (P->compact ? 0 : (size_t)c0 * nsp), P->d_defined + (size_t)c0 * P->nwords, P->nwords, P->rho);
+            }
             if (P->compact) {
                 hipLaunchKernelGGL(k_lsd_prefix, dim3(m), dim3(256), 0, st, P->d_defined + (size_t)c0 * P->nwords, P->d_defmask + (size_t)c0 * P->nwords,
                                    P->d_wprefix + (size_t)c0 * P->nwords, P->d_fcount + c0, P->nwords);

@@ -72,6 +72,29 @@ def test_lines_compact_records(hvo, orc, synth, monkeypatch, dense, frac, chunk)
             ctx.close()
 
 
+@pytest.mark.parametrize("split", ["0", "1"])
+@pytest.mark.parametrize("hh,ww", [(480, 640), (397, 501), (960, 1280)])
+def test_lines_preamble_fused_and_split(hvo, orc, synth, monkeypatch, split, hh, ww):
+    """k_lsd_pre (one kernel from the u8 image to the gradient records, streaming down bands of 192 scaled columns) and the pair
+    k_lsd_blur + k_lsd_resize_grad with its fp64 image between them (HVO_LSD_PRE_SPLIT=1) are the same arithmetic in the same order:
+    both against the oracle, on a batch (bands x segments x frames), an odd geometry (a partial last band and segment) and 1280x960"""
+    monkeypatch.setenv("HVO_LSD_PRE_SPLIT", split)
+    big = synth.make_gray("std", 12, 1280, 960) if ww > 704 else synth.make_gray("std", 11, 704, 480)
+    g = np.ascontiguousarray(np.stack([big[:hh, :ww], np.flipud(big[:hh, :ww])]))
+    ctx = hvo.Context(max_batch=2)
+    try:
+        ctx.batch_upload(g, np.zeros((2, hh, ww), np.uint16))
+        for _ in range(2):
+            ctx.batch_run(hvo.STAGE_LSD)
+            res = ctx.batch_download(hvo.STAGE_LSD)
+            for b in range(2):
+                kl_o, d_o, fn_o = orc.line_extract(g[b])
+                assert res[b]["status"] == 0 and len(kl_o) > 10
+                check(res[b]["kl"], res[b]["ldesc"], res[b]["linefn"], kl_o, d_o, fn_o)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("hh,ww", [(397, 501), (479, 638), (400, 642)])
 def test_lines_odd_geometry(hvo, orc, synth, hh, ww):
     """widths that are not a multiple of 4 (scalar tails of the LBD blur / Sobel strips, unaligned Sobel rows) and lines
