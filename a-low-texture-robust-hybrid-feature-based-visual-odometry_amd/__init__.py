@@ -66,7 +66,7 @@ EXPORTS = [
     "hvo_hamming_matrix", "hvo_hamming_knn2", "hvo_match_nnr", "hvo_search_by_projection", "hvo_stereo_from_rgbd",
     "hvo_undistort_keypoints", "hvo_image_bounds", "hvo_assign_features_to_grid", "hvo_assign_lines_to_grid",
     "hvo_extract_lsd_culled", "hvo_set_line_culling", "hvo_lines_3d", "hvo_vanishing_points", "hvo_plane_clouds", "hvo_surface_normals", "hvo_search_by_projection_map", "hvo_frame_bf_match", "hvo_search_double",
-    "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch", "hvo_batch_slab_layout", "hvo_batch_pack_results", "hvo_batch_slab_layout_ex", "hvo_batch_pack_results_ex",
+    "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch", "hvo_batch_slab_layout", "hvo_batch_pack_results", "hvo_batch_slab_layout_ex", "hvo_batch_pack_results_ex", "hvo_batch_stage_upload", "hvo_batch_commit_staged", "hvo_batch_results_async", "hvo_batch_results_wait",
     "hvo_profile_last", "hvo_profile_enable", "hvo_pin_host", "hvo_unpin_host",
     "hvo_stream_create", "hvo_stream_destroy", "hvo_stream_last_error", "hvo_stream_capacity", "hvo_stream_image_bounds",
     "hvo_stream_submit", "hvo_stream_poll", "hvo_stream_collect", "hvo_stream_stage_ms",
@@ -514,6 +514,44 @@ class Context:
                 fi[b].depth = depth[s].ctypes.data; fi[b].depth_stride = depth.strides[1]
         self._chk(lib().hvo_batch_upload(self.h, B, fi, w, h), "batch_upload")
         self._B, self._w, self._h = B, w, h
+
+    def _frames_in(self, gray, depth, repeat):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        B0, h, w = gray.shape
+        if depth is not None:
+            depth = np.ascontiguousarray(depth, np.uint16)
+        B = B0 * repeat
+        fi = (FrameIn * B)()
+        for b in range(B):
+            s = b % B0
+            fi[b].gray = gray[s].ctypes.data; fi[b].gray_stride = gray.strides[1]
+            if depth is not None:
+                fi[b].depth = depth[s].ctypes.data; fi[b].depth_stride = depth.strides[1]
+        return fi, B, w, h, (gray, depth)
+
+    def batch_stage_upload(self, gray, depth=None, repeat=1, frames_in=None):
+        """the NEXT batch's images into the staging slabs, enqueued on a copy stream of its own (returns at once; the host arrays must
+        stay alive and unchanged until batch_commit_staged).  frames_in: a tuple from a previous call (the FrameIn table is reused)."""
+        fr = frames_in if frames_in is not None else self._frames_in(gray, depth, repeat)
+        fi, B, w, h, _keep = fr
+        self._chk(lib().hvo_batch_stage_upload(self.h, B, fi, w, h), "batch_stage_upload")
+        self._staged = fr
+        return fr
+
+    def batch_commit_staged(self):
+        """wait for the staged upload and make it the resident batch (device-to-device)"""
+        self._chk(lib().hvo_batch_commit_staged(self.h), "batch_commit_staged")
+        _, self._B, self._w, self._h, _ = self._staged
+
+    def batch_results_async(self, n, host_slabs, labels=True):
+        """pack the first n frames' results (hvo_batch_pack_results_ex) and start ONE copy of the slabs into `host_slabs` (a page-locked
+        uint8 array of n * slab_bytes); batch_results_wait() waits for it.  The resident batch may run again at once."""
+        fn = lib().hvo_batch_results_async
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_void_p]
+        self._chk(fn(self.h, n, SLAB_LABELS if labels else 0, host_slabs.ctypes.data), "batch_results_async")
+
+    def batch_results_wait(self):
+        self._chk(lib().hvo_batch_results_wait(self.h), "batch_results_wait")
 
     def batch_run(self, stages=STAGE_ALL):
         self._chk(lib().hvo_batch_run(self.h, stages), "batch_run")

@@ -120,6 +120,12 @@ void hvo_destroy(hvo_ctx *ctx)
     for (int i = 0; i < 2; i++) if (ctx->ev_stage[i]) (void)hipEventDestroy(ctx->ev_stage[i]);
     for (auto &r : ctx->prof) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
     if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
+    if (ctx->s_stage_up) (void)hipStreamDestroy(ctx->s_stage_up);
+    if (ctx->s_stage_down) (void)hipStreamDestroy(ctx->s_stage_down);
+    if (ctx->ev_stage_up) (void)hipEventDestroy(ctx->ev_stage_up);
+    if (ctx->d_stage_gray) (void)hipFree(ctx->d_stage_gray);
+    if (ctx->d_stage_depth) (void)hipFree(ctx->d_stage_depth);
+    if (ctx->d_result_slab) (void)hipFree(ctx->d_result_slab);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->s_lsd) (void)hipStreamDestroy(ctx->s_lsd);
     if (ctx->s_peac) (void)hipStreamDestroy(ctx->s_peac);
@@ -181,6 +187,80 @@ int hvo_batch_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h)
     if (ctx->have_depth) { rc = peac_upload(ctx, n, in, w, h); if (rc) return rc; }
     ctx->batch_n = n; ctx->batch_w = w; ctx->batch_h = h;
     ctx->last_stages = 0;                                  // nothing has been computed for this batch yet
+    return HVO_OK;
+}
+
+int hvo_batch_stage_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h)
+{
+    if (!ctx || !in || n < 1) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    if (!ctx->s_stage_up) {
+        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HVO_HIP(hipStreamCreateWithPriority(&ctx->s_stage_up, hipStreamNonBlocking, hi)); HVO_HIP(hipStreamCreateWithPriority(&ctx->s_stage_down, hipStreamNonBlocking, hi));
+        HVO_HIP(hipEventCreateWithFlags(&ctx->ev_stage_up, hipEventDisableTiming));
+    }
+    // the plans first (their geometry gives the staging slabs' sizes); nothing of the resident batch is touched
+    int rc = orb_ensure_plan(ctx, w, h, std::max(n, ctx->p.max_batch));
+    if (rc) return rc;
+    bool depth = true;
+    for (int f = 0; f < n; f++) if (!in[f].depth) depth = false;
+    const size_t gb = (size_t)ctx->orb.batch * ctx->orb.pyr_bytes;
+    if (ctx->stage_gray_bytes < gb) { if (ctx->d_stage_gray) (void)hipFree(ctx->d_stage_gray); ctx->d_stage_gray = nullptr; ctx->stage_gray_bytes = 0; HVO_HIP(hipMalloc((void **)&ctx->d_stage_gray, gb)); ctx->stage_gray_bytes = gb; }
+    PeacView pv; memset(&pv, 0, sizeof(pv));
+    if (depth) {
+        if ((rc = peac_prepare(ctx, w, h, std::max(n, ctx->p.max_batch), &pv))) return rc;
+        const size_t db = (size_t)std::max(n, ctx->p.max_batch) * pv.dframe * sizeof(uint16_t);
+        if (ctx->stage_depth_bytes < db) { if (ctx->d_stage_depth) (void)hipFree(ctx->d_stage_depth); ctx->d_stage_depth = nullptr; ctx->stage_depth_bytes = 0; HVO_HIP(hipMalloc((void **)&ctx->d_stage_depth, db)); ctx->stage_depth_bytes = db; }
+    }
+    ctx->stage_gray_dst = ctx->d_stage_gray; ctx->stage_depth_dst = depth ? ctx->d_stage_depth : nullptr;
+    rc = orb_upload(ctx, n, in, w, h, false);
+    if (!rc && depth) rc = peac_upload(ctx, n, in, w, h, false);
+    ctx->stage_gray_dst = nullptr; ctx->stage_depth_dst = nullptr;
+    if (rc) return rc;
+    HVO_HIP(hipEventRecord(ctx->ev_stage_up, ctx->s_stage_up));
+    ctx->stage_n = n; ctx->stage_w = w; ctx->stage_h = h; ctx->stage_depth = depth;
+    return HVO_OK;
+}
+
+int hvo_batch_commit_staged(hvo_ctx *ctx)
+{
+    if (!ctx || ctx->stage_n < 1) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    const int n = ctx->stage_n, w = ctx->stage_w, h = ctx->stage_h;
+    HVO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_stage_up, 0));
+    HVO_HIP(hipMemcpyAsync(ctx->orb.d_pyr, ctx->d_stage_gray, (size_t)n * ctx->orb.pyr_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    if (ctx->stage_depth) {
+        PeacView pv; memset(&pv, 0, sizeof(pv));
+        int rc = peac_prepare(ctx, w, h, std::max(n, ctx->p.max_batch), &pv);
+        if (rc) return rc;
+        HVO_HIP(hipMemcpyAsync(pv.d_depth, ctx->d_stage_depth, (size_t)n * pv.dframe * sizeof(uint16_t), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    HVO_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->have_depth = ctx->stage_depth;
+    ctx->batch_n = n; ctx->batch_w = w; ctx->batch_h = h; ctx->last_stages = 0; ctx->stage_n = 0;
+    return HVO_OK;
+}
+
+int hvo_batch_results_async(hvo_ctx *ctx, int n, unsigned flags, void *host_slabs)
+{
+    if (!ctx || !host_slabs || n < 1 || n > ctx->batch_n) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    size_t sb = 0;
+    int rc = hvo_batch_slab_layout_ex(ctx, flags, nullptr, nullptr, nullptr, nullptr, &sb);
+    if (rc) return rc;
+    if (!ctx->s_stage_down) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HVO_HIP(hipStreamCreateWithPriority(&ctx->s_stage_down, hipStreamNonBlocking, hi)); }
+    HVO_HIP(hipStreamSynchronize(ctx->s_stage_down));       // the slab's previous content has left
+    if (ctx->result_slab_bytes < (size_t)n * sb) { if (ctx->d_result_slab) (void)hipFree(ctx->d_result_slab); ctx->d_result_slab = nullptr; ctx->result_slab_bytes = 0; HVO_HIP(hipMalloc((void **)&ctx->d_result_slab, (size_t)n * sb)); ctx->result_slab_bytes = (size_t)n * sb; }
+    if ((rc = hvo_batch_pack_results_ex(ctx, n, ctx->d_result_slab, flags))) return rc;       // device to device, waited for: the next run may overwrite the results
+    HVO_HIP(hipMemcpyAsync(host_slabs, ctx->d_result_slab, (size_t)n * sb, hipMemcpyDeviceToHost, ctx->s_stage_down));
+    return HVO_OK;
+}
+
+int hvo_batch_results_wait(hvo_ctx *ctx)
+{
+    if (!ctx) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    if (ctx->s_stage_down) HVO_HIP(hipStreamSynchronize(ctx->s_stage_down));
     return HVO_OK;
 }
 

@@ -97,6 +97,13 @@ struct hvo_ctx {
     int sched = 1;                         // overlap policy in force (hvo_batch_run sets it per batch), see api.hip
     int sched_cfg = -1;                    // HVO_SCHED, or -1 = by batch size: 5 from 3072 resident frames on, 1 below
     bool orb_blur_late = false;            // k_blur7 behind k_fast_cells instead of before it (HVO_ORB_BLUR_LATE)
+    // double-buffered batches (hvo_batch_stage_upload / _commit_staged / _results_async): the NEXT batch's images go into staging slabs and
+    // the LAST batch's results leave from a packed slab while the resident batch runs
+    uint8_t *d_stage_gray = nullptr; uint16_t *d_stage_depth = nullptr; size_t stage_gray_bytes = 0, stage_depth_bytes = 0;
+    uint8_t *stage_gray_dst = nullptr; uint16_t *stage_depth_dst = nullptr;      // when set, orb_upload / peac_upload write here instead of the resident slabs
+    int stage_n = 0, stage_w = 0, stage_h = 0; bool stage_depth = false;
+    hipStream_t s_stage_up = nullptr, s_stage_down = nullptr; hipEvent_t ev_stage_up = nullptr;
+    char *d_result_slab = nullptr; size_t result_slab_bytes = 0;
     hipStream_t s_copy = nullptr; bool copy_hi = false;   // batch uploads / downloads go on a stream of their own, above the compute streams (hvo_copy_stream)
     std::vector<std::pair<int, int *>> perms;   // launch orders (hvo_frame_perm), one device array per length asked for
     double cull_dis = 5.0, cull_angle = 2.5, cull_endpoint = 15.0;   // Frame::cullingLine(im, 5, 2.5, 15, 30), Frame.cc:934

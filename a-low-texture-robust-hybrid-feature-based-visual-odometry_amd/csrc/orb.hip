@@ -928,10 +928,11 @@ static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch)
 
 int orb_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool sync)
 {
-    const hipStream_t cs = hvo_copy_stream(ctx, ctx->stream);
+    const hipStream_t cs = ctx->stage_gray_dst ? ctx->s_stage_up : hvo_copy_stream(ctx, ctx->stream);
     int rc = orb_ensure_plan(ctx, w, h, std::max(n, ctx->p.max_batch));
     if (rc) return rc;
     OrbPlan &P = ctx->orb;
+    uint8_t *const dst = ctx->stage_gray_dst ? ctx->stage_gray_dst : P.d_pyr;      // the resident level-0 slab, or the staging slab of a double-buffered batch
     for (int f = 0; f < n; f++) if (!in[f].gray) return HVO_ERR_INVALID_ARG;
     // Frames that are dense (stride == width == device pitch) go up in RUNS: consecutive frames evenly spaced in host memory are ONE 2-D
     // copy whose "rows" are whole frames.  A copy call costs ~20 us, which at one call per frame is the whole upload (2048 frames of
@@ -944,11 +945,11 @@ int orb_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool s
             const ptrdiff_t step = in[f + 1].gray - in[f].gray;
             if (step >= (ptrdiff_t)w * h) {
                 while (f + run < n && in[f + run].gray_stride == w && in[f + run].gray - in[f + run - 1].gray == step) run++;
-                if (run > 1) HVO_HIP(hipMemcpy2DAsync(P.d_pyr + (size_t)f * P.pyr_bytes, P.pyr_bytes, in[f].gray, (size_t)step, (size_t)w * h, run, hipMemcpyHostToDevice, cs));
+                if (run > 1) HVO_HIP(hipMemcpy2DAsync(dst + (size_t)f * P.pyr_bytes, P.pyr_bytes, in[f].gray, (size_t)step, (size_t)w * h, run, hipMemcpyHostToDevice, cs));
             }
         }
         if (run == 1)
-            HVO_HIP(hipMemcpy2DAsync(P.d_pyr + (size_t)f * P.pyr_bytes, P.lev[0].pitch, in[f].gray, in[f].gray_stride, w, h, hipMemcpyHostToDevice, cs));
+            HVO_HIP(hipMemcpy2DAsync(dst + (size_t)f * P.pyr_bytes, P.lev[0].pitch, in[f].gray, in[f].gray_stride, w, h, hipMemcpyHostToDevice, cs));
         f += run;
     }
     if (sync) HVO_HIP(hipStreamSynchronize(cs));

@@ -1994,11 +1994,12 @@ int peac_prepare(hvo_ctx *ctx, int w, int h, int batch, PeacView *v)
 
 int peac_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool sync)
 {
-    const hipStream_t cs = hvo_copy_stream(ctx, ctx->s_peac);
+    const hipStream_t cs = ctx->stage_depth_dst ? ctx->s_stage_up : hvo_copy_stream(ctx, ctx->s_peac);
     int rc = peac_ensure_plan(ctx, w, h, std::max(n, ctx->p.max_batch));
     if (rc) return rc;
     PeacPlan *P = plan_of(ctx);
     const size_t dframe = (size_t)P->pitch * (h + 1);
+    uint16_t *const dst = ctx->stage_depth_dst ? ctx->stage_depth_dst : P->d_depth;      // the resident depth slab, or the staging slab of a double-buffered batch
     for (int f = 0; f < n; f++) if (!in[f].depth) return HVO_ERR_INVALID_ARG;
     // dense host frames go up in runs of evenly spaced frames: one 2-D copy per run whose rows are whole frames (see orb_upload)
     const bool dense = P->pitch == w && !(getenv("HVO_UPLOAD_SINGLE") && atoi(getenv("HVO_UPLOAD_SINGLE")) == 0);
@@ -2009,11 +2010,11 @@ int peac_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool 
             const ptrdiff_t step = (const char *)in[f + 1].depth - (const char *)in[f].depth;
             if (step >= (ptrdiff_t)((size_t)w * h * sizeof(uint16_t))) {
                 while (f + run < n && in[f + run].depth_stride == dstride && (const char *)in[f + run].depth - (const char *)in[f + run - 1].depth == step) run++;
-                if (run > 1) HVO_HIP(hipMemcpy2DAsync(P->d_depth + (size_t)f * dframe, dframe * sizeof(uint16_t), in[f].depth, (size_t)step, (size_t)w * h * sizeof(uint16_t), run, hipMemcpyHostToDevice, cs));
+                if (run > 1) HVO_HIP(hipMemcpy2DAsync(dst + (size_t)f * dframe, dframe * sizeof(uint16_t), in[f].depth, (size_t)step, (size_t)w * h * sizeof(uint16_t), run, hipMemcpyHostToDevice, cs));
             }
         }
         if (run == 1)
-            HVO_HIP(hipMemcpy2DAsync(P->d_depth + (size_t)f * dframe, P->pitch * sizeof(uint16_t), in[f].depth, in[f].depth_stride,
+            HVO_HIP(hipMemcpy2DAsync(dst + (size_t)f * dframe, P->pitch * sizeof(uint16_t), in[f].depth, in[f].depth_stride,
                                      (size_t)w * sizeof(uint16_t), h, hipMemcpyHostToDevice, cs));
         f += run;
     }

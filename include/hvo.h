@@ -350,6 +350,17 @@ int hvo_batch_pack_results(hvo_ctx *ctx, int n, void *d_slabs);
 #define HVO_SLAB_LABELS 1u
 int hvo_batch_slab_layout_ex(hvo_ctx *ctx, unsigned flags, int *kp_cap, int *kl_cap, int *pl_cap, size_t *labels_off, size_t *slab_bytes);
 int hvo_batch_pack_results_ex(hvo_ctx *ctx, int n, void *d_slabs, unsigned flags);
+/* Double-buffered batches: the end-to-end rate of consecutive batches at the resident batch's efficiency.  While the resident batch runs,
+ * the NEXT batch's images go up into staging slabs (hvo_batch_stage_upload: enqueued on a copy stream of its own, returns at once) and the
+ * LAST batch's results come down from one packed slab (hvo_batch_results_async: hvo_batch_pack_results_ex into a device slab, then ONE
+ * contiguous copy into `host_slabs`, n * slab_bytes of page-locked memory; hvo_batch_results_wait waits for it).  hvo_batch_commit_staged
+ * waits for the staged upload and makes it the resident batch (a device-to-device copy: ~6 ms per 8192 frames).  One host thread:
+ *     stage_upload(0); commit
+ *     loop k:  stage_upload(k + 1);  hvo_batch_run;  results_async(k);  commit            -- run(k) overlaps upload(k + 1) and download(k - 1) */
+int hvo_batch_stage_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h);
+int hvo_batch_commit_staged(hvo_ctx *ctx);
+int hvo_batch_results_async(hvo_ctx *ctx, int n, unsigned flags, void *host_slabs);
+int hvo_batch_results_wait(hvo_ctx *ctx);
 /* upload + run + download */
 int hvo_extract_batch(hvo_ctx *ctx, int n, const hvo_frame_in *in, hvo_frame_out *out, int w, int h,
                       unsigned stages);

@@ -209,3 +209,42 @@ def test_tum_directory_through_the_stream_bench(hvo, orc, synth, tmp_path):
             check_frame(r, g[k], d[k], orc, orb)
     finally:
         st.close()
+
+
+def test_double_buffered_batches(hvo, orc, synth):
+    """hvo_batch_stage_upload / _commit_staged / _results_async: while a batch runs, the next one's images go up into staging slabs and
+    the last one's results come down from one packed slab.  Three different batches through one context: every slab equals what
+    hvo_batch_download gives for that batch, and the staged images never disturb the batch that is running."""
+    import importlib
+    hd = importlib.import_module("hvo_amd.dist")
+    batches = [synth.make_batch("std", 0x5EED5000 + 16 * k, 3) for k in range(3)]
+    ctx = hvo.Context(max_batch=3)
+    try:
+        ctx.batch_stage_upload(*batches[0]); ctx.batch_commit_staged()
+        kc, lc, pc, sb, lo = None, None, None, None, None
+        host = [None, None]
+        got = []
+        for k in range(3):
+            if k + 1 < 3: ctx.batch_stage_upload(*batches[k + 1])          # goes up while batch k runs
+            ctx.batch_run(hvo.STAGE_ALL)
+            ref = ctx.batch_download(hvo.STAGE_ALL)
+            if sb is None:
+                kc, lc, pc, sb, lo = ctx.slab_layout(labels=True)
+                host = [hvo.pin(np.zeros(3 * sb, np.uint8)), hvo.pin(np.zeros(3 * sb, np.uint8))]
+            ctx.batch_results_async(3, host[k & 1])
+            if k + 1 < 3: ctx.batch_commit_staged()
+            ctx.batch_results_wait()
+            back = hd.unpack_results(hvo, host[k & 1].reshape(3, sb), kc, lc, pc, label_shape=(480, 640))
+            for a, b in zip(back, ref):
+                for key in ("kp", "desc", "kl", "ldesc", "linefn", "planes", "labels"):
+                    assert np.array_equal(a[key], b[key]), (k, key)
+            got.append(ref)
+        for h_ in host: hvo.unpin(h_)
+        o = orc.Orb()
+        for k in range(3):                                                  # and each batch is ITS images' result
+            kp_o, d_o = o.extract(batches[k][0][1])
+            assert np.array_equal(got[k][1]["desc"], d_o)
+            lab_o, _ = orc.peac(batches[k][1][2])
+            assert np.array_equal(got[k][2]["labels"], lab_o)
+    finally:
+        ctx.close()
