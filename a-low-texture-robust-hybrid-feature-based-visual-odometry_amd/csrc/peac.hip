@@ -2087,23 +2087,40 @@ int peac_run(hvo_ctx *ctx, int n)
         int heads_max = 256; { const char *e8 = getenv("HVO_PEAC_HEADS_MAXN"); if (e8) heads_max = atoi(e8); }
         // three heads + the queue wave = one wave per SIMD of the frame's CU: 256 frames fill the chip exactly, and a lone frame loses nothing
         // against four (a round costs 7.3 instead of 8.0 us for 2.12 instead of 2.34 pops; batch256 9.6 against 9.0 k frames/s)
-        int heads = (gl <= 0 && n <= heads_max && a.tq_n0 * 16 <= 64 * MH_MAXE) ? 3 : 0;
-        { const char *e6 = getenv("HVO_PEAC_HEADS"); if (e6 && a.tq_n0 * 16 <= 64 * MH_MAXE) heads = atoi(e6); }
+        // frames whose per-id keys and list headers do not fit LDS (1280x960: 24 704 node ids) take the BIG form: bucket minima, front and
+        // conflict bitmaps in LDS, keys in global memory, headers in the node records
+        const bool heads_fit = a.tq_n0 * 16 <= 64 * MH_MAXE, heads_big = !heads_fit && a.tq_n0 * 16 <= 64 * MH_MAXE_BIG;
+        int heads = (gl <= 0 && n <= heads_max && (heads_fit || heads_big)) ? 3 : 0;
+        { const char *e6 = getenv("HVO_PEAC_HEADS"); if (e6 && (heads_fit || heads_big)) heads = atoi(e6); }
+        bool big = heads_big;
+        { const char *e9 = getenv("HVO_PEAC_HEADS_BIG"); if (e9 && heads_fit) big = atoi(e9) != 0; }      // tests: the BIG form on a frame that would fit
         if (heads >= 2 && heads <= 4) {
             ClArgs b = a;
             { const char *e7 = getenv("HVO_PEAC_POOLCAP"); if (e7 && atoi(e7) >= 7 * a.nblk && atoi(e7) < a.poolcap) b.poolcap = atoi(e7); }   // tests: force the pool's compaction
             const size_t segpad = (size_t)a.tq_n0 * 256;
-            const size_t lds = segpad * 8 + (size_t)a.tq_n0 * 16 * 12 + segpad / 8 * 4 + 4 * sizeof(MhHead) + 32 + segpad * 8 + 512;
-            static size_t lds_set3 = 0;
-            if (lds > lds_set3) {
-                HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                lds_set3 = lds;
+            const size_t lds = (big ? 0 : segpad * 8) + (size_t)a.tq_n0 * 16 * 12 + segpad / 8 * 4 + 4 * sizeof(MhHead) + 32 + (big ? 0 : segpad * 8) + 512;
+            static size_t lds_set3[2] = { 0, 0 };
+            if (lds > lds_set3[big]) {
+                if (big) {
+                    HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                } else {
+                    HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                }
+                lds_set3[big] = lds;
             }
-            if (heads == 2) hipLaunchKernelGGL(k_peac_cluster_heads<2>, dim3(n), dim3(192), lds, st, b, n);
-            else if (heads == 3) hipLaunchKernelGGL(k_peac_cluster_heads<3>, dim3(n), dim3(256), lds, st, b, n);
-            else hipLaunchKernelGGL(k_peac_cluster_heads<4>, dim3(n), dim3(320), lds, st, b, n);
+            if (big) {
+                if (heads == 2) hipLaunchKernelGGL((k_peac_cluster_heads<2, true>), dim3(n), dim3(192), lds, st, b, n);
+                else if (heads == 3) hipLaunchKernelGGL((k_peac_cluster_heads<3, true>), dim3(n), dim3(256), lds, st, b, n);
+                else hipLaunchKernelGGL((k_peac_cluster_heads<4, true>), dim3(n), dim3(320), lds, st, b, n);
+            } else {
+                if (heads == 2) hipLaunchKernelGGL((k_peac_cluster_heads<2, false>), dim3(n), dim3(192), lds, st, b, n);
+                else if (heads == 3) hipLaunchKernelGGL((k_peac_cluster_heads<3, false>), dim3(n), dim3(256), lds, st, b, n);
+                else hipLaunchKernelGGL((k_peac_cluster_heads<4, false>), dim3(n), dim3(320), lds, st, b, n);
+            }
         }
         else if (use == 64) {
             size_t lds = lq;

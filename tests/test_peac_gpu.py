@@ -266,14 +266,18 @@ def test_peac_lat_kernel_parity(hvo, orc, synth, monkeypatch):
             ctx.close()
 
 
-@pytest.mark.parametrize("heads,poolcap", [("4", None), ("3", None), ("2", None), ("4", "22000"), ("3", "22000"), ("0", None)])
-def test_peac_queue_heads(hvo, orc, synth, monkeypatch, heads, poolcap):
+@pytest.mark.parametrize("heads,poolcap,big", [("4", None, None), ("3", None, None), ("2", None, None), ("4", "22000", None), ("3", "22000", None), ("0", None, None),
+                                               ("3", None, "1"), ("4", "22000", "1"), ("2", None, "1")])
+def test_peac_queue_heads(hvo, orc, synth, monkeypatch, heads, poolcap, big):
     """k_peac_cluster_heads (the AHC of small batches: several queue heads per round, one wave each, the longest conflict-free
     prefix committed) against the oracle -- at four and two heads, with a list pool small enough to be compacted on the way,
     and HVO_PEAC_HEADS=0 = the one-wave kernel it replaces for a lone frame.  The scenes: textured rooms, an exact plane (every
     candidate ties at mse ~ 0: the tie rule and the created ids decide), a three-plane corner, no depth at all."""
     monkeypatch.setenv("HVO_PEAC_HEADS", heads)
     if poolcap: monkeypatch.setenv("HVO_PEAC_POOLCAP", poolcap)
+    # big: the form for frames whose queue does not fit LDS (1280x960: keys in global memory, list headers in the node records), forced
+    # onto 640x480 frames where every scene of this test exists
+    if big: monkeypatch.setenv("HVO_PEAC_HEADS_BIG", big)
     j = np.arange(640)[None, :]; i = np.arange(480)[:, None]
     exact = np.rint(2.0 / (0.1 * (j - 320.1) / 535.4 + 0.2 * (i - 247.6) / 539.2 + 1.0) * 5000).astype(np.uint16)
     depth = [synth.make_depth(s) for s in (0x5EED0002, 0x5EED1000, 0x5EED1003, 77)] + [exact, corner_depth(3, 25, cu=323.0, cv=236.0), np.zeros((480, 640), np.uint16)]
