@@ -1624,6 +1624,7 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     // a handful of frames: W waves per frame grow regions side by side and commit them in seed order (lsd_async.inc); HVO_LSD_ASYNC = W, 0: off
     // (default: up to 16 frames; at 32 frames the one-wave kernel beside the plane chain is the faster whole, tools/latency.py)
     int aw = n <= 8 ? 32 : n <= 16 ? 16 : 0;
+    if (n <= 2 && (size_t)sw * sh >= 600000) aw = 64;          // a lone large frame (1280x960: 5.4 k seeds): more regions in flight
     { const char *e = getenv("HVO_LSD_ASYNC"); if (e) aw = std::min(std::max(atoi(e), 0), LA_MAXW); }
     if (aw > 0 && n <= 64 && !P->compact) {
         if (!P->d_atags) {

@@ -260,7 +260,7 @@ def test_lines_async_growing(hvo, orc, synth, monkeypatch, workers, early):
             assert ctl[3] == 1 and ctl[6] == 0                      # done, not aborted
             regions, spec, valid = ctl[8], ctl[9], ctl[10]
             assert regions > 100 and valid > regions // 2 and spec >= valid, (regions, spec, valid)      # most regions were committed from a speculative growth
-            assert ctl[64] != 0 and ctl[65] == 0                    # one XCD, nobody elsewhere
+            assert ctl[32] != 0 and ctl[33] == 0                    # one XCD, nobody elsewhere
         finally:
             ctx.close()
 
