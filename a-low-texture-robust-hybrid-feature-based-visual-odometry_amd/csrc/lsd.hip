@@ -1639,7 +1639,13 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
             HVO_HIP(hipMemsetAsync(P->d_actl, 0, (size_t)n * sizeof(LaCtl), st));
             LaArgs a; a.g = g; a.tags = P->d_atags; a.ctl = (LaCtl *)P->d_actl; a.lists = P->d_alists; a.blocked = P->d_ablk; a.freg = P->d_afreg; a.W = aw; a.n = n; a.early = 1;
             { const char *e = getenv("HVO_LSD_ASYNC_EARLY"); if (e) a.early = atoi(e); }
-            hipLaunchKernelGGL(k_lsd_grow_async, dim3(((n + 7) / 8) * 8 * aw), dim3(64), 0, st, a);      // workgroups b, b + 8, ... of a frame: one XCD
+            // (an LDS request keeps these one-wave workgroups off the CUs where a frame's AHC waves sit -- k_peac_cluster_heads takes 108 KB --:
+            // both are bound by instruction issue and a shared SIMD slows both; HVO_LSD_ASYNC_LDS: bytes [0 for a lone frame's 32-64 workers, 56 K beside other frames])
+            size_t alds = n > 2 ? 56 * 1024 : 0;
+            { const char *e = getenv("HVO_LSD_ASYNC_LDS"); if (e) alds = (size_t)std::min(std::max(atoi(e), 0), 150 * 1024); }
+            static size_t alds_set = 0;
+            if (alds > 48 * 1024 && alds > alds_set) { HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lsd_grow_async), hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds)); alds_set = alds; }
+            hipLaunchKernelGGL(k_lsd_grow_async, dim3(((n + 7) / 8) * 8 * aw), dim3(64), alds, st, a);      // workgroups b, b + 8, ... of a frame: one XCD
         } else aw = 0;
     } else aw = 0;
     if (aw > 0) {

@@ -254,7 +254,7 @@ def test_lines_async_growing(hvo, orc, synth, monkeypatch, workers, early):
                     assert res[b]["status"] == 0
                     check(res[b]["kl"], res[b]["ldesc"], res[b]["linefn"], kl_o, d_o, fn_o)
             L = hvo.lib(); L.hvo_debug_lsd_async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
-            ac = (ctypes.c_uint * 128)()
+            ac = (ctypes.c_uint * 256)()
             assert L.hvo_debug_lsd_async(ctx.h, 0, ac) == 0
             ctl = list(ac)
             assert ctl[3] == 1 and ctl[6] == 0                      # done, not aborted

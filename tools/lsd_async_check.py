@@ -38,7 +38,7 @@ def main():
                         i = next(iter(diff.values()))[0] if diff else 0
                         print("   e.g. line", i, {f: (res[b]["kl"][f][i].item(), kl_o[f][i].item()) for f in ("sx", "sy", "ex", "ey", "response", "class_id")}, flush=True)
             st = (ctypes.c_longlong * 8)(); L.hvo_debug_lsd_stats(ctx.h, 0, st)
-            ac = (ctypes.c_uint * 128)(); actl = list(ac) if W and L.hvo_debug_lsd_async(ctx.h, 0, ac) == 0 and not print('   ctl:', dict(zip(('lock','F','G','done','nseg','flags','abort'), list(ac)[:7])), 'ticks disp/grow/wait/head/tail/front, turns, gap', list(ac)[16:24], 'xcd, foreign', list(ac)[32:34], flush=True) else None
+            ac = (ctypes.c_uint * 256)(); actl = list(ac) if W and L.hvo_debug_lsd_async(ctx.h, 0, ac) == 0 and not print('   ctl:', dict(zip(('lock','F','G','done','nseg','flags','abort'), list(ac)[:7])), 'ticks disp/grow/wait/head/tail/front, turns, gap', list(ac)[16:24], 'xcd, foreign', list(ac)[32:34], flush=True) else None
             ctx.profile_enable(2)
             ts = []
             for _ in range(3): ctx.batch_run(hvo.STAGE_LSD); ts.append(ctx.profile_last().get("lsd_grow", -1))
