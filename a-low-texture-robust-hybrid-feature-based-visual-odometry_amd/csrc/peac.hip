@@ -2092,7 +2092,11 @@ int peac_run(hvo_ctx *ctx, int n)
         const bool heads_fit = a.tq_n0 * 16 <= 64 * MH_MAXE, heads_big = !heads_fit && a.tq_n0 * 16 <= 64 * MH_MAXE_BIG;
         int heads = (gl <= 0 && n <= heads_max && (heads_fit || heads_big)) ? 3 : 0;
         { const char *e6 = getenv("HVO_PEAC_HEADS"); if (e6 && (heads_fit || heads_big)) heads = atoi(e6); }
-        bool big = heads_big;
+        // The LDS form takes 108 KB: one workgroup per CU.  From ~130 frames on the workgroups need (nearly) every CU AT ONCE, and whichever
+        // streaming kernel holds more than 52 KB of a CU's LDS at that moment (the ORB tiles, the LSD preamble, the flood) sends one of them
+        // into a second turn: batch256 took 27.5 or 33 ms from step to step (profiles/r04_batch256_modes.txt).  The BIG form (32 KB) shares
+        // a CU: 10 % slower for a lone frame, no second mode at 256 frames.
+        bool big = heads_big || n > 128;
         { const char *e9 = getenv("HVO_PEAC_HEADS_BIG"); if (e9 && heads_fit) big = atoi(e9) != 0; }      // tests: the BIG form on a frame that would fit
         if (heads >= 2 && heads <= 4) {
             ClArgs b = a;
