@@ -418,15 +418,31 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
     const unsigned long long lt = lanemask_lt();
 
     // ---- gather the cells' candidates in cell order (vToDistributeKeys) ----
+    // 64 cells at a time: their counts in one load, a wave prefix sum for the offsets (LDS), then the chunk's candidates copied with all
+    // lanes (a binary search over the 65 offsets finds an element's cell) -- not one dependent count load per cell (815 per frame)
+    __shared__ int goff[65];
     int nc = 0;
     bool overflow = false;
-    for (int ci = 0; ci < L.ncells; ci++) {
-        const size_t cidx = (size_t)frame * a.ncells + L.cell_off + ci;
-        int cnt = a.cell_cnt[cidx];
-        const uint32_t *src = a.cell_kp + cidx * HVO_CELL_CAP;
-        if (nc + cnt > L.cand_cap) { cnt = L.cand_cap - nc; overflow = true; }
-        for (int i = lane; i < cnt; i += 64) cand[nc + i] = src[i];
-        nc += cnt;
+    for (int cbase = 0; cbase < L.ncells; cbase += 64) {
+        const int ci = cbase + lane;
+        const size_t cidx0 = (size_t)frame * a.ncells + L.cell_off + cbase;
+        int cnt = ci < L.ncells ? a.cell_cnt[cidx0 + lane] : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        goff[lane + 1] = incl;
+        if (lane == 0) goff[0] = 0;
+        __syncthreads();
+        int total = goff[64];
+        if (nc + total > L.cand_cap) { total = L.cand_cap - nc; overflow = true; }
+        for (int t = lane; t < total; t += 64) {
+            int lo = 0, hi = 64;                       // the cell c with goff[c] <= t < goff[c + 1]
+#pragma unroll
+            for (int step = 0; step < 6; step++) { const int mid = (lo + hi) >> 1; if (goff[mid] <= t) lo = mid; else hi = mid; }
+            cand[nc + t] = a.cell_kp[(cidx0 + lo) * HVO_CELL_CAP + (t - goff[lo])];
+        }
+        nc += total;
+        __syncthreads();
     }
     if (overflow && lane == 0) atomicOr(&a.flags[frame], 2);
     if (nc == 0 || L.nCols < 1 || L.nRows < 1) { if (lane == 0) *outcnt = 0; return; }
@@ -452,7 +468,7 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
                 bool in = false;
                 if (k < nc) in = ((int)__fdiv_rn((float)cand_x(cand[k]), hX)) == i;
                 unsigned long long m = __ballot(in);
-                if (in) keys[koff + cnt + __popcll(m & lt)] = k;
+                if (in) keys[koff + cnt + __popcll(m & lt)] = (int)cand[k];      // a node's keys ARE its candidates (x | y << 12 | score << 24): no second, dependent access per key
                 cnt += __popcll(m);
             }
             if (cnt > 0) {   // empty initial nodes are erased right away (ORBextractor.cc:580-581)
@@ -480,28 +496,41 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
         const int mx = A.x + halfX, my = A.y + halfY;
         const int koff = B.x, nk = B.y;
         int cnt[4] = { 0, 0, 0, 0 };
-        for (int b = 0; b < nk; b += 64) {
-            int i = b + lane;
-            int cls = -1;
-            if (i < nk) { uint32_t cd = cand[keys[koff + i]]; cls = (cand_x(cd) < mx ? 0 : 1) + (cand_y(cd) < my ? 0 : 2); }
+        int off[4];
+        if (nk <= 64) {
+            // the usual node: its keys fit the wave -- one load, four ballots, one store in place (every key is in a register before any is written)
+            uint32_t cd = 0; int cls = -1;
+            if (lane < nk) { cd = (uint32_t)keys[koff + lane]; cls = (cand_x(cd) < mx ? 0 : 1) + (cand_y(cd) < my ? 0 : 2); }
+            unsigned long long mq[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) cnt[q] += __popcll(__ballot(cls == q));
-        }
-        int off[4] = { 0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2] };
-        int run[4] = { 0, 0, 0, 0 };
-        for (int b = 0; b < nk; b += 64) {
-            int i = b + lane;
-            int cls = -1, k = 0;
-            if (i < nk) { k = keys[koff + i]; uint32_t cd = cand[k]; cls = (cand_x(cd) < mx ? 0 : 1) + (cand_y(cd) < my ? 0 : 2); }
+            for (int q = 0; q < 4; q++) { mq[q] = __ballot(cls == q); cnt[q] = __popcll(mq[q]); }
+            off[0] = 0; off[1] = cnt[0]; off[2] = cnt[0] + cnt[1]; off[3] = cnt[0] + cnt[1] + cnt[2];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                unsigned long long m = __ballot(cls == q);
-                if (cls == q) ktmp[koff + off[q] + run[q] + __popcll(m & lt)] = k;
-                run[q] += __popcll(m);
+            for (int q = 0; q < 4; q++) if (cls == q) keys[koff + off[q] + __popcll(mq[q] & lt)] = (int)cd;
+        } else {
+            for (int b = 0; b < nk; b += 64) {
+                int i = b + lane;
+                int cls = -1;
+                if (i < nk) { uint32_t cd = (uint32_t)keys[koff + i]; cls = (cand_x(cd) < mx ? 0 : 1) + (cand_y(cd) < my ? 0 : 2); }
+#pragma unroll
+                for (int q = 0; q < 4; q++) cnt[q] += __popcll(__ballot(cls == q));
             }
+            off[0] = 0; off[1] = cnt[0]; off[2] = cnt[0] + cnt[1]; off[3] = cnt[0] + cnt[1] + cnt[2];
+            int run[4] = { 0, 0, 0, 0 };
+            for (int b = 0; b < nk; b += 64) {
+                int i = b + lane;
+                int cls = -1, k = 0;
+                if (i < nk) { k = keys[koff + i]; uint32_t cd = (uint32_t)k; cls = (cand_x(cd) < mx ? 0 : 1) + (cand_y(cd) < my ? 0 : 2); }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    unsigned long long m = __ballot(cls == q);
+                    if (cls == q) ktmp[koff + off[q] + run[q] + __popcll(m & lt)] = k;
+                    run[q] += __popcll(m);
+                }
+            }
+            __syncthreads();
+            for (int i = lane; i < nk; i += 64) keys[koff + i] = ktmp[koff + i];
         }
-        __syncthreads();
-        for (int i = lane; i < nk; i += 64) keys[koff + i] = ktmp[koff + i];
         int nchild = (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0) + (cnt[3] > 0);
         if (nn + nchild > L.node_cap) { nodes_full = true; __syncthreads(); return false; }
         if (lane == 0) {
@@ -583,8 +612,8 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
     __syncthreads();
     for (int i = lane; i < cntn; i += 64) {
         const int4 B = nB[order[i]];
-        uint32_t best = cand[keys[B.x]];
-        for (int k = 1; k < B.y; k++) { uint32_t c = cand[keys[B.x + k]]; if (cand_s(c) > cand_s(best)) best = c; }
+        uint32_t best = (uint32_t)keys[B.x];
+        for (int k = 1; k < B.y; k++) { uint32_t c = (uint32_t)keys[B.x + k]; if (cand_s(c) > cand_s(best)) best = c; }
         outkp[i] = best;
     }
     if (lane == 0) *outcnt = cntn;
