@@ -455,6 +455,7 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
     const float hX = __fdiv_rn((float)bw, (float)nIni);
 
     int nn = 0;               // nodes created
+    int nexp0 = 0;            // initial nodes that hold more than one key
     int head = -1, tail = -1, size = 0;
     bool nodes_full = false;
 
@@ -476,7 +477,9 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
                     nA[nn] = make_int4((int)(hX * (float)i), 0, (int)(hX * (float)(i + 1)), bh);
                     nB[nn] = make_int4(koff, cnt, tail, -1);
                     if (tail >= 0) nB[tail].w = nn;
+                    if (cnt > 1) vp[nexp0] = make_int2(cnt, nn);          // the first round's nodes to divide, in list order
                 }
+                if (cnt > 1) nexp0++;
                 if (head < 0) head = nn;
                 tail = nn; nn++; size++;
             }
@@ -486,6 +489,7 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
     __syncthreads();
 
     int nvs = 0;
+    int2 *wr = vs;            // where divide() lists the children that hold more than one key
     // divide node `ni`: partitions its keys, creates the non-empty children, pushes them to the
     // front of the list in order n1..n4 and unlinks `ni`.  Everything below is wave-uniform.
     auto divide = [&](int ni) {
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
                 nA[id] = make_int4(bx[q][0], bx[q][1], bx[q][2], bx[q][3]);
                 nB[id] = make_int4(koff + off[q], cnt[q], -1, h);
                 nB[h].z = id;          // h is never -1 here: `ni` is still linked
-                if (cnt[q] > 1) vs[nvs + (q > 0 && cnt[0] > 1) + (q > 1 && cnt[1] > 1) + (q > 2 && cnt[2] > 1)] = make_int2(cnt[q], id);
+                if (cnt[q] > 1) wr[nvs + (q > 0 && cnt[0] > 1) + (q > 1 && cnt[1] > 1) + (q > 2 && cnt[2] > 1)] = make_int2(cnt[q], id);
                 h = id; id++;
             }
             // unlink ni
@@ -565,41 +569,46 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
         return true;
     };
 
+    // A round divides every node that holds more than one key, in LIST order.  Those are exactly the children of the previous round that
+    // got more than one key -- pushed to the front one after the other, so the list holds them in the reverse of their creation order --
+    // (the initial nodes, in creation order, for the first round): the round walks that array instead of the whole list, whose other
+    // nodes (one key each, hundreds of them in the later rounds) cost a dependent access apiece only to be skipped.
     bool finish = false;
+    int2 *rd = vp; int nrd = nexp0; bool fwd = true;
+    wr = vs;
     while (!finish) {
         int prevSize = size;
         nvs = 0;
         int nToExpand = 0;
-        int it = head;
-        while (it >= 0) {
-            const int4 B = nB[it];
-            if (B.y == 1) { it = B.w; continue; }
+        for (int q = 0; q < nrd; q++) {
+            const int it = rd[fwd ? q : nrd - 1 - q].y;
             int before = nvs;
-            int nxt = B.w;
             if (!divide(it)) { finish = true; break; }
             nToExpand += nvs - before;
-            it = nxt;
         }
+        { int2 *t = rd; rd = wr; wr = t; nrd = nvs; fwd = false; }         // this round's children are the next round's nodes to divide
         if (finish) break;
         if (size >= N || size == prevSize) {
             finish = true;
         } else if (size + nToExpand * 3 > N) {
             while (!finish) {
                 prevSize = size;
-                const int nvp = nvs;
-                // rank sort of (size, node) ascending; keys are unique
+                const int nvp = nrd;
+                int2 *srt = wr;                          // (size, node) ascending into the free array; keys are unique
                 for (int i = lane; i < nvp; i += 64) {
-                    int2 me = vs[i];
+                    int2 me = rd[i];
                     int r = 0;
-                    for (int j = 0; j < nvp; j++) { int2 o = vs[j]; r += (o.x < me.x) || (o.x == me.x && o.y < me.y); }
-                    vp[r] = me;
+                    for (int j = 0; j < nvp; j++) { int2 o = rd[j]; r += (o.x < me.x) || (o.x == me.x && o.y < me.y); }
+                    srt[r] = me;
                 }
                 __syncthreads();
+                wr = rd;                                 // the divisions below write the next candidates where the unsorted ones were
                 nvs = 0;
                 for (int j = nvp - 1; j >= 0; j--) {
-                    if (!divide(vp[j].y)) { finish = true; break; }
+                    if (!divide(srt[j].y)) { finish = true; break; }
                     if (size >= N) break;
                 }
+                rd = wr; wr = srt; nrd = nvs;
                 if (size >= N || size == prevSize) finish = true;
             }
         }
