@@ -289,6 +289,21 @@ public:
                                            match_idx.data(), dist.data(), &n), "hvo_search_by_projection_map");
         return n;
     }
+    // SearchByProjection(F, vpMapPoints, th) from the tracker's own per-point fields: the window prologue (ORBmatcher.cc:55-70,
+    // RadiusByViewingCos 134-140) runs on the device.  One entry per map point with mbTrackInView && !isBad().
+    int SearchByProjection(const uint8_t *mp_desc, int nq, const float *mTrackProjX, const float *mTrackProjY, const float *mTrackProjXR,
+                           const int32_t *mnTrackScaleLevel, const float *mTrackViewCos, const uint8_t *q_blocks, float th,
+                           const KeyPoint *t_kp, const float *t_uright, const uint8_t *t_occupied, const uint8_t *t_desc, int nt,
+                           float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, float nnratio, std::vector<int> &match_idx) const
+    {
+        match_idx.assign(nq, -1);
+        std::vector<int> dist(nq);
+        int n = 0;
+        check(hvo_search_by_projection_tracked(ctx_, mp_desc, nq, mTrackProjX, mTrackProjY, mTrackProjXR, mnTrackScaleLevel, mTrackViewCos, q_blocks, th,
+                                               t_kp, t_uright, t_occupied, t_desc, nt, mnMinX, mnMinY, mnMaxX, mnMaxY, TH_HIGH, nnratio,
+                                               match_idx.data(), dist.data(), &n), "hvo_search_by_projection_tracked");
+        return n;
+    }
 private:
     hvo_ctx *ctx_;
 };
@@ -370,6 +385,20 @@ public:
         c.normals = t.normals.data(); c.normals_cap = nn; c.pt_cell_start = t.pt_cell_start.data(); c.pt_cell_items = t.pt_cell_items.data(); c.pt_items_cap = kp_cap_;
         c.ln_cell_start = t.ln_cell_start.data(); c.ln_cell_items = t.ln_cell_items.data(); c.ln_items_cap = lc;
         check(hvo_stream_collect_tail(s_, ticket, &c), "hvo_stream_collect_tail");
+    }
+    // ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) whole (ORBmatcher.cc:1353-1497) between two resident frames: the
+    // projection prologue (1364-1405) and the search core on the device.  Tcw / Tlw: rows 0..2 of the frames' mTcw (row-major 3 x 4);
+    // q_index[i] = last-frame feature whose map point (no outlier) has world position x3Dw[3 i ..].  Returns the number of matches.
+    int SearchByProjection(int64_t cur, int64_t last, const hvo_camera &cam, const float *Tcw, const float *Tlw, int nq, const int32_t *q_index,
+                           const float *x3Dw, const uint8_t *q_blocks, const uint8_t *t_occupied, float th, bool bMono, bool checkOrientation,
+                           std::vector<int32_t> &match_idx)
+    {
+        match_idx.assign(nq, -1);
+        std::vector<int32_t> dist(nq > 0 ? nq : 1);
+        int n = 0;
+        check(hvo_stream_project_last(s_, cur, last, &cam, Tcw, Tlw, nq, q_index, x3Dw, q_blocks, nullptr, t_occupied, th, bMono ? 1 : 0, 100,
+                                      checkOrientation ? 1 : 0, match_idx.data(), dist.data(), &n, nullptr), "hvo_stream_project_last");
+        return n;
     }
     // LSDmatcher::match / FrameBFMatch / SearchDouble between two resident frames (mode = HVO_LINE_MATCH_*)
     int matchLines(int64_t from, int64_t to, int mode, float th, float nnratio, std::vector<int32_t> &matches12)
