@@ -607,6 +607,9 @@ def main():
             if orb_ms > 0:
                 roof["orb_pyramid_brief_pass_GBps"] = round(pass_bytes * B / (orb_ms * 1e-3) / 1e9, 2)
                 roof["orb_pyramid_brief_pass_frac"] = round(pass_bytes * B / (orb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                # ... and with the quadtree, which sits between FAST and the orientation on the same stream
+                oq = orb_ms + groups.get("orb_octree", 0.0)
+                roof["orb_pyramid_brief_pass_with_quadtree_frac"] = round(pass_bytes * B / (oq * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         out = {
             "metric": "RGB-D frames/sec (640×480, 1k ORB + LSD + PEAC) at 1/2/4/8 GPUs", "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 4),
