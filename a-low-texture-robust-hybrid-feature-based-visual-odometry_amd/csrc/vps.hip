@@ -75,15 +75,19 @@ __global__ __launch_bounds__(256) void k_vp_pairs(const double *__restrict__ par
 // cells), fill in arrival order, sort each cell's few pairs by pair index = the reference's loop order -- and adds.  (The first
 // formulation had the owner of every one of the 32 400 cells scan all 19 900 pairs: 1.1 ms.)
 #define VP_CPT 32                                    // cells per thread: 1024 x 32 >= 32 400
+#define VP_BIG 48                                    // a cell with more pairs than this is ordered by the whole workgroup
+#define VP_BIGMAX 2048                               // such cells a frame can have (523 776 pairs / 48 would be 10 912: the rest keep the owner's sort)
 __global__ __launch_bounds__(1024) void k_vp_grid(const int *__restrict__ cell, const double *__restrict__ val, const int *__restrict__ n_ptr, int n_fixed, double *__restrict__ raw,
-                                                  int *__restrict__ order)
+                                                  int *__restrict__ order, int *__restrict__ order2)
 {
+    __shared__ int nbig, bigs[VP_BIGMAX][3];          // (cell, start, end) of the cells the workgroup orders together
     extern __shared__ int vg_cnt[];                  // VP_CPT * 1024 cursors + 16 wave sums
     int *wsum = vg_cnt + VP_CPT * 1024;
     const int n = n_ptr ? min(*n_ptr, n_fixed) : n_fixed;
     const int npairs = n < 2 ? 0 : n * (n - 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c0 = tid * VP_CPT;
     for (int q = 0; q < VP_CPT; q++) vg_cnt[c0 + q] = 0;
+    if (tid == 0) nbig = 0;
     __syncthreads();
     for (int p = tid; p < npairs; p += 1024) { const int c = cell[p]; if (c >= 0) atomicAdd(&vg_cnt[c], 1); }
     __syncthreads();
@@ -103,15 +107,40 @@ __global__ __launch_bounds__(1024) void k_vp_grid(const int *__restrict__ cell, 
     int s0 = base + incl - mine;
     for (int q = 0; q < VP_CPT; q++) {
         const int c = c0 + q, e0 = vg_cnt[c];
-        double acc = 0.0;
-        for (int x = s0 + 1; x < e0; x++) {                  // insertion sort by pair index
-            const int v = order[x]; int y = x - 1;
-            while (y >= s0 && order[y] > v) { order[y + 1] = order[y]; y--; }
-            order[y + 1] = v;
+        // Many line pairs can meet in ONE sphere cell (a Manhattan scene: 100 parallel lines give ~5 k pairs at their vanishing point): the
+        // owner's insertion sort is quadratic in a cell's population -- millions of dependent global accesses by one lane.  Such cells
+        // are listed and ordered by the whole workgroup below (rank by counting); the owner then only adds.
+        bool big = false;
+        if (e0 - s0 > VP_BIG) { const int slot = atomicAdd(&nbig, 1); if (slot < VP_BIGMAX) { bigs[slot][0] = c; bigs[slot][1] = s0; bigs[slot][2] = e0; big = true; } }
+        if (!big) {
+            double acc = 0.0;
+            for (int x = s0 + 1; x < e0; x++) {                  // insertion sort by pair index
+                const int v = order[x]; int y = x - 1;
+                while (y >= s0 && order[y] > v) { order[y + 1] = order[y]; y--; }
+                order[y + 1] = v;
+            }
+            for (int x = s0; x < e0; x++) acc += val[order[x]];
+            if (c < VP_CELLS) raw[c] = acc;
         }
-        for (int x = s0; x < e0; x++) acc += val[order[x]];
-        if (c < VP_CELLS) raw[c] = acc;
         s0 = e0;
+    }
+    __syncthreads();
+    const int nb = min(nbig, VP_BIGMAX);
+    for (int b = 0; b < nb; b++) {
+        const int bs = bigs[b][1], be = bigs[b][2];
+        for (int x = bs + tid; x < be; x += 1024) {              // pair indices are unique: the rank is the position
+            const int v = order[x];
+            int r = 0;
+            for (int y = bs; y < be; y++) r += order[y] < v;
+            order2[bs + r] = v;
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < nb; b += 1024) {                       // the sums in pair order, one cell per thread
+        const int c = bigs[b][0], bs = bigs[b][1], be = bigs[b][2];
+        double acc = 0.0;
+        for (int x = bs; x < be; x++) acc += val[order2[x]];
+        if (c < VP_CELLS) raw[c] = acc;
     }
 }
 
@@ -258,7 +287,7 @@ static int vp_iterations()
 size_t vp_scratch_bytes(int nmax)
 {
     const size_t npairs = (size_t)nmax * (nmax > 0 ? nmax - 1 : 0) / 2, nh = (size_t)vp_iterations() * VP_NUM2;
-    return (5 * (size_t)nmax + npairs + 2 * VP_CELLS + 10 * nh) * sizeof(double) + 2 * npairs * sizeof(int) + 256;
+    return (5 * (size_t)nmax + npairs + 2 * VP_CELLS + 10 * nh) * sizeof(double) + 3 * npairs * sizeof(int) + 256;
 }
 
 // device-resident form: key lines and their count (d_n, capped by nmax; or nmax itself when d_n is null) already in HBM; scratch of
@@ -273,7 +302,7 @@ int vp_enqueue(hvo_ctx *ctx, hipStream_t st, const hvo_keyline *d_kl, const int 
     const size_t npairs = (size_t)nmax * (nmax - 1) / 2;
     double *para = (double *)scratch, *len = para + 3 * (size_t)nmax, *ori = len + nmax, *val = ori + nmax, *raw = val + npairs, *grid = raw + VP_CELLS,
            *hyp = grid + VP_CELLS, *score = hyp + 9 * (size_t)nh;
-    int *dcell = (int *)(score + nh), *dorder = dcell + npairs;
+    int *dcell = (int *)(score + nh), *dorder = dcell + npairs, *dorder2 = dorder + npairs;
     const double fx = P.fx, fy = P.fy, cx = P.cx, cy = P.cy;
     hipLaunchKernelGGL(k_vp_lines, dim3((nmax + 255) / 256), dim3(256), 0, st, d_kl, d_n, nmax, para, len, ori);
     if (nmax > 1) hipLaunchKernelGGL(k_vp_pairs, dim3((nmax + 255) / 256, nmax - 1), dim3(256), 0, st, para, len, ori, d_n, nmax, fx, cx, cy, dcell, val);
@@ -281,7 +310,7 @@ int vp_enqueue(hvo_ctx *ctx, hipStream_t st, const hvo_keyline *d_kl, const int 
         const size_t lds = (VP_CPT * 1024 + 16) * sizeof(int);            // 131 KB: one workgroup owns the CU
         static bool attr = false;
         if (!attr) { HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_vp_grid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-        hipLaunchKernelGGL(k_vp_grid, dim3(1), dim3(1024), lds, st, dcell, val, d_n, nmax, raw, dorder);
+        hipLaunchKernelGGL(k_vp_grid, dim3(1), dim3(1024), lds, st, dcell, val, d_n, nmax, raw, dorder, dorder2);
     }
     hipLaunchKernelGGL(k_vp_smooth, dim3((VP_CELLS + 255) / 256), dim3(256), 0, st, raw, grid);
     hipLaunchKernelGGL(k_vp_hyp, dim3(it), dim3(384), 0, st, para, d_n, nmax, fx, cx, cy, seed, grid, hyp, score);

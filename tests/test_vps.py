@@ -133,3 +133,30 @@ def test_vp_gpu_manhattan_and_edges(hvo, orc):
             ctx.vanishing_points(np.zeros(2000, hvo.KEYLINE_DT))
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_vp_gpu_one_crowded_cell(hvo, orc):
+    """all lines through ONE vanishing point: every pair of the 240 lines (28 680 pairs) meets in the same few sphere cells -- the cells
+    whose pairs the whole workgroup orders (a lone lane's insertion sort is quadratic there); the grid must still be the
+    oracle's sums in pair order"""
+    fx, fy, cx, cy = 535.4, 539.2, 320.1, 247.6
+    rng = np.random.RandomState(9)
+    n = 240
+    kl = np.zeros(n, orc.KEYLINE_DT)
+    vx, vy = 900.0, 120.0
+    for i in range(n):
+        mx, my = rng.uniform(40, 600), rng.uniform(40, 440)
+        d = np.array([vx - mx, vy - my]); d /= np.linalg.norm(d)
+        L = rng.uniform(15, 50)
+        kl["sx"][i], kl["sy"][i] = mx - d[0] * L, my - d[1] * L
+        kl["ex"][i], kl["ey"][i] = mx + d[0] * L, my + d[1] * L
+    ref = orc.vanishing_points(kl, seed=4)
+    assert (ref["grid"] > 0).sum() < 200 and ref["grid"].max() > 1000          # a few crowded cells
+    ctx = hvo.Context(lsd_nfeatures=n)
+    try:
+        got = ctx.vanishing_points(kl, seed=4, want_grid=True)
+    finally:
+        ctx.close()
+    assert np.allclose(got["grid"], ref["grid"], rtol=1e-10, atol=1e-9)
+    assert np.array_equal(got["vp_idx"], ref["vp_idx"]) and abs(got["score"] - ref["score"]) <= 1e-9 * max(1.0, ref["score"])
