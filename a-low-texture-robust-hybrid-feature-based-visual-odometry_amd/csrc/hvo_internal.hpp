@@ -76,7 +76,7 @@ struct OrbPlan {
     uint8_t *d_pyr_base = nullptr;                          // the allocation behind d_pyr (256 guard bytes in front: orb_level.hip's 16-byte tile loads may start 4 bytes before a row)
     uint32_t *d_cell_kp = nullptr; int *d_cell_cnt = nullptr;
     uint32_t *d_cand = nullptr; int *d_keys = nullptr, *d_keys_tmp = nullptr;
-    int4 *d_nodeA = nullptr, *d_nodeB = nullptr; int2 *d_vs = nullptr, *d_vp = nullptr; int *d_order = nullptr;
+    int oct_slot_cap = 0;               // quadtree nodes alive at once, any level (k_octree keeps them in LDS: 36 bytes a slot)
     uint32_t *d_lvl_kp = nullptr; int *d_lvl_cnt = nullptr;
     hvo_keypoint *d_kp = nullptr; uint8_t *d_desc = nullptr; int *d_nkp = nullptr;
     int *d_flags = nullptr;             // per frame error flags

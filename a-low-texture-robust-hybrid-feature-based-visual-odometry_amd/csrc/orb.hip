@@ -385,21 +385,31 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
 // =====================================================================================
 // K3: quadtree distribution -- one wave per (frame, level), serial semantics
 // =====================================================================================
-// Node record: A = {ulx, uly, brx, bry}, B = {koff, nk, prev, next}.  bNoMore <=> nk == 1.
-// Keys are indices into the level's candidate array; a node's keys live in keys[koff, koff+nk)
-// and its children re-use that range (stable 4-way partition), so no pool growth.
-// Tie rule for the (size, node*) sort of ORBextractor.cc:682: node creation order.
+// A node's keys ARE its candidates (x | y << 12 | score << 24): they live in keys[koff, koff + nk) (global) and its children re-use
+// that range (stable 4-way partition), so no pool growth.  bNoMore <=> nk == 1.  Everything else about a node lives in LDS (round 4:
+// a division used to be ~4 dependent global round trips -- record, links, the next round's list -- and a store drain at its barrier):
+//   nd[slot] = {x0 | y0 << 16, x1 | y1 << 16, koff, nk}      lk[slot] = prev | next << 16   (OCT_NONE: no such node)
+//   la / lb  = the nodes this round / the next one divides: (keys, seq | slot << 16)
+// The list stops growing at N nodes and a division removes one node and adds at most four, so at most max(N + 3, 4 nIni) nodes are
+// alive: a divided node's slot goes to its first child, the other children take fresh slots, and the slots never run out (slot_cap,
+// orb_plan_build).  Tie rule of the (size, node*) sort of ORBextractor.cc:682: node creation order -- `seq`, not the slot.
+// One wave, so LDS needs no barrier (a wave's LDS accesses complete in order); the round loop prefetches the keys of the node it
+// divides next before it divides the current one.
 struct OctArgs {
     const LevelGeom *lev;
     const uint32_t *cell_kp; const int *cell_cnt; int ncells;
-    uint32_t *cand; int *keys; int *keys_tmp; int4 *nodeA; int4 *nodeB; int2 *vs; int2 *vp; int *order;
+    uint32_t *cand; int *keys; int *keys_tmp;
     uint32_t *lvl_kp; int *lvl_cnt; int *flags;
-    int cand_total, node_total, kp_total, nlevels;
+    int cand_total, kp_total, nlevels, slot_cap;
 };
+#define OCT_NONE 0xFFFFu
+#define OCT_SLOT_BYTES 36                              // uint4 record + link word + an entry in each of the two lists
 
 static __device__ __forceinline__ int cand_x(uint32_t c) { return c & 0xFFF; }
 static __device__ __forceinline__ int cand_y(uint32_t c) { return (c >> 12) & 0xFFF; }
 static __device__ __forceinline__ int cand_s(uint32_t c) { return c >> 24; }
+
+extern __shared__ uint4 oct_lds[];
 
 __global__ __launch_bounds__(64) void k_octree(OctArgs a)
 {
@@ -408,14 +418,13 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
     uint32_t *cand = a.cand + (size_t)frame * a.cand_total + L.cand_off;
     int *keys = a.keys + (size_t)frame * a.cand_total + L.cand_off;
     int *ktmp = a.keys_tmp + (size_t)frame * a.cand_total + L.cand_off;
-    int4 *nA = a.nodeA + (size_t)frame * a.node_total + L.node_off;
-    int4 *nB = a.nodeB + (size_t)frame * a.node_total + L.node_off;
-    int2 *vs = a.vs + (size_t)frame * a.node_total + L.node_off;
-    int2 *vp = a.vp + (size_t)frame * a.node_total + L.node_off;
-    int *order = a.order + (size_t)frame * a.node_total + L.node_off;
     uint32_t *outkp = a.lvl_kp + (size_t)frame * a.kp_total + L.kp_off;
     int *outcnt = a.lvl_cnt + (size_t)frame * a.nlevels + level;
     const unsigned long long lt = lanemask_lt();
+    const int cap = a.slot_cap;
+    uint4 *nd = oct_lds;
+    unsigned *lk = reinterpret_cast<unsigned *>(nd + cap);
+    int2 *la = reinterpret_cast<int2 *>(lk + cap), *lb = la + cap;
 
     // ---- gather the cells' candidates in cell order (vToDistributeKeys) ----
     // 64 cells at a time: their counts in one load, a wave prefix sum for the offsets (LDS), then the chunk's candidates copied with all
@@ -423,6 +432,11 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
     __shared__ int goff[65];
     int nc = 0;
     bool overflow = false;
+    const int N = L.nfeat;
+    const int bw = L.maxBX - L.minBX, bh = L.maxBY - L.minBY;
+    const int nIni = (int)roundf(__fdiv_rn((float)bw, (float)bh));
+    // one initial node (any image that is not wider than 1.5 x its height): it holds every candidate, in this order -- the gather writes its keys
+    uint32_t *gdst = nIni == 1 ? reinterpret_cast<uint32_t *>(keys) : cand;
     for (int cbase = 0; cbase < L.ncells; cbase += 64) {
         const int ci = cbase + lane;
         const size_t cidx0 = (size_t)frame * a.ncells + L.cell_off + cbase;
@@ -439,7 +453,7 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
             int lo = 0, hi = 64;                       // the cell c with goff[c] <= t < goff[c + 1]
 #pragma unroll
             for (int step = 0; step < 6; step++) { const int mid = (lo + hi) >> 1; if (goff[mid] <= t) lo = mid; else hi = mid; }
-            cand[nc + t] = a.cell_kp[(cidx0 + lo) * HVO_CELL_CAP + (t - goff[lo])];
+            gdst[nc + t] = a.cell_kp[(cidx0 + lo) * HVO_CELL_CAP + (t - goff[lo])];
         }
         nc += total;
         __syncthreads();
@@ -448,145 +462,198 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
     if (nc == 0 || L.nCols < 1 || L.nRows < 1) { if (lane == 0) *outcnt = 0; return; }
     __syncthreads();
 
-    const int N = L.nfeat;
-    const int bw = L.maxBX - L.minBX, bh = L.maxBY - L.minBY;
-    const int nIni = (int)roundf(__fdiv_rn((float)bw, (float)bh));
     if (nIni < 1) { if (lane == 0) *outcnt = 0; return; }
     const float hX = __fdiv_rn((float)bw, (float)nIni);
 
-    int nn = 0;               // nodes created
+    int nslot = 0;            // slots handed out
+    int nseq = 0;             // nodes created
     int nexp0 = 0;            // initial nodes that hold more than one key
-    int head = -1, tail = -1, size = 0;
+    int head = -1, size = 0;
     bool nodes_full = false;
 
     // ---- initial nodes: stable filter of candidates by (int)(x / hX) ----
     {
-        int koff = 0;
+        int koff = 0, tail = -1;
         for (int i = 0; i < nIni; i++) {
             int cnt = 0;
-            for (int b = 0; b < nc; b += 64) {
+            if (nIni == 1) cnt = nc;                   // (int)(x / hX) == 0 for every x < bw: the gather has written this node's keys
+            else for (int b = 0; b < nc; b += 64) {
                 int k = b + lane;
                 bool in = false;
                 if (k < nc) in = ((int)__fdiv_rn((float)cand_x(cand[k]), hX)) == i;
                 unsigned long long m = __ballot(in);
-                if (in) keys[koff + cnt + __popcll(m & lt)] = (int)cand[k];      // a node's keys ARE its candidates (x | y << 12 | score << 24): no second, dependent access per key
+                if (in) keys[koff + cnt + __popcll(m & lt)] = (int)cand[k];
                 cnt += __popcll(m);
             }
             if (cnt > 0) {   // empty initial nodes are erased right away (ORBextractor.cc:580-581)
+                if (nslot >= cap) { nodes_full = true; break; }
                 if (lane == 0) {
-                    nA[nn] = make_int4((int)(hX * (float)i), 0, (int)(hX * (float)(i + 1)), bh);
-                    nB[nn] = make_int4(koff, cnt, tail, -1);
-                    if (tail >= 0) nB[tail].w = nn;
-                    if (cnt > 1) vp[nexp0] = make_int2(cnt, nn);          // the first round's nodes to divide, in list order
+                    nd[nslot] = make_uint4((unsigned)(int)(hX * (float)i), (unsigned)(int)(hX * (float)(i + 1)) | ((unsigned)bh << 16), (unsigned)koff, (unsigned)cnt);
+                    lk[nslot] = (tail < 0 ? OCT_NONE : (unsigned)tail) | (OCT_NONE << 16);
+                    if (tail >= 0) lk[tail] = (lk[tail] & 0xFFFFu) | ((unsigned)nslot << 16);
+                    if (cnt > 1) la[nexp0] = make_int2(cnt, nseq | (nslot << 16));           // the first round's nodes to divide, in list order
                 }
                 if (cnt > 1) nexp0++;
-                if (head < 0) head = nn;
-                tail = nn; nn++; size++;
+                if (head < 0) head = nslot;
+                tail = nslot; nslot++; nseq++; size++;
             }
             koff += cnt;
         }
     }
-    __syncthreads();
+    __syncthreads();                                   // (the keys just written are read below: drains the stores)
 
     int nvs = 0;
-    int2 *wr = vs;            // where divide() lists the children that hold more than one key
-    // divide node `ni`: partitions its keys, creates the non-empty children, pushes them to the
-    // front of the list in order n1..n4 and unlinks `ni`.  Everything below is wave-uniform.
-    auto divide = [&](int ni) {
-        const int4 A = nA[ni];
-        const int4 B = nB[ni];
-        const int halfX = (int)ceilf((float)(A.z - A.x) * 0.5f);
-        const int halfY = (int)ceilf((float)(A.w - A.y) * 0.5f);
-        const int mx = A.x + halfX, my = A.y + halfY;
-        const int koff = B.x, nk = B.y;
+    int2 *wr = lb;            // where divide() lists the children that hold more than one key
+    // the keys of a node, loaded before the division in front of it runs (a node of more than 64 keys is read by divide() itself)
+    auto fetch = [&](int ey, uint32_t &pre) -> bool {
+        const uint4 R = nd[(unsigned)ey >> 16];
+        const bool fits = (int)R.w <= 64;
+        pre = (fits && lane < (int)R.w) ? (uint32_t)keys[(int)R.z + lane] : 0u;
+        return fits;
+    };
+    // divide the node of list entry `ey` (seq | slot << 16): partitions its keys, unlinks it, creates the non-empty children and pushes
+    // them to the front of the list in order n1..n4.  Everything below is wave-uniform but the four lanes that write a child each.
+    auto divide = [&](int ey, uint32_t pre, bool have_pre) -> bool {
+        const int ni = (int)((unsigned)ey >> 16);
+        const uint4 R = nd[ni];
+        const unsigned LK = lk[ni];
+        const int x0 = (int)(R.x & 0xFFFFu), y0 = (int)(R.x >> 16), x1 = (int)(R.y & 0xFFFFu), y1 = (int)(R.y >> 16);
+        const int koff = (int)R.z, nk = (int)R.w;
+        const int halfX = (int)ceilf((float)(x1 - x0) * 0.5f);
+        const int halfY = (int)ceilf((float)(y1 - y0) * 0.5f);
+        const int mx = x0 + halfX, my = y0 + halfY;
         int cnt[4] = { 0, 0, 0, 0 };
         int off[4];
         if (nk <= 64) {
             // the usual node: its keys fit the wave -- one load, four ballots, one store in place (every key is in a register before any is written)
             uint32_t cd = 0; int cls = -1;
-            if (lane < nk) { cd = (uint32_t)keys[koff + lane]; cls = (cand_x(cd) < mx ? 0 : 1) + (cand_y(cd) < my ? 0 : 2); }
+            if (lane < nk) { cd = have_pre ? pre : (uint32_t)keys[koff + lane]; cls = (cand_x(cd) < mx ? 0 : 1) + (cand_y(cd) < my ? 0 : 2); }
             unsigned long long mq[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) { mq[q] = __ballot(cls == q); cnt[q] = __popcll(mq[q]); }
             off[0] = 0; off[1] = cnt[0]; off[2] = cnt[0] + cnt[1]; off[3] = cnt[0] + cnt[1] + cnt[2];
 #pragma unroll
             for (int q = 0; q < 4; q++) if (cls == q) keys[koff + off[q] + __popcll(mq[q] & lt)] = (int)cd;
-        } else {
-            for (int b = 0; b < nk; b += 64) {
-                int i = b + lane;
-                int cls = -1;
-                if (i < nk) { uint32_t cd = (uint32_t)keys[koff + i]; cls = (cand_x(cd) < mx ? 0 : 1) + (cand_y(cd) < my ? 0 : 2); }
+        } else if (nk <= 256) {
+            // up to four keys per lane: still one load round trip and an in-place store (every key is in a register before any is written)
+            uint32_t cd[4]; int cls[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) cnt[q] += __popcll(__ballot(cls == q));
+            for (int j = 0; j < 4; j++) {
+                const int i = 64 * j + lane;
+                cd[j] = i < nk ? (uint32_t)keys[koff + i] : 0u;
+            }
+            unsigned long long mq[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                cls[j] = 64 * j + lane < nk ? (cand_x(cd[j]) < mx ? 0 : 1) + (cand_y(cd[j]) < my ? 0 : 2) : -1;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { mq[j][q] = __ballot(cls[j] == q); cnt[q] += __popcll(mq[j][q]); }
             }
             off[0] = 0; off[1] = cnt[0]; off[2] = cnt[0] + cnt[1]; off[3] = cnt[0] + cnt[1] + cnt[2];
             int run[4] = { 0, 0, 0, 0 };
-            for (int b = 0; b < nk; b += 64) {
-                int i = b + lane;
-                int cls = -1, k = 0;
-                if (i < nk) { k = keys[koff + i]; uint32_t cd = (uint32_t)k; cls = (cand_x(cd) < mx ? 0 : 1) + (cand_y(cd) < my ? 0 : 2); }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    unsigned long long m = __ballot(cls == q);
-                    if (cls == q) ktmp[koff + off[q] + run[q] + __popcll(m & lt)] = k;
-                    run[q] += __popcll(m);
+                    if (cls[j] == q) keys[koff + off[q] + run[q] + __popcll(mq[j][q] & lt)] = (int)cd[j];
+                    run[q] += __popcll(mq[j][q]);
+                }
+            }
+        } else {
+            // the few nodes of the first rounds: two passes of 256 keys a step (four loads in flight), through the spare array
+            for (int b = 0; b < nk; b += 256) {
+                uint32_t cd[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const int i = b + 64 * j + lane; cd[j] = i < nk ? (uint32_t)keys[koff + i] : 0u; }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int cls = b + 64 * j + lane < nk ? (cand_x(cd[j]) < mx ? 0 : 1) + (cand_y(cd[j]) < my ? 0 : 2) : -1;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) cnt[q] += __popcll(__ballot(cls == q));
+                }
+            }
+            off[0] = 0; off[1] = cnt[0]; off[2] = cnt[0] + cnt[1]; off[3] = cnt[0] + cnt[1] + cnt[2];
+            int run[4] = { 0, 0, 0, 0 };
+            for (int b = 0; b < nk; b += 256) {
+                uint32_t cd[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const int i = b + 64 * j + lane; cd[j] = i < nk ? (uint32_t)keys[koff + i] : 0u; }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int cls = b + 64 * j + lane < nk ? (cand_x(cd[j]) < mx ? 0 : 1) + (cand_y(cd[j]) < my ? 0 : 2) : -1;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const unsigned long long m = __ballot(cls == q);
+                        if (cls == q) ktmp[koff + off[q] + run[q] + __popcll(m & lt)] = (int)cd[j];
+                        run[q] += __popcll(m);
+                    }
                 }
             }
             __syncthreads();
-            for (int i = lane; i < nk; i += 64) keys[koff + i] = ktmp[koff + i];
-        }
-        int nchild = (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0) + (cnt[3] > 0);
-        if (nn + nchild > L.node_cap) { nodes_full = true; __syncthreads(); return false; }
-        if (lane == 0) {
-            const int bx[4][4] = { { A.x, A.y, mx, my }, { mx, A.y, A.z, my }, { A.x, my, mx, A.w }, { mx, my, A.z, A.w } };
-            int h = head, id = nn;
-            for (int q = 0; q < 4; q++) {
-                if (!cnt[q]) continue;
-                nA[id] = make_int4(bx[q][0], bx[q][1], bx[q][2], bx[q][3]);
-                nB[id] = make_int4(koff + off[q], cnt[q], -1, h);
-                nB[h].z = id;          // h is never -1 here: `ni` is still linked
-                if (cnt[q] > 1) wr[nvs + (q > 0 && cnt[0] > 1) + (q > 1 && cnt[1] > 1) + (q > 2 && cnt[2] > 1)] = make_int2(cnt[q], id);
-                h = id; id++;
+            for (int b = 0; b < nk; b += 256) {
+                int t[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const int i = b + 64 * j + lane; t[j] = i < nk ? ktmp[koff + i] : 0; }
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const int i = b + 64 * j + lane; if (i < nk) keys[koff + i] = t[j]; }
             }
-            // unlink ni
-            int4 Bn = nB[ni];
-            if (Bn.z >= 0) nB[Bn.z].w = Bn.w;
-            if (Bn.w >= 0) nB[Bn.w].z = Bn.z;
+            __syncthreads();
         }
-        // uniform bookkeeping
-        {
-            // `ni` can only be the head if no child was pushed before it -- children are pushed first
-            int last_child = nn + nchild - 1;
-            if (B.w < 0) tail = (B.z >= 0) ? B.z : ((nchild > 0) ? nn : -1);   // ni was the tail
-            // prev of ni may be a just-created child when ni was head:
-            if (B.z < 0 && B.w < 0 && nchild > 0) tail = nn;   // single-element list: first child becomes tail
-            head = (nchild > 0) ? last_child : ((B.z < 0) ? B.w : head);
-            nvs += (cnt[0] > 1) + (cnt[1] > 1) + (cnt[2] > 1) + (cnt[3] > 1);
-            nn += nchild;
-            size += nchild - 1;
+        const int e0 = cnt[0] > 0, e1 = cnt[1] > 0, e2 = cnt[2] > 0, e3 = cnt[3] > 0;
+        const int g0 = cnt[0] > 1, g1 = cnt[1] > 1, g2 = cnt[2] > 1, g3 = cnt[3] > 1;
+        const int nchild = e0 + e1 + e2 + e3;            // >= 1: only nodes of two or more keys are divided
+        if (nslot + nchild - 1 > cap) { nodes_full = true; return false; }
+        const unsigned prev = LK & 0xFFFFu, next = LK >> 16;
+        const unsigned h0 = prev == OCT_NONE ? next : (unsigned)head;          // the list's head once `ni` is unlinked
+        if (lane == 0) {
+            if (prev != OCT_NONE) lk[prev] = (lk[prev] & 0xFFFFu) | (next << 16);
+            if (next != OCT_NONE) lk[next] = (lk[next] & 0xFFFF0000u) | prev;
+            if (h0 != OCT_NONE) lk[h0] = (lk[h0] & 0xFFFF0000u) | (unsigned)ni;  // the first child (it takes ni's slot) goes in front of it
         }
-        __syncthreads();
+        if (lane < 4) {
+            const int myc = lane == 0 ? cnt[0] : lane == 1 ? cnt[1] : lane == 2 ? cnt[2] : cnt[3];
+            const int myo = lane == 0 ? 0 : lane == 1 ? off[1] : lane == 2 ? off[2] : off[3];
+            if (myc > 0) {
+                const int r = (lane > 0 ? e0 : 0) + (lane > 1 ? e1 : 0) + (lane > 2 ? e2 : 0);        // my place among the children
+                const int slot = r == 0 ? ni : nslot + r - 1;
+                const unsigned nx = r == 0 ? h0 : (unsigned)(r == 1 ? ni : nslot + r - 2);            // pushed in front of the child before me
+                const unsigned pv = r == nchild - 1 ? OCT_NONE : (unsigned)(nslot + r);               // the child after me is pushed in front of me
+                const int cx0 = (lane & 1) ? mx : x0, cx1 = (lane & 1) ? x1 : mx, cy0 = (lane & 2) ? my : y0, cy1 = (lane & 2) ? y1 : my;
+                nd[slot] = make_uint4((unsigned)cx0 | ((unsigned)cy0 << 16), (unsigned)cx1 | ((unsigned)cy1 << 16), (unsigned)(koff + myo), (unsigned)myc);
+                lk[slot] = pv | (nx << 16);
+                if (myc > 1) wr[nvs + (lane > 0 ? g0 : 0) + (lane > 1 ? g1 : 0) + (lane > 2 ? g2 : 0)] = make_int2(myc, (nseq + r) | (slot << 16));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        head = nchild == 1 ? ni : nslot + nchild - 2;    // the last child
+        nvs += g0 + g1 + g2 + g3;
+        nslot += nchild - 1; nseq += nchild; size += nchild - 1;
         return true;
     };
 
     // A round divides every node that holds more than one key, in LIST order.  Those are exactly the children of the previous round that
     // got more than one key -- pushed to the front one after the other, so the list holds them in the reverse of their creation order --
     // (the initial nodes, in creation order, for the first round): the round walks that array instead of the whole list, whose other
-    // nodes (one key each, hundreds of them in the later rounds) cost a dependent access apiece only to be skipped.
-    bool finish = false;
-    int2 *rd = vp; int nrd = nexp0; bool fwd = true;
-    wr = vs;
+    // nodes (one key each, hundreds of them in the later rounds) would cost an access apiece only to be skipped.
+    bool finish = nodes_full;
+    int2 *rd = la; int nrd = nexp0; bool fwd = true;
     while (!finish) {
         int prevSize = size;
         nvs = 0;
         int nToExpand = 0;
+        uint32_t pre = 0; bool hp = false;
+        if (nrd > 0) hp = fetch(rd[fwd ? 0 : nrd - 1].y, pre);
         for (int q = 0; q < nrd; q++) {
-            const int it = rd[fwd ? q : nrd - 1 - q].y;
-            int before = nvs;
-            if (!divide(it)) { finish = true; break; }
+            const int ey = rd[fwd ? q : nrd - 1 - q].y;
+            uint32_t pre2 = 0; bool hp2 = false;
+            if (q + 1 < nrd) hp2 = fetch(rd[fwd ? q + 1 : nrd - 2 - q].y, pre2);
+            const int before = nvs;
+            if (!divide(ey, pre, hp)) { finish = true; break; }
             nToExpand += nvs - before;
+            pre = pre2; hp = hp2;
         }
         { int2 *t = rd; rd = wr; wr = t; nrd = nvs; fwd = false; }         // this round's children are the next round's nodes to divide
+        __syncthreads();                                                   // (keys written in this round are read in the next)
         if (finish) break;
         if (size >= N || size == prevSize) {
             finish = true;
@@ -594,21 +661,27 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
             while (!finish) {
                 prevSize = size;
                 const int nvp = nrd;
-                int2 *srt = wr;                          // (size, node) ascending into the free array; keys are unique
+                int2 *srt = wr;                          // (keys, seq) ascending into the free array; (keys, seq) pairs are unique
                 for (int i = lane; i < nvp; i += 64) {
-                    int2 me = rd[i];
+                    const int2 me = rd[i];
                     int r = 0;
-                    for (int j = 0; j < nvp; j++) { int2 o = rd[j]; r += (o.x < me.x) || (o.x == me.x && o.y < me.y); }
+                    for (int j = 0; j < nvp; j++) { const int2 o = rd[j]; r += (o.x < me.x) || (o.x == me.x && (o.y & 0xFFFF) < (me.y & 0xFFFF)); }
                     srt[r] = me;
                 }
-                __syncthreads();
+                __builtin_amdgcn_wave_barrier();
                 wr = rd;                                 // the divisions below write the next candidates where the unsorted ones were
                 nvs = 0;
+                if (nvp > 0) hp = fetch(srt[nvp - 1].y, pre);
                 for (int j = nvp - 1; j >= 0; j--) {
-                    if (!divide(srt[j].y)) { finish = true; break; }
+                    const int ey = srt[j].y;
+                    uint32_t pre2 = 0; bool hp2 = false;
+                    if (j > 0) hp2 = fetch(srt[j - 1].y, pre2);
+                    if (!divide(ey, pre, hp)) { finish = true; break; }
                     if (size >= N) break;
+                    pre = pre2; hp = hp2;
                 }
                 rd = wr; wr = srt; nrd = nvs;
+                __syncthreads();
                 if (size >= N || size == prevSize) finish = true;
             }
         }
@@ -617,12 +690,13 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
 
     // ---- retain the best point of each node, list order (ORBextractor.cc:737-758) ----
     int cntn = 0;
-    for (int it = head; it >= 0 && cntn < L.kp_cap; it = nB[it].w) { if (lane == 0) order[cntn] = it; cntn++; }
-    __syncthreads();
+    int2 *order = la;                                  // (the two lists are dead)
+    for (unsigned it = head < 0 ? OCT_NONE : (unsigned)head; it != OCT_NONE && cntn < L.kp_cap && cntn < cap; it = lk[it] >> 16) { if (lane == 0) order[cntn] = make_int2((int)it, 0); cntn++; }
+    __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < cntn; i += 64) {
-        const int4 B = nB[order[i]];
-        uint32_t best = (uint32_t)keys[B.x];
-        for (int k = 1; k < B.y; k++) { uint32_t c = (uint32_t)keys[B.x + k]; if (cand_s(c) > cand_s(best)) best = c; }
+        const uint4 R = nd[order[i].x];
+        uint32_t best = (uint32_t)keys[R.z];
+        for (unsigned k = 1; k < R.w; k++) { uint32_t c = (uint32_t)keys[R.z + k]; if (cand_s(c) > cand_s(best)) best = c; }
         outkp[i] = best;
     }
     if (lane == 0) *outcnt = cntn;
@@ -763,8 +837,8 @@ void orb_free_plan(hvo_ctx *ctx)
 {
     OrbPlan &P = ctx->orb;
     void *ptrs[] = { P.d_lev, P.d_cells, P.d_rs_xofs, P.d_rs_xalpha, P.d_rs_yofs, P.d_rs_ybeta, P.d_tiles, P.d_pyr_base, P.d_blur,
-                     P.d_cell_kp, P.d_cell_cnt, P.d_cand, P.d_keys, P.d_keys_tmp, P.d_nodeA, P.d_nodeB, P.d_vs, P.d_vp,
-                     P.d_order, P.d_lvl_kp, P.d_lvl_cnt, P.d_kp, P.d_desc, P.d_nkp, P.d_flags, P.d_ltiles, P.d_kpchunks, P.d_lvl_base };
+                     P.d_cell_kp, P.d_cell_cnt, P.d_cand, P.d_keys, P.d_keys_tmp,
+                     P.d_lvl_kp, P.d_lvl_cnt, P.d_kp, P.d_desc, P.d_nkp, P.d_flags, P.d_ltiles, P.d_kpchunks, P.d_lvl_base };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     P = OrbPlan();
 }
@@ -801,7 +875,7 @@ static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch)
 {
     OrbPlan &P = ctx->orb;
     const int nl = ctx->p.orb_nlevels;
-    P.w = w; P.h = h; P.nlevels = nl; P.batch = batch;
+    P.w = w; P.h = h; P.nlevels = nl; P.batch = batch; P.oct_slot_cap = 0;
     std::vector<CellDesc> cells;
     std::vector<int> xofs, xalpha, yofs, ybeta;
     std::vector<int4> tiles;
@@ -855,9 +929,13 @@ static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch)
         // so the per-cell slab capacity is also the exact bound for the level's candidate list
         L.cand_cap = L.ncells * HVO_CELL_CAP;
         cand_total += L.cand_cap;
-        L.node_off = node_total;
-        L.node_cap = 6 * L.nfeat + 256;
-        node_total += L.node_cap;
+        L.node_off = 0; L.node_cap = 6 * L.nfeat + 256;       // (nodes a level may CREATE: k_octree's creation numbers are 16 bits wide)
+        if (L.node_cap > 0xFFFF) return HVO_ERR_UNSUPPORTED;
+        {   // nodes alive at once in k_octree: the list stops at nfeat (+ 3), the unconditional first round makes up to 4 nIni
+            const int bw = L.maxBX - L.minBX, bh = L.maxBY - L.minBY;
+            const int nIni = bh > 0 ? (int)roundf((float)bw / (float)bh) : 0;
+            P.oct_slot_cap = std::max(P.oct_slot_cap, (std::max(L.nfeat + 3, 4 * nIni) + 5 + 3) & ~3);
+        }
         L.kp_off = kp_total;
         L.kp_cap = L.nfeat + 8;
         kp_total += L.kp_cap;
@@ -905,12 +983,17 @@ static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     // budget of 48 GB allows: the whole batch at 640x480 (8192 resident frames: 45 GB; two chunks of 4096 cost 5 ms of a 194 ms step),
     // 1024 frames at 1280x960, where the memory buys resident frames instead.
     {
-        const size_t per = P.lvl_bytes + P.blur_bytes + (size_t)cells.size() * HVO_CELL_CAP * 4 + (size_t)cand_total * 12 + (size_t)node_total * 52 + (size_t)kp_total * 4;
+        const size_t per = P.lvl_bytes + P.blur_bytes + (size_t)cells.size() * HVO_CELL_CAP * 4 + (size_t)cand_total * 12 + (size_t)kp_total * 4;
         P.chunk = batch;
         while (P.chunk > 1024 && (size_t)P.chunk * per > ((size_t)48 << 30)) P.chunk = (P.chunk + 1) / 2;
     }
     { const char *e = getenv("HVO_ORB_CHUNK"); if (e && atoi(e) > 0) P.chunk = std::min(batch, atoi(e)); }
     P.ncells = (int)cells.size(); P.cand_total = cand_total; P.node_total = node_total; P.kp_total = kp_total;
+    {   // k_octree's node slots are dynamic LDS
+        const size_t lds = (size_t)P.oct_slot_cap * OCT_SLOT_BYTES;
+        if (lds > 150 * 1024) return HVO_ERR_UNSUPPORTED;
+        if (lds > 48 * 1024) HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     P.ntiles = (int)tiles.size();
     P.kp_cap = kp_total;       // >= sum(nfeat)+8*nlevels: never truncates the octree output
     const size_t B = (size_t)batch;
@@ -943,11 +1026,6 @@ static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     if ((rc = dev_alloc(ctx, &P.d_cand, CB * cand_total))) return rc;
     if ((rc = dev_alloc(ctx, &P.d_keys, CB * cand_total))) return rc;
     if ((rc = dev_alloc(ctx, &P.d_keys_tmp, CB * cand_total))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_nodeA, CB * node_total))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_nodeB, CB * node_total))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_vs, CB * node_total))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_vp, CB * node_total))) return rc;
-    if ((rc = dev_alloc(ctx, &P.d_order, CB * node_total))) return rc;
     if ((rc = dev_alloc(ctx, &P.d_lvl_kp, CB * kp_total))) return rc;
     if ((rc = dev_alloc(ctx, &P.d_lvl_cnt, CB * nl))) return rc;
     if ((rc = dev_alloc(ctx, &P.d_kp, B * P.kp_cap))) return rc;
@@ -1062,10 +1140,9 @@ int orb_run(hvo_ctx *ctx, int n)
     id = hvo_prof_begin(ctx, "orb_octree", st);
     OctArgs oa;
     oa.lev = P.d_lev; oa.cell_kp = P.d_cell_kp; oa.cell_cnt = P.d_cell_cnt; oa.ncells = P.ncells;
-    oa.cand = P.d_cand; oa.keys = P.d_keys; oa.keys_tmp = P.d_keys_tmp; oa.nodeA = P.d_nodeA; oa.nodeB = P.d_nodeB;
-    oa.vs = P.d_vs; oa.vp = P.d_vp; oa.order = P.d_order; oa.lvl_kp = P.d_lvl_kp; oa.lvl_cnt = P.d_lvl_cnt; oa.flags = flags;
-    oa.cand_total = P.cand_total; oa.node_total = P.node_total; oa.kp_total = P.kp_total; oa.nlevels = nl;
-    hipLaunchKernelGGL(k_octree, dim3(nl, m), dim3(64), 0, st, oa);
+    oa.cand = P.d_cand; oa.keys = P.d_keys; oa.keys_tmp = P.d_keys_tmp; oa.lvl_kp = P.d_lvl_kp; oa.lvl_cnt = P.d_lvl_cnt; oa.flags = flags;
+    oa.cand_total = P.cand_total; oa.kp_total = P.kp_total; oa.nlevels = nl; oa.slot_cap = P.oct_slot_cap;
+    hipLaunchKernelGGL(k_octree, dim3(nl, m), dim3(64), (size_t)P.oct_slot_cap * OCT_SLOT_BYTES, st, oa);
     hvo_prof_end(ctx, id);
     { const int rd = orb_describe_run(ctx, c0, m, st); if (rd) return rd; }
     }   // chunks
