@@ -383,18 +383,22 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
 }
 
 // =====================================================================================
-// K3: quadtree distribution -- one wave per (frame, level), serial semantics
+// K3: quadtree distribution -- one wave per (frame, level); the reference's serial semantics, evaluated a whole round at a time
 // =====================================================================================
-// A node's keys ARE its candidates (x | y << 12 | score << 24): they live in keys[koff, koff + nk) (global) and its children re-use
-// that range (stable 4-way partition), so no pool growth.  bNoMore <=> nk == 1.  Everything else about a node lives in LDS (round 4:
-// a division used to be ~4 dependent global round trips -- record, links, the next round's list -- and a store drain at its barrier):
-//   nd[slot] = {x0 | y0 << 16, x1 | y1 << 16, koff, nk}      lk[slot] = prev | next << 16   (OCT_NONE: no such node)
-//   la / lb  = the nodes this round / the next one divides: (keys, seq | slot << 16)
-// The list stops growing at N nodes and a division removes one node and adds at most four, so at most max(N + 3, 4 nIni) nodes are
-// alive: a divided node's slot goes to its first child, the other children take fresh slots, and the slots never run out (slot_cap,
-// orb_plan_build).  Tie rule of the (size, node*) sort of ORBextractor.cc:682: node creation order -- `seq`, not the slot.
-// One wave, so LDS needs no barrier (a wave's LDS accesses complete in order); the round loop prefetches the keys of the node it
-// divides next before it divides the current one.
+// DistributeOctTree walks a std::list: a round divides every node that holds more than one key (children pushed to the FRONT in order
+// n1..n4, the node erased), and once the list is close to N nodes it divides one node at a time, largest first, until N is reached
+// (ORBextractor.cc:588-735).  Within a round -- and within one pass of the largest-first loop -- the divisions do not depend on each
+// other: what a division does to the list, the creation number of a child (the tie rule of the (size, node*) sort at 682: SURVEY H2)
+// and the point at which the largest-first loop stops are prefix sums over the child counts of the nodes in processing order.  So:
+//   * a LANE owns a node of the round (64 at a time): it counts its keys per quadrant, a wave scan numbers the children, finds the
+//     stopping point and hands out slots, the lane writes its children's records and partitions its keys (stable) into the other of
+//     two key buffers.  Nodes of more than 64 keys (the first two or three rounds) are counted and partitioned by the whole wave.
+//   * the list is an ARRAY of slots, rebuilt per round: this round's children in reverse creation order, then the old list without
+//     the divided nodes (a divided node's slot goes to its first child: `born[slot] == round` marks it).
+// Per node in LDS: rec[slot] = {x0 | y0 << 16, x1 | y1 << 16, koff, nk | buffer << 31}; a node's keys ARE its candidates
+// (x | y << 12 | score << 24) in kbuf[buffer][koff, koff + nk).  bNoMore <=> nk == 1.  At most max(N + 3, 4 nIni) nodes are alive
+// (slot_cap, orb_build_plan).  Round 3's kernel divided one node at a time with the whole wave: ~2900 cycles a division, 6.85 ms per
+// 8192 frames; its records were in global memory.
 struct OctArgs {
     const LevelGeom *lev;
     const uint32_t *cell_kp; const int *cell_cnt; int ncells;
@@ -402,8 +406,7 @@ struct OctArgs {
     uint32_t *lvl_kp; int *lvl_cnt; int *flags;
     int cand_total, kp_total, nlevels, slot_cap;
 };
-#define OCT_NONE 0xFFFFu
-#define OCT_SLOT_BYTES 36                              // uint4 record + link word + an entry in each of the two lists
+#define OCT_SLOT_BYTES 40                              // uint4 record, an entry in each of the two round lists, born + two list arrays + creation order (u16)
 
 static __device__ __forceinline__ int cand_x(uint32_t c) { return c & 0xFFF; }
 static __device__ __forceinline__ int cand_y(uint32_t c) { return (c >> 12) & 0xFFF; }
@@ -416,15 +419,16 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
     const int level = blockIdx.x, frame = blockIdx.y, lane = threadIdx.x;
     const LevelGeom L = a.lev[level];
     uint32_t *cand = a.cand + (size_t)frame * a.cand_total + L.cand_off;
-    int *keys = a.keys + (size_t)frame * a.cand_total + L.cand_off;
-    int *ktmp = a.keys_tmp + (size_t)frame * a.cand_total + L.cand_off;
+    int *kbuf0 = a.keys + (size_t)frame * a.cand_total + L.cand_off;
+    int *kbuf1 = a.keys_tmp + (size_t)frame * a.cand_total + L.cand_off;
     uint32_t *outkp = a.lvl_kp + (size_t)frame * a.kp_total + L.kp_off;
     int *outcnt = a.lvl_cnt + (size_t)frame * a.nlevels + level;
     const unsigned long long lt = lanemask_lt();
     const int cap = a.slot_cap;
-    uint4 *nd = oct_lds;
-    unsigned *lk = reinterpret_cast<unsigned *>(nd + cap);
-    int2 *la = reinterpret_cast<int2 *>(lk + cap), *lb = la + cap;
+    uint4 *rec = oct_lds;
+    int2 *DA = reinterpret_cast<int2 *>(rec + cap), *DB = DA + cap;              // the nodes a round divides: (keys, creation number | slot << 16)
+    unsigned short *born = reinterpret_cast<unsigned short *>(DB + cap);          // the round a slot's record was written in
+    unsigned short *lstO = born + cap, *lstN = lstO + cap, *tmpC = lstN + cap;    // the list, the list being built, this round's children in creation order
 
     // ---- gather the cells' candidates in cell order (vToDistributeKeys) ----
     // 64 cells at a time: their counts in one load, a wave prefix sum for the offsets (LDS), then the chunk's candidates copied with all
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
     const int bw = L.maxBX - L.minBX, bh = L.maxBY - L.minBY;
     const int nIni = (int)roundf(__fdiv_rn((float)bw, (float)bh));
     // one initial node (any image that is not wider than 1.5 x its height): it holds every candidate, in this order -- the gather writes its keys
-    uint32_t *gdst = nIni == 1 ? reinterpret_cast<uint32_t *>(keys) : cand;
+    uint32_t *gdst = nIni == 1 ? reinterpret_cast<uint32_t *>(kbuf0) : cand;
     for (int cbase = 0; cbase < L.ncells; cbase += 64) {
         const int ci = cbase + lane;
         const size_t cidx0 = (size_t)frame * a.ncells + L.cell_off + cbase;
@@ -467,13 +471,12 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
 
     int nslot = 0;            // slots handed out
     int nseq = 0;             // nodes created
+    int nlist = 0;            // nodes in the list (lNodes.size())
     int nexp0 = 0;            // initial nodes that hold more than one key
-    int head = -1, size = 0;
-    bool nodes_full = false;
 
     // ---- initial nodes: stable filter of candidates by (int)(x / hX) ----
     {
-        int koff = 0, tail = -1;
+        int koff = 0;
         for (int i = 0; i < nIni; i++) {
             int cnt = 0;
             if (nIni == 1) cnt = nc;                   // (int)(x / hX) == 0 for every x < bw: the gather has written this node's keys
@@ -482,221 +485,212 @@ __global__ __launch_bounds__(64) void k_octree(OctArgs a)
                 bool in = false;
                 if (k < nc) in = ((int)__fdiv_rn((float)cand_x(cand[k]), hX)) == i;
                 unsigned long long m = __ballot(in);
-                if (in) keys[koff + cnt + __popcll(m & lt)] = (int)cand[k];
+                if (in) kbuf0[koff + cnt + __popcll(m & lt)] = (int)cand[k];
                 cnt += __popcll(m);
             }
             if (cnt > 0) {   // empty initial nodes are erased right away (ORBextractor.cc:580-581)
-                if (nslot >= cap) { nodes_full = true; break; }
+                if (nslot >= cap) { if (lane == 0) { atomicOr(&a.flags[frame], 4); *outcnt = 0; } return; }
                 if (lane == 0) {
-                    nd[nslot] = make_uint4((unsigned)(int)(hX * (float)i), (unsigned)(int)(hX * (float)(i + 1)) | ((unsigned)bh << 16), (unsigned)koff, (unsigned)cnt);
-                    lk[nslot] = (tail < 0 ? OCT_NONE : (unsigned)tail) | (OCT_NONE << 16);
-                    if (tail >= 0) lk[tail] = (lk[tail] & 0xFFFFu) | ((unsigned)nslot << 16);
-                    if (cnt > 1) la[nexp0] = make_int2(cnt, nseq | (nslot << 16));           // the first round's nodes to divide, in list order
+                    rec[nslot] = make_uint4((unsigned)(int)(hX * (float)i), (unsigned)(int)(hX * (float)(i + 1)) | ((unsigned)bh << 16), (unsigned)koff, (unsigned)cnt);
+                    born[nslot] = 0;
+                    lstO[nlist] = (unsigned short)nslot;
+                    if (cnt > 1) DA[nexp0] = make_int2(cnt, nseq | (nslot << 16));           // the first round's nodes to divide, in list order
                 }
                 if (cnt > 1) nexp0++;
-                if (head < 0) head = nslot;
-                tail = nslot; nslot++; nseq++; size++;
+                nslot++; nseq++; nlist++;
             }
             koff += cnt;
         }
     }
     __syncthreads();                                   // (the keys just written are read below: drains the stores)
 
-    int nvs = 0;
-    int2 *wr = lb;            // where divide() lists the children that hold more than one key
-    // the keys of a node, loaded before the division in front of it runs (a node of more than 64 keys is read by divide() itself)
-    auto fetch = [&](int ey, uint32_t &pre) -> bool {
-        const uint4 R = nd[(unsigned)ey >> 16];
-        const bool fits = (int)R.w <= 64;
-        pre = (fits && lane < (int)R.w) ? (uint32_t)keys[(int)R.z + lane] : 0u;
-        return fits;
-    };
-    // divide the node of list entry `ey` (seq | slot << 16): partitions its keys, unlinks it, creates the non-empty children and pushes
-    // them to the front of the list in order n1..n4.  Everything below is wave-uniform but the four lanes that write a child each.
-    auto divide = [&](int ey, uint32_t pre, bool have_pre) -> bool {
-        const int ni = (int)((unsigned)ey >> 16);
-        const uint4 R = nd[ni];
-        const unsigned LK = lk[ni];
-        const int x0 = (int)(R.x & 0xFFFFu), y0 = (int)(R.x >> 16), x1 = (int)(R.y & 0xFFFFu), y1 = (int)(R.y >> 16);
-        const int koff = (int)R.z, nk = (int)R.w;
-        const int halfX = (int)ceilf((float)(x1 - x0) * 0.5f);
-        const int halfY = (int)ceilf((float)(y1 - y0) * 0.5f);
-        const int mx = x0 + halfX, my = y0 + halfY;
-        int cnt[4] = { 0, 0, 0, 0 };
-        int off[4];
-        if (nk <= 64) {
-            // the usual node: its keys fit the wave -- one load, four ballots, one store in place (every key is in a register before any is written)
-            uint32_t cd = 0; int cls = -1;
-            if (lane < nk) { cd = have_pre ? pre : (uint32_t)keys[koff + lane]; cls = (cand_x(cd) < mx ? 0 : 1) + (cand_y(cd) < my ? 0 : 2); }
-            unsigned long long mq[4];
+    int round = 0;
+    bool nodes_full = false;
+    // One round: the nodes D[0, nD) (backwards if `rev`) are divided in that order -- with `cut`, only until the list holds N nodes.
+    // The children that hold more than one key go to D2 in creation order; returns how many.
+    auto run_round = [&](const int2 *D, int nD, bool rev, bool cut, int2 *D2) -> int {
+        round++;
+        int stepC = 0, stepG = 0, grown = 0;           // children / children with more than one key / growth of the list, so far in this round
+        bool stop = false;
+        for (int base = 0; base < nD && !stop; base += 64) {
+            const int i = base + lane;
+            const bool valid = i < nD;
+            const int ey = valid ? D[rev ? nD - 1 - i : i].y : 0;
+            const int slot = (int)((unsigned)ey >> 16);
+            const uint4 R = valid ? rec[slot] : make_uint4(0, 0, 0, 0);
+            const int x0 = (int)(R.x & 0xFFFFu), y0 = (int)(R.x >> 16), x1 = (int)(R.y & 0xFFFFu), y1 = (int)(R.y >> 16);
+            const int koff = (int)R.z, nk = (int)(R.w & 0x7FFFFFFFu), buf = (int)(R.w >> 31);
+            const int mx = x0 + (int)ceilf((float)(x1 - x0) * 0.5f), my = y0 + (int)ceilf((float)(y1 - y0) * 0.5f);
+            const int *src = buf ? kbuf1 : kbuf0;
+            int *dst = buf ? kbuf0 : kbuf1;
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            // ---- keys per quadrant: nodes of more than 64 keys by the whole wave, one after the other ...
+            const unsigned long long bigm = __ballot(valid && nk > 64);
+            for (unsigned long long bm = bigm; bm; bm &= bm - 1) {
+                const int o = __ffsll(bm) - 1;
+                const int bk = __shfl(koff, o), bn = __shfl(nk, o), bmx = __shfl(mx, o), bmy = __shfl(my, o);
+                const int *bs = __shfl(buf, o) ? kbuf1 : kbuf0;
+                int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+                for (int b = 0; b < bn; b += 256) {
+                    uint32_t cd[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) { mq[q] = __ballot(cls == q); cnt[q] = __popcll(mq[q]); }
-            off[0] = 0; off[1] = cnt[0]; off[2] = cnt[0] + cnt[1]; off[3] = cnt[0] + cnt[1] + cnt[2];
+                    for (int j = 0; j < 4; j++) { const int k = b + 64 * j + lane; cd[j] = k < bn ? (uint32_t)bs[bk + k] : 0u; }
 #pragma unroll
-            for (int q = 0; q < 4; q++) if (cls == q) keys[koff + off[q] + __popcll(mq[q] & lt)] = (int)cd;
-        } else if (nk <= 256) {
-            // up to four keys per lane: still one load round trip and an in-place store (every key is in a register before any is written)
-            uint32_t cd[4]; int cls[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int i = 64 * j + lane;
-                cd[j] = i < nk ? (uint32_t)keys[koff + i] : 0u;
+                    for (int j = 0; j < 4; j++) {
+                        const int cls = b + 64 * j + lane < bn ? (cand_x(cd[j]) < bmx ? 0 : 1) + (cand_y(cd[j]) < bmy ? 0 : 2) : -1;
+                        t0 += __popcll(__ballot(cls == 0)); t1 += __popcll(__ballot(cls == 1)); t2 += __popcll(__ballot(cls == 2)); t3 += __popcll(__ballot(cls == 3));
+                    }
+                }
+                if (lane == o) { c0 = t0; c1 = t1; c2 = t2; c3 = t3; }
             }
-            unsigned long long mq[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                cls[j] = 64 * j + lane < nk ? (cand_x(cd[j]) < mx ? 0 : 1) + (cand_y(cd[j]) < my ? 0 : 2) : -1;
-#pragma unroll
-                for (int q = 0; q < 4; q++) { mq[j][q] = __ballot(cls[j] == q); cnt[q] += __popcll(mq[j][q]); }
+            // ---- ... the others each by its lane
+            {
+                const int mynk = (valid && nk <= 64) ? nk : 0;
+                for (int k = 0; __ballot(k < mynk) != 0ull; k += 2) {
+                    const uint32_t ca = k < mynk ? (uint32_t)src[koff + k] : 0u, cb = k + 1 < mynk ? (uint32_t)src[koff + k + 1] : 0u;
+                    if (k < mynk) { const int cls = (cand_x(ca) < mx ? 0 : 1) + (cand_y(ca) < my ? 0 : 2); c0 += cls == 0; c1 += cls == 1; c2 += cls == 2; c3 += cls == 3; }
+                    if (k + 1 < mynk) { const int cls = (cand_x(cb) < mx ? 0 : 1) + (cand_y(cb) < my ? 0 : 2); c0 += cls == 0; c1 += cls == 1; c2 += cls == 2; c3 += cls == 3; }
+                }
             }
-            off[0] = 0; off[1] = cnt[0]; off[2] = cnt[0] + cnt[1]; off[3] = cnt[0] + cnt[1] + cnt[2];
-            int run[4] = { 0, 0, 0, 0 };
+            // ---- number the children: one scan of (children | list growth << 10 | children with more than one key << 20)
+            const int nch = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);               // >= 1: only nodes of two or more keys are divided
+            const int packed = valid ? (nch | ((nch - 1) << 10) | (((c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1)) << 20)) : 0;
+            int incl = packed;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            bool ex = valid;
+            if (cut) {                                  // "if ((int)lNodes.size() >= N) break" after each division (ORBextractor.cc:725)
+                const unsigned long long cm = __ballot(valid && nlist + grown + ((incl >> 10) & 0x3FF) >= N);
+                if (cm) { ex = valid && lane <= __ffsll(cm) - 1; stop = true; }
+            }
+            const unsigned long long exm = __ballot(ex);
+            const int tot = __shfl(incl, 63 - __clzll(exm));                          // (exm != 0: lane 0 is valid)
+            const int totC = tot & 0x3FF, totI = (tot >> 10) & 0x3FF, totG = tot >> 20;
+            const int excl = incl - packed;
+            const int Cpre = excl & 0x3FF, Ipre = (excl >> 10) & 0x3FF, Gpre = excl >> 20;
+            if (nslot + totI > cap || nseq + stepC + totC > 0xFFFF) { nodes_full = true; return 0; }
+            const int o1 = c0, o2 = c0 + c1, o3 = c0 + c1 + c2;
+            if (ex) {
+                int r = 0, rr = 0;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    if (cls[j] == q) keys[koff + off[q] + run[q] + __popcll(mq[j][q] & lt)] = (int)cd[j];
-                    run[q] += __popcll(mq[j][q]);
-                }
-            }
-        } else {
-            // the few nodes of the first rounds: two passes of 256 keys a step (four loads in flight), through the spare array
-            for (int b = 0; b < nk; b += 256) {
-                uint32_t cd[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) { const int i = b + 64 * j + lane; cd[j] = i < nk ? (uint32_t)keys[koff + i] : 0u; }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int cls = b + 64 * j + lane < nk ? (cand_x(cd[j]) < mx ? 0 : 1) + (cand_y(cd[j]) < my ? 0 : 2) : -1;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) cnt[q] += __popcll(__ballot(cls == q));
-                }
-            }
-            off[0] = 0; off[1] = cnt[0]; off[2] = cnt[0] + cnt[1]; off[3] = cnt[0] + cnt[1] + cnt[2];
-            int run[4] = { 0, 0, 0, 0 };
-            for (int b = 0; b < nk; b += 256) {
-                uint32_t cd[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) { const int i = b + 64 * j + lane; cd[j] = i < nk ? (uint32_t)keys[koff + i] : 0u; }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int cls = b + 64 * j + lane < nk ? (cand_x(cd[j]) < mx ? 0 : 1) + (cand_y(cd[j]) < my ? 0 : 2) : -1;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const unsigned long long m = __ballot(cls == q);
-                        if (cls == q) ktmp[koff + off[q] + run[q] + __popcll(m & lt)] = (int)cd[j];
-                        run[q] += __popcll(m);
+                    const int cq = q == 0 ? c0 : q == 1 ? c1 : q == 2 ? c2 : c3;
+                    if (cq > 0) {
+                        const int cslot = r == 0 ? slot : nslot + Ipre + r - 1;      // the first child takes the divided node's slot
+                        const int cidx = stepC + Cpre + r;
+                        const int cx0 = (q & 1) ? mx : x0, cx1 = (q & 1) ? x1 : mx, cy0 = (q & 2) ? my : y0, cy1 = (q & 2) ? y1 : my;
+                        const int ko = koff + (q == 0 ? 0 : q == 1 ? o1 : q == 2 ? o2 : o3);
+                        rec[cslot] = make_uint4((unsigned)cx0 | ((unsigned)cy0 << 16), (unsigned)cx1 | ((unsigned)cy1 << 16), (unsigned)ko, (unsigned)cq | ((unsigned)(buf ^ 1) << 31));
+                        born[cslot] = (unsigned short)round;
+                        tmpC[cidx] = (unsigned short)cslot;
+                        if (cq > 1) { D2[stepG + Gpre + rr] = make_int2(cq, (nseq + cidx) | (cslot << 16)); rr++; }
+                        r++;
                     }
                 }
             }
-            __syncthreads();
-            for (int b = 0; b < nk; b += 256) {
-                int t[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) { const int i = b + 64 * j + lane; t[j] = i < nk ? ktmp[koff + i] : 0; }
-#pragma unroll
-                for (int j = 0; j < 4; j++) { const int i = b + 64 * j + lane; if (i < nk) keys[koff + i] = t[j]; }
+            // ---- the keys, stable, into the other buffer: the lanes' own nodes ...
+            {
+                const int mynk = (ex && nk <= 64) ? nk : 0;
+                int d0 = koff, d1 = koff + o1, d2 = koff + o2, d3 = koff + o3;
+                for (int k = 0; __ballot(k < mynk) != 0ull; k += 2) {
+                    const uint32_t ca = k < mynk ? (uint32_t)src[koff + k] : 0u, cb = k + 1 < mynk ? (uint32_t)src[koff + k + 1] : 0u;
+                    if (k < mynk) {
+                        const int cls = (cand_x(ca) < mx ? 0 : 1) + (cand_y(ca) < my ? 0 : 2);
+                        const int d = cls == 0 ? d0 : cls == 1 ? d1 : cls == 2 ? d2 : d3;
+                        dst[d] = (int)ca; d0 += cls == 0; d1 += cls == 1; d2 += cls == 2; d3 += cls == 3;
+                    }
+                    if (k + 1 < mynk) {
+                        const int cls = (cand_x(cb) < mx ? 0 : 1) + (cand_y(cb) < my ? 0 : 2);
+                        const int d = cls == 0 ? d0 : cls == 1 ? d1 : cls == 2 ? d2 : d3;
+                        dst[d] = (int)cb; d0 += cls == 0; d1 += cls == 1; d2 += cls == 2; d3 += cls == 3;
+                    }
+                }
             }
-            __syncthreads();
-        }
-        const int e0 = cnt[0] > 0, e1 = cnt[1] > 0, e2 = cnt[2] > 0, e3 = cnt[3] > 0;
-        const int g0 = cnt[0] > 1, g1 = cnt[1] > 1, g2 = cnt[2] > 1, g3 = cnt[3] > 1;
-        const int nchild = e0 + e1 + e2 + e3;            // >= 1: only nodes of two or more keys are divided
-        if (nslot + nchild - 1 > cap) { nodes_full = true; return false; }
-        const unsigned prev = LK & 0xFFFFu, next = LK >> 16;
-        const unsigned h0 = prev == OCT_NONE ? next : (unsigned)head;          // the list's head once `ni` is unlinked
-        if (lane == 0) {
-            if (prev != OCT_NONE) lk[prev] = (lk[prev] & 0xFFFFu) | (next << 16);
-            if (next != OCT_NONE) lk[next] = (lk[next] & 0xFFFF0000u) | prev;
-            if (h0 != OCT_NONE) lk[h0] = (lk[h0] & 0xFFFF0000u) | (unsigned)ni;  // the first child (it takes ni's slot) goes in front of it
-        }
-        if (lane < 4) {
-            const int myc = lane == 0 ? cnt[0] : lane == 1 ? cnt[1] : lane == 2 ? cnt[2] : cnt[3];
-            const int myo = lane == 0 ? 0 : lane == 1 ? off[1] : lane == 2 ? off[2] : off[3];
-            if (myc > 0) {
-                const int r = (lane > 0 ? e0 : 0) + (lane > 1 ? e1 : 0) + (lane > 2 ? e2 : 0);        // my place among the children
-                const int slot = r == 0 ? ni : nslot + r - 1;
-                const unsigned nx = r == 0 ? h0 : (unsigned)(r == 1 ? ni : nslot + r - 2);            // pushed in front of the child before me
-                const unsigned pv = r == nchild - 1 ? OCT_NONE : (unsigned)(nslot + r);               // the child after me is pushed in front of me
-                const int cx0 = (lane & 1) ? mx : x0, cx1 = (lane & 1) ? x1 : mx, cy0 = (lane & 2) ? my : y0, cy1 = (lane & 2) ? y1 : my;
-                nd[slot] = make_uint4((unsigned)cx0 | ((unsigned)cy0 << 16), (unsigned)cx1 | ((unsigned)cy1 << 16), (unsigned)(koff + myo), (unsigned)myc);
-                lk[slot] = pv | (nx << 16);
-                if (myc > 1) wr[nvs + (lane > 0 ? g0 : 0) + (lane > 1 ? g1 : 0) + (lane > 2 ? g2 : 0)] = make_int2(myc, (nseq + r) | (slot << 16));
+            // ---- ... and the big ones by the whole wave
+            for (unsigned long long bm = bigm & exm; bm; bm &= bm - 1) {
+                const int o = __ffsll(bm) - 1;
+                const int bk = __shfl(koff, o), bn = __shfl(nk, o), bmx = __shfl(mx, o), bmy = __shfl(my, o), bb = __shfl(buf, o);
+                const int bo1 = __shfl(o1, o), bo2 = __shfl(o2, o), bo3 = __shfl(o3, o);
+                const int *bs = bb ? kbuf1 : kbuf0;
+                int *bd = bb ? kbuf0 : kbuf1;
+                int r0 = bk, r1 = bk + bo1, r2 = bk + bo2, r3 = bk + bo3;
+                for (int b = 0; b < bn; b += 256) {
+                    uint32_t cd[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { const int k = b + 64 * j + lane; cd[j] = k < bn ? (uint32_t)bs[bk + k] : 0u; }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int cls = b + 64 * j + lane < bn ? (cand_x(cd[j]) < bmx ? 0 : 1) + (cand_y(cd[j]) < bmy ? 0 : 2) : -1;
+                        const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
+                        if (cls >= 0) {
+                            const int d = cls == 0 ? r0 + __popcll(m0 & lt) : cls == 1 ? r1 + __popcll(m1 & lt) : cls == 2 ? r2 + __popcll(m2 & lt) : r3 + __popcll(m3 & lt);
+                            bd[d] = (int)cd[j];
+                        }
+                        r0 += __popcll(m0); r1 += __popcll(m1); r2 += __popcll(m2); r3 += __popcll(m3);
+                    }
+                }
             }
+            stepC += totC; stepG += totG; nslot += totI; grown += totI;
         }
         __builtin_amdgcn_wave_barrier();
-        head = nchild == 1 ? ni : nslot + nchild - 2;    // the last child
-        nvs += g0 + g1 + g2 + g3;
-        nslot += nchild - 1; nseq += nchild; size += nchild - 1;
-        return true;
+        // ---- the list: this round's children, last created first, then the old list without the divided nodes ----
+        for (int j = lane; j < stepC; j += 64) lstN[j] = tmpC[stepC - 1 - j];
+        int pos = stepC;
+        for (int base = 0; base < nlist; base += 64) {
+            const int p = base + lane;
+            const int s = p < nlist ? lstO[p] : 0;
+            const bool keep = p < nlist && born[s] != (unsigned short)round;
+            const unsigned long long m = __ballot(keep);
+            if (keep) lstN[pos + __popcll(m & lt)] = (unsigned short)s;
+            pos += __popcll(m);
+        }
+        nlist = pos;
+        { unsigned short *t = lstO; lstO = lstN; lstN = t; }
+        nseq += stepC;
+        __syncthreads();                               // (keys written in this round are read in the next: drains the stores)
+        return stepG;
     };
 
     // A round divides every node that holds more than one key, in LIST order.  Those are exactly the children of the previous round that
     // got more than one key -- pushed to the front one after the other, so the list holds them in the reverse of their creation order --
-    // (the initial nodes, in creation order, for the first round): the round walks that array instead of the whole list, whose other
-    // nodes (one key each, hundreds of them in the later rounds) would cost an access apiece only to be skipped.
-    bool finish = nodes_full;
-    int2 *rd = la; int nrd = nexp0; bool fwd = true;
+    // (the initial nodes, in creation order, for the first round).
+    bool finish = false;
+    int2 *Dcur = DA, *Dnxt = DB;
+    int nD = nexp0; bool rev = false;
     while (!finish) {
-        int prevSize = size;
-        nvs = 0;
-        int nToExpand = 0;
-        uint32_t pre = 0; bool hp = false;
-        if (nrd > 0) hp = fetch(rd[fwd ? 0 : nrd - 1].y, pre);
-        for (int q = 0; q < nrd; q++) {
-            const int ey = rd[fwd ? q : nrd - 1 - q].y;
-            uint32_t pre2 = 0; bool hp2 = false;
-            if (q + 1 < nrd) hp2 = fetch(rd[fwd ? q + 1 : nrd - 2 - q].y, pre2);
-            const int before = nvs;
-            if (!divide(ey, pre, hp)) { finish = true; break; }
-            nToExpand += nvs - before;
-            pre = pre2; hp = hp2;
-        }
-        { int2 *t = rd; rd = wr; wr = t; nrd = nvs; fwd = false; }         // this round's children are the next round's nodes to divide
-        __syncthreads();                                                   // (keys written in this round are read in the next)
-        if (finish) break;
-        if (size >= N || size == prevSize) {
+        int prevSize = nlist;
+        const int nToExpand = run_round(Dcur, nD, rev, false, Dnxt);
+        { int2 *t = Dcur; Dcur = Dnxt; Dnxt = t; } nD = nToExpand; rev = true;
+        if (nodes_full) break;
+        if (nlist >= N || nlist == prevSize) {
             finish = true;
-        } else if (size + nToExpand * 3 > N) {
+        } else if (nlist + nToExpand * 3 > N) {
             while (!finish) {
-                prevSize = size;
-                const int nvp = nrd;
-                int2 *srt = wr;                          // (keys, seq) ascending into the free array; (keys, seq) pairs are unique
-                for (int i = lane; i < nvp; i += 64) {
-                    const int2 me = rd[i];
+                prevSize = nlist;
+                // (keys, creation number) DESCENDING into the free array: the order the reference pops vPrevSizeAndPointerToNode in; pairs are unique
+                for (int i = lane; i < nD; i += 64) {
+                    const int2 me = Dcur[i];
                     int r = 0;
-                    for (int j = 0; j < nvp; j++) { const int2 o = rd[j]; r += (o.x < me.x) || (o.x == me.x && (o.y & 0xFFFF) < (me.y & 0xFFFF)); }
-                    srt[r] = me;
+                    for (int j = 0; j < nD; j++) { const int2 o = Dcur[j]; r += (o.x > me.x) || (o.x == me.x && (o.y & 0xFFFF) > (me.y & 0xFFFF)); }
+                    Dnxt[r] = me;
                 }
                 __builtin_amdgcn_wave_barrier();
-                wr = rd;                                 // the divisions below write the next candidates where the unsorted ones were
-                nvs = 0;
-                if (nvp > 0) hp = fetch(srt[nvp - 1].y, pre);
-                for (int j = nvp - 1; j >= 0; j--) {
-                    const int ey = srt[j].y;
-                    uint32_t pre2 = 0; bool hp2 = false;
-                    if (j > 0) hp2 = fetch(srt[j - 1].y, pre2);
-                    if (!divide(ey, pre, hp)) { finish = true; break; }
-                    if (size >= N) break;
-                    pre = pre2; hp = hp2;
-                }
-                rd = wr; wr = srt; nrd = nvs;
-                __syncthreads();
-                if (size >= N || size == prevSize) finish = true;
+                nD = run_round(Dnxt, nD, false, true, Dcur);          // (the unsorted array is free: the round lists its children there)
+                if (nodes_full) break;
+                if (nlist >= N || nlist == prevSize) finish = true;
             }
         }
     }
-    if (nodes_full && lane == 0) atomicOr(&a.flags[frame], 4);
+    if (nodes_full) { if (lane == 0) { atomicOr(&a.flags[frame], 4); *outcnt = 0; } return; }
 
     // ---- retain the best point of each node, list order (ORBextractor.cc:737-758) ----
-    int cntn = 0;
-    int2 *order = la;                                  // (the two lists are dead)
-    for (unsigned it = head < 0 ? OCT_NONE : (unsigned)head; it != OCT_NONE && cntn < L.kp_cap && cntn < cap; it = lk[it] >> 16) { if (lane == 0) order[cntn] = make_int2((int)it, 0); cntn++; }
-    __builtin_amdgcn_wave_barrier();
+    const int cntn = min(nlist, L.kp_cap);
     for (int i = lane; i < cntn; i += 64) {
-        const uint4 R = nd[order[i].x];
-        uint32_t best = (uint32_t)keys[R.z];
-        for (unsigned k = 1; k < R.w; k++) { uint32_t c = (uint32_t)keys[R.z + k]; if (cand_s(c) > cand_s(best)) best = c; }
+        const uint4 R = rec[lstO[i]];
+        const int *src = (R.w >> 31) ? kbuf1 : kbuf0;
+        const int nk = (int)(R.w & 0x7FFFFFFFu);
+        uint32_t best = (uint32_t)src[R.z];
+        for (int k = 1; k < nk; k++) { uint32_t c = (uint32_t)src[R.z + k]; if (cand_s(c) > cand_s(best)) best = c; }
         outkp[i] = best;
     }
     if (lane == 0) *outcnt = cntn;
