@@ -35,6 +35,41 @@ def test_orb_parity_random_noise(gpu_ctx, orc):
     check_orb(kp_g, d_g, kp_o, d_o)
 
 
+@pytest.mark.parametrize("hh,ww", [(200, 640), (160, 704)])
+def test_orb_wide_image_several_initial_nodes(hvo, orc, synth, hh, ww):
+    """DistributeOctTree starts from round(width / height) nodes (ORBextractor.cc:541-560): 4 and 5 of them here, on a textured and a
+    noise image (initial nodes filtered by x, the first round walks them forwards)"""
+    big = synth.make_gray("std", 21, 704, 480)
+    rng = np.random.default_rng(5)
+    for g in (np.ascontiguousarray(big[:hh, :ww]), rng.integers(0, 256, (hh, ww), dtype=np.uint8)):
+        kp_o, d_o = orc.Orb().extract(g)
+        ctx = hvo.Context()
+        try:
+            kp_g, d_g = ctx.extract_orb(g)
+        finally:
+            ctx.close()
+        assert len(kp_o) > 300
+        check_orb(kp_g, d_g, kp_o, d_o)
+
+
+@pytest.mark.parametrize("nfeat", [40, 300, 5000])
+def test_orb_quota_sweep(hvo, orc, synth, nfeat):
+    """the quadtree's three ways out: the quota met inside the largest-first loop (40, 300 per frame) and every node down to one key
+    before the quota is met (5000: the list stops growing, ORBextractor.cc:666); noise and a low-texture frame; a blank frame has no key point"""
+    rng = np.random.default_rng(9)
+    frames = [rng.integers(0, 256, (480, 640), dtype=np.uint8), synth.make_gray("lowtex", 0x5EED0001), np.full((480, 640), 90, np.uint8)]
+    ctx = hvo.Context(orb_nfeatures=nfeat)
+    o = orc.Orb(nfeatures=nfeat)
+    try:
+        for g in frames:
+            kp_o, d_o = o.extract(g)
+            kp_g, d_g = ctx.extract_orb(g)
+            check_orb(kp_g, d_g, kp_o, d_o)
+        assert len(kp_g) == 0
+    finally:
+        ctx.close()
+
+
 def test_orb_parity_1280(hvo, orc, synth):
     """BASELINE config 3 geometry: 1280x960, 2000 features"""
     g = synth.make_gray("std", 0x5EED0003, 1280, 960)
