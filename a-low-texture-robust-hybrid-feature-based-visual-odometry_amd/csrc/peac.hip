@@ -33,10 +33,6 @@
 #define SEG_D 16          // doubles per seg: st[9], center[3], normal[3], mse
 #define SEG_I 8           // ints per seg: N, rid, nouse, nb_off, nb_cnt, nb_cap, valid, pad
 #define LCAP 1024         // neighbour-list length staged in LDS
-#define LAT_MAX_BATCH 2048     // plans up to this many frames also allocate k_peac_cluster_lat's node records (1.6 MB per 640x480 frame)
-#ifndef LAT_DEFAULT_BATCH
-#define LAT_DEFAULT_BATCH 0    // k_peac_cluster_lat is opt-in (HVO_PEAC_LAT=1): 28.7 ms per frame against 27.0 ms for k_peac_cluster<64>
-#endif
 
 struct PeacPlan {
     int w = 0, h = 0, pitch = 0, Nw = 0, Nh = 0, nblk = 0, segcap = 0, poolcap = 0, qcap = 0, batch = 0;
@@ -51,7 +47,6 @@ struct PeacPlan {
     unsigned long long *d_adj = nullptr;
     void *d_hot = nullptr;                                                 // HotNode records of the grouped AHC kernel
     double *d_hkey = nullptr, *d_m1k = nullptr; int *d_hid = nullptr;      // TQueue: keys, bucket minima, their ids
-    void *d_nodes = nullptr; int lat_batch = 0;     // k_peac_cluster_lat's 256-byte node records (plans of fewer than LAT_MAX_BATCH frames)
     double c15 = 0, c60 = 0, c30 = 0;   // cos thresholds evaluated on the host (glibc), like the oracle
     double ang_factor = 0, ang_near = 0;
 };
@@ -1323,7 +1318,6 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
 #undef SD
 }
 
-#include "peac_lat.inc"
 #include "peac_heads.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -1923,7 +1917,7 @@ void peac_free(hvo_ctx *ctx)
     PeacPlan *P = plan_of(ctx);
     if (!P) return;
     void *ptrs[] = { P->d_depth, P->d_segD, P->d_segI, P->d_pool, P->d_pool2, P->d_parent, P->d_dsize, P->d_eflag, P->d_meta, P->d_extracted,
-                     P->d_blkmap, P->d_labels, P->d_state, P->d_queue, P->d_plidmap, P->d_isvalid, P->d_planes, P->d_adj, P->d_hkey, P->d_m1k, P->d_hid, P->d_nodes, P->d_hot };
+                     P->d_blkmap, P->d_labels, P->d_state, P->d_queue, P->d_plidmap, P->d_isvalid, P->d_planes, P->d_adj, P->d_hkey, P->d_m1k, P->d_hid, P->d_hot };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
     ctx->peac = nullptr;
@@ -1971,9 +1965,6 @@ static int peac_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_adj, B * MAX_PLANES * sizeof(unsigned long long));
     PA(P->d_hot, B * P->segcap * 128);
     { const size_t n0 = (P->segcap + 255) / 256; PA(P->d_hkey, B * n0 * 256 * sizeof(double)); PA(P->d_m1k, B * n0 * 16 * sizeof(double)); PA(P->d_hid, B * n0 * 16 * sizeof(int)); }   // TQueue
-    // the low-latency kernel keeps the whole heap (10 bytes per block) and one bit per node in LDS: up to ~14 k blocks (1280x960 has 12 288)
-    const bool want_lat = LAT_DEFAULT_BATCH > 0 || (getenv("HVO_PEAC_LAT") && atoi(getenv("HVO_PEAC_LAT")) != 0);    // opt-in: its node records cost 1.6 MB per frame
-    if (want_lat && batch <= LAT_MAX_BATCH && P->segcap <= 65535 && (size_t)P->nblk * 10 + (size_t)P->segcap * 2 + 64 <= 150 * 1024) { PA(P->d_nodes, B * P->segcap * sizeof(Node2)); P->lat_batch = batch; }
 #undef PA
     // stream-ordered fill: a null-stream hipMemset is not ordered against the non-blocking ctx stream
     HVO_HIP(hipMemsetAsync(P->d_depth, 0, B * P->pitch * (h + 1) * sizeof(uint16_t), ctx->s_peac));
@@ -2055,23 +2046,7 @@ int peac_run(hvo_ctx *ctx, int n)
             a.edges_done = 1;
         }
     }
-    // k_peac_cluster_lat (one frame per workgroup, queue in LDS, adjacency inline in 256-byte node records): an experiment in
-    // trading memory round trips for instructions that did not pay (a lone wave issues one instruction every 5-8 cycles,
-    // whatever it waits for); kept behind HVO_PEAC_LAT=1 with its parity tests, see DESIGN.md section 4
-    bool lat = P->d_nodes != nullptr && n <= P->lat_batch && n <= LAT_DEFAULT_BATCH;
-    { const char *e = getenv("HVO_PEAC_LAT"); if (e) lat = atoi(e) != 0 && P->d_nodes != nullptr && n <= P->lat_batch; }
-    if (lat) {
-        Cl2Args A2; A2.a = a; A2.nodes = (Node2 *)P->d_nodes; A2.ovf = (unsigned short *)P->d_pool2; A2.ovfcap = P->poolcap;
-        { const char *e = getenv("HVO_PEAC_OVFCAP"); if (e && atoi(e) > 0 && atoi(e) < P->poolcap) A2.ovfcap = atoi(e); }     // tests: force the pool compaction
-        A2.heap_lds = P->nblk;
-        const size_t lds = ((((size_t)A2.heap_lds * 10 + (size_t)P->segcap * 2) + 15) & ~(size_t)15) + 16;
-        static size_t lds_set = 0;
-        if (lds > 48 * 1024 && lds > lds_set) {
-            HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_lat), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_set = lds;
-        }
-        hipLaunchKernelGGL(k_peac_cluster_lat, dim3(n), dim3(64), lds, st, A2, n);
-    } else {
+    {
         // 4 frames per wave pay off once the wave slots are saturated (measured: >= ~3000 resident frames);
         // HVO_PEAC_GL forces a group width (tests run the 16-lane path on small batches with it)
         const char *e = getenv("HVO_PEAC_GL");

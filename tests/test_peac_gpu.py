@@ -249,23 +249,6 @@ def test_peac_large_batch_adaptive(hvo, orc, synth):
         check(res[b]["labels"], res[b]["planes"], lo, po)
 
 
-def test_peac_lat_kernel_parity(hvo, orc, synth, monkeypatch):
-    """k_peac_cluster_lat (HVO_PEAC_LAT=1: inline adjacency, union-find roots in the node records, queue in LDS) gives the
-    oracle's planes and labels, also when its list pool is small enough to be compacted on the way (HVO_PEAC_OVFCAP)"""
-    for cap in (None, "1500"):
-        monkeypatch.setenv("HVO_PEAC_LAT", "1")
-        if cap: monkeypatch.setenv("HVO_PEAC_OVFCAP", cap)
-        ctx = hvo.Context()
-        try:
-            for seed in (0x5EED0002, 0x5EED1003):
-                d = synth.make_depth(seed)
-                lg, pg = ctx.compute_planes(d)
-                lo, po = orc.peac(d)
-                check(lg, pg, lo, po)
-        finally:
-            ctx.close()
-
-
 @pytest.mark.parametrize("heads,poolcap,big", [("4", None, None), ("3", None, None), ("2", None, None), ("4", "22000", None), ("3", "22000", None), ("0", None, None),
                                                ("3", None, "1"), ("4", "22000", "1"), ("2", None, "1")])
 def test_peac_queue_heads(hvo, orc, synth, monkeypatch, heads, poolcap, big):

@@ -77,7 +77,6 @@ with open(os.path.join(P, tag + "_stream_scaling.txt"), "w") as f:
             "# but 3.6-7.6 frames/s at depth 6 (hardware queues oversubscribed).\n")
 shutil.copy(os.path.join(src, "match_rate.txt"), os.path.join(P, tag + "_match_rate.txt"))
 shutil.copy(os.path.join(src, "peac_timing_batch.txt"), os.path.join(P, tag + "_peac_cluster_phases_batch8192.txt"))
-shutil.copy(os.path.join(src, "peac_lat_timing.txt"), os.path.join(P, tag + "_peac_cluster_lat_phases_1frame.txt"))
 print("value", d["value"], "frames/s; under rocprof", u["value"])
 for a, b in (("peac_heads_timing.txt", "_peac_cluster_heads_phases_1frame.txt"), ("lsd_stats.txt", "_lsd_grow_one_frame_stats.txt")):
     if os.path.exists(os.path.join(src, a)): shutil.copy(os.path.join(src, a), os.path.join(P, tag + b))

@@ -27,7 +27,7 @@ echo "[b5] stream scaling"; timeout -k 10 300 python3 tools/stream_scaling.py 15
 echo "[b6] pcie"; (for a in "1024 1" "1024 3" "2048 3" "3072 3"; do timeout -k 10 200 python3 tools/pcie_overlap.py $a 4 2>/dev/null | tail -1; done; LOCKS=0 timeout -k 10 200 python3 tools/pcie_overlap.py 2048 3 4 2>/dev/null | tail -1) > $O/pcie_note.txt
 echo "[b7] footprint"; timeout -k 10 300 python3 tools/mem_per_frame.py > $O/hbm_footprint.txt 2>&1
 echo "[b8] matching"; (timeout -k 10 100 python3 tools/match_rate.py 2000 2000 2>/dev/null | tail -1; timeout -k 10 100 python3 tools/match_rate.py 1000 1000 2>/dev/null | tail -1) > $O/match_rate.txt
-echo "[b9] ahc timing"; timeout -k 10 300 python3 tools/peac_timing.py --batch 8192 > $O/peac_timing_batch.txt 2>&1; timeout -k 10 300 python3 tools/peac_lat_timing.py > $O/peac_lat_timing.txt 2>&1
+echo "[b9] ahc timing"; timeout -k 10 300 python3 tools/peac_timing.py --batch 8192 > $O/peac_timing_batch.txt 2>&1
 echo "[b10] heads kernel phases, one frame's kernels, 1280x960 latency"; timeout -k 10 300 python3 tools/peac_heads_timing.py > $O/peac_heads_timing.txt 2>&1
 timeout -k 10 300 python3 tools/latency.py std 1280 960 1,32 > $O/latency_1280.json 2>/dev/null
 timeout -k 10 300 python3 tools/lsd_stats.py > $O/lsd_stats.txt 2>&1; timeout -k 10 300 python3 tools/lsd_stats.py 1280 960 >> $O/lsd_stats.txt 2>&1
