@@ -1210,20 +1210,20 @@ __global__ __launch_bounds__(64) void k_lbd_desc(const short2 *__restrict__ dxyI
         for (int b = 0; b < 9; b++) {
             const float invN = (b == 0 || b == 8) ? invN2 : invN3;
             float tmp = __fmul_rn(band[b][0], invN);
-            dv[8 * b] = tmp; dv[8 * b + 4] = __fsqrt_rn(__fsub_rn(__fmul_rn(band[b][2], invN), __fmul_rn(tmp, tmp)));
+            dv[8 * b] = tmp; dv[8 * b + 4] = sqrtf(__fsub_rn(__fmul_rn(band[b][2], invN), __fmul_rn(tmp, tmp)));
             tmp = __fmul_rn(band[b][1], invN);
-            dv[8 * b + 1] = tmp; dv[8 * b + 5] = __fsqrt_rn(__fsub_rn(__fmul_rn(band[b][3], invN), __fmul_rn(tmp, tmp)));
+            dv[8 * b + 1] = tmp; dv[8 * b + 5] = sqrtf(__fsub_rn(__fmul_rn(band[b][3], invN), __fmul_rn(tmp, tmp)));
             tmp = __fmul_rn(band[b][4], invN);
-            dv[8 * b + 2] = tmp; dv[8 * b + 6] = __fsqrt_rn(__fsub_rn(__fmul_rn(band[b][6], invN), __fmul_rn(tmp, tmp)));
+            dv[8 * b + 2] = tmp; dv[8 * b + 6] = sqrtf(__fsub_rn(__fmul_rn(band[b][6], invN), __fmul_rn(tmp, tmp)));
             tmp = __fmul_rn(band[b][5], invN);
-            dv[8 * b + 3] = tmp; dv[8 * b + 7] = __fsqrt_rn(__fsub_rn(__fmul_rn(band[b][7], invN), __fmul_rn(tmp, tmp)));
+            dv[8 * b + 3] = tmp; dv[8 * b + 7] = sqrtf(__fsub_rn(__fmul_rn(band[b][7], invN), __fmul_rn(tmp, tmp)));
         }
         float tempM = 0, tempS = 0;
         for (int b = 0; b < 9; b++) {
             for (int q = 0; q < 4; q++) tempM = __fadd_rn(tempM, __fmul_rn(dv[8 * b + q], dv[8 * b + q]));
             for (int q = 4; q < 8; q++) tempS = __fadd_rn(tempS, __fmul_rn(dv[8 * b + q], dv[8 * b + q]));
         }
-        tempM = __fdiv_rn(1.f, __fsqrt_rn(tempM)); tempS = __fdiv_rn(1.f, __fsqrt_rn(tempS));
+        tempM = __fdiv_rn(1.f, sqrtf(tempM)); tempS = __fdiv_rn(1.f, sqrtf(tempS));
         for (int b = 0; b < 9; b++) {
             for (int q = 0; q < 4; q++) dv[8 * b + q] = __fmul_rn(dv[8 * b + q], tempM);
             for (int q = 4; q < 8; q++) dv[8 * b + q] = __fmul_rn(dv[8 * b + q], tempS);
@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(64) void k_lbd_desc(const short2 *__restrict__ dxyI
         for (int i = 0; i < 72; i++) if ((double)dv[i] > 0.4) dv[i] = (float)0.4;
         float tmp = 0;
         for (int i = 0; i < 72; i++) tmp = __fadd_rn(tmp, __fmul_rn(dv[i], dv[i]));
-        tmp = __fdiv_rn(1.f, __fsqrt_rn(tmp));
+        tmp = __fdiv_rn(1.f, sqrtf(tmp));
         for (int i = 0; i < 72; i++) dv[i] = __fmul_rn(dv[i], tmp);
     }
     __syncthreads();
