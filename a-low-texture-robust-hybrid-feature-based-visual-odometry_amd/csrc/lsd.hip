@@ -63,7 +63,7 @@ struct LsdPlan {
     long long *d_stats = nullptr;      // per frame 8 counters (diagnostics: hvo_debug_lsd_stats)
     // k_lsd_grow_async (lsd_async.inc), allocated at its first launch for the first `async_b` frames of the plan
     bool pre_fused = true;             // k_lsd_pre instead of k_lsd_blur + k_lsd_resize_grad (HVO_LSD_PRE_SPLIT=1: the pair, with its fp64 image)
-    int async_b = 0; unsigned *d_atags = nullptr; void *d_actl = nullptr; int *d_alists = nullptr, *d_ablk = nullptr, *d_afreg = nullptr;
+    int async_b = 0; unsigned *d_atags = nullptr; void *d_actl = nullptr; int *d_alists = nullptr, *d_ablk = nullptr, *d_afreg = nullptr; unsigned *d_ainreg = nullptr;
 };
 static LsdPlan *plan_of(hvo_ctx *ctx) { return (LsdPlan *)ctx->lsd; }
 
@@ -1410,7 +1410,7 @@ void lsd_free(hvo_ctx *ctx)
     if (!P) return;
     void *ptrs[] = { P->d_kl2, P->d_desc2, P->d_fn2, P->d_nkl2, P->d_blur, P->d_px, P->d_defined, P->d_reg, P->d_segs, P->d_kl_all, P->d_kl,
                      P->d_desc, P->d_fn, P->d_nkl, P->d_flags, P->d_b5, P->d_dxy, P->d_xofs, P->d_yofs, P->d_xa, P->d_yb, P->d_gL, P->d_gG, P->d_stats,
-                     P->d_pool, P->d_defmask, P->d_wprefix, P->d_fbase, P->d_fcount, P->d_pooltop, P->d_atags, P->d_actl, P->d_alists, P->d_ablk, P->d_afreg };
+                     P->d_pool, P->d_defmask, P->d_wprefix, P->d_fbase, P->d_fcount, P->d_pooltop, P->d_atags, P->d_actl, P->d_alists, P->d_ablk, P->d_afreg, P->d_ainreg };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
     ctx->lsd = nullptr;
@@ -1632,12 +1632,13 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
             HVO_HIP(hipMalloc((void **)&P->d_atags, AB * P->nwords * 32 * 4)); HVO_HIP(hipMalloc((void **)&P->d_actl, AB * sizeof(LaCtl)));
             HVO_HIP(hipMalloc((void **)&P->d_alists, AB * LA_MAXW * LA_CAP * 4)); HVO_HIP(hipMalloc((void **)&P->d_ablk, AB * LA_MAXW * 2 * LA_BCAP * 4));
             HVO_HIP(hipMalloc((void **)&P->d_afreg, AB * 2 * nsp * 4));
+            HVO_HIP(hipMalloc((void **)&P->d_ainreg, AB * LA_MAXW * P->nwords * 4)); HVO_HIP(hipMemsetAsync(P->d_ainreg, 0, AB * LA_MAXW * P->nwords * 4, st));   // a worker's bitmap of its region: all zero between growths
             HVO_HIP(hipMemsetAsync(P->d_atags, 0xFF, AB * P->nwords * 32 * 4, st));      // every region releases its tags: all free between launches
             P->async_b = (int)AB;
         }
         if (n <= P->async_b) {
             HVO_HIP(hipMemsetAsync(P->d_actl, 0, (size_t)n * sizeof(LaCtl), st));
-            LaArgs a; a.g = g; a.tags = P->d_atags; a.ctl = (LaCtl *)P->d_actl; a.lists = P->d_alists; a.blocked = P->d_ablk; a.freg = P->d_afreg; a.W = aw; a.n = n; a.early = 1;
+            LaArgs a; a.g = g; a.tags = P->d_atags; a.inreg = P->d_ainreg; a.ctl = (LaCtl *)P->d_actl; a.lists = P->d_alists; a.blocked = P->d_ablk; a.freg = P->d_afreg; a.W = aw; a.n = n; a.early = 1;
             { const char *e = getenv("HVO_LSD_ASYNC_EARLY"); if (e) a.early = atoi(e); }
             // (an LDS request keeps these one-wave workgroups off the CUs where a frame's AHC waves sit -- k_peac_cluster_heads takes 108 KB --:
             // both are bound by instruction issue and a shared SIMD slows both; HVO_LSD_ASYNC_LDS: bytes [0 for a lone frame's 32-64 workers, 56 K beside other frames])

@@ -292,3 +292,23 @@ def test_lbd_float_sqrt_is_correctly_rounded(hvo, orc, synth):
     assert len(kl) == len(kl_o) and int(kl_o["num_pixels"][13]) == 3
     assert np.array_equal(dsc, d_o)
 
+
+def test_lines_async_stolen_tags_stress(hvo, orc, synth, monkeypatch):
+    """Low-texture frames on which round 4's first async kernel produced, once in ~100 runs, a degenerate extra segment at a seed: an older
+    region took a pixel's owner tag from a growing region and let it go again (dropped as void), the pixel read as free and was added a
+    second time; at the frontier a committed region's not-yet-removed tag did the same.  Membership is a bitmap of the worker's own now
+    (lsd_async.inc), the frontier takes tags unconditionally.  8 workers per frame made it most frequent: 16 frames x 24 runs."""
+    monkeypatch.setenv("HVO_LSD_ASYNC", "8")
+    gray, _ = synth.make_batch("lowtex", 0xF00F4000 + 16, 16)
+    gray = np.ascontiguousarray(gray[:, :479, :638])
+    ref = [orc.line_extract(g) for g in gray]
+    ctx = hvo.Context(max_batch=16)
+    try:
+        for rep in range(24):
+            ctx.batch_upload(gray, np.zeros((16, 479, 638), np.uint16)); ctx.batch_run(hvo.STAGE_LSD); res = ctx.batch_download(hvo.STAGE_LSD)
+            for b in range(16):
+                kl_o, d_o, _ = ref[b]
+                assert res[b]["status"] == 0 and len(res[b]["kl"]) == len(kl_o) and np.array_equal(res[b]["ldesc"], d_o), (rep, b, len(res[b]["kl"]), len(kl_o))
+    finally:
+        ctx.close()
+

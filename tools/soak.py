@@ -18,11 +18,18 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--crop", default="", help="HxW: crop the generated frames to this size (odd geometries)")
+    ap.add_argument("--tail", action="store_true", help="also the rest of the Frame constructor (3-D lines, vanishing points, plane clouds / refit / normals, grids) against the oracle")
     args = ap.parse_args()
     hvo = ge.package(); orc = ge.oracle()
     synth = importlib.import_module("hvo_amd.synth")
     o = orc.Orb()
     ctx = hvo.Context(max_batch=args.chunk)
+    mask = hvo.STAGE_ALL
+    if args.tail:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        from test_tail_gpu import check_tail
+        mask = hvo.STAGE_ALL | hvo.STAGE_LINES3D | hvo.STAGE_VP | hvo.STAGE_PLANE_TAIL | hvo.STAGE_GRIDS
+        ctx.set_tail_params(seed=1000)
     bad, t0 = [], time.time()
     for c0 in range(0, args.frames, args.chunk):
         n = min(args.chunk, args.frames - c0)
@@ -30,7 +37,8 @@ def main():
         if args.crop:
             ch, cw = (int(v) for v in args.crop.lower().split("x"))
             gray = np.ascontiguousarray(gray[:, :ch, :cw]); depth = np.ascontiguousarray(depth[:, :ch, :cw])
-        ctx.batch_upload(gray, depth); ctx.batch_run(hvo.STAGE_ALL); res = ctx.batch_download(hvo.STAGE_ALL)
+        ctx.batch_upload(gray, depth); ctx.batch_run(mask); res = ctx.batch_download(hvo.STAGE_ALL)
+        if args.tail: ctx.batch_download_tail(mask, res)
         for b in range(n):
             why = []
             if res[b]["status"] != 0: why.append("status %d" % res[b]["status"])
@@ -42,6 +50,9 @@ def main():
             lo, po = orc.peac(depth[b])
             if not np.array_equal(res[b]["labels"], lo) or len(res[b]["planes"]) != len(po): why.append("planes")
             elif len(po) and not np.allclose(res[b]["planes"]["normal"], po["normal"], rtol=1e-9, atol=1e-12): why.append("plane floats")
+            if args.tail and not why:
+                try: check_tail(res[b], depth[b], orc, 1000 + b, (0.0, float(gray.shape[2]), 0.0, float(gray.shape[1])))
+                except AssertionError as e: why.append("tail: %s" % (str(e)[:80] or "assert"))
             if why: bad.append((c0 + b, why))
         print("frames %d..%d done, %d differ so far, %.0f s" % (c0, c0 + n - 1, len(bad), time.time() - t0), flush=True)
     ctx.close()
