@@ -1632,12 +1632,15 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
             HVO_HIP(hipMalloc((void **)&P->d_atags, AB * P->nwords * 32 * 4)); HVO_HIP(hipMalloc((void **)&P->d_actl, AB * sizeof(LaCtl)));
             HVO_HIP(hipMalloc((void **)&P->d_alists, AB * LA_MAXW * LA_CAP * 4)); HVO_HIP(hipMalloc((void **)&P->d_ablk, AB * LA_MAXW * 2 * LA_BCAP * 4));
             HVO_HIP(hipMalloc((void **)&P->d_afreg, AB * 2 * nsp * 4));
-            HVO_HIP(hipMalloc((void **)&P->d_ainreg, AB * LA_MAXW * P->nwords * 4)); HVO_HIP(hipMemsetAsync(P->d_ainreg, 0, AB * LA_MAXW * P->nwords * 4, st));   // a worker's bitmap of its region: all zero between growths
-            HVO_HIP(hipMemsetAsync(P->d_atags, 0xFF, AB * P->nwords * 32 * 4, st));      // every region releases its tags: all free between launches
+            HVO_HIP(hipMalloc((void **)&P->d_ainreg, AB * LA_MAXW * P->nwords * 4));   // a worker's bitmap of its region
             P->async_b = (int)AB;
         }
         if (n <= P->async_b) {
             HVO_HIP(hipMemsetAsync(P->d_actl, 0, (size_t)n * sizeof(LaCtl), st));
+            // tags and region bitmaps are all-free / all-zero after a launch that ran to its end; a launch that aborted (flag 4) may have
+            // left some behind, so every launch starts from a clean state (2.4 MB per 640x480 frame, microseconds)
+            HVO_HIP(hipMemsetAsync(P->d_atags, 0xFF, (size_t)n * P->nwords * 32 * 4, st));
+            HVO_HIP(hipMemsetAsync(P->d_ainreg, 0, (size_t)n * LA_MAXW * P->nwords * 4, st));
             LaArgs a; a.g = g; a.tags = P->d_atags; a.inreg = P->d_ainreg; a.ctl = (LaCtl *)P->d_actl; a.lists = P->d_alists; a.blocked = P->d_ablk; a.freg = P->d_afreg; a.W = aw; a.n = n; a.early = 1;
             { const char *e = getenv("HVO_LSD_ASYNC_EARLY"); if (e) a.early = atoi(e); }
             // (an LDS request keeps these one-wave workgroups off the CUs where a frame's AHC waves sit -- k_peac_cluster_heads takes 108 KB --:
