@@ -63,7 +63,7 @@ struct LsdPlan {
     long long *d_stats = nullptr;      // per frame 8 counters (diagnostics: hvo_debug_lsd_stats)
     // k_lsd_grow_async (lsd_async.inc), allocated at its first launch for the first `async_b` frames of the plan
     bool pre_fused = true;             // k_lsd_pre instead of k_lsd_blur + k_lsd_resize_grad (HVO_LSD_PRE_SPLIT=1: the pair, with its fp64 image)
-    int async_b = 0; unsigned *d_atags = nullptr; void *d_actl = nullptr; int *d_alists = nullptr, *d_ablk = nullptr, *d_afreg = nullptr; unsigned *d_ainreg = nullptr;
+    int async_b = 0; unsigned *d_atags = nullptr; void *d_actl = nullptr; int *d_alists = nullptr, *d_ablk = nullptr, *d_afreg = nullptr; unsigned char *d_ainreg = nullptr; int ainreg_b = 0;
 };
 static LsdPlan *plan_of(hvo_ctx *ctx) { return (LsdPlan *)ctx->lsd; }
 
@@ -1632,15 +1632,17 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
             HVO_HIP(hipMalloc((void **)&P->d_atags, AB * P->nwords * 32 * 4)); HVO_HIP(hipMalloc((void **)&P->d_actl, AB * sizeof(LaCtl)));
             HVO_HIP(hipMalloc((void **)&P->d_alists, AB * LA_MAXW * LA_CAP * 4)); HVO_HIP(hipMalloc((void **)&P->d_ablk, AB * LA_MAXW * 2 * LA_BCAP * 4));
             HVO_HIP(hipMalloc((void **)&P->d_afreg, AB * 2 * nsp * 4));
-            HVO_HIP(hipMalloc((void **)&P->d_ainreg, AB * LA_MAXW * P->nwords * 4));   // a worker's bitmap of its region
+            // a worker's map of its region, a byte per scaled pixel: for the 16 frames the growing is used for by default (a forced HVO_LSD_ASYNC on more falls back)
+            P->ainreg_b = (int)std::min(AB, (size_t)16);
+            HVO_HIP(hipMalloc((void **)&P->d_ainreg, (size_t)P->ainreg_b * LA_MAXW * P->nwords * 32));
             P->async_b = (int)AB;
         }
-        if (n <= P->async_b) {
+        if (n <= P->async_b && n <= P->ainreg_b) {
             HVO_HIP(hipMemsetAsync(P->d_actl, 0, (size_t)n * sizeof(LaCtl), st));
             // tags and region bitmaps are all-free / all-zero after a launch that ran to its end; a launch that aborted (flag 4) may have
-            // left some behind, so every launch starts from a clean state (2.4 MB per 640x480 frame, microseconds)
+            // left some behind, so every launch starts from a clean state (7 MB per 640x480 frame at 32 workers, microseconds)
             HVO_HIP(hipMemsetAsync(P->d_atags, 0xFF, (size_t)n * P->nwords * 32 * 4, st));
-            HVO_HIP(hipMemsetAsync(P->d_ainreg, 0, (size_t)n * LA_MAXW * P->nwords * 4, st));
+            HVO_HIP(hipMemsetAsync(P->d_ainreg, 0, (size_t)n * aw * P->nwords * 32, st));
             LaArgs a; a.g = g; a.tags = P->d_atags; a.inreg = P->d_ainreg; a.ctl = (LaCtl *)P->d_actl; a.lists = P->d_alists; a.blocked = P->d_ablk; a.freg = P->d_afreg; a.W = aw; a.n = n; a.early = 1;
             { const char *e = getenv("HVO_LSD_ASYNC_EARLY"); if (e) a.early = atoi(e); }
             // (an LDS request keeps these one-wave workgroups off the CUs where a frame's AHC waves sit -- k_peac_cluster_heads takes 108 KB --:
