@@ -33,7 +33,8 @@
 
 #define LSD_PI 3.1415926535897932384626433832795
 #define LSD_NOTDEF (-1024.0)
-#define LSD_MAXSEG 4096           // segments kept per frame before the top-N selection
+// (segments per frame before the top-N selection: as many as the scaled image can hold -- pixels / min_reg_size, LsdPlan::maxseg; a fixed
+// 4096 turned dense periodic patterns, 4800-6700 segments, into HVO_ERR_CAPACITY where the reference just keeps its 200 longest)
 #ifndef LSD_RING
 #define LSD_RING 256              // pending region points mirrored in LDS (older ones are read back from reg[])
 #endif
@@ -49,8 +50,9 @@ struct LsdPlan {
     long long *d_fbase = nullptr; int *d_fcount = nullptr; unsigned long long *d_pooltop = nullptr;   // per frame: base in the pool (-1: no room), defined pixels; records asked for so far
     unsigned *d_defined = nullptr;                          // bitmask, nwords per frame
     int *d_reg = nullptr;                                   // sw*sh ints
-    float *d_segs = nullptr;                                // LSD_MAXSEG x 4
-    hvo_keyline *d_kl_all = nullptr;                        // LSD_MAXSEG
+    float *d_segs = nullptr;                                // maxseg x 4
+    hvo_keyline *d_kl_all = nullptr;                        // maxseg
+    int maxseg = 0;
     hvo_keyline *d_kl = nullptr; uint8_t *d_desc = nullptr; double *d_fn = nullptr; int *d_nkl = nullptr; int *d_flags = nullptr;
     hvo_keyline *d_kl2 = nullptr; uint8_t *d_desc2 = nullptr; double *d_fn2 = nullptr; int *d_nkl2 = nullptr;   // after cullingLine
     uint8_t *d_b5 = nullptr; short2 *d_dxy = nullptr;       // Sobel (dx, dy) interleaved
@@ -412,7 +414,7 @@ struct GrowArgs {
     const double4 *px4; unsigned *avail; int *reg; float *segs; const int *perm;
     const unsigned *defmask, *wprefix; const long long *fbase;      // compact plans: px4 is the pool
     hvo_keyline *kl_all, *kl; double *fn; int *nkl; int *flags; long long *stats;
-    int sw, sh, nwords, w, h, nfeat, kl_cap;
+    int sw, sh, nwords, w, h, nfeat, kl_cap, maxseg;
     double rho, prec, p; unsigned min_reg;
 };
 
@@ -828,7 +830,7 @@ static __device__ __forceinline__ int lsd_emit_keylines(const GrowArgs &g, int f
     const int lane = threadIdx.x & 63;
     __syncthreads();
     // ---- KeyLines (LSDDetector_custom.cpp:161-196) ----
-    hvo_keyline *all = g.kl_all + (size_t)f * LSD_MAXSEG;
+    hvo_keyline *all = g.kl_all + (size_t)f * g.maxseg;
     const int w = g.w, h = g.h;
     for (int i = lane; i < nseg; i += 64) {
         float e0 = segs[4 * i], e1 = segs[4 * i + 1], e2 = segs[4 * i + 2], e3 = segs[4 * i + 3];
@@ -897,7 +899,7 @@ static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
         for (int i = lane; i < nwords; i += 64) lsd_lds_mask[i] = S.avail[i];
         __syncthreads();
     }
-    float *segs = g.segs + (size_t)f * LSD_MAXSEG * 4;
+    float *segs = g.segs + (size_t)f * g.maxseg * 4;
 #ifdef HVO_LSD_TIMING
     S.t_gather = S.t_add = S.n_rounds = 0;
 #endif
@@ -930,7 +932,7 @@ static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
             const bool okr = refine_wave<CP>(S, reg_size, reg_angle, g.prec, rec, 0.7, b0, b1, b2, n_addr);
             st_tf += wall_clock64() - t2;
             if (!okr) continue;
-            if (nseg < LSD_MAXSEG) {
+            if (nseg < g.maxseg) {
                 if (lane == 0) {
                     double x1 = rec.x1 + 0.5, y1 = rec.y1 + 0.5, x2 = rec.x2 + 0.5, y2 = rec.y2 + 0.5;
                     x1 /= 0.8; y1 /= 0.8; x2 /= 0.8; y2 /= 0.8;
@@ -1443,6 +1445,7 @@ static int lsd_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     P->prec = LSD_PI * ANG_TH / 180; P->p = ANG_TH / 180; P->rho = 2.0 / sin(P->prec);
     const double LOG_NT = 5 * (log10((double)P->sw) + log10((double)P->sh)) / 2 + log10(11.0);
     P->min_reg = (unsigned)(-LOG_NT / log10(P->p));
+    P->maxseg = (int)(((size_t)P->sw * P->sh) / std::max(P->min_reg, 1u)) + 64;     // every segment is a region of at least min_reg pixels of its own
     {   // getGaussianKernel(7, 0.75, CV_64F)
         const double sigma = 0.6 / SCALE; double k[7], sum = 0;
         for (int i = 0; i < 7; i++) { double x = i - 3.0; k[i] = exp(-0.5 / (sigma * sigma) * x * x); sum += k[i]; }
@@ -1509,7 +1512,7 @@ static int lsd_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     } else
         PA(P->d_px, B * nsp * sizeof(double4));
     PA(P->d_defined, B * P->nwords * 4); PA(P->d_reg, B * nsp * 4);
-    PA(P->d_segs, B * LSD_MAXSEG * 16); PA(P->d_kl_all, B * LSD_MAXSEG * sizeof(hvo_keyline));
+    PA(P->d_segs, B * P->maxseg * 16); PA(P->d_kl_all, B * P->maxseg * sizeof(hvo_keyline));
     PA(P->d_kl, B * P->nfeat * sizeof(hvo_keyline)); PA(P->d_desc, B * P->nfeat * 32); PA(P->d_fn, B * P->nfeat * 24);
     PA(P->d_nkl, B * 4); PA(P->d_flags, B * 4);
     PA(P->d_kl2, B * P->nfeat * sizeof(hvo_keyline)); PA(P->d_desc2, B * P->nfeat * 32); PA(P->d_fn2, B * P->nfeat * 24); PA(P->d_nkl2, B * 4);
@@ -1615,7 +1618,7 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     g.defmask = P->d_defmask; g.wprefix = P->d_wprefix; g.fbase = P->d_fbase;
     g.stats = P->d_stats; g.kl_all = P->d_kl_all; g.kl = P->d_kl; g.fn = P->d_fn; g.nkl = P->d_nkl; g.flags = P->d_flags;
     g.sw = sw; g.sh = sh; g.nwords = P->nwords; g.w = w; g.h = h; g.nfeat = P->nfeat; g.kl_cap = P->nfeat;
-    g.rho = P->rho; g.prec = P->prec; g.p = P->p; g.min_reg = P->min_reg;
+    g.rho = P->rho; g.prec = P->prec; g.p = P->p; g.min_reg = P->min_reg; g.maxseg = P->maxseg;
     bool dense = n > 5 * 1024;
     { const char *e = getenv("HVO_LSD_DENSE"); if (e) dense = atoi(e) != 0; }              // tests force either kernel on small batches
     // a handful of frames (the streamed mode, a tracker's small batches): the latency variant with the mask in LDS
@@ -1689,7 +1692,7 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
         if (cull) {                                     // Frame::cullingLine + the second LBD pass (Frame.cc:934, 952-1116)
             id = hvo_prof_begin(ctx, "lsd_cull", st);
             CullArgs c;
-            c.kl = P->d_kl + ko; c.fn = P->d_fn + ko * 3; c.nkl = P->d_nkl + c0; c.tmp = P->d_kl_all + (size_t)c0 * LSD_MAXSEG; c.tmp_stride = LSD_MAXSEG;
+            c.kl = P->d_kl + ko; c.fn = P->d_fn + ko * 3; c.nkl = P->d_nkl + c0; c.tmp = P->d_kl_all + (size_t)c0 * P->maxseg; c.tmp_stride = P->maxseg;
             c.kl_out = P->d_kl2 + ko; c.fn_out = P->d_fn2 + ko * 3; c.nkl_out = P->d_nkl2 + c0;
             c.cap = P->nfeat; c.w = w; c.h = h; c.dis = ctx->cull_dis; c.cos_th = cos(ctx->cull_angle * 0.0174533); c.endpoint_dis = ctx->cull_endpoint;
             hipLaunchKernelGGL(k_cull_lines, dim3(m), dim3(64), 0, st, c);

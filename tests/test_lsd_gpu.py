@@ -312,3 +312,22 @@ def test_lines_async_stolen_tags_stress(hvo, orc, synth, monkeypatch):
     finally:
         ctx.close()
 
+
+def test_lines_more_segments_than_a_fixed_cap(hvo, orc):
+    """A 5-pixel checkerboard has ~4800 line segments before the 200 longest are kept (LineExtractor.cpp:351-360); a fixed capacity of 4096
+    turned it into HVO_ERR_CAPACITY.  The capacity is what the scaled image can hold now (pixels / min_reg_size).  Lone frame (async growing) and a batch."""
+    y, x = np.mgrid[0:480, 0:640]
+    g = np.where(((x // 5) + (y // 5)) % 2 == 0, 30, 220).astype(np.uint8)
+    assert len(orc.lsd_detect(g)) > 4096
+    kl_o, d_o, fn_o = orc.line_extract(g)
+    ctx = hvo.Context(max_batch=3)
+    try:
+        kl, dsc, fn = ctx.extract_lsd(g)
+        check(kl, dsc, fn, kl_o, d_o, fn_o)
+        ctx.batch_upload(np.stack([g, g[::-1].copy(), g]), np.zeros((3, 480, 640), np.uint16)); ctx.batch_run(hvo.STAGE_LSD); res = ctx.batch_download(hvo.STAGE_LSD)
+        assert all(r["status"] == 0 for r in res)
+        check(res[0]["kl"], res[0]["ldesc"], res[0]["linefn"], kl_o, d_o, fn_o)
+        check(res[2]["kl"], res[2]["ldesc"], res[2]["linefn"], kl_o, d_o, fn_o)
+    finally:
+        ctx.close()
+
