@@ -26,6 +26,11 @@ def main():
     for i, g in enumerate(imgs):
         try: cmp("lone", i, ctx.extract_lsd(g))
         except Exception as e: bad.append(("lone", i, str(e)[:70]))
+        try:                                               # Frame::cullingLine on top (merging of near-collinear segments, second LBD): periodic edges merge a lot
+            ck_o, cd_o, cf_o = orc.cull_lines(g, *[ref[i][k] for k in (0, 2)])
+            ck_g, cd_g, cf_g = ctx.extract_lsd(g, culled=True)
+            check(ck_g, cd_g, cf_g, ck_o, cd_o, cf_o)
+        except Exception as e: bad.append(("culled", i, str(e)[:70] or "assert"))
     ctx.close()
     for B in (6, 16, 48):
         ctx = hvo.Context(max_batch=B)

@@ -17,9 +17,12 @@ def scene(rng, w=640, h=480):
     nplanes = int(rng.integers(1, 6))
     z = np.zeros((h, w))
     region = np.zeros((h, w), int)
-    mode = int(rng.integers(0, 3))
+    mode = int(rng.integers(0, 4))
+    if mode == 3: nplanes = int(rng.choice([12, 24, 35, 48]))                            # a grid of many small planes (up to 48 of them; the library holds 64)
     if mode == 0: region = (u * nplanes // w)                                     # vertical strips
     elif mode == 1: region = ((u // 40) + (v // 40)) % nplanes                        # block-aligned checker (blocks are 10x10: boundaries on block edges)
+    elif mode == 3:
+        nx = int(np.ceil(np.sqrt(nplanes * 4 / 3))); ny = int(np.ceil(nplanes / nx)); region = np.minimum((v * ny // h) * nx + (u * nx // w), nplanes - 1)
     else:                                                                            # oblique half-planes
         for k in range(1, nplanes):
             a = rng.uniform(0, np.pi); c = rng.uniform(0.2, 0.8)
