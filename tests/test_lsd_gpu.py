@@ -314,10 +314,10 @@ def test_lines_async_stolen_tags_stress(hvo, orc, synth, monkeypatch):
 
 
 def test_lines_more_segments_than_a_fixed_cap(hvo, orc):
-    """A 5-pixel checkerboard has ~4800 line segments before the 200 longest are kept (LineExtractor.cpp:351-360); a fixed capacity of 4096
+    """A diagonal checkerboard of period 13 has ~6600 line segments before the 200 longest are kept (LineExtractor.cpp:351-360); a fixed capacity of 4096
     turned it into HVO_ERR_CAPACITY.  The capacity is what the scaled image can hold now (pixels / min_reg_size).  Lone frame (async growing) and a batch."""
     y, x = np.mgrid[0:480, 0:640]
-    g = np.where(((x // 5) + (y // 5)) % 2 == 0, 30, 220).astype(np.uint8)
+    g = np.where(((x + y) // 13 + (x - y + 4096) // 13) % 2 == 0, 30, 220).astype(np.uint8)
     assert len(orc.lsd_detect(g)) > 4096
     kl_o, d_o, fn_o = orc.line_extract(g)
     ctx = hvo.Context(max_batch=3)
