@@ -248,3 +248,67 @@ def test_double_buffered_batches(hvo, orc, synth):
             assert np.array_equal(got[k][2]["labels"], lab_o)
     finally:
         ctx.close()
+
+
+def test_three_contexts_on_three_threads(hvo, orc, synth):
+    """The reference runs ORB, LSD and the planes of a frame on three threads (src/Frame.cc:210-215); include/hvo.h allows the same with one context
+    per thread.  Three contexts, three threads, 12 frames each way round: every result against the oracle (the lone-frame kernels -- async line
+    growing, multi-head AHC -- of different contexts share the device)."""
+    import threading
+    from test_lsd_gpu import check as check_lines
+    from test_peac_gpu import check as check_planes
+    from test_orb_gpu import check_orb
+    g, d = synth.make_batch("std", 0x5EED7000, 8); g2, d2 = synth.make_batch("lowtex", 0x5EED7100, 4)
+    g = np.concatenate([g, g2]); d = np.concatenate([d, d2]); n = len(g)
+    orb = orc.Orb()
+    ref = [(orb.extract(g[i]), orc.line_extract(g[i]), orc.peac(d[i])) for i in range(n)]
+    ctxs = [hvo.Context() for _ in range(3)]
+    out = [[None] * n for _ in range(3)]; err = []
+    def work(k):
+        try:
+            for rep in range(2):
+                for i in range(n):
+                    j = (i + 4 * k) % n                      # the threads are on different frames at any time
+                    out[k][j] = ctxs[k].extract_orb(g[j]) if k == 0 else ctxs[k].extract_lsd(g[j]) if k == 1 else ctxs[k].compute_planes(d[j])
+        except Exception as e:                               # (an assertion in a thread would be lost)
+            err.append((k, repr(e)))
+    try:
+        th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert not err, err
+        for i in range(n):
+            check_orb(out[0][i][0], out[0][i][1], *ref[i][0])
+            check_lines(out[1][i][0], out[1][i][1], out[1][i][2], *ref[i][1])
+            check_planes(out[2][i][0], out[2][i][1], *ref[i][2])
+    finally:
+        for c in ctxs: c.close()
+
+
+def test_two_contexts_both_growing_lines(hvo, orc, synth):
+    """two threads, two contexts, both in hvo_extract_lsd at once: two async growing kernels share the device (each frame's workers must still
+    sit on one XCD -- the kernel checks, a worker elsewhere counts itself out)"""
+    import threading
+    from test_lsd_gpu import check as check_lines
+    g, _ = synth.make_batch("lowtex", 0x5EED7200, 6); g2, _ = synth.make_batch("std", 0x5EED7300, 6)
+    g = np.concatenate([g, g2]); n = len(g)
+    ref = [orc.line_extract(x) for x in g]
+    ctxs = [hvo.Context() for _ in range(2)]
+    out = [[None] * n for _ in range(2)]; err = []
+    def work(k):
+        try:
+            for rep in range(3):
+                for i in range(n):
+                    j = (i + 5 * k) % n
+                    out[k][j] = ctxs[k].extract_lsd(g[j])
+        except Exception as e:
+            err.append((k, repr(e)))
+    try:
+        th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert not err, err
+        for k in range(2):
+            for i in range(n): check_lines(out[k][i][0], out[k][i][1], out[k][i][2], *ref[i])
+    finally:
+        for c in ctxs: c.close()
