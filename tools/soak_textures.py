@@ -60,15 +60,21 @@ def main():
         kp, desc = ctx.extract_orb(g); kl, ld, fn = ctx.extract_lsd(g); lab, pl = ctx.compute_planes(d)
         cmp("lone", i, kp, desc, kl, ld, fn, lab, pl)
     ctx.close()
+    from test_tail_gpu import check_tail
+    full = hvo.STAGE_ALL | hvo.STAGE_LINES3D | hvo.STAGE_VP | hvo.STAGE_PLANE_TAIL | hvo.STAGE_GRIDS
     for B in (16, 64):
         ctx = hvo.Context(max_batch=B)
+        ctx.set_tail_params(seed=500)
         for c0 in range(0, n, B):
             m = min(B, n - c0)
-            ctx.batch_upload(np.stack([fr[c0 + b][0] for b in range(m)]), np.stack([fr[c0 + b][1] for b in range(m)])); ctx.batch_run(hvo.STAGE_ALL); res = ctx.batch_download(hvo.STAGE_ALL)
+            ctx.batch_upload(np.stack([fr[c0 + b][0] for b in range(m)]), np.stack([fr[c0 + b][1] for b in range(m)])); ctx.batch_run(full); res = ctx.batch_download(hvo.STAGE_ALL); ctx.batch_download_tail(full, res)
             for b in range(m):
                 r = res[b]
                 if r["status"] != 0: bad.append(("batch%d" % B, c0 + b, "status %d" % r["status"], ""))
-                else: cmp("batch%d" % B, c0 + b, r["kp"], r["desc"], r["kl"], r["ldesc"], r["linefn"], r["labels"], r["planes"])
+                else:
+                    cmp("batch%d" % B, c0 + b, r["kp"], r["desc"], r["kl"], r["ldesc"], r["linefn"], r["labels"], r["planes"])
+                    try: check_tail(r, fr[c0 + b][1], orc, 500 + b, (0.0, 640.0, 0.0, 480.0))      # the rest of the Frame constructor
+                    except AssertionError as e: bad.append(("batch%d" % B, c0 + b, "tail", str(e)[:50]))
         ctx.close()
     print("RESULT textures soak frames=%d seed=%#x key points %.0f, lines %.0f, planes %.1f per frame (means) differing=%d %s" % (
         n, seed, np.mean([len(r[0][0]) for r in ref]), np.mean([len(r[1][0]) for r in ref]), np.mean([len(r[2][1]) for r in ref]), len(bad), bad[:8]))
