@@ -199,18 +199,25 @@ int hvo_batch_stage_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, i
         HVO_HIP(hipStreamCreateWithPriority(&ctx->s_stage_up, hipStreamNonBlocking, hi)); HVO_HIP(hipStreamCreateWithPriority(&ctx->s_stage_down, hipStreamNonBlocking, hi));
         HVO_HIP(hipEventCreateWithFlags(&ctx->ev_stage_up, hipEventDisableTiming));
     }
-    // the plans first (their geometry gives the staging slabs' sizes); nothing of the resident batch is touched
-    int rc = orb_ensure_plan(ctx, w, h, std::max(n, ctx->p.max_batch));
-    if (rc) return rc;
     bool depth = true;
     for (int f = 0; f < n; f++) if (!in[f].depth) depth = false;
+    // A resident batch must not be touched: building a plan for another geometry or a larger batch frees and zeroes the resident slabs
+    // (batch k would then run on blank images in the documented stage(k + 1) / run(k) loop).  Such a call is refused; a first batch, or a
+    // context whose resident batch was given up (hvo_batch_upload of the new geometry), builds the plans here.
+    const int pb = std::max(n, ctx->p.max_batch);
+    if (ctx->batch_n > 0 && (!orb_plan_covers(ctx, w, h, pb) || (depth && !peac_plan_covers(ctx, w, h, pb)))) return HVO_ERR_INVALID_ARG;
+    // the plans first (their geometry gives the staging slabs' sizes)
+    int rc = orb_ensure_plan(ctx, w, h, pb);
+    if (rc) return rc;
     const size_t gb = (size_t)ctx->orb.batch * ctx->orb.pyr_bytes;
-    if (ctx->stage_gray_bytes < gb) { if (ctx->d_stage_gray) (void)hipFree(ctx->d_stage_gray); ctx->d_stage_gray = nullptr; ctx->stage_gray_bytes = 0; HVO_HIP(hipMalloc((void **)&ctx->d_stage_gray, gb)); ctx->stage_gray_bytes = gb; }
+    if (ctx->stage_gray_bytes < gb) { if (ctx->d_stage_gray) (void)hipFree(ctx->d_stage_gray); ctx->d_stage_gray = nullptr; ctx->stage_gray_bytes = 0; HVO_HIP(hipMalloc((void **)&ctx->d_stage_gray, gb)); ctx->stage_gray_bytes = gb;
+        HVO_HIP(hipMemsetAsync(ctx->d_stage_gray, 0, gb, ctx->s_stage_up)); }      // pitch padding and the 256-byte round-up travel with a commit: zero, as in the resident slab
     PeacView pv; memset(&pv, 0, sizeof(pv));
     if (depth) {
         if ((rc = peac_prepare(ctx, w, h, std::max(n, ctx->p.max_batch), &pv))) return rc;
         const size_t db = (size_t)std::max(n, ctx->p.max_batch) * pv.dframe * sizeof(uint16_t);
-        if (ctx->stage_depth_bytes < db) { if (ctx->d_stage_depth) (void)hipFree(ctx->d_stage_depth); ctx->d_stage_depth = nullptr; ctx->stage_depth_bytes = 0; HVO_HIP(hipMalloc((void **)&ctx->d_stage_depth, db)); ctx->stage_depth_bytes = db; }
+        if (ctx->stage_depth_bytes < db) { if (ctx->d_stage_depth) (void)hipFree(ctx->d_stage_depth); ctx->d_stage_depth = nullptr; ctx->stage_depth_bytes = 0; HVO_HIP(hipMalloc((void **)&ctx->d_stage_depth, db)); ctx->stage_depth_bytes = db;
+            HVO_HIP(hipMemsetAsync(ctx->d_stage_depth, 0, db, ctx->s_stage_up)); }      // row h and the pitch padding of every frame
     }
     ctx->stage_gray_dst = ctx->d_stage_gray; ctx->stage_depth_dst = depth ? ctx->d_stage_depth : nullptr;
     rc = orb_upload(ctx, n, in, w, h, false);
@@ -227,12 +234,17 @@ int hvo_batch_commit_staged(hvo_ctx *ctx)
     if (!ctx || ctx->stage_n < 1) return HVO_ERR_INVALID_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
     const int n = ctx->stage_n, w = ctx->stage_w, h = ctx->stage_h;
+    // the plans the staging slabs were sized with must still be the current ones (another call may have rebuilt them for another geometry
+    // since): the copies below use the CURRENT plan's frame sizes
+    if (!orb_plan_covers(ctx, w, h, n) || (size_t)n * ctx->orb.pyr_bytes > ctx->stage_gray_bytes) return HVO_ERR_INVALID_ARG;
+    if (ctx->stage_depth && !peac_plan_covers(ctx, w, h, n)) return HVO_ERR_INVALID_ARG;
     HVO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_stage_up, 0));
     HVO_HIP(hipMemcpyAsync(ctx->orb.d_pyr, ctx->d_stage_gray, (size_t)n * ctx->orb.pyr_bytes, hipMemcpyDeviceToDevice, ctx->stream));
     if (ctx->stage_depth) {
         PeacView pv; memset(&pv, 0, sizeof(pv));
         int rc = peac_prepare(ctx, w, h, std::max(n, ctx->p.max_batch), &pv);
         if (rc) return rc;
+        if ((size_t)n * pv.dframe * sizeof(uint16_t) > ctx->stage_depth_bytes) return HVO_ERR_INVALID_ARG;
         HVO_HIP(hipMemcpyAsync(pv.d_depth, ctx->d_stage_depth, (size_t)n * pv.dframe * sizeof(uint16_t), hipMemcpyDeviceToDevice, ctx->stream));
     }
     HVO_HIP(hipStreamSynchronize(ctx->stream));
@@ -411,7 +423,7 @@ int hvo_batch_pack_results_ex(hvo_ctx *ctx, int n, void *d_slabs, unsigned flags
     HVO_HIP(field(pv.d_planes, (size_t)pc * sizeof(hvo_plane), (size_t)pc * sizeof(hvo_plane), pv.d_planes != nullptr));
     if (flags & HVO_SLAB_LABELS) {
         const size_t lb = (size_t)ctx->batch_w * ctx->batch_h, lbp = (lb + 15) & ~(size_t)15;
-        if (pv.d_labels8) HVO_HIP(hipMemcpy2DAsync(S + lab_off, sb, pv.d_labels8, (size_t)pv.npix, lb, (size_t)n, hipMemcpyDeviceToDevice, st));
+        if (pv.d_labels8) HVO_HIP(hipMemcpy2DAsync(S + lab_off, sb, pv.d_labels8, pv.lstride, lb, (size_t)n, hipMemcpyDeviceToDevice, st));
         else HVO_HIP(hipMemset2DAsync(S + lab_off, sb, 0xFF, lb, (size_t)n, st));          // no plane stage ran: every pixel "no plane"
         if (lbp > lb) HVO_HIP(hipMemset2DAsync(S + lab_off + lb, sb, 0, lbp - lb, (size_t)n, st));
     }

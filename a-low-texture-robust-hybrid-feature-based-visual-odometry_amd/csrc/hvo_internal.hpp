@@ -202,6 +202,7 @@ int hvo_staged_d2h(hvo_ctx *ctx, hipStream_t st, const void *dev_base, size_t de
 // orb.hip
 int orb_init_tables(hvo_ctx *ctx);
 int orb_ensure_plan(hvo_ctx *ctx, int w, int h, int batch);
+bool orb_plan_covers(const hvo_ctx *ctx, int w, int h, int batch);      // the current plan serves (w, h, batch) without being rebuilt
 void orb_free_plan(hvo_ctx *ctx);
 // Bit-reversed order of the frames 0..n-1 (device array; nullptr when n < 2 or on failure = identity).  The kernels that give a
 // frame one wave for its whole life (k_lsd_grow, k_peac_flood) take workgroup b's frame from it: the waves that share a SIMD are
@@ -315,7 +316,8 @@ int tail_batch_run(hvo_ctx *ctx, unsigned stages);
 void tail_batch_free(hvo_ctx *ctx);
 
 // peac.hip
-struct PeacView { uint16_t *d_depth; int pitch; size_t dframe; int8_t *d_labels8; hvo_plane *d_planes; int *d_meta; int npix, max_planes; };
+struct PeacView { uint16_t *d_depth; int pitch; size_t dframe; int8_t *d_labels8; hvo_plane *d_planes; int *d_meta; int npix, max_planes; size_t lstride /* bytes between two frames' label images */; };
+bool peac_plan_covers(const hvo_ctx *ctx, int w, int h, int batch);
 int peac_prepare(hvo_ctx *ctx, int w, int h, int batch, PeacView *v);      // plan for this geometry + where its inputs / results live
 int peac_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool sync = true);  // sync = false: the caller waits for ctx->s_peac
 int peac_run(hvo_ctx *ctx, int n);

@@ -854,6 +854,7 @@ static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch);
 // The cache key (w, h, batch) stays valid only if every table and slab behind it exists: a geometry that is rejected
 // half-way (a level below 38 pixels, a cell larger than the LDS tile, an allocation failure) frees the partial plan,
 // which resets the key, so that the next call with the same geometry is rejected again instead of running on null slabs.
+bool orb_plan_covers(const hvo_ctx *ctx, int w, int h, int batch) { const OrbPlan &P = ctx->orb; return P.w == w && P.h == h && P.batch >= batch; }
 int orb_ensure_plan(hvo_ctx *ctx, int w, int h, int batch)
 {
     OrbPlan &P = ctx->orb;

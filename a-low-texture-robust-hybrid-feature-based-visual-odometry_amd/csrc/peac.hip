@@ -1973,13 +1973,18 @@ static int peac_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     return HVO_OK;
 }
 
+bool peac_plan_covers(const hvo_ctx *ctx, int w, int h, int batch)
+{
+    const PeacPlan *P = static_cast<const PeacPlan *>(ctx->peac);
+    return P && P->w == w && P->h == h && P->batch >= batch;
+}
 int peac_prepare(hvo_ctx *ctx, int w, int h, int batch, PeacView *v)
 {
     int rc = peac_ensure_plan(ctx, w, h, batch);
     if (rc) return rc;
     PeacPlan *P = plan_of(ctx);
     v->d_depth = P->d_depth; v->pitch = P->pitch; v->dframe = (size_t)P->pitch * (h + 1); v->d_labels8 = P->d_labels; v->d_planes = P->d_planes;
-    v->d_meta = P->d_meta; v->npix = w * h; v->max_planes = MAX_PLANES;
+    v->d_meta = P->d_meta; v->npix = w * h; v->max_planes = MAX_PLANES; v->lstride = ((size_t)w * h + 3) & ~(size_t)3;
     return HVO_OK;
 }
 

@@ -498,7 +498,13 @@ int orc_peac_run(const uint16_t *depth, int w, int h, int stride_bytes,
     float *distMap = (float *)malloc(sizeof(float) * npix);
     for (int i = 0; i < npix; i++) distMap[i] = FLT_MAX;
     const double th_refine = cos(deg2rad(30.0));
+#ifdef ORC_PEAC_FLOOD_STATS                 /* tools/flood_gen_sim.c: generations of the FIFO (entries pushed by the generation before) */
+    int gen_end = nq, ngen = 0; ORC_PEAC_FLOOD_STATS(0, 0, nq);
+#endif
     for (int k = 0; k < nq; ++k) {
+#ifdef ORC_PEAC_FLOOD_STATS
+        if (k == gen_end) { ++ngen; ORC_PEAC_FLOOD_STATS(ngen, k, nq); gen_end = nq; }
+#endif
         const int sIdx = qpix[k], seedy = sIdx / w, seedx = sIdx - seedy * w, plid = qpl[k];
         const seg_t *pl = &f->seg[oldp[plid]];
         int nbs[4]; const int nn = valid4(seedy, seedx, h, w, nbs);

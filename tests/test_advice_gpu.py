@@ -59,3 +59,61 @@ def test_batch_download_reports_only_stages_that_ran(hvo, synth):
         assert all(len(r["kp"]) > 500 and len(r["kl"]) == 0 and len(r["planes"]) >= 3 for r in res)
     finally:
         ctx.close()
+
+
+def test_staged_upload_never_rebuilds_under_a_resident_batch(hvo, orc, synth):
+    """hvo_batch_stage_upload of another geometry, or of more frames than the plans hold, would rebuild the plans and blank the
+    resident slabs while batch k is still to run.  Such a call is refused (HVO_ERR_INVALID_ARG = -1), the resident batch still gives ITS
+    images' results, and a staged batch of FEWER frames of the same geometry is fine; hvo_batch_upload switches the geometry."""
+    g, d = synth.make_batch("std", 0x5EED5100, 3)
+    g2, d2 = synth.make_batch("std", 0x5EED5110, 2, w=512, h=384)
+    g4, d4 = synth.make_batch("std", 0x5EED5120, 4)
+    ctx = hvo.Context(max_batch=3)
+    try:
+        ctx.batch_stage_upload(g, d); ctx.batch_commit_staged()
+        for gg, dd in ((g2, d2), (g4, d4)):                      # another geometry; more frames than max_batch
+            with pytest.raises(hvo.HvoError) as e:
+                ctx.batch_stage_upload(gg, dd)
+            assert e.value.status == -1
+        ctx.batch_stage_upload(g[:2], d[:2])                       # fewer frames, same geometry: allowed, and batch 0 is untouched
+        ctx.batch_run(hvo.STAGE_ORB | hvo.STAGE_PLANES)
+        res = ctx.batch_download(hvo.STAGE_ALL)
+        o = orc.Orb()
+        for k in range(3):
+            assert np.array_equal(res[k]["desc"], o.extract(g[k])[1])
+            assert np.array_equal(res[k]["labels"], orc.peac(d[k])[0])
+        ctx.batch_commit_staged()
+        ctx.batch_run(hvo.STAGE_ORB)
+        res = ctx.batch_download(hvo.STAGE_ORB)
+        assert len(res) == 2 and np.array_equal(res[1]["desc"], o.extract(g[1])[1])
+        ctx.batch_upload(g2, d2)                                   # the way to another geometry; then staging that geometry works
+        ctx.batch_stage_upload(g2, d2); ctx.batch_commit_staged()
+        ctx.batch_run(hvo.STAGE_ORB | hvo.STAGE_PLANES)
+        res = ctx.batch_download(hvo.STAGE_ALL)
+        assert np.array_equal(res[1]["desc"], o.extract(g2[1])[1]) and np.array_equal(res[1]["labels"], orc.peac(d2[1])[0])
+    finally:
+        ctx.close()
+
+
+def test_label_slab_of_an_odd_geometry(hvo, orc, synth):
+    """the device label images of a batch are (w*h + 3) & ~3 bytes apart; 255 x 161 pixels is not a multiple of 4, so frames 1
+    and 2 of the packed slab must still be THEIR label images"""
+    import importlib
+    hd = importlib.import_module("hvo_amd.dist")
+    w, h = 255, 161
+    g, d = synth.make_batch("std", 0x5EED5200, 3, w=w, h=h)
+    ctx = hvo.Context(max_batch=3)
+    try:
+        ctx.batch_upload(g, d)
+        ctx.batch_run(hvo.STAGE_ORB | hvo.STAGE_PLANES)
+        ref = ctx.batch_download(hvo.STAGE_ALL)
+        kc, lc, pc, sb, lo = ctx.slab_layout(labels=True)
+        host = hvo.pin(np.zeros(3 * sb, np.uint8))
+        ctx.batch_results_async(3, host); ctx.batch_results_wait()
+        back = hd.unpack_results(hvo, host.reshape(3, sb), kc, lc, pc, label_shape=(h, w))
+        for k in range(3):
+            assert np.array_equal(back[k]["labels"], ref[k]["labels"]), k
+            assert np.array_equal(ref[k]["labels"], orc.peac(d[k])[0]), k
+        hvo.unpin(host)
+    finally:
+        ctx.close()
