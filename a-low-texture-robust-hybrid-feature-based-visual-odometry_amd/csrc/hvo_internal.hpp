@@ -186,6 +186,20 @@ static __device__ __forceinline__ void edge_fix(const EdgeSel &e, unsigned &W0, 
 // Workgroup dispatch costs ~6 ns on MI355X: an EMPTY kernel over 834k tiny workgroups takes 5 ms.
 // Streaming kernels therefore launch a bounded number of persistent workgroups that grid-stride over
 // flattened work items (cdna_hip_programming.md Guideline 11).
+// a / b for a divisor that is the same for a whole kernel (the camera's fx, fy), CORRECTLY ROUNDED -- the bits of the IEEE division the
+// oracle and the reference perform -- in five instructions instead of the ~30 issue slots of v_div_scale / v_rcp_f64 / v_div_fmas / v_div_fixup:
+// y = RN(1 / b) is computed once; q0 = RN(a y) is within two ulps; the residual a - q b is exact in an FMA; one correction makes q faithful,
+// and by Markstein's theorem a second one from an exact residual rounds it correctly whenever y is the correctly rounded reciprocal and b's
+// significand is not all ones (b is a float widened to double: 29 trailing zero bits).  No special cases are taken: a is finite, |a| is far
+// from the subnormal range, and a is never -0 ((j - cx) z with z > 0; pixels with z == 0 are rejected before).  Checked against `/` on
+// 9e8 operands of the path's own shape and random ones (tools/microbench/div_const_check.c; tests/test_oracle_known_answers.py runs it).
+static __device__ __forceinline__ double hvo_div_const(double a, double b, double y)
+{
+    const double q0 = a * y;
+    const double q1 = fma(fma(-q0, b, a), y, q0);
+    return fma(fma(-q1, b, a), y, q1);
+}
+
 static inline int hvo_grid(long long items, int wg_per_cu) {
     const long long cap = 256LL * wg_per_cu;
     return (int)(items < cap ? (items < 1 ? 1 : items) : cap);

@@ -41,7 +41,7 @@ struct PeacPlan {
     int *d_parent = nullptr, *d_dsize = nullptr, *d_eflag = nullptr;
     int *d_meta = nullptr;          // per frame 16 ints: [0]=nseg [1]=pooltop [2]=nextracted [3]=flags [4]=nfinal [5]=nq
     int *d_extracted = nullptr;     // per frame MAX_PLANES seg ids (coarse planes), then MAX_PLANES final
-    int *d_blkmap = nullptr; int8_t *d_labels = nullptr; uint2 *d_state = nullptr;     // labels: int8 on the device and on the wire (<= 64 planes), int32 at the ABI
+    int *d_blkmap = nullptr; int8_t *d_labels = nullptr; uint32_t *d_state = nullptr;     // labels: int8 on the device and on the wire (<= 64 planes), int32 at the ABI
     int *d_queue = nullptr; int *d_plidmap = nullptr; int *d_isvalid = nullptr;
     hvo_plane *d_planes = nullptr;
     unsigned long long *d_adj = nullptr;
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(64) void k_peac_blocks(const uint16_t *__restrict__
     int N = 0;
     bool valid = true;
     const double dfx = (double)fx, dfy = (double)fy, dcx = (double)cx, dcy = (double)cy, df = (double)dfac;
+    const double rfx = 1.0 / dfx, rfy = 1.0 / dfy;                // hvo_div_const: 200 divisions by fx, fy per thread
     // A block row is 10 depths + the right neighbour of the last one: six aligned dwords (20 * bj bytes into a 64-byte
     // aligned row; the pair beyond the image edge is never used).  The row below is requested before this row is
     // processed and only needed for its "down" jump test, so its latency hides behind the row's arithmetic; the
@@ -164,8 +165,8 @@ __global__ __launch_bounds__(64) void k_peac_blocks(const uint16_t *__restrict__
                 const int dn = (int)((cur[(jc + 1) >> 1] >> (16 * ((jc + 1) & 1))) & 0xFFFFu);
                 if (dn != 0) { const double zn = (double)dn * df; if (fabs(z - zn) > 0.04 * fabs(z) + 0.02) rowok = false; }
             }
-            const double x = ((double)j - dcx) * z / dfx;
-            const double y = yk * z / dfy;
+            const double x = hvo_div_const(((double)j - dcx) * z, dfx, rfx);
+            const double y = hvo_div_const(yk * z, dfy, rfy);
             st[0] += x; st[1] += y; st[2] += z;
             st[3] += x * x; st[4] += y * y; st[5] += z * z;
             st[6] += x * y; st[7] += y * z; st[8] += x * z;
@@ -1323,21 +1324,25 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
 // ------------------------------------------------------------------------------------------------
 // k_peac_blkmap: findBlockMembership (block erosion) + coarse membership image
 // ------------------------------------------------------------------------------------------------
-// Per-pixel flood state, 8 bytes, so that one scattered access per event fetches everything the
-// floodFill state machine needs:  x = (int8 membership "trail") | FS_VALID (pixel of a block that
-// survived the erosion: never touched) | depth << 16,  y = distMap entry (float bits).
+// Per-pixel flood state, 4 bytes (round 5; 8 before), so that one scattered access per event fetches everything the
+// floodFill state machine needs:  (int8 membership "trail") | FS_VALID (pixel of a block that
+// survived the erosion: never touched) | depth << 16.  The reference's distMap entry is NOT stored: it is FLT_MAX until a pixel is
+// claimed and from then on the point-plane distance of the pixel to the plane that owns it (trail >= 0) -- trail and distMap are only
+// ever written together (AHCPlaneFitter.hpp:466-469) -- so the few events that contest an owned pixel recompute it from the owner's
+// plane, with the operations that produced the stored value (k_peac_flood, `owner_dist`).  Half the bytes per state: half the lines a
+// front touches, half of what k_peac_blkmap writes and k_peac_relabel reads, 1.2 MB per 640x480 frame less.
 #define FS_VALID 0x100u
 #define FS_LABEL(x) ((int)(signed char)((x) & 0xFFu))
-// Flood-state layout: 4x4-pixel tiles, one 128-byte line each (a pixel's four neighbours mostly share its tile, and a front
-// that advances through a tile finds it in L2 for four rings instead of one row-major line per ring): FS_TW tiles per row.
-#define FS_TW(w) (((w) + 3) >> 2)
+// Flood-state layout: 8x4-pixel tiles, one 128-byte line each (a pixel's four neighbours mostly share its tile, and a front
+// that advances through a tile finds it in L2 for several rings instead of one row-major line per ring): FS_TW tiles per row.
+#define FS_TW(w) (((w) + 7) >> 3)
 #define FS_TH(h) (((h) + 3) >> 2)
-#define FS_IDX(x, y, tw) (((((y) >> 2) * (tw) + ((x) >> 2)) << 4) | (((y) & 3) << 2) | ((x) & 3))
-#define FS_FRAME(w, h) ((size_t)FS_TW(w) * FS_TH(h) * 16)
+#define FS_IDX(x, y, tw) (((((y) >> 2) * (tw) + ((x) >> 3)) << 5) | (((y) & 3) << 3) | ((x) & 7))
+#define FS_FRAME(w, h) ((size_t)FS_TW(w) * FS_TH(h) * 32)
 #define FS_MAKE(lab, valid, d) (((unsigned)(lab) & 0xFFu) | ((valid) ? FS_VALID : 0u) | ((unsigned)(d) << 16))
 __global__ __launch_bounds__(256) void k_peac_blkmap(const int *__restrict__ parent_, const int *__restrict__ dsize_,
                                                      const int *__restrict__ segI_, const int *__restrict__ ext_, const int *__restrict__ meta_,
-                                                     int *__restrict__ blkmap_, int *__restrict__ isvalid_, uint2 *__restrict__ state_,
+                                                     int *__restrict__ blkmap_, int *__restrict__ isvalid_, uint32_t *__restrict__ state_,
                                                      const uint16_t *__restrict__ depth_, size_t dframe, int pitch,
                                                      int nblk, int Nw, int Nh, int w, int h, int segcap)
 {
@@ -1349,7 +1354,7 @@ __global__ __launch_bounds__(256) void k_peac_blkmap(const int *__restrict__ par
     const int *ext = ext_ + (size_t)frame * 2 * MAX_PLANES;
     const int next = meta_[(size_t)frame * 16 + 2];
     int *blkmap = blkmap_ + (size_t)frame * nblk, *isvalid = isvalid_ + (size_t)frame * MAX_PLANES;
-    uint2 *state = state_ + (size_t)frame * FS_FRAME(w, h);
+    uint32_t *state = state_ + (size_t)frame * FS_FRAME(w, h);
     const uint16_t *D = depth_ + (size_t)frame * dframe;
     // phase 1: one thread per block
     for (int b = tid; b < nblk; b += 256) {
@@ -1373,14 +1378,14 @@ __global__ __launch_bounds__(256) void k_peac_blkmap(const int *__restrict__ par
     __syncthreads();
     // phase 2: the frame's pixels in state order (tile by tile: coalesced stores, depth read in 8-byte row pieces);
     // pixels outside the block grid get -1, tile padding outside the image is never read
-    const int tw = FS_TW(w), nst = tw * FS_TH(h) * 16;
+    const int tw = FS_TW(w), nst = tw * FS_TH(h) * 32;
     for (int i = slice * 256 + tid; i < nst; i += 256 * nslices) {
-        const int t = i >> 4, ty = t / tw, tx = t - ty * tw;
-        const int x = tx * 4 + (i & 3), y = ty * 4 + ((i >> 2) & 3);
+        const int t = i >> 5, ty = t / tw, tx = t - ty * tw;
+        const int x = tx * 8 + (i & 7), y = ty * 4 + ((i >> 3) & 3);
         if (x >= w || y >= h) continue;
         const int by = y / WIN, bx = x / WIN;
         const int lab = (by < Nh && bx < Nw) ? blkmap[by * Nw + bx] : -1;
-        state[i] = make_uint2(FS_MAKE(lab, lab >= 0, D[(size_t)y * pitch + x]), 0x7F7FFFFFu);   // FLT_MAX
+        state[i] = FS_MAKE(lab, lab >= 0, D[(size_t)y * pitch + x]);
     }
 }
 
@@ -1391,7 +1396,7 @@ struct RfArgs {
     ClArgs c;
     const uint16_t *depth; size_t dframe; int pitch, w, h;
     float fx, fy, cx, cy, dfac;
-    int *blkmap; int *isvalid; uint2 *state; int *queue; int qcap; int *plidmap; const int *perm;
+    int *blkmap; int *isvalid; uint32_t *state; int *queue; int qcap; int *plidmap; const int *perm;
     hvo_plane *planes; double c30;
 };
 
@@ -1456,7 +1461,7 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
     const int *ext = a.extracted + (size_t)frame * 2 * MAX_PLANES;
     const double *segD = a.segD + (size_t)frame * a.segcap * SEG_D;
     const int *blkmap = r.blkmap + (size_t)frame * nblk;
-    uint2 *state = r.state + (size_t)frame * FS_FRAME(w, h);
+    uint32_t *state = r.state + (size_t)frame * FS_FRAME(w, h);
     const int stw = FS_TW(w);
     int *queue = r.queue + (size_t)frame * r.qcap;
     int flags = 0;
@@ -1538,6 +1543,7 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
     int nq = s_nq;
     if (nq > r.qcap) { nq = r.qcap; flags |= 32; }
     const double dfx = (double)r.fx, dfy = (double)r.fy, dcx = (double)r.cx, dcy = (double)r.cy, df = (double)r.dfac;
+    const double rfx = 1.0 / dfx, rfy = 1.0 / dfy;                // hvo_div_const
 #ifdef HVO_PEAC_TIMING
     unsigned long long ft[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, ftl = clock64();
 #define FT(i) { const unsigned long long t_ = clock64(); ft[i] += t_ - ftl; ftl = t_; }
@@ -1546,14 +1552,20 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
 #endif
     FT(0)
     // point-plane distance of pixel (px, py) with raw depth d to coarse plane P (AHCPlaneFitter.hpp:463-467)
-    auto geom = [&](const double *P, int px, int py, int d, float &cdist, bool &ok) {
-        cdist = -1; ok = false;
+    // `own` >= 0: the plane that owns the pixel; odist = its distMap entry, recomputed (FLT_MAX for a pixel nobody has claimed).  An owned
+    // pixel has a depth (only an event that passed the distance test claims), so d != 0 whenever own >= 0.
+    auto geom = [&](const double *P, int px, int py, int d, int own, float &cdist, bool &ok, float &odist) {
+        cdist = -1; ok = false; odist = __uint_as_float(0x7F7FFFFFu);
         if (d != 0) {
             const double z = (double)d * df;
-            const double x = ((double)px - dcx) * z / dfx, y = ((double)py - dcy) * z / dfy;
+            const double x = hvo_div_const(((double)px - dcx) * z, dfx, rfx), y = hvo_div_const(((double)py - dcy) * z, dfy, rfy);
             const double sd = P[3] * (x - P[0]) + P[4] * (y - P[1]) + P[5] * (z - P[2]);
             cdist = (float)fabs(sd);
             ok = ((double)cdist * (double)cdist) < 9 * P[6] + 1e-5;
+            if (own >= 0) {
+                const double *O = pl[own];
+                odist = (float)fabs(O[3] * (x - O[0]) + O[4] * (y - O[1]) + O[5] * (z - O[2]));
+            }
         }
     };
     const unsigned long long ltm = (1ull << lane) - 1;
@@ -1585,14 +1597,14 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
         // ---- fetch the four neighbour states (getValid4Neighbor order: left, right, up, down), keep the live events ----
         int wtot = 0;
         {
-            uint2 st[EPL][4]; int below[EPL], etot[EPL], off[EPL];
+            uint32_t st[EPL][4]; int below[EPL], etot[EPL], off[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; e++) {
                 const int sx = q[e] & 8191, sy = (q[e] >> 13) & 8191;
                 const bool ex[4] = { own[e] && sx > 0, own[e] && sx < w - 1, own[e] && sy > 0, own[e] && sy < h - 1 };
                 const int px[4] = { sx - 1, sx + 1, sx, sx }, py[4] = { sy, sy, sy - 1, sy + 1 };
 #pragma unroll
-                for (int j = 0; j < 4; j++) { st[e][j] = make_uint2(FS_VALID, 0); if (ex[j]) st[e][j] = state[FS_IDX(px[j], py[j], stw)]; }   // the only scattered reads
+                for (int j = 0; j < 4; j++) { st[e][j] = FS_VALID; if (ex[j]) st[e][j] = state[FS_IDX(px[j], py[j], stw)]; }   // the only scattered reads
             }
             unsigned actm = 0;
 #pragma unroll
@@ -1601,8 +1613,8 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                 below[e] = 0; etot[e] = 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const int trail = FS_LABEL(st[e][j].x);
-                    const bool act = !(st[e][j].x & FS_VALID) && trail > -6 && trail != plid;     // pixels of still-valid blocks are never touched
+                    const int trail = FS_LABEL(st[e][j]);
+                    const bool act = !(st[e][j] & FS_VALID) && trail > -6 && trail != plid;     // pixels of still-valid blocks are never touched
                     if (act) actm |= 1u << (e * 4 + j);
                     const unsigned long long bm = __ballot(act);
                     below[e] += __popcll(bm & ltm); etot[e] += __popcll(bm);
@@ -1627,7 +1639,7 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                 const int px[4] = { sx - 1, sx + 1, sx, sx }, py[4] = { sy, sy, sy - 1, sy + 1 };
                 int c = off[e] + below[e];
 #pragma unroll
-                for (int j = 0; j < 4; j++) if (actm & (1u << (e * 4 + j))) { rec[c] = make_uint4((unsigned)FQ_PACK(px[j], py[j], plid), st[e][j].x, st[e][j].y, 0u); c++; }
+                for (int j = 0; j < 4; j++) if (actm & (1u << (e * 4 + j))) { rec[c] = make_uint4((unsigned)FQ_PACK(px[j], py[j], plid), st[e][j], 0u, 0u); c++; }
             }
         }
         lds_barrier();
@@ -1647,10 +1659,10 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                 ev[p] = c < na;
                 if (ev[p]) {
                     const uint4 R = rec[c];
-                    eq[p] = R.x; es[p] = R.y; ed[p] = __uint_as_float(R.z);
+                    eq[p] = R.x; es[p] = R.y;
                     const int ep = (int)(R.x >> 26), ex_ = (int)(R.x & 8191u), ey = (int)((R.x >> 13) & 8191u);
                     eix[p] = FS_IDX(ex_, ey, stw);
-                    geom(pl[ep], ex_, ey, (int)(R.y >> 16), ecd[p], eok[p]);
+                    geom(pl[ep], ex_, ey, (int)(R.y >> 16), FS_LABEL(R.y), ecd[p], eok[p], ed[p]);
                     int s = (int)(((unsigned)eix[p] * 2654435761u) >> 19) & (FLOOD_HS - 1);
                     for (;;) {
                         const int old = atomicCAS(&hkeys[s], -1, eix[p]);
@@ -1705,9 +1717,8 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                     const bool closer = eok[p] && ecd[p] < ed[p];
                     if (eok[p] && trail >= 0 && ((simok[ep] >> trail) & 1ull)) { atomicOr(&adj[trail], 1ull << ep); atomicOr(&adj[ep], 1ull << trail); }
                     const int nl = closer ? ep : (trail < 0 ? max(trail - cnt[p], -6) : trail);
-                    const float nd = closer ? ecd[p] : ed[p];
                     push[p] = closer;
-                    if (nl != trail || closer) state[eix[p]] = make_uint2((es[p] & ~0xFFu) | ((unsigned)nl & 0xFFu), __float_as_uint(nd));
+                    if (nl != trail) state[eix[p]] = (es[p] & ~0xFFu) | ((unsigned)nl & 0xFFu);          // (closer: nl = ep != trail)
                 }
             }
             if (cxr & 1) {
@@ -1742,7 +1753,7 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                             dist = closer ? cd : dist;
                             rec[c].z = closer ? 1u : 0u;
                         }
-                        state[eix[p]] = make_uint2((es[p] & ~0xFFu) | ((unsigned)trail & 0xFFu), __float_as_uint(dist));
+                        state[eix[p]] = (es[p] & ~0xFFu) | ((unsigned)trail & 0xFFu);
                     }
                 }
                 lds_barrier();
@@ -1785,17 +1796,17 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                         const int x = x0 + (j == 0 ? -1 : j == 1 ? 1 : 0), y = y0 + (j == 2 ? -1 : j == 3 ? 1 : 0);
                         if (x < 0 || x >= w || y < 0 || y >= h) continue;
                         const int ix = FS_IDX(x, y, stw);
-                        const uint2 s = state[ix];
-                        int trail = FS_LABEL(s.x); float dist = __uint_as_float(s.y);
-                        if ((s.x & FS_VALID) || trail <= -6 || trail == ep) continue;
+                        const uint32_t s = state[ix];
+                        int trail = FS_LABEL(s); float dist;
+                        if ((s & FS_VALID) || trail <= -6 || trail == ep) continue;
                         float cd; bool ok;
-                        geom(pl[ep], x, y, (int)(s.x >> 16), cd, ok);
+                        geom(pl[ep], x, y, (int)(s >> 16), trail, cd, ok, dist);
                         if (ok) {
                             if (trail >= 0 && ((simok[ep] >> trail) & 1ull)) { atomicOr(&adj[trail], 1ull << ep); atomicOr(&adj[ep], 1ull << trail); }
                             if (cd < dist) { trail = ep; dist = cd; if (nqs < r.qcap) queue[nqs] = FQ_PACK(x, y, ep); nqs++; }
                             else if (trail < 0) trail -= 1;
                         } else if (trail < 0) trail -= 1;
-                        state[ix] = make_uint2((s.x & ~0xFFu) | ((unsigned)trail & 0xFFu), __float_as_uint(dist));
+                        state[ix] = (s & ~0xFFu) | ((unsigned)trail & 0xFFu);
                     }
                 }
                 s_nq = nqs - nq;
@@ -1882,29 +1893,31 @@ __global__ __launch_bounds__(64) void k_peac_final(RfArgs r, const unsigned long
 }
 
 // labels are written as int8 (plane ids < MAX_PLANES = 64, -1 = none); a thread takes one row of a state tile (32 contiguous
-// bytes) and stores its four labels as one word when the width allows; the label slab of a frame is padded to a multiple of 4 bytes
-__global__ __launch_bounds__(256) void k_peac_relabel(const uint2 *__restrict__ state, int8_t *__restrict__ labels, const int *__restrict__ plidmap, int w, int h, size_t lframe)
+// bytes = eight pixels) and stores its labels as words when the width allows; the label slab of a frame is padded to a multiple of 4 bytes
+__global__ __launch_bounds__(256) void k_peac_relabel(const uint32_t *__restrict__ state, int8_t *__restrict__ labels, const int *__restrict__ plidmap, int w, int h, size_t lframe)
 {
     const int frame = blockIdx.y;
     const int tw = FS_TW(w), nrow = tw * FS_TH(h) * 4;
-    const uint2 *S = state + (size_t)frame * FS_FRAME(w, h);
+    const uint32_t *S = state + (size_t)frame * FS_FRAME(w, h);
     int8_t *L = labels + (size_t)frame * lframe;
     const int *pm = plidmap + (size_t)frame * MAX_PLANES;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nrow; i += gridDim.x * 256) {
         const int t = i >> 2, ty = t / tw, tx = t - ty * tw;
-        const int x0 = tx * 4, y = ty * 4 + (i & 3);
+        const int x0 = tx * 8, y = ty * 4 + (i & 3);
         if (y >= h) continue;
-        const uint4 a = reinterpret_cast<const uint4 *>(S + (size_t)i * 4)[0], b = reinterpret_cast<const uint4 *>(S + (size_t)i * 4)[1];
-        const unsigned sx[4] = { a.x, a.z, b.x, b.z };
-        int lab[4];
+        const uint4 a = reinterpret_cast<const uint4 *>(S + (size_t)i * 8)[0], b = reinterpret_cast<const uint4 *>(S + (size_t)i * 8)[1];
+        const unsigned sx[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+        int lab[8];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { const int v = FS_LABEL(sx[k]); lab[k] = (v >= 0 && pm[v] >= 0) ? pm[v] : -1; }
+        for (int k = 0; k < 8; k++) { const int v = FS_LABEL(sx[k]); lab[k] = (v >= 0 && pm[v] >= 0) ? pm[v] : -1; }
         int8_t *dst = L + (size_t)y * w + x0;
-        if ((w & 3) == 0) {
-            *reinterpret_cast<unsigned *>(dst) = ((unsigned)lab[0] & 0xFFu) | (((unsigned)lab[1] & 0xFFu) << 8) | (((unsigned)lab[2] & 0xFFu) << 16) | (((unsigned)lab[3] & 0xFFu) << 24);
+        if ((w & 3) == 0) {                                         // (x0 and y * w are multiples of 4: whole words, each inside the row or outside it)
+#pragma unroll
+            for (int q = 0; q < 2; q++) if (x0 + 4 * q < w)
+                reinterpret_cast<unsigned *>(dst)[q] = ((unsigned)lab[4 * q] & 0xFFu) | (((unsigned)lab[4 * q + 1] & 0xFFu) << 8) | (((unsigned)lab[4 * q + 2] & 0xFFu) << 16) | (((unsigned)lab[4 * q + 3] & 0xFFu) << 24);
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (x0 + k < w) dst[k] = (int8_t)lab[k];
+            for (int k = 0; k < 8; k++) if (x0 + k < w) dst[k] = (int8_t)lab[k];
         }
     }
 }
@@ -1958,7 +1971,7 @@ static int peac_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_pool2, B * P->poolcap * sizeof(int));
     PA(P->d_parent, B * P->nblk * sizeof(int)); PA(P->d_dsize, B * P->nblk * sizeof(int)); PA(P->d_eflag, B * P->nblk * sizeof(int));
     PA(P->d_meta, B * 16 * sizeof(int)); PA(P->d_extracted, B * 2 * MAX_PLANES * sizeof(int));
-    PA(P->d_blkmap, B * P->nblk * sizeof(int)); PA(P->d_labels, B * ((npix + 3) & ~(size_t)3)); PA(P->d_state, B * FS_FRAME(w, h) * sizeof(uint2));
+    PA(P->d_blkmap, B * P->nblk * sizeof(int)); PA(P->d_labels, B * ((npix + 3) & ~(size_t)3)); PA(P->d_state, B * FS_FRAME(w, h) * sizeof(uint32_t));
     PA(P->d_queue, B * P->qcap * sizeof(int));
     PA(P->d_plidmap, B * MAX_PLANES * sizeof(int)); PA(P->d_isvalid, B * MAX_PLANES * sizeof(int));
     PA(P->d_planes, B * MAX_PLANES * sizeof(hvo_plane));

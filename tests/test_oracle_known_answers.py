@@ -2,6 +2,7 @@
 (SURVEY.md section 8c).  The reference ships no tests/fixtures for this path, so these are the
 only external pins -- the oracle header says "parity unpinned"."""
 import numpy as np
+import pytest
 
 
 def test_umax_table(orc):
@@ -227,3 +228,16 @@ def test_lbd_float_descriptor_is_unit_and_clipped(orc, synth):
     ok = ~np.isnan(f).any(axis=1)
     assert ok.mean() > 0.9
     assert np.allclose(np.linalg.norm(f[ok], axis=1), 1.0, atol=1e-5)
+
+
+def test_division_by_a_kernel_constant_is_the_ieee_division(tmp_path):
+    """csrc/hvo_internal.hpp hvo_div_const (five instructions for x = (j - cx) z / fx in k_peac_blocks and the flood) must give the bits of `/`:
+    tools/microbench/div_const_check.c runs the same sequence with the host's fma on 15 divisors x 2e6 operands (9e8 in the committed run)"""
+    import os, shutil, subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "div_const_check")
+    subprocess.check_call(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-o", exe, os.path.join(root, "tools", "microbench", "div_const_check.c"), "-lm"])
+    p = subprocess.run([exe, "2000000"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "two corrections 0" in p.stdout, p.stdout
