@@ -63,7 +63,7 @@ assert PLANE_CLOUD_DT.itemsize == 40 and SURFACE_NORMAL_DT.itemsize == 32
 EXPORTS = [
     "hvo_abi_version", "hvo_default_params", "hvo_create", "hvo_destroy", "hvo_strerror", "hvo_last_error",
     "hvo_extract_orb", "hvo_extract_lsd", "hvo_compute_planes",
-    "hvo_hamming_matrix", "hvo_hamming_knn2", "hvo_match_nnr", "hvo_search_by_projection", "hvo_stereo_from_rgbd",
+    "hvo_hamming_matrix", "hvo_hamming_knn2", "hvo_match_nnr", "hvo_match_lines_geom", "hvo_search_lines_by_projection", "hvo_stream_match_lines_geom", "hvo_stream_search_lines_by_projection", "hvo_search_by_projection", "hvo_stereo_from_rgbd",
     "hvo_undistort_keypoints", "hvo_image_bounds", "hvo_assign_features_to_grid", "hvo_assign_lines_to_grid",
     "hvo_extract_lsd_culled", "hvo_set_line_culling", "hvo_lines_3d", "hvo_vanishing_points", "hvo_plane_clouds", "hvo_surface_normals", "hvo_search_by_projection_map", "hvo_frame_bf_match", "hvo_search_double",
     "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch", "hvo_batch_slab_layout", "hvo_batch_pack_results", "hvo_batch_slab_layout_ex", "hvo_batch_pack_results_ex", "hvo_batch_stage_upload", "hvo_batch_commit_staged", "hvo_batch_results_async", "hvo_batch_results_wait",
@@ -192,6 +192,10 @@ def lib():
         L.hvo_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_void_p] * 4 + [C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.hvo_frame_bf_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_int)]
         L.hvo_search_double.argtypes = L.hvo_frame_bf_match.argtypes
+        L.hvo_match_lines_geom.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.hvo_search_lines_by_projection.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.hvo_stream_match_lines_geom.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.hvo_stream_search_lines_by_projection.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.hvo_search_by_projection_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_void_p] * 4 + [C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.hvo_stereo_from_rgbd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         L.hvo_extract_lsd_culled.argtypes = L.hvo_extract_lsd.argtypes
@@ -423,6 +427,31 @@ class Context:
         fn = lib().hvo_search_double if mutual else lib().hvo_frame_bf_match
         self._chk(fn(self.h, _p(d1), len(d1), _p(d2), len(d2), TH, nnratio, _p(m), C.byref(n)), "frame_bf_match")
         return n.value, m[: len(d1)]
+
+    def match_lines_geom(self, d_last, kl_last, d_cur, kl_cur, bounds4, desc_th=0.9, last_has_mapline=None):
+        """LSDmatcher::SearchByGeomNApearance (src/LSDmatcher.cpp:36-108) -> (lmatches, matches12, accepted)"""
+        d_last = np.ascontiguousarray(d_last, np.uint8); d_cur = np.ascontiguousarray(d_cur, np.uint8)
+        kl_last = np.ascontiguousarray(kl_last); kl_cur = np.ascontiguousarray(kl_cur); b = np.ascontiguousarray(bounds4, np.float32)
+        n1, n2 = len(kl_last), len(kl_cur)
+        hm = None if last_has_mapline is None else np.ascontiguousarray(last_has_mapline, np.uint8)
+        m = np.zeros(max(n1, 1), np.int32); acc = np.zeros(max(n1, 1), np.uint8); n = C.c_int(0)
+        self._chk(lib().hvo_match_lines_geom(self.h, _p(d_last), _p(kl_last), None if hm is None else _p(hm), n1, _p(d_cur), _p(kl_cur), n2, desc_th, _p(b),
+                                             _p(m), _p(acc), C.byref(n)), "match_lines_geom")
+        return n.value, m[:n1], acc[:n1]
+
+    def search_lines_by_projection(self, q_xyxy, q_kl, q_desc, q_blocks, t_kl, t_linefn, t_desc, t_occupied, cell_start, cell_items, bounds4, th):
+        """LSDmatcher::SearchByProjection(Cur, Last, th) core (src/LSDmatcher.cpp:561-662) -> (nmatches, match_idx, match_dist)"""
+        q_xyxy = np.ascontiguousarray(q_xyxy, np.float32).reshape(-1, 4); nq = len(q_xyxy)
+        q_kl = np.ascontiguousarray(q_kl); t_kl = np.ascontiguousarray(t_kl); nt = len(t_kl)
+        q_desc = np.ascontiguousarray(q_desc, np.uint8); t_desc = np.ascontiguousarray(t_desc, np.uint8)
+        q_blocks = np.ascontiguousarray(q_blocks, np.uint8); t_occupied = np.ascontiguousarray(t_occupied, np.uint8)
+        t_linefn = np.ascontiguousarray(t_linefn, np.float64); b = np.ascontiguousarray(bounds4, np.float32)
+        cs = np.ascontiguousarray(cell_start, np.int32); ci = np.ascontiguousarray(cell_items, np.int32)
+        if len(ci) == 0: ci = np.zeros(1, np.int32)
+        mi = np.zeros(max(nq, 1), np.int32); md = np.zeros(max(nq, 1), np.int32); n = C.c_int(0)
+        self._chk(lib().hvo_search_lines_by_projection(self.h, nq, _p(q_xyxy), _p(q_kl), _p(q_desc), _p(q_blocks), _p(t_kl), _p(t_linefn), _p(t_desc), _p(t_occupied), nt,
+                                                       _p(cs), _p(ci), _p(b), th, _p(mi), _p(md), C.byref(n)), "search_lines_by_projection")
+        return n.value, mi[:nq], md[:nq]
 
     def search_by_projection_map(self, q_desc, q_u, q_v, q_radius, q_min_level, q_max_level, q_ur, q_blocks,
                                  t_kp, t_uright, t_occupied, t_desc, bounds, th_high=100, nn_ratio=0.8):
@@ -819,6 +848,25 @@ class Stream:
         self._chk(lib().hvo_stream_search_by_projection(self.h, cur, last, nq, _p(q_index), pp(q_desc), _p(q_u), _p(q_v), _p(q_radius), _p(q_min_level),
                                                         _p(q_max_level), pp(q_ur), _p(q_blocks), pp(t_occupied), th_high, 1 if check_orientation else 0,
                                                         _p(mi), _p(md), C.byref(n)), "stream_search_by_projection")
+        return n.value, mi[:nq], md[:nq]
+
+    def match_lines_geom(self, cur, last, desc_th=0.9, last_has_mapline=None):
+        """LSDmatcher::SearchByGeomNApearance(Cur, Last) between two resident frames -> (lmatches, matches12, accepted)"""
+        m = np.full(self.kl_cap, -1, np.int32); acc = np.zeros(self.kl_cap, np.uint8); n1 = C.c_int(0); n = C.c_int(0)
+        hm = None if last_has_mapline is None else np.ascontiguousarray(last_has_mapline, np.uint8)
+        self._chk(lib().hvo_stream_match_lines_geom(self.h, cur, last, desc_th, None if hm is None else _p(hm), _p(m), _p(acc), C.byref(n1), C.byref(n)), "stream_match_lines_geom")
+        return n.value, m[: n1.value], acc[: n1.value]
+
+    def search_lines_by_projection(self, cur, last, q_index, q_xyxy, th, q_blocks=None, t_occupied=None, q_desc=None):
+        """LSDmatcher::SearchByProjection(Cur, Last, th) core between two resident frames -> (nmatches, match_idx, match_dist)"""
+        q_index = np.ascontiguousarray(q_index, np.int32); nq = len(q_index)
+        q_xyxy = np.ascontiguousarray(q_xyxy, np.float32).reshape(-1, 4)
+        pp = lambda a, t: _p(np.ascontiguousarray(a, t)) if a is not None else None
+        keep = [np.ascontiguousarray(a, t) if a is not None else None for a, t in ((q_desc, np.uint8), (q_blocks, np.uint8), (t_occupied, np.uint8))]
+        mi = np.zeros(max(nq, 1), np.int32); md = np.zeros(max(nq, 1), np.int32); n = C.c_int(0)
+        self._chk(lib().hvo_stream_search_lines_by_projection(self.h, cur, last, nq, _p(q_index), _p(q_xyxy), None if keep[0] is None else _p(keep[0]),
+                                                              None if keep[1] is None else _p(keep[1]), None if keep[2] is None else _p(keep[2]), th,
+                                                              _p(mi), _p(md), C.byref(n)), "stream_search_lines_by_projection")
         return n.value, mi[:nq], md[:nq]
 
     def match_lines(self, frm, to, mode=LINE_MATCH_NNR, th=50.0, nnratio=0.95):

@@ -553,6 +553,39 @@ int hvo_frame_bf_match(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d
     return match_lines(ctx, d1, n1, d2, n2, th, nnratio, HVO_LINE_MATCH_BF, m12, n_matches);
 }
 
+// LSDmatcher::SearchByGeomNApearance (LSDmatcher.cpp:36-108): matchNNR, then the angle and end-point gates (line_track.inc)
+int hvo_match_lines_geom(hvo_ctx *ctx, const uint8_t *d_last, const hvo_keyline *kl_last, const uint8_t *last_has_mapline, int n_last,
+                         const uint8_t *d_cur, const hvo_keyline *kl_cur, int n_cur, float desc_th, const float bounds4[4],
+                         int32_t *matches12, uint8_t *accepted, int *n_accepted)
+{
+    if (!ctx || !matches12 || !accepted || !n_accepted || !bounds4 || n_last < 0 || n_cur < 0) return HVO_ERR_INVALID_ARG;
+    *n_accepted = 0;
+    for (int i = 0; i < n_last; i++) { matches12[i] = -1; accepted[i] = 0; }
+    if (n_last == 0 || n_cur < 2) return HVO_OK;                  // knnMatch(k = 2) needs two train rows (as hvo_match_nnr)
+    if (!d_last || !kl_last || !d_cur || !kl_cur) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    return match_lines_geom(ctx, d_last, kl_last, last_has_mapline, n_last, d_cur, kl_cur, n_cur, desc_th, bounds4, matches12, accepted, n_accepted);
+}
+
+// LSDmatcher::SearchByProjection(Cur, Last, th) core (LSDmatcher.cpp:561-662) over Frame::GetFeaturesInAreaForLine (Frame.cc:1557-1627)
+int hvo_search_lines_by_projection(hvo_ctx *ctx, int nq, const float *q_xyxy, const hvo_keyline *q_kl, const uint8_t *q_desc, const uint8_t *q_blocks,
+                                   const hvo_keyline *t_kl, const double *t_linefn, const uint8_t *t_desc, const uint8_t *t_occupied, int nt,
+                                   const int32_t *cell_start, const int32_t *cell_items, const float bounds4[4], float th,
+                                   int32_t *match_idx, int32_t *match_dist, int *n_matches)
+{
+    if (!ctx || !match_idx || !match_dist || !n_matches || !bounds4 || nq < 0 || nt < 0) return HVO_ERR_INVALID_ARG;
+    *n_matches = 0;
+    for (int i = 0; i < nq; i++) { match_idx[i] = -1; match_dist[i] = 256; }
+    if (nq == 0 || nt == 0) return HVO_OK;
+    if (!q_xyxy || !q_kl || !q_desc || !t_kl || !t_linefn || !t_desc || !cell_start) return HVO_ERR_INVALID_ARG;
+    if (!(bounds4[1] > bounds4[0]) || !(bounds4[3] > bounds4[2])) return HVO_ERR_INVALID_ARG;
+    const int n_items = cell_start[HVO_GRID_COLS * HVO_GRID_ROWS];
+    if (n_items < 0 || (n_items > 0 && !cell_items)) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    return match_search_lines_by_projection(ctx, nq, q_xyxy, q_kl, q_desc, q_blocks, t_kl, t_linefn, t_desc, t_occupied, nt, cell_start, cell_items, n_items, bounds4, th,
+                                            match_idx, match_dist, n_matches);
+}
+
 // LSDmatcher::SearchDouble / SearchByDescriptor core (LSDmatcher.cpp:902-939): FrameBFMatch in both directions + mutual check
 int hvo_search_double(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float th, float nnratio,
                       int32_t *m12, int *n_matches)

@@ -274,6 +274,30 @@ size_t match_lines_scratch_bytes(int n1, int n2);
 int match_lines_enqueue(hipStream_t st, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float TH, float nnratio, int mode,
                         void *scratch, int32_t *d_m12, int *d_nmatch);
 int match_lines(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float th, float nnratio, int mode, int32_t *m12, int *n_matches);
+// line_track.inc (part of match.hip): the line tracker's own calls -- LSDmatcher::SearchByGeomNApearance and SearchByProjection(Cur, Last, th)
+// device-resident arguments of the guided line search; visit positions are 24 bits (three windows over < 2^22 grid items)
+struct LsbpDev {
+    int nq, nt;
+    const float *q_xyxy; const hvo_keyline *q_kl; const int32_t *q_index;      // q_index != null: query q is line q_index[q] of q_kl / q_desc_all
+    const uint8_t *q_desc; const uint8_t *q_desc_all; const uint8_t *q_blocks;
+    const hvo_keyline *t_kl; const double *t_fn; const uint8_t *t_desc; const uint8_t *t_occ;
+    const int32_t *cell_start, *cell_items; int n_items;
+    float mnMinX, mnMaxX, mnMinY, mnMaxY, th; double cos_th;
+    unsigned long long *keys; int32_t *match_idx, *match_dist; int *n_matches;
+};
+
+size_t match_lsbp_scratch_bytes(int nq, int nt);
+int match_lsbp_enqueue(hipStream_t st, LsbpDev a, void *scratch);
+int match_lines_geom_enqueue(hipStream_t st, const uint8_t *d_last, const hvo_keyline *kl_last, const uint8_t *has_ml, int n_last,
+                             const uint8_t *d_cur, const hvo_keyline *kl_cur, int n_cur, float desc_th, const float *bounds4,
+                             void *scratch, int32_t *d_m12, uint8_t *d_acc);
+int match_lines_geom(hvo_ctx *ctx, const uint8_t *d_last, const hvo_keyline *kl_last, const uint8_t *has_ml, int n_last,
+                     const uint8_t *d_cur, const hvo_keyline *kl_cur, int n_cur, float desc_th, const float *bounds4,
+                     int32_t *m12, uint8_t *accepted, int *n_accepted);
+int match_search_lines_by_projection(hvo_ctx *ctx, int nq, const float *q_xyxy, const hvo_keyline *q_kl, const uint8_t *q_desc, const uint8_t *q_blocks,
+                                     const hvo_keyline *t_kl, const double *t_linefn, const uint8_t *t_desc, const uint8_t *t_occupied, int nt,
+                                     const int32_t *cell_start, const int32_t *cell_items, int n_items, const float *bounds4, float th,
+                                     int32_t *match_idx, int32_t *match_dist, int *n_matches);
 int match_stereo_enqueue(hipStream_t st, const hvo_keypoint *d_kp, const hvo_keypoint *d_kpun, const int *d_n, int n_max, const uint16_t *d_depth, int pitch,
                          int w, int h, float dfac, float bf, float *d_uright, float *d_zdepth);
 int match_stereo_from_rgbd(hvo_ctx *ctx, const hvo_keypoint *kp, const hvo_keypoint *kpun, int n, const uint16_t *depth, int w, int h, int stride,

@@ -747,3 +747,5 @@ extern "C" int hvo_debug_match_rate(hvo_ctx *ctx, const uint8_t *q, int nq, cons
     *ms = tot / iters;
     return HVO_OK;
 }
+
+#include "line_track.inc"

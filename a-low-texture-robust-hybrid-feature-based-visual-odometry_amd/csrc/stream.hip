@@ -165,7 +165,8 @@ int hvo_stream_create(const hvo_params *p, const hvo_stream_params *sp, hvo_stre
     if (!rc) {
         const int nq = s->kp_cap;
         s->ms_bytes = al64((size_t)nq * 32) + 13 * al64((size_t)nq * 4) + 2 * al64((size_t)nq) + al64((size_t)s->kp_cap) + 3 * al64((size_t)nq * 4 + 64) +
-                      match_sbp_scratch_bytes(nq) + match_lines_scratch_bytes(s->nfeat, s->nfeat) + al64((size_t)s->nfeat * 4 + 64) + 4096;
+                      match_sbp_scratch_bytes(nq) + match_lines_scratch_bytes(s->nfeat, s->nfeat) + al64((size_t)s->nfeat * 4 + 64) + 4096 +
+                      match_lsbp_scratch_bytes(s->nfeat, s->nfeat) + 8 * al64((size_t)s->nfeat * 32);      // (the guided line search: a key per (query, line))
         if (hipMalloc((void **)&s->d_ms, s->ms_bytes) != hipSuccess || hipHostMalloc((void **)&s->h_ms, s->ms_bytes, hipHostMallocDefault) != hipSuccess ||
             hipStreamCreateWithPriority(&s->s_match, hipStreamNonBlocking, -1) != hipSuccess) rc = HVO_ERR_HIP;
     }
@@ -596,6 +597,97 @@ int hvo_stream_match_lines(hvo_stream *s, int64_t from, int64_t to, int mode, fl
     ST_HIP(hipStreamSynchronize(st));
     memcpy(matches12, hm, (size_t)n1 * 4);
     *n_matches = hm[n1];
+    return HVO_OK;
+}
+
+// LSDmatcher::SearchByGeomNApearance(Cur, Last) between two resident frames (src/Tracking.cc:2299 -> src/LSDmatcher.cpp:36-108): the descriptor
+// match AND the angle / end-point gates on the resident key lines; only the per-line "has a map line" flags go up
+int hvo_stream_match_lines_geom(hvo_stream *s, int64_t cur, int64_t last, float desc_th, const uint8_t *last_has_mapline,
+                                int32_t *matches12, uint8_t *accepted, int *n_last, int *n_accepted)
+{
+    if (!s || !matches12 || !accepted || !n_accepted) return HVO_ERR_INVALID_ARG;
+    *n_accepted = 0;
+    if (!(s->sp.stages & (HVO_STAGE_LSD | HVO_STAGE_LSD_CULL))) return HVO_ERR_INVALID_ARG;
+    StreamSlot *A = slot_of(s, last), *B = slot_of(s, cur);
+    if (!A || !B || A == B) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(s->p.device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    ST_HIP(hipEventSynchronize(A->ev_lsd));
+    ST_HIP(hipEventSynchronize(B->ev_lsd));
+    const int n1 = ((const int *)(A->h_out + s->lay.counts))[4], n2 = ((const int *)(B->h_out + s->lay.counts))[4];
+    if (n_last) *n_last = n1;
+    for (int i = 0; i < n1; i++) { matches12[i] = -1; accepted[i] = 0; }
+    if (n1 <= 0 || n2 < 2) return HVO_OK;
+    hipStream_t st = s->s_match;
+    char *d = s->d_ms, *hh = s->h_ms; size_t off = 0;
+    int32_t *dm = (int32_t *)(d + off); int32_t *hm = (int32_t *)(hh + off); off += al64(((size_t)n1 + 1) * 4);
+    uint8_t *da = (uint8_t *)(d + off); uint8_t *ha = (uint8_t *)(hh + off); off += al64((size_t)n1);
+    uint8_t *dml = (uint8_t *)(d + off); uint8_t *hml = (uint8_t *)(hh + off); off += al64((size_t)n1);
+    void *scratch = d + off; off += match_lines_scratch_bytes(n1, n2);
+    if (off > s->ms_bytes) { s->last_error = "matching scratch too small"; return HVO_ERR_CAPACITY; }
+    if (last_has_mapline) { memcpy(hml, last_has_mapline, (size_t)n1); ST_HIP(hipMemcpyAsync(dml, hml, (size_t)n1, hipMemcpyHostToDevice, st)); }
+    int rc = match_lines_geom_enqueue(st, A->lv.d_desc, A->lv.d_kl, last_has_mapline ? dml : nullptr, n1, B->lv.d_desc, B->lv.d_kl, n2, desc_th, s->bounds4(), scratch, dm, da);
+    if (rc) return rc;
+    ST_HIP(hipMemcpyAsync(hm, dm, ((size_t)n1 + 1) * 4, hipMemcpyDeviceToHost, st));
+    ST_HIP(hipMemcpyAsync(ha, da, (size_t)n1, hipMemcpyDeviceToHost, st));
+    ST_HIP(hipStreamSynchronize(st));
+    memcpy(matches12, hm, (size_t)n1 * 4); memcpy(accepted, ha, (size_t)n1);
+    *n_accepted = hm[n1];
+    return HVO_OK;
+}
+
+// LSDmatcher::SearchByProjection(Cur, Last, th) core between two resident frames (src/LSDmatcher.cpp:561-662): query i = last-frame line q_index[i]
+// (its key line and -- unless q_desc is given -- its descriptor are read from the last frame's slot), the current frame's key lines, line functions,
+// descriptors and LINE GRID are the resident ones (the stream must run HVO_STAGE_GRIDS); per query only the four projected coordinates go up
+int hvo_stream_search_lines_by_projection(hvo_stream *s, int64_t cur, int64_t last, int nq, const int32_t *q_index, const float *q_xyxy, const uint8_t *q_desc,
+                                          const uint8_t *q_blocks, const uint8_t *t_occupied, float th, int32_t *match_idx, int32_t *match_dist, int *n_matches)
+{
+    if (!s || !match_idx || !match_dist || !n_matches || nq < 0) return HVO_ERR_INVALID_ARG;
+    *n_matches = 0;
+    if (!(s->sp.stages & (HVO_STAGE_LSD | HVO_STAGE_LSD_CULL)) || !(s->tail_stages & HVO_STAGE_GRIDS)) return HVO_ERR_INVALID_ARG;
+    StreamSlot *A = slot_of(s, last), *B = slot_of(s, cur);
+    if (!A || !B || A == B) return HVO_ERR_INVALID_ARG;
+    for (int i = 0; i < nq; i++) { match_idx[i] = -1; match_dist[i] = 256; }
+    if (nq == 0) return HVO_OK;
+    if (!q_index || !q_xyxy) return HVO_ERR_INVALID_ARG;
+    if (hipSetDevice(s->p.device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    ST_HIP(hipEventSynchronize(A->ev_lsd));
+    ST_HIP(hipEventSynchronize(B->ev_lsd));                     // (recorded behind the line grid and its download)
+    const int n1 = ((const int *)(A->h_out + s->lay.counts))[4], n2 = ((const int *)(B->h_out + s->lay.counts))[4];
+    for (int i = 0; i < nq; i++) if (q_index[i] < 0 || q_index[i] >= n1) return HVO_ERR_INVALID_ARG;
+    if (n2 <= 0) return HVO_OK;
+    const TailLayout &T = s->tl;
+    const int n_items = ((const int *)(B->h_tail + T.counts))[3];
+    if (n_items < 0 || n_items > T.ln_cap) { s->last_error = "line grid overflowed its capacity"; return HVO_ERR_CAPACITY; }
+    hipStream_t st = s->s_match;
+    char *d = s->d_ms, *hh = s->h_ms; size_t off = 0;
+    auto up = [&](const void *src, size_t bytes) -> void * {
+        void *dp = d + off, *hp = hh + off; off += al64(bytes);
+        if (off > s->ms_bytes) return nullptr;
+        memcpy(hp, src, bytes);
+        if (hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return nullptr;
+        return dp;
+    };
+    LsbpDev a; memset(&a, 0, sizeof(a));
+    a.nq = nq; a.nt = n2;
+    a.q_xyxy = (const float *)up(q_xyxy, (size_t)nq * 16); a.q_index = (const int32_t *)up(q_index, (size_t)nq * 4);
+    a.q_kl = A->lv.d_kl; a.q_desc_all = A->lv.d_desc;
+    a.q_desc = q_desc ? (const uint8_t *)up(q_desc, (size_t)nq * 32) : nullptr;
+    a.q_blocks = q_blocks ? (const uint8_t *)up(q_blocks, (size_t)nq) : nullptr;
+    a.t_occ = t_occupied ? (const uint8_t *)up(t_occupied, (size_t)n2) : nullptr;
+    if (!a.q_xyxy || !a.q_index || (q_desc && !a.q_desc) || (q_blocks && !a.q_blocks) || (t_occupied && !a.t_occ)) { s->last_error = "matching scratch too small"; return HVO_ERR_CAPACITY; }
+    a.t_kl = B->lv.d_kl; a.t_fn = B->lv.d_fn; a.t_desc = B->lv.d_desc;
+    a.cell_start = (const int32_t *)(B->d_tail + T.ln_start); a.cell_items = (const int32_t *)(B->d_tail + T.ln_items); a.n_items = n_items;
+    a.mnMinX = s->bounds[0]; a.mnMaxX = s->bounds[1]; a.mnMinY = s->bounds[2]; a.mnMaxY = s->bounds[3]; a.th = th; a.cos_th = cos(10.0 / 180.0 * M_PI);
+    int32_t *dout = (int32_t *)(d + off); int32_t *hout = (int32_t *)(hh + off); off += al64((2 * (size_t)nq + 1) * 4);
+    void *scratch = d + off; off += match_lsbp_scratch_bytes(nq, n2);
+    if (off > s->ms_bytes) { s->last_error = "matching scratch too small"; return HVO_ERR_CAPACITY; }
+    a.match_idx = dout; a.match_dist = dout + nq; a.n_matches = dout + 2 * nq;
+    int rc = match_lsbp_enqueue(st, a, scratch);
+    if (rc) return rc;
+    ST_HIP(hipMemcpyAsync(hout, dout, (2 * (size_t)nq + 1) * 4, hipMemcpyDeviceToHost, st));
+    ST_HIP(hipStreamSynchronize(st));
+    memcpy(match_idx, hout, (size_t)nq * 4); memcpy(match_dist, hout + nq, (size_t)nq * 4);
+    *n_matches = hout[2 * nq];
     return HVO_OK;
 }
 

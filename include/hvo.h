@@ -151,6 +151,19 @@ int hvo_frame_bf_match(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d
 int hvo_search_double(hvo_ctx *ctx, const uint8_t *d1, int n1, const uint8_t *d2, int n2, float th, float nnratio,
                       int32_t *matches12, int *n_matches);
 
+/* LSDmatcher::SearchByGeomNApearance (reference src/LSDmatcher.cpp:36-108) on host arrays: see hvo_stream_match_lines_geom.  bounds4 = {mnMinX,
+ * mnMaxX, mnMinY, mnMaxY} of the current frame; matches12 / accepted: n_last entries. */
+int hvo_match_lines_geom(hvo_ctx *ctx, const uint8_t *d_last, const hvo_keyline *kl_last, const uint8_t *last_has_mapline, int n_last,
+                         const uint8_t *d_cur, const hvo_keyline *kl_cur, int n_cur, float desc_th, const float bounds4[4],
+                         int32_t *matches12, uint8_t *accepted, int *n_accepted);
+/* LSDmatcher::SearchByProjection(Cur, Last, th) core (reference src/LSDmatcher.cpp:561-662, Frame::GetFeaturesInAreaForLine src/Frame.cc:1557-1627)
+ * on host arrays: q_kl[i] = LastFrame.mvKeylinesUn of query i; t_linefn (nt x 3) = mvKeyLineFunctions; cell_start / cell_items = the current frame's
+ * line grid as hvo_assign_lines_to_grid returns it; at most 2048 current lines.  See hvo_stream_search_lines_by_projection. */
+int hvo_search_lines_by_projection(hvo_ctx *ctx, int nq, const float *q_xyxy, const hvo_keyline *q_kl, const uint8_t *q_desc, const uint8_t *q_blocks,
+                                   const hvo_keyline *t_kl, const double *t_linefn, const uint8_t *t_desc, const uint8_t *t_occupied, int nt,
+                                   const int32_t *cell_start, const int32_t *cell_items, const float bounds4[4], float th,
+                                   int32_t *match_idx, int32_t *match_dist, int *n_matches);
+
 /* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, mono) core (reference src/ORBmatcher.cc:1353-1497,
  * Frame::GetFeaturesInArea src/Frame.cc:1502-1555).  One query per last-frame map point that passed the
  * projection tests (:1381-1404): projected (u,v), radius = th * scale[octave], octave band [min,max] with
@@ -431,6 +444,23 @@ int  hvo_stream_project_last(hvo_stream *s, int64_t cur, int64_t last, const hvo
 /* line matching between two resident frames: query = lines of `from`, train = lines of `to`; matches12 needs kl_cap entries,
  * *n_from receives n_kl(from) */
 int  hvo_stream_match_lines(hvo_stream *s, int64_t from, int64_t to, int mode, float th, float nnratio, int32_t *matches12, int *n_from, int *n_matches);
+
+/* LSDmatcher::SearchByGeomNApearance(CurrentFrame, LastFrame, desc_th, matches_12) WHOLE between two resident frames (reference
+ * src/Tracking.cc:2299 -> src/LSDmatcher.cpp:36-108; computeAngle2D 20-34): match(Last.mLdesc, Cur.mLdesc) and then, per pair, the 20-degree
+ * angle gate on the in-octave end points and the position gate (start OR end point within a tenth of the image bounds in both axes).
+ * last_has_mapline (n_kl(last) flags, NULL = every line has one): LastFrame.mvpMapLines[i] != NULL; a line without one is passed over and keeps
+ * its descriptor match in matches12, as in the reference (57).  accepted[i] = 1 where the reference assigns CurrentFrame.mvpMapLines[matches12[i]]
+ * = LastFrame.mvpMapLines[i]; *n_accepted = the reference's return value.  matches12 / accepted need kl_cap entries. */
+int  hvo_stream_match_lines_geom(hvo_stream *s, int64_t cur, int64_t last, float desc_th, const uint8_t *last_has_mapline,
+                                 int32_t *matches12, uint8_t *accepted, int *n_last, int *n_accepted);
+/* LSDmatcher::SearchByProjection(CurrentFrame, LastFrame, th) core between two resident frames (reference src/LSDmatcher.cpp:561-662 over
+ * Frame::GetFeaturesInAreaForLine src/Frame.cc:1557-1627), the tracker's retry when the descriptor match finds too few lines.  Query i =
+ * last-frame line q_index[i] whose map line passed isInFrustum: q_xyxy[4 i ..] = (mTrackProjX1, mTrackProjY1, mTrackProjX2, mTrackProjY2);
+ * q_desc (nq x 32, may be NULL: the last frame's own descriptors) = pML->GetDescriptor(); q_blocks[i] != 0 when the map line has observations;
+ * t_occupied (n_kl(cur) flags, may be NULL): current lines already holding an observed map line.  The current frame's key lines, line functions,
+ * descriptors and line grid are the resident ones: the stream must run HVO_STAGE_GRIDS.  match_idx[i] = current line or -1 (accepted at <= 95). */
+int  hvo_stream_search_lines_by_projection(hvo_stream *s, int64_t cur, int64_t last, int nq, const int32_t *q_index, const float *q_xyxy, const uint8_t *q_desc,
+                                           const uint8_t *q_blocks, const uint8_t *t_occupied, float th, int32_t *match_idx, int32_t *match_dist, int *n_matches);
 
 /* Page-lock (hipHostRegister) / unlock a caller's host buffer.  Images handed to hvo_batch_upload / hvo_stream_submit and result
  * slabs handed to hvo_batch_download move by DMA at the link rate when they are pinned (no staging copy on either side); equally

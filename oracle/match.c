@@ -353,3 +353,131 @@ void orc_track_windows(int n, const int32_t *level, const float *view_cos, float
         q_min_level[i] = level[i] - 1; q_max_level[i] = level[i];
     }
 }
+
+/* ----------------------------------------------------------------------------------------------
+ * The line tracker's own two calls (round 5; SURVEY.md 8(f) widening of a20 / a21 to lines).
+ *
+ * LSDmatcher::computeAngle2D (src/LSDmatcher.cpp:20-34): |cos| of the angle between two 2-vectors.  The vectors are built in
+ * cv::Mat_<double>(1, 2) from FLOAT differences of the key lines' in-octave end points (66-72); cv::Mat::dot on two doubles is
+ * a0 b0 then + a1 b1 (ASSUMED OpenCV 3.2 dotProd_64f: no blocking below four elements).
+ * ---------------------------------------------------------------------------------------------- */
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+static double angle2d_abs_cos(const orc_keyline *a, const orc_keyline *b)
+{
+    const double ax = (double)(a->eox - a->sox), ay = (double)(a->eoy - a->soy);
+    const double bx = (double)(b->eox - b->sox), by = (double)(b->eoy - b->soy);
+    double dot = 0.0; dot += ax * bx; dot += ay * by;
+    const double ma = sqrt(ax * ax + ay * ay), mb = sqrt(bx * bx + by * by);
+    return fabs(dot / (ma * mb));
+}
+
+/* LSDmatcher::SearchByGeomNApearance(CurrentFrame, LastFrame, desc_th, matches_12) (src/LSDmatcher.cpp:36-108):
+ * match(Last.mLdesc, Cur.mLdesc) = matchNNR (42, 803-826), then per pair, in this order: a last-frame line without a map line is
+ * passed over (57: its entry of matches_12 is LEFT as matchNNR set it), so is a pair whose current line has startPointX == 0 (63);
+ * the angle gate |cos| >= cos(20 deg) (75-81) and the position gate -- start OR end point within a tenth of the image bounds
+ * in both axes (94-98) -- reset the entry to -1; what remains is accepted (CurrentFrame.mvpMapLines[i2] = LastFrame.mvpMapLines[i1]).
+ * matches12: n_last entries; accepted: n_last flags; returns lmatches. */
+int orc_lines_geom_match(const uint8_t *d_last, const orc_keyline *kl_last, const uint8_t *last_has_mapline, int n_last,
+                         const uint8_t *d_cur, const orc_keyline *kl_cur, int n_cur, float desc_th, const float *bounds4,
+                         int32_t *matches12, uint8_t *accepted)
+{
+    for (int i = 0; i < n_last; i++) { matches12[i] = -1; accepted[i] = 0; }
+    if (n_last < 1) return 0;
+    if (n_cur >= 2) orc_match_nnr(d_last, n_last, d_cur, n_cur, desc_th, matches12);       /* knnMatch(k = 2) needs two train rows (as hvo_match_nnr) */
+    const double deltaWidth = (bounds4[1] - bounds4[0]) * 0.1, deltaHeight = (bounds4[3] - bounds4[2]) * 0.1;
+    const double th_angle = 20.0, th_rad = th_angle / 180.0 * M_PI, cos_th_angle = cos(th_rad);
+    int lmatches = 0;
+    for (int i1 = 0; i1 < n_last; ++i1) {
+        if (last_has_mapline && !last_has_mapline[i1]) continue;
+        const int i2 = matches12[i1];
+        if (i2 < 0) continue;
+        if (kl_cur[i2].sx == 0) continue;
+        const double angle = angle2d_abs_cos(&kl_cur[i2], &kl_last[i1]);
+        if (angle < cos_th_angle) { matches12[i1] = -1; continue; }
+        const orc_keyline *c = &kl_cur[i2], *l = &kl_last[i1];
+        if ((fabs(c->sox - l->sox) > deltaWidth || fabs(c->soy - l->soy) > deltaHeight) && (fabs(c->eox - l->eox) > deltaWidth || fabs(c->eoy - l->eoy) > deltaHeight)) { matches12[i1] = -1; continue; }
+        accepted[i1] = 1; ++lmatches;
+    }
+    return lmatches;
+}
+
+/* LSDmatcher::SearchByProjection(CurrentFrame, LastFrame, th) core (src/LSDmatcher.cpp:561-662) over
+ * Frame::GetFeaturesInAreaForLine (src/Frame.cc:1557-1627).  One query per last-frame line whose map line is in the current frustum:
+ * q_xyxy = (mTrackProjX1, Y1, X2, Y2), q_kl = LastFrame.mvKeylinesUn[i], q_desc = pML->GetDescriptor(), q_blocks != 0 when the map line has
+ * observations (the current line it claims is then passed over by later queries, 607-609).  t_*: the current frame's key lines, line
+ * functions (mvKeyLineFunctions), descriptors, lines already holding an observed map line, and its line grid (mGridForLine as CSR,
+ * cell = ix * 48 + iy).  GetFeaturesInAreaForLine as written: float arithmetic throughout, the three sample points start / middle /
+ * end with (x1 + x2) / 2.0 rounded back to float, the window of each in grid cells, cells ix-major, a cell's lines in insertion
+ * order, a line kept at its FIRST visit that passes |cos| >= 0.96 against the query's direction and |Lfunc . (x, y, 1)| < r for that
+ * sample point (the level arguments are not looked at).  Then, in that order: occupancy, the 10-degree orientation gate on the
+ * in-octave end points, the Hamming distance, the length ratio min / max >= 0.75, first strict minimum; accepted if <= 95.
+ * (The reference declares a rotation histogram and never fills it.)  Returns nmatches. */
+int orc_search_lines_by_projection(int nq, const float *q_xyxy, const orc_keyline *q_kl, const uint8_t *q_desc, const uint8_t *q_blocks,
+                                   const orc_keyline *t_kl, const double *t_linefn, const uint8_t *t_desc, const uint8_t *t_occupied, int nt,
+                                   const int32_t *cell_start, const int32_t *cell_items, const float *bounds4, float th,
+                                   int32_t *match_idx, int32_t *match_dist)
+{
+    const float mnMinX = bounds4[0], mnMaxX = bounds4[1], mnMinY = bounds4[2], mnMaxY = bounds4[3];
+    const float invW = (float)GRID_COLS / (mnMaxX - mnMinX), invH = (float)GRID_ROWS / (mnMaxY - mnMinY);
+    const double cos_th_angle = cos(10.0 / 180.0 * M_PI);
+    const float TH = 0.96f;
+    uint8_t *occ = (uint8_t *)calloc(nt + 1, 1), *seen = (uint8_t *)malloc(nt + 1);
+    int *vind = (int *)malloc(sizeof(int) * (nt + 1));
+    for (int i = 0; i < nt; i++) occ[i] = t_occupied ? t_occupied[i] : 0;
+    int nmatches = 0;
+    for (int q = 0; q < nq; q++) {
+        match_idx[q] = -1; match_dist[q] = 256;
+        const float x1 = q_xyxy[4 * q], y1 = q_xyxy[4 * q + 1], x2 = q_xyxy[4 * q + 2], y2 = q_xyxy[4 * q + 3], r = th;
+        const float x[3] = { x1, (float)((x1 + x2) / 2.0), x2 }, y[3] = { y1, (float)((y1 + y2) / 2.0), y2 };
+        float delta1x = x1 - x2, delta1y = y1 - y2;
+        const float norm_delta1 = sqrtf(delta1x * delta1x + delta1y * delta1y);
+        delta1x /= norm_delta1; delta1y /= norm_delta1;
+        int nv = 0;
+        memset(seen, 0, nt + 1);
+        for (int i = 0; i < 3; i++) {
+            int nMinCellX = (int)floorf((x[i] - mnMinX - r) * invW); if (nMinCellX < 0) nMinCellX = 0;
+            if (nMinCellX >= GRID_COLS) continue;
+            int nMaxCellX = (int)ceilf((x[i] - mnMinX + r) * invW); if (nMaxCellX > GRID_COLS - 1) nMaxCellX = GRID_COLS - 1;
+            if (nMaxCellX < 0) continue;
+            int nMinCellY = (int)floorf((y[i] - mnMinY - r) * invH); if (nMinCellY < 0) nMinCellY = 0;
+            if (nMinCellY >= GRID_ROWS) continue;
+            int nMaxCellY = (int)ceilf((y[i] - mnMinY + r) * invH); if (nMaxCellY > GRID_ROWS - 1) nMaxCellY = GRID_ROWS - 1;
+            if (nMaxCellY < 0) continue;
+            for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+                for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                    const int c = ix * GRID_ROWS + iy;
+                    for (int k = cell_start[c]; k < cell_start[c + 1]; k++) {
+                        const int j = cell_items[k];
+                        if (seen[j]) continue;
+                        float delta2x = t_kl[j].sx - t_kl[j].ex, delta2y = t_kl[j].sy - t_kl[j].ey;
+                        const float norm_delta2 = sqrtf(delta2x * delta2x + delta2y * delta2y);
+                        delta2x /= norm_delta2; delta2y /= norm_delta2;
+                        const float CosSita = fabsf(delta1x * delta2x + delta1y * delta2y);
+                        if (CosSita < TH) continue;
+                        const float dist = (float)(t_linefn[3 * j] * (double)x[i] + t_linefn[3 * j + 1] * (double)y[i] + t_linefn[3 * j + 2]);
+                        if (fabs(dist) < r) { vind[nv++] = j; seen[j] = 1; }
+                    }
+                }
+        }
+        if (nv == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int v = 0; v < nv; v++) {
+            const int i2 = vind[v];
+            if (occ[i2]) continue;
+            if (angle2d_abs_cos(&t_kl[i2], &q_kl[q]) < cos_th_angle) continue;
+            const int dist = orc_descriptor_distance(q_desc + 32 * (size_t)q, t_desc + 32 * (size_t)i2);
+            const float mx = q_kl[q].length > t_kl[i2].length ? q_kl[q].length : t_kl[i2].length;       /* std::max(a, b): a < b ? b : a */
+            const float mn = t_kl[i2].length < q_kl[q].length ? t_kl[i2].length : q_kl[q].length;       /* std::min(a, b): b < a ? b : a */
+            if (mn / mx < 0.75) continue;
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= 95) {
+            match_idx[q] = bestIdx2; match_dist[q] = bestDist; nmatches++;
+            if (q_blocks && q_blocks[q]) occ[bestIdx2] = 1;
+        }
+    }
+    free(occ); free(seen); free(vind);
+    return nmatches;
+}

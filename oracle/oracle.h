@@ -184,6 +184,16 @@ int  orc_assign_features_to_grid(const orc_keypoint *kp_un, int n, const float *
 /* Frame::AssignFeaturesToGridForLine (src/Frame.cc:849-872, src/lineIterator.cpp:34-76) as CSR */
 int  orc_assign_lines_to_grid(const orc_keyline *kl, int n, const float *bounds4, int32_t *cell_start, int32_t *cell_items, int cap);
 
+/* the line tracker's own calls (match.c): LSDmatcher::SearchByGeomNApearance (src/LSDmatcher.cpp:36-108) and
+ * LSDmatcher::SearchByProjection(Cur, Last, th) (561-662) over Frame::GetFeaturesInAreaForLine (src/Frame.cc:1557-1627) */
+int  orc_lines_geom_match(const uint8_t *d_last, const orc_keyline *kl_last, const uint8_t *last_has_mapline, int n_last,
+                          const uint8_t *d_cur, const orc_keyline *kl_cur, int n_cur, float desc_th, const float *bounds4,
+                          int32_t *matches12, uint8_t *accepted);
+int  orc_search_lines_by_projection(int nq, const float *q_xyxy, const orc_keyline *q_kl, const uint8_t *q_desc, const uint8_t *q_blocks,
+                                    const orc_keyline *t_kl, const double *t_linefn, const uint8_t *t_desc, const uint8_t *t_occupied, int nt,
+                                    const int32_t *cell_start, const int32_t *cell_items, const float *bounds4, float th,
+                                    int32_t *match_idx, int32_t *match_dist);
+
 /* Frame::cullingLine (src/Frame.cc:952-1116; helpers 1117-1202), SURVEY.md 8f.2 */
 int  orc_line_iterator_count_clipped(int w, int h, float x1, float y1, float x2, float y2);
 int  orc_cull_lines(const uint8_t *gray, int w, int h, int stride, const orc_keyline *kl, const double *fn, int n,

@@ -494,6 +494,35 @@ def assign_lines_to_grid(kl, bounds4, cap=None):
     return start, items[:max(n, 0)], n
 
 
+def lines_geom_match(d_last, kl_last, d_cur, kl_cur, bounds4, desc_th=0.9, last_has_mapline=None):
+    """LSDmatcher::SearchByGeomNApearance -> (lmatches, matches12, accepted)"""
+    d_last = np.ascontiguousarray(d_last, np.uint8); d_cur = np.ascontiguousarray(d_cur, np.uint8)
+    kl_last = np.ascontiguousarray(kl_last); kl_cur = np.ascontiguousarray(kl_cur); b = np.ascontiguousarray(bounds4, np.float32)
+    n1, n2 = len(kl_last), len(kl_cur)
+    hm = None if last_has_mapline is None else np.ascontiguousarray(last_has_mapline, np.uint8)
+    m = np.zeros(max(n1, 1), np.int32); acc = np.zeros(max(n1, 1), np.uint8)
+    L = lib()
+    L.orc_lines_geom_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = L.orc_lines_geom_match(_p(d_last), _p(kl_last), None if hm is None else _p(hm), n1, _p(d_cur), _p(kl_cur), n2, desc_th, _p(b), _p(m), _p(acc))
+    return n, m[:n1], acc[:n1]
+
+
+def search_lines_by_projection(q_xyxy, q_kl, q_desc, q_blocks, t_kl, t_linefn, t_desc, t_occupied, cell_start, cell_items, bounds4, th):
+    """LSDmatcher::SearchByProjection(Cur, Last, th) core -> (nmatches, match_idx, match_dist)"""
+    q_xyxy = np.ascontiguousarray(q_xyxy, np.float32).reshape(-1, 4); nq = len(q_xyxy)
+    q_kl = np.ascontiguousarray(q_kl); t_kl = np.ascontiguousarray(t_kl); nt = len(t_kl)
+    q_desc = np.ascontiguousarray(q_desc, np.uint8); t_desc = np.ascontiguousarray(t_desc, np.uint8)
+    q_blocks = np.ascontiguousarray(q_blocks, np.uint8); t_occupied = np.ascontiguousarray(t_occupied, np.uint8)
+    t_linefn = np.ascontiguousarray(t_linefn, np.float64); b = np.ascontiguousarray(bounds4, np.float32)
+    cs = np.ascontiguousarray(cell_start, np.int32); ci = np.ascontiguousarray(cell_items, np.int32)
+    mi = np.zeros(max(nq, 1), np.int32); md = np.zeros(max(nq, 1), np.int32)
+    L = lib()
+    L.orc_search_lines_by_projection.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    n = L.orc_search_lines_by_projection(nq, _p(q_xyxy), _p(q_kl), _p(q_desc), _p(q_blocks), _p(t_kl), _p(t_linefn), _p(t_desc), _p(t_occupied), nt,
+                                         _p(cs), _p(ci), _p(b), th, _p(mi), _p(md))
+    return n, mi[:nq], md[:nq]
+
+
 def cull_lines(gray, kl, fn, dis=5.0, angle=2.5, endpoint_dis=15.0):
     """Frame::cullingLine(im, 5, 2.5, 15, 30) (src/Frame.cc:934, 952-1116) -> (keylines, descriptors, line functions)"""
     gray = np.ascontiguousarray(gray, np.uint8); kl = np.ascontiguousarray(kl); fn = np.ascontiguousarray(fn, np.float64)
