@@ -67,7 +67,7 @@ EXPORTS = [
     "hvo_undistort_keypoints", "hvo_image_bounds", "hvo_assign_features_to_grid", "hvo_assign_lines_to_grid",
     "hvo_extract_lsd_culled", "hvo_set_line_culling", "hvo_lines_3d", "hvo_vanishing_points", "hvo_plane_clouds", "hvo_surface_normals", "hvo_search_by_projection_map", "hvo_frame_bf_match", "hvo_search_double",
     "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch", "hvo_batch_slab_layout", "hvo_batch_pack_results", "hvo_batch_slab_layout_ex", "hvo_batch_pack_results_ex", "hvo_batch_stage_upload", "hvo_batch_commit_staged", "hvo_batch_results_async", "hvo_batch_results_wait",
-    "hvo_profile_last", "hvo_profile_enable", "hvo_pin_host", "hvo_unpin_host",
+    "hvo_profile_last", "hvo_profile_enable", "hvo_lsd_async_report", "hvo_pin_host", "hvo_unpin_host",
     "hvo_stream_create", "hvo_stream_destroy", "hvo_stream_last_error", "hvo_stream_capacity", "hvo_stream_image_bounds",
     "hvo_stream_submit", "hvo_stream_poll", "hvo_stream_collect", "hvo_stream_stage_ms",
     "hvo_stream_search_by_projection", "hvo_stream_match_lines", "hvo_stream_project_last", "hvo_search_by_projection_tracked",
@@ -452,6 +452,13 @@ class Context:
         self._chk(lib().hvo_search_lines_by_projection(self.h, nq, _p(q_xyxy), _p(q_kl), _p(q_desc), _p(q_blocks), _p(t_kl), _p(t_linefn), _p(t_desc), _p(t_occupied), nt,
                                                        _p(cs), _p(ci), _p(b), th, _p(mi), _p(md), C.byref(n)), "search_lines_by_projection")
         return n.value, mi[:nq], md[:nq]
+
+    def lsd_async_report(self):
+        """(frames grown again by the one-wave kernel, workers that sat on a foreign XCD, workers per frame) of the last async line growing"""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        lib().hvo_lsd_async_report.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        self._chk(lib().hvo_lsd_async_report(self.h, C.byref(a), C.byref(b), C.byref(c)), "lsd_async_report")
+        return a.value, b.value, c.value
 
     def search_by_projection_map(self, q_desc, q_u, q_v, q_radius, q_min_level, q_max_level, q_ur, q_blocks,
                                  t_kp, t_uright, t_occupied, t_desc, bounds, th_high=100, nn_ratio=0.8):

@@ -11,10 +11,27 @@
 #include <new>
 #include <vector>
 
+#include <map>
+#include <mutex>
+int hvo_ensure_dyn_lds(const void *kernel, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> have;
+    if (bytes <= 48 * 1024) return HVO_OK;
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    size_t &h = have[std::make_pair(dev, kernel)];
+    if (bytes > h) {
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) { (void)hipGetLastError(); return HVO_ERR_HIP; }
+        h = bytes;
+    }
+    return HVO_OK;
+}
+
 const int *hvo_frame_perm(hvo_ctx *ctx, int n)
 {
     if (n < 2) return nullptr;
-    { const char *e = getenv("HVO_FRAME_PERM"); if (e && atoi(e) == 0) return nullptr; }      // A/B knob
+    if (ctx->kn_frame_perm.off()) return nullptr;                // HVO_FRAME_PERM=0: A/B knob
     for (auto &e : ctx->perms) if (e.first == n) return e.second;
     int bits = 0; while ((1 << bits) < n) bits++;
     std::vector<int> p; p.reserve(n);
@@ -94,6 +111,7 @@ int hvo_create(const hvo_params *p, hvo_ctx **out)
         hipEventCreateWithFlags(&ctx->ev_lsd_pre, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fast, hipEventDisableTiming) != hipSuccess) { hvo_destroy(ctx); return HVO_ERR_HIP; }
     { const char *e = getenv("HVO_SCHED"); if (e) ctx->sched_cfg = atoi(e); }
+    ctx->kn_frame_perm.read("HVO_FRAME_PERM"); ctx->kn_upload_single.read("HVO_UPLOAD_SINGLE");
     { const char *e = getenv("HVO_ORB_BLUR_LATE"); if (e) ctx->orb_blur_late = atoi(e) != 0; }
     int rc = orb_init_tables(ctx);
     if (rc) { hvo_destroy(ctx); return rc; }
@@ -157,6 +175,13 @@ int hvo_profile_last(const hvo_ctx *ctx, const char **names, float *ms, int cap)
         if (names) names[n] = ctx->prof[i].name;
         if (ms) ms[n] = tot;
         n++;
+    }
+    // two counts ride along when the last line growing was the async one (small batches): frames the one-wave kernel had to grow again and
+    // workers that found themselves on a foreign XCD (hvo_lsd_async_report; > 0 = slower than it should be, never wrong)
+    int regrown = 0, foreign = 0, wpf = 0;
+    if (ctx->profile && hvo_lsd_async_report(const_cast<hvo_ctx *>(ctx), &regrown, &foreign, &wpf) == HVO_OK && wpf > 0) {
+        if (n < cap) { if (names) names[n] = "lsd_async_regrown_frames"; if (ms) ms[n] = (float)regrown; n++; }
+        if (n < cap) { if (names) names[n] = "lsd_async_foreign_workers"; if (ms) ms[n] = (float)foreign; n++; }
     }
     return n;
 }

@@ -5,6 +5,7 @@
 // of the resident batch so that launch latency is amortised over the batch.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -84,8 +85,21 @@ struct OrbPlan {
 
 struct ProfileRec { const char *name; hipEvent_t e0, e1; float ms; bool used; hipStream_t st; };
 
+// A tuning variable (environment) as it stood when a context or a plan was BUILT: launches read the copy, never the environment
+// (~25 getenv calls per launch; tests set a variable and make a new context, tools use HVO_LIB for A/B builds).
+struct Knob {
+    bool set = false; int v = 0;
+    void read(const char *name) { const char *e = getenv(name); set = e != nullptr; v = e ? atoi(e) : 0; }
+    int or_(int dflt) const { return set ? v : dflt; }
+    bool off() const { return set && v == 0; }
+};
+// hipFuncAttributeMaxDynamicSharedMemorySize for a kernel that is about to be launched with `bytes` of dynamic LDS (> 48 KB): raised under a
+// lock, per device -- contexts are driven from several host threads (api.hip)
+int hvo_ensure_dyn_lds(const void *kernel, size_t bytes);
+
 struct hvo_ctx {
     hvo_params p;
+    Knob kn_frame_perm, kn_upload_single;  // HVO_FRAME_PERM, HVO_UPLOAD_SINGLE (read by hvo_create)
     int device = 0;
     hipStream_t stream = nullptr;          // ORB + matching + uploads
     hipStream_t s_lsd = nullptr;           // LSD/LBD kernels   } the three subsystems are independent and run

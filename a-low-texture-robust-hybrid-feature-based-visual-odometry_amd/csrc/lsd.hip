@@ -65,6 +65,9 @@ struct LsdPlan {
     long long *d_stats = nullptr;      // per frame 8 counters (diagnostics: hvo_debug_lsd_stats)
     // k_lsd_grow_async (lsd_async.inc), allocated at its first launch for the first `async_b` frames of the plan
     bool pre_fused = true;             // k_lsd_pre instead of k_lsd_blur + k_lsd_resize_grad (HVO_LSD_PRE_SPLIT=1: the pair, with its fp64 image)
+    // tuning variables, read when the plan is built (lsd_build_plan)
+    struct { Knob dense, lat, async_w, async_early, async_lds, lat_lds, lbd_split, spin_max; } kn;
+    int *d_redo = nullptr; int async_last_n = 0, async_last_w = 0;      // frames the one-wave kernel grew again after the async growing gave up; the last async launch
     int async_b = 0; unsigned *d_atags = nullptr; void *d_actl = nullptr; int *d_alists = nullptr, *d_ablk = nullptr, *d_afreg = nullptr; unsigned char *d_ainreg = nullptr; int ainreg_b = 0;
 };
 static LsdPlan *plan_of(hvo_ctx *ctx) { return (LsdPlan *)ctx->lsd; }
@@ -241,8 +244,10 @@ __global__ __launch_bounds__(256) void k_lsd_resize_grad(const double *__restric
 __global__ __launch_bounds__(256) void k_lsd_pre(const uint8_t *__restrict__ gray, size_t gframe, int gpitch, int w, int h, int sw, int sh,
                                                  const int *__restrict__ xofs, const float *__restrict__ xa, const int *__restrict__ yofs, const float *__restrict__ yb,
                                                  double4 *__restrict__ px4, unsigned *__restrict__ defined, int nwords, double rho,
-                                                 double k0, double k1, double k2, double k3)
+                                                 double k0, double k1, double k2, double k3, const int *__restrict__ redo_flags)
 {
+    // redo_flags: only the frames whose growing gave up (flag 4: k_lsd_grow_async's bounded wait) are formed again -- their availability mask was consumed
+    if (redo_flags && !(redo_flags[blockIdx.z] & 4)) return;
     __shared__ double bl[4][256];                     // ring of blurred source rows (row & 3), one value per thread's column
     __shared__ double sc[2][PRE_TW + 1];              // the last two scaled rows
     __shared__ double la[512], lm[512]; __shared__ int lpos[512];
@@ -416,6 +421,8 @@ struct GrowArgs {
     hvo_keyline *kl_all, *kl; double *fn; int *nkl; int *flags; long long *stats;
     int sw, sh, nwords, w, h, nfeat, kl_cap, maxseg;
     double rho, prec, p; unsigned min_reg;
+    int redo;                 // 1: only frames whose flags carry 4 (the async growing gave up on them) are grown, the others return at once
+    int *redo_count;          // ... and counted (hvo_lsd_async_report)
 };
 
 struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy; };
@@ -886,6 +893,7 @@ static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
     __shared__ int n_addr[64];
     __shared__ int ring[LSD_RING];
     const int f = g.perm ? g.perm[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;       // hvo_frame_perm
+    if (g.redo) { if (!(g.flags[f] & 4)) return; if (lane == 0) atomicAdd(g.redo_count, 1); }
     const int sw = g.sw, sh = g.sh, wpr = (sw + 31) / 32, nwords = g.nwords;
     const size_t np = (size_t)sw * sh;
     GrowState S;
@@ -1412,7 +1420,7 @@ void lsd_free(hvo_ctx *ctx)
     if (!P) return;
     void *ptrs[] = { P->d_kl2, P->d_desc2, P->d_fn2, P->d_nkl2, P->d_blur, P->d_px, P->d_defined, P->d_reg, P->d_segs, P->d_kl_all, P->d_kl,
                      P->d_desc, P->d_fn, P->d_nkl, P->d_flags, P->d_b5, P->d_dxy, P->d_xofs, P->d_yofs, P->d_xa, P->d_yb, P->d_gL, P->d_gG, P->d_stats,
-                     P->d_pool, P->d_defmask, P->d_wprefix, P->d_fbase, P->d_fcount, P->d_pooltop, P->d_atags, P->d_actl, P->d_alists, P->d_ablk, P->d_afreg, P->d_ainreg };
+                     P->d_pool, P->d_defmask, P->d_wprefix, P->d_fbase, P->d_fcount, P->d_pooltop, P->d_atags, P->d_actl, P->d_alists, P->d_ablk, P->d_afreg, P->d_ainreg, P->d_redo };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
     ctx->lsd = nullptr;
@@ -1484,6 +1492,8 @@ static int lsd_build_plan(hvo_ctx *ctx, int w, int h, int batch)
 #define PA(ptr, n) HVO_HIP(hipMalloc((void **)&(ptr), (n)))
     // transient images (the fp64 blurred image between k_lsd_blur and k_lsd_resize_grad, the Sobel image between k_lbd_blur_sobel and
     // k_lbd_desc) exist for a CHUNK of the batch only: lsd_run walks the batch chunk by chunk through those kernels (3.7 MB per frame saved)
+    P->kn.dense.read("HVO_LSD_DENSE"); P->kn.lat.read("HVO_LSD_LAT"); P->kn.async_w.read("HVO_LSD_ASYNC"); P->kn.async_early.read("HVO_LSD_ASYNC_EARLY");
+    P->kn.async_lds.read("HVO_LSD_ASYNC_LDS"); P->kn.lat_lds.read("HVO_LSD_LAT_LDS"); P->kn.lbd_split.read("HVO_LBD_SPLIT"); P->kn.spin_max.read("HVO_LSD_ASYNC_SPIN_MAX");
     P->chunk = (int)std::min<size_t>(B, 512);
     { const char *e = getenv("HVO_LSD_CHUNK"); if (e && atoi(e) > 0) P->chunk = (int)std::min<size_t>(B, (size_t)atoi(e)); }
     // compact records (HVO_LSD_COMPACT): the dense record image exists for a chunk only
@@ -1516,7 +1526,7 @@ static int lsd_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_kl, B * P->nfeat * sizeof(hvo_keyline)); PA(P->d_desc, B * P->nfeat * 32); PA(P->d_fn, B * P->nfeat * 24);
     PA(P->d_nkl, B * 4); PA(P->d_flags, B * 4);
     PA(P->d_kl2, B * P->nfeat * sizeof(hvo_keyline)); PA(P->d_desc2, B * P->nfeat * 32); PA(P->d_fn2, B * P->nfeat * 24); PA(P->d_nkl2, B * 4);
-    if (getenv("HVO_LBD_SPLIT")) PA(P->d_b5, CB * npix);
+    if (P->kn.lbd_split.set) PA(P->d_b5, CB * npix);
     PA(P->d_dxy, CB * npix * sizeof(short2));
     PA(P->d_xofs, P->sw * 4); PA(P->d_yofs, P->sh * 4); PA(P->d_xa, P->sw * 8); PA(P->d_yb, P->sh * 8);
     PA(P->d_gL, 21 * 4); PA(P->d_gG, 63 * 4); PA(P->d_stats, B * 64);
@@ -1575,7 +1585,7 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
                 id = hvo_prof_begin(ctx, "lsd_gradient", st);
                 hipLaunchKernelGGL(k_lsd_pre, dim3((sw + PRE_TW - 1) / PRE_TW, (sh - 1 + PRE_SEG - 1) / PRE_SEG, m), dim3(256), 0, st, gray + (size_t)c0 * O.pyr_bytes, O.pyr_bytes, gpitch,
                                    w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb, P->d_px + (P->compact ? 0 : (size_t)c0 * nsp),
-                                   P->d_defined + (size_t)c0 * P->nwords, P->nwords, P->rho, P->k7[0], P->k7[1], P->k7[2], P->k7[3]);
+                                   P->d_defined + (size_t)c0 * P->nwords, P->nwords, P->rho, P->k7[0], P->k7[1], P->k7[2], P->k7[3], (const int *)nullptr);
             } else {
             id = hvo_prof_begin(ctx, "lsd_blur_scale", st);
             hipLaunchKernelGGL(k_lsd_blur, dim3((w + 255) / 256, (h + LSD_BLUR_ROWS - 1) / LSD_BLUR_ROWS, m), dim3(256), 0, st, gray + (size_t)c0 * O.pyr_bytes, O.pyr_bytes, gpitch, P->d_blur, w, h,
@@ -1618,17 +1628,17 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     g.defmask = P->d_defmask; g.wprefix = P->d_wprefix; g.fbase = P->d_fbase;
     g.stats = P->d_stats; g.kl_all = P->d_kl_all; g.kl = P->d_kl; g.fn = P->d_fn; g.nkl = P->d_nkl; g.flags = P->d_flags;
     g.sw = sw; g.sh = sh; g.nwords = P->nwords; g.w = w; g.h = h; g.nfeat = P->nfeat; g.kl_cap = P->nfeat;
-    g.rho = P->rho; g.prec = P->prec; g.p = P->p; g.min_reg = P->min_reg; g.maxseg = P->maxseg;
+    g.rho = P->rho; g.prec = P->prec; g.p = P->p; g.min_reg = P->min_reg; g.maxseg = P->maxseg; g.redo = 0; g.redo_count = nullptr;
     bool dense = n > 5 * 1024;
-    { const char *e = getenv("HVO_LSD_DENSE"); if (e) dense = atoi(e) != 0; }              // tests force either kernel on small batches
+    if (P->kn.dense.set) dense = P->kn.dense.v != 0;              // HVO_LSD_DENSE: tests force either kernel on small batches
     // a handful of frames (the streamed mode, a tracker's small batches): the latency variant with the mask in LDS
     bool lat = n <= 64 && (size_t)P->nwords * 4 <= 150 * 1024 && !P->compact;
-    { const char *e = getenv("HVO_LSD_LAT"); if (e) lat = atoi(e) != 0 && (size_t)P->nwords * 4 <= 150 * 1024 && !P->compact; }
+    if (P->kn.lat.set) lat = P->kn.lat.v != 0 && (size_t)P->nwords * 4 <= 150 * 1024 && !P->compact;      // HVO_LSD_LAT
     // a handful of frames: W waves per frame grow regions side by side and commit them in seed order (lsd_async.inc); HVO_LSD_ASYNC = W, 0: off
     // (default: up to 16 frames; at 32 frames the one-wave kernel beside the plane chain is the faster whole, tools/latency.py)
     int aw = n <= 8 ? 32 : n <= 16 ? 16 : 0;
     if (n <= 2 && (size_t)sw * sh >= 600000) aw = 64;          // a lone large frame (1280x960: 5.4 k seeds): more regions in flight
-    { const char *e = getenv("HVO_LSD_ASYNC"); if (e) aw = std::min(std::max(atoi(e), 0), LA_MAXW); }
+    if (P->kn.async_w.set) aw = std::min(std::max(P->kn.async_w.v, 0), LA_MAXW);
     if (aw > 0 && n <= 64 && !P->compact) {
         if (!P->d_atags) {
             const size_t AB = (size_t)std::min(P->batch, 64);
@@ -1638,23 +1648,35 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
             // a worker's map of its region, a byte per scaled pixel: for the 16 frames the growing is used for by default (a forced HVO_LSD_ASYNC on more falls back)
             P->ainreg_b = (int)std::min(AB, (size_t)16);
             HVO_HIP(hipMalloc((void **)&P->d_ainreg, (size_t)P->ainreg_b * LA_MAXW * P->nwords * 32));
+            HVO_HIP(hipMalloc((void **)&P->d_redo, 64));
             P->async_b = (int)AB;
         }
         if (n <= P->async_b && n <= P->ainreg_b) {
             HVO_HIP(hipMemsetAsync(P->d_actl, 0, (size_t)n * sizeof(LaCtl), st));
+            HVO_HIP(hipMemsetAsync(P->d_redo, 0, 4, st)); P->async_last_n = n; P->async_last_w = aw;
             // tags and region bitmaps are all-free / all-zero after a launch that ran to its end; a launch that aborted (flag 4) may have
             // left some behind, so every launch starts from a clean state (7 MB per 640x480 frame at 32 workers, microseconds)
             HVO_HIP(hipMemsetAsync(P->d_atags, 0xFF, (size_t)n * P->nwords * 32 * 4, st));
             HVO_HIP(hipMemsetAsync(P->d_ainreg, 0, (size_t)n * aw * P->nwords * 32, st));
-            LaArgs a; a.g = g; a.tags = P->d_atags; a.inreg = P->d_ainreg; a.ctl = (LaCtl *)P->d_actl; a.lists = P->d_alists; a.blocked = P->d_ablk; a.freg = P->d_afreg; a.W = aw; a.n = n; a.early = 1;
-            { const char *e = getenv("HVO_LSD_ASYNC_EARLY"); if (e) a.early = atoi(e); }
+            LaArgs a; a.g = g; a.tags = P->d_atags; a.inreg = P->d_ainreg; a.ctl = (LaCtl *)P->d_actl; a.lists = P->d_alists; a.blocked = P->d_ablk; a.freg = P->d_afreg; a.W = aw; a.n = n; a.early = P->kn.async_early.or_(1);
+            // the turn's wait is bounded (a frame whose wait expires is grown again below, by the one-wave kernel); HVO_LSD_ASYNC_SPIN_MAX: a test hook
+            a.spin_max = P->kn.spin_max.set ? (unsigned)std::max(P->kn.spin_max.v, 0) : LA_SPIN_MAX;
             // (an LDS request keeps these one-wave workgroups off the CUs where a frame's AHC waves sit -- k_peac_cluster_heads takes 108 KB --:
             // both are bound by instruction issue and a shared SIMD slows both; HVO_LSD_ASYNC_LDS: bytes [0 for a lone frame's 32-64 workers, 56 K beside other frames])
             size_t alds = n > 2 ? 56 * 1024 : 0;
-            { const char *e = getenv("HVO_LSD_ASYNC_LDS"); if (e) alds = (size_t)std::min(std::max(atoi(e), 0), 150 * 1024); }
-            static size_t alds_set = 0;
-            if (alds > 48 * 1024 && alds > alds_set) { HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lsd_grow_async), hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds)); alds_set = alds; }
+            if (P->kn.async_lds.set) alds = (size_t)std::min(std::max(P->kn.async_lds.v, 0), 150 * 1024);
+            if (hvo_ensure_dyn_lds(reinterpret_cast<const void *>(k_lsd_grow_async), alds)) return HVO_ERR_HIP;
             hipLaunchKernelGGL(k_lsd_grow_async, dim3(((n + 7) / 8) * 8 * aw), dim3(64), alds, st, a);      // workgroups b, b + 8, ... of a frame: one XCD
+            // FAIL SOFT: a frame the workers gave up on (flag 4: the bounded wait expired, or no worker sat on the frame's XCD) is
+            // answered with lines, not with an error -- its records and availability mask are formed again (the commits consumed the mask) and
+            // the deterministic one-wave kernel grows it; both launches return at once for every other frame (~10 us per call when nothing failed)
+            if (P->pre_fused)
+                hipLaunchKernelGGL(k_lsd_pre, dim3((sw + PRE_TW - 1) / PRE_TW, (sh - 1 + PRE_SEG - 1) / PRE_SEG, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch,
+                                   w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb, P->d_px, P->d_defined, P->nwords, P->rho, P->k7[0], P->k7[1], P->k7[2], P->k7[3], (const int *)P->d_flags);
+            else
+                hipLaunchKernelGGL(k_lsd_resize_grad, dim3(gx, (sh + GRAD_ROWS - 1) / GRAD_ROWS, n), dim3(256), 0, st, P->d_blur, w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb,
+                                   P->d_px, P->d_defined, P->nwords, P->rho);      // (the split preamble: n <= 16 <= chunk, the blurred images are still there; every frame is formed again)
+            { GrowArgs g2 = g; g2.redo = 1; g2.redo_count = P->d_redo; g2.perm = nullptr; hipLaunchKernelGGL(k_lsd_grow, dim3(n), dim3(64), 0, st, g2); }
         } else aw = 0;
     } else aw = 0;
     if (aw > 0) {
@@ -1662,10 +1684,9 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
         // The LDS request also keeps this one-wave workgroup off the CUs where a frame's five AHC waves sit (k_peac_cluster_heads takes
         // 108 KB): both are bound by instruction issue and a shared SIMD slows both (HVO_LSD_LAT_LDS: bytes requested at least [56 K])
         size_t lds = (size_t)P->nwords * 4, floor_ = 56 * 1024;
-        { const char *e2 = getenv("HVO_LSD_LAT_LDS"); if (e2) floor_ = (size_t)atoi(e2); }
+        if (P->kn.lat_lds.set) floor_ = (size_t)std::max(P->kn.lat_lds.v, 0);      // HVO_LSD_LAT_LDS
         if (lds < floor_ && floor_ <= 150 * 1024) lds = floor_;
-        static size_t lat_lds_set = 0;
-        if (lds > 48 * 1024 && lds > lat_lds_set) { HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lsd_grow_lat), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); lat_lds_set = lds; }
+        if (hvo_ensure_dyn_lds(reinterpret_cast<const void *>(k_lsd_grow_lat), lds)) return HVO_ERR_HIP;
         hipLaunchKernelGGL(k_lsd_grow_lat, dim3(n), dim3(64), lds, st, g);
     } else if (P->compact) {
         if (dense) hipLaunchKernelGGL(k_lsd_grow_dense_c, dim3(n), dim3(64), 0, st, g);
@@ -1798,6 +1819,32 @@ extern "C" int hvo_debug_lsd_stats(hvo_ctx *ctx, int frame, long long *out8)
     LsdPlan *P = ctx ? plan_of(ctx) : nullptr;
     if (!P || frame < 0 || frame >= P->batch) return HVO_ERR_INVALID_ARG;
     HVO_HIP(hipMemcpy(out8, P->d_stats + (size_t)frame * 8, 64, hipMemcpyDeviceToHost));
+    return HVO_OK;
+}
+
+// What the last async line growing (batches of a few frames, the streamed mode) had to fall back on: frames the one-wave kernel grew again
+// because the workers' bounded wait expired or no worker sat on the frame's XCD, and workers that found themselves on another XCD than
+// their frame's (they count themselves out: exact, but slower -- the round-robin dealing of workgroups b, b + 8, ... to one XCD is an
+// assumption about the dispatcher).  Waits for the line stream.  workers_per_frame = 0: the last launch was not async.
+extern "C" int hvo_lsd_async_report(hvo_ctx *ctx, int *frames_regrown, int *foreign_workers, int *workers_per_frame)
+{
+    LsdPlan *P = ctx ? plan_of(ctx) : nullptr;
+    if (!ctx) return HVO_ERR_INVALID_ARG;
+    if (frames_regrown) *frames_regrown = 0;
+    if (foreign_workers) *foreign_workers = 0;
+    if (workers_per_frame) *workers_per_frame = 0;
+    if (!P || !P->d_actl || P->async_last_n < 1) return HVO_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HVO_ERR_NO_DEVICE;
+    HVO_HIP(hipStreamSynchronize(hvo_stream_lsd(ctx)));
+    int redo = 0;
+    HVO_HIP(hipMemcpy(&redo, P->d_redo, 4, hipMemcpyDeviceToHost));
+    std::vector<LaCtl> ctl((size_t)P->async_last_n);
+    HVO_HIP(hipMemcpy(ctl.data(), P->d_actl, ctl.size() * sizeof(LaCtl), hipMemcpyDeviceToHost));
+    int nf = 0;
+    for (const LaCtl &c : ctl) nf += (int)c.n_foreign;
+    if (frames_regrown) *frames_regrown = redo;
+    if (foreign_workers) *foreign_workers = nf;
+    if (workers_per_frame) *workers_per_frame = P->async_last_w;
     return HVO_OK;
 }
 

@@ -987,7 +987,7 @@ static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     {   // k_octree's node slots are dynamic LDS
         const size_t lds = (size_t)P.oct_slot_cap * OCT_SLOT_BYTES;
         if (lds > 150 * 1024) return HVO_ERR_UNSUPPORTED;
-        if (lds > 48 * 1024) HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (hvo_ensure_dyn_lds(reinterpret_cast<const void *>(k_octree), lds)) return HVO_ERR_HIP;
     }
     P.ntiles = (int)tiles.size();
     P.kp_cap = kp_total;       // >= sum(nfeat)+8*nlevels: never truncates the octree output
@@ -1049,7 +1049,7 @@ int orb_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool s
     // copy whose "rows" are whole frames.  A copy call costs ~20 us, which at one call per frame is the whole upload (2048 frames of
     // 307 KB: 20 GB/s against the link's 57, profiles/r03_pcie_raw.txt); a batch that cycles through k distinct host frames is k-spaced
     // runs -- a handful of calls.
-    const bool dense = P.lev[0].pitch == w && !(getenv("HVO_UPLOAD_SINGLE") && atoi(getenv("HVO_UPLOAD_SINGLE")) == 0);
+    const bool dense = P.lev[0].pitch == w && !ctx->kn_upload_single.off();
     for (int f = 0; f < n;) {
         int run = 1;
         if (dense && in[f].gray_stride == w && f + 1 < n && in[f + 1].gray_stride == w) {

@@ -49,6 +49,8 @@ struct PeacPlan {
     double *d_hkey = nullptr, *d_m1k = nullptr; int *d_hid = nullptr;      // TQueue: keys, bucket minima, their ids
     double c15 = 0, c60 = 0, c30 = 0;   // cos thresholds evaluated on the host (glibc), like the oracle
     double ang_factor = 0, ang_near = 0;
+    // tuning variables, read when the plan is built (peac_build_plan)
+    struct { Knob edges, gl, perm, heads_maxn, heads, heads_big, poolcap, ldsq, flood_t, flood_epl, flood_perm; } kn;
 };
 
 static PeacPlan *plan_of(hvo_ctx *ctx) { return (PeacPlan *)ctx->peac; }
@@ -1953,6 +1955,9 @@ static int peac_build_plan(hvo_ctx *ctx, int w, int h, int batch)
 {
     PeacPlan *P = new PeacPlan();
     ctx->peac = P;
+    P->kn.edges.read("HVO_PEAC_EDGES"); P->kn.gl.read("HVO_PEAC_GL"); P->kn.perm.read("HVO_PEAC_PERM"); P->kn.heads_maxn.read("HVO_PEAC_HEADS_MAXN");
+    P->kn.heads.read("HVO_PEAC_HEADS"); P->kn.heads_big.read("HVO_PEAC_HEADS_BIG"); P->kn.poolcap.read("HVO_PEAC_POOLCAP"); P->kn.ldsq.read("HVO_PEAC_LDSQ");
+    P->kn.flood_t.read("HVO_FLOOD_T"); P->kn.flood_epl.read("HVO_FLOOD_EPL"); P->kn.flood_perm.read("HVO_FLOOD_PERM");
     P->w = w; P->h = h; P->pitch = (w + 31) & ~31; P->Nw = w / WIN; P->Nh = h / WIN; P->nblk = P->Nw * P->Nh;
     P->segcap = 2 * P->nblk + 2 * MAX_PLANES; P->poolcap = 16 * P->nblk + 2 * MAX_PLANES * MAX_PLANES; P->qcap = 2 * w * h + 65536; P->batch = batch;
 #define HVO_DEG2RAD(d) ((d) * 3.14159265358979323846 / 180.0)      /* MACRO_DEG2RAD, AHCParamSet.hpp:33: (d)*M_PI/180.0, in that order */
@@ -2011,7 +2016,7 @@ int peac_upload(hvo_ctx *ctx, int n, const hvo_frame_in *in, int w, int h, bool 
     uint16_t *const dst = ctx->stage_depth_dst ? ctx->stage_depth_dst : P->d_depth;      // the resident depth slab, or the staging slab of a double-buffered batch
     for (int f = 0; f < n; f++) if (!in[f].depth) return HVO_ERR_INVALID_ARG;
     // dense host frames go up in runs of evenly spaced frames: one 2-D copy per run whose rows are whole frames (see orb_upload)
-    const bool dense = P->pitch == w && !(getenv("HVO_UPLOAD_SINGLE") && atoi(getenv("HVO_UPLOAD_SINGLE")) == 0);
+    const bool dense = P->pitch == w && !ctx->kn_upload_single.off();
     const int dstride = (int)(w * sizeof(uint16_t));
     for (int f = 0; f < n;) {
         int run = 1;
@@ -2056,10 +2061,9 @@ int peac_run(hvo_ctx *ctx, int n)
     a.edges_done = 0;
     {
         const size_t elds = (size_t)P->nblk * 34 + 16;
-        const char *ee = getenv("HVO_PEAC_EDGES");                 // 0: the passes stay inside the clustering kernels (A/B runs, tests)
-        if (elds <= 150 * 1024 && !(ee && atoi(ee) == 0)) {
-            static size_t elds_set = 0;
-            if (elds > 48 * 1024 && elds > elds_set) { HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_edges), hipFuncAttributeMaxDynamicSharedMemorySize, (int)elds)); elds_set = elds; }
+        // HVO_PEAC_EDGES=0: the passes stay inside the clustering kernels (A/B runs, tests)
+        if (elds <= 150 * 1024 && !P->kn.edges.off()) {
+            if (hvo_ensure_dyn_lds(reinterpret_cast<const void *>(k_peac_edges), elds)) return HVO_ERR_HIP;
             hipLaunchKernelGGL(k_peac_edges, dim3(n), dim3(512), elds, st, a, n);
             a.edges_done = 1;
         }
@@ -2067,47 +2071,38 @@ int peac_run(hvo_ctx *ctx, int n)
     {
         // 4 frames per wave pay off once the wave slots are saturated (measured: >= ~3000 resident frames);
         // HVO_PEAC_GL forces a group width (tests run the 16-lane path on small batches with it)
-        const char *e = getenv("HVO_PEAC_GL");
-        const int gl = e ? atoi(e) : -1;
+        const int gl = P->kn.gl.or_(-1);
         const int use = gl > 0 ? gl : (n >= 3072 ? 16 : 64);
         const size_t lq = (size_t)a.tq_n0 * 12;                  // LDS per group: the queue's top level
         // the waves that share a SIMD are a fixed stride apart: their frames are decorrelated (hvo_frame_perm over the waves; the
         // frames of one wave stay consecutive, lockstep likes them alike); HVO_PEAC_PERM=0 for A/B runs
         a.perm = hvo_frame_perm(ctx, (n + (64 / use) - 1) / (64 / use));
-        { const char *e4 = getenv("HVO_PEAC_PERM"); if (e4 && atoi(e4) == 0) a.perm = nullptr; }
+        if (P->kn.perm.off()) a.perm = nullptr;
         a.tq_lds_keys = 0;
         // a handful of frames (the latency case): several queue heads per round, one wave each (peac_heads.inc); HVO_PEAC_HEADS = 0 / 2 / 3 / 4
-        int heads_max = 256; { const char *e8 = getenv("HVO_PEAC_HEADS_MAXN"); if (e8) heads_max = atoi(e8); }
+        const int heads_max = P->kn.heads_maxn.or_(256);
         // three heads + the queue wave = one wave per SIMD of the frame's CU: 256 frames fill the chip exactly, and a lone frame loses nothing
         // against four (a round costs 7.3 instead of 8.0 us for 2.12 instead of 2.34 pops; batch256 9.6 against 9.0 k frames/s)
         // frames whose per-id keys and list headers do not fit LDS (1280x960: 24 704 node ids) take the BIG form: bucket minima, front and
         // conflict bitmaps in LDS, keys in global memory, headers in the node records
         const bool heads_fit = a.tq_n0 * 16 <= 64 * MH_MAXE, heads_big = !heads_fit && a.tq_n0 * 16 <= 64 * MH_MAXE_BIG;
         int heads = (gl <= 0 && n <= heads_max && (heads_fit || heads_big)) ? 3 : 0;
-        { const char *e6 = getenv("HVO_PEAC_HEADS"); if (e6 && (heads_fit || heads_big)) heads = atoi(e6); }
+        if (P->kn.heads.set && (heads_fit || heads_big)) heads = P->kn.heads.v;
         // The LDS form takes 108 KB: one workgroup per CU.  From ~130 frames on the workgroups need (nearly) every CU AT ONCE, and whichever
         // streaming kernel holds more than 52 KB of a CU's LDS at that moment (the ORB tiles, the LSD preamble, the flood) sends one of them
         // into a second turn: batch256 took 27.5 or 33 ms from step to step (profiles/r04_batch256_modes.txt).  The BIG form (32 KB) shares
         // a CU: 10 % slower for a lone frame, no second mode at 256 frames.
         bool big = heads_big || n > 128;
-        { const char *e9 = getenv("HVO_PEAC_HEADS_BIG"); if (e9 && heads_fit) big = atoi(e9) != 0; }      // tests: the BIG form on a frame that would fit
+        if (P->kn.heads_big.set && heads_fit) big = P->kn.heads_big.v != 0;      // tests: the BIG form on a frame that would fit
         if (heads >= 2 && heads <= 4) {
             ClArgs b = a;
-            { const char *e7 = getenv("HVO_PEAC_POOLCAP"); if (e7 && atoi(e7) >= 7 * a.nblk && atoi(e7) < a.poolcap) b.poolcap = atoi(e7); }   // tests: force the pool's compaction
+            if (P->kn.poolcap.set && P->kn.poolcap.v >= 7 * a.nblk && P->kn.poolcap.v < a.poolcap) b.poolcap = P->kn.poolcap.v;   // tests: force the pool's compaction
             const size_t segpad = (size_t)a.tq_n0 * 256;
             const size_t lds = (big ? 0 : segpad * 8) + (size_t)a.tq_n0 * 16 * 12 + segpad / 8 * 4 + 4 * sizeof(MhHead) + 32 + (big ? 0 : segpad * 8) + 512;
-            static size_t lds_set3[2] = { 0, 0 };
-            if (lds > lds_set3[big]) {
-                if (big) {
-                    HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                } else {
-                    HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster_heads<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                }
-                lds_set3[big] = lds;
+            {
+                const void *kf = big ? (heads == 2 ? reinterpret_cast<const void *>(k_peac_cluster_heads<2, true>) : heads == 3 ? reinterpret_cast<const void *>(k_peac_cluster_heads<3, true>) : reinterpret_cast<const void *>(k_peac_cluster_heads<4, true>))
+                                     : (heads == 2 ? reinterpret_cast<const void *>(k_peac_cluster_heads<2, false>) : heads == 3 ? reinterpret_cast<const void *>(k_peac_cluster_heads<3, false>) : reinterpret_cast<const void *>(k_peac_cluster_heads<4, false>));
+                if (hvo_ensure_dyn_lds(kf, lds)) return HVO_ERR_HIP;
             }
             if (big) {
                 if (heads == 2) hipLaunchKernelGGL((k_peac_cluster_heads<2, true>), dim3(n), dim3(192), lds, st, b, n);
@@ -2122,12 +2117,11 @@ int peac_run(hvo_ctx *ctx, int n)
         else if (use == 64) {
             size_t lds = lq;
             bool ldsq = n <= 256;                                  // at most one such frame per CU
-            { const char *e5 = getenv("HVO_PEAC_LDSQ"); if (e5) ldsq = atoi(e5) != 0; }
+            if (P->kn.ldsq.set) ldsq = P->kn.ldsq.v != 0;
             const size_t full = ((lq + 15) & ~(size_t)15) + (size_t)a.tq_n0 * (256 * 8 + 16 * 12);
             if (ldsq && full <= 150 * 1024) {
                 a.tq_lds_keys = 1; lds = full;
-                static size_t lds_set2 = 0;
-                if (lds > 48 * 1024 && lds > lds_set2) { HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_peac_cluster<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); lds_set2 = lds; }
+                if (hvo_ensure_dyn_lds(reinterpret_cast<const void *>(k_peac_cluster<64>), lds)) return HVO_ERR_HIP;
             }
             hipLaunchKernelGGL(k_peac_cluster<64>, dim3(n), dim3(64), lds, st, a, n);
         }
@@ -2145,16 +2139,14 @@ int peac_run(hvo_ctx *ctx, int n)
     r.qcap = P->qcap; r.plidmap = P->d_plidmap; r.planes = P->d_planes; r.c30 = P->c30;
     {
         // threads per frame (one queue entry = 4 events per thread and round); HVO_FLOOD_T overrides
-        const char *e = getenv("HVO_FLOOD_T");
-        const int flood_t = e ? atoi(e) : -1;
+        const int flood_t = P->kn.flood_t.or_(-1);
         // measured: 256 threads per frame up to ~4096 resident frames, one wave per frame (less LDS, all frames in flight) beyond
         // a lone frame (the latency case) takes 512: the flood's rounds are serial, so its time goes with the events a round retires
         const int ft = flood_t > 0 ? flood_t : (n >= 6144 ? 64 : n <= 8 ? 512 : 256);
-        const char *e2 = getenv("HVO_FLOOD_EPL");          // queue entries per thread and round (one-wave variant only)
-        const int fe = e2 ? atoi(e2) : 1;
+        const int fe = P->kn.flood_epl.or_(1);             // HVO_FLOOD_EPL: queue entries per thread and round (one-wave variant only)
         r.perm = hvo_frame_perm(ctx, n);                   // one wave per frame for its whole life: frames of a SIMD decorrelated
         if ((ctx->sched == 5 || ctx->sched == 7) && ctx->fast_recorded && !ctx->serialize) HVO_HIP(hipStreamWaitEvent(st, ctx->ev_fast, 0));      // experiment: the flood takes all LDS, k_fast_cells needs some
-        { const char *e3 = getenv("HVO_FLOOD_PERM"); if (e3 && atoi(e3) == 0) r.perm = nullptr; }
+        if (P->kn.flood_perm.off()) r.perm = nullptr;
         if (ft == 64 && fe == 2) hipLaunchKernelGGL((k_peac_flood<64, 2>), dim3(n), dim3(64), 0, st, r, P->d_adj);
         else if (ft == 64) hipLaunchKernelGGL((k_peac_flood<64, 1>), dim3(n), dim3(64), 0, st, r, P->d_adj);
         else if (ft == 512) hipLaunchKernelGGL((k_peac_flood<512, 1>), dim3(n), dim3(512), 0, st, r, P->d_adj);

@@ -468,6 +468,12 @@ int  hvo_stream_search_lines_by_projection(hvo_stream *s, int64_t cur, int64_t l
 int hvo_pin_host(void *p, size_t bytes);
 int hvo_unpin_host(void *p);
 
+/* What the line growing of the last small batch / streamed frame fell back on (lsd_async.inc: several waves per frame, used for up to 16 frames):
+ * frames that were grown again by the one-wave kernel because the workers gave up (never an error: the result is the same lines), workers that
+ * found themselves on another XCD than their frame's and counted themselves out (exact, slower; > 0 means the dispatcher does not deal
+ * workgroups b, b + 8, ... to one XCD on this system: set HVO_LSD_ASYNC=0), and the workers per frame of that launch (0: it was not async). */
+int hvo_lsd_async_report(hvo_ctx *ctx, int *frames_regrown, int *foreign_workers, int *workers_per_frame);
+
 /* ---- measurement hooks (bench.py) ---- */
 /* Per-kernel-group device time of the last hvo_batch_run, measured with hipEvents on the ctx
  * stream.  names[i] points at static strings.  Returns the number of groups written (<= cap). */

@@ -331,3 +331,36 @@ def test_lines_more_segments_than_a_fixed_cap(hvo, orc):
     finally:
         ctx.close()
 
+
+
+@pytest.mark.parametrize("n,workers", [(1, "32"), (5, "8")])
+def test_lines_async_gives_up_and_the_frame_is_grown_again(hvo, orc, synth, monkeypatch, n, workers):
+    """VERDICT r4 (fail soft): a frame on which the async growing's bounded wait expires used to come back as HVO_ERR_CAPACITY with no lines.
+    HVO_LSD_ASYNC_SPIN_MAX=0 (a test hook, read when the plan is built) makes every wait of 16 polls expire: the frames are formed again
+    and grown by the one-wave kernel inside the same hvo_batch_run -- status 0, the oracle's lines, and the report says so."""
+    monkeypatch.setenv("HVO_LSD_ASYNC", workers); monkeypatch.setenv("HVO_LSD_ASYNC_SPIN_MAX", "0")
+    g = np.stack([synth.make_gray("std" if k != 1 else "lowtex", 0x5EED7300 + k) for k in range(n)])
+    ctx = hvo.Context(max_batch=n)
+    try:
+        ctx.batch_upload(g, np.zeros((n, 480, 640), np.uint16))
+        regrown_total = 0
+        for _ in range(2):
+            ctx.batch_run(hvo.STAGE_LSD)
+            res = ctx.batch_download(hvo.STAGE_LSD)
+            regrown, foreign, wpf = ctx.lsd_async_report()
+            assert wpf == int(workers) and foreign == 0 and 0 <= regrown <= n
+            regrown_total += regrown
+            for b in range(n):
+                assert res[b]["status"] == 0
+                check(res[b]["kl"], res[b]["ldesc"], res[b]["linefn"], *orc.line_extract(g[b]))
+        assert regrown_total > 0                                    # the hook did force the fallback
+    finally:
+        ctx.close()
+    # and without the hook nothing is grown twice
+    monkeypatch.delenv("HVO_LSD_ASYNC_SPIN_MAX")
+    ctx = hvo.Context(max_batch=n)
+    try:
+        ctx.batch_upload(g, np.zeros((n, 480, 640), np.uint16)); ctx.batch_run(hvo.STAGE_LSD)
+        assert ctx.lsd_async_report()[0] == 0
+    finally:
+        ctx.close()
