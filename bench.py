@@ -118,6 +118,22 @@ def load_json(rel):
         return None
 
 
+def sources_sha16():
+    """sha256 of the kernel sources (csrc/*.hip, *.inc, *.hpp), first 16 hex digits: the replayed counter profiles carry the hash of the
+    sources they were measured on, and the bench line says `*_stale: true` when a kernel has changed since"""
+    import glob, hashlib
+    hsh = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "a-low-texture-robust-hybrid-feature-based-visual-odometry_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".inc", ".hpp")):
+            hsh.update(os.path.basename(f).encode()); hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def profile_stale(rel):
+    t = load_json(rel)
+    return bool(t is None or t.get("sources_sha16") != sources_sha16())
+
+
 def hbm_traffic(group, B, width):
     """HBM bytes per launch of a kernel group from the PMC counters (FETCH_SIZE + WRITE_SIZE, collected in separate
     rocprofv3 --pmc passes of this same command; the counters cannot be read from inside the process, so the figure is
@@ -338,10 +354,26 @@ def end_to_end(hvo, np, ctx, g, d, mask, B, rounds=4):
         # what came down is what a download gives: the header of the last slab against the batch's own counts
         hdr = host[(rounds - 1) & 1][:16].view(np.int32)
         ok = int(hdr[0]) > 0 and int(hdr[3]) == 0
+        # ... and its PAYLOAD: the first 32 frames of the last slab (records and the int8 label image, as they crossed PCIe through the pack +
+        # async-copy path) byte for byte against hvo_batch_download of the same images run once more (every batch of this loop is the same
+        # images, and the pipeline is deterministic)
+        import importlib
+        hd = importlib.import_module("hvo_amd.dist")
+        kc, lc, pc, sb2, _ = ctx.slab_layout(labels=True)
+        ctx.batch_run(mask)
+        m = min(32, n)
+        ref = ctx.batch_download(mask, n=m)
+        hh, ww = g.shape[1], g.shape[2]
+        back = hd.unpack_results(hvo, host[(rounds - 1) & 1][: m * sb2].reshape(m, sb2), kc, lc, pc, label_shape=(hh, ww))
+        nbad = 0
+        for a, b in zip(back, ref):
+            for key in ("kp", "desc", "kl", "ldesc", "linefn", "planes", "labels"):
+                if key in b and not np.array_equal(a[key], b[key]): nbad += 1
+        ok = ok and nbad == 0 and len(back) == m
     finally:
         for a in host: hvo.unpin(a)
         hvo.unpin(g); hvo.unpin(d)
-    return round(rounds * n / el, 1), ok, "%d rounds of %d frames, one context, inputs and results double-buffered; %.1f MB up and %.1f MB down per frame" % (rounds, n, (g[0].nbytes + d[0].nbytes) / 1e6, sb / 1e6)
+    return round(rounds * n / el, 1), ok, "%d rounds of %d frames, one context, inputs and results double-buffered; %.1f MB up and %.1f MB down per frame; results_ok = %d frames of the last slab byte-equal to hvo_batch_download (records + label image)" % (rounds, n, (g[0].nbytes + d[0].nbytes) / 1e6, sb / 1e6, m)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -573,6 +605,27 @@ def main():
     e2e = None
     if rank == 0 and world == 1 and not args.no_extras and args.config != "big1280" and mask == hvo.STAGE_ALL:
         e2e = end_to_end(hvo, np, ctx, g0, d0, mask, B)
+    # the same step on `std` frames only (SURVEY.md 8d item 4 specifies 256 `std` frames; the headline's mix holds a quarter of `lowtex`
+    # frames, whose line stage is five times cheaper): the mix's std frames + as many new ones as it has lowtex frames, same batch size
+    std_only = None
+    if rank == 0 and world == 1 and not args.no_extras and args.config == "std640":
+        keep = [k for k in range(ndistinct) if kinds[k] == "std"]
+        gs = np.empty_like(g0); ds = np.empty_like(d0)
+        gs[: len(keep)] = g0[keep]; ds[: len(keep)] = d0[keep]
+        for k in range(len(keep), ndistinct):
+            gs[k], ds[k] = synth.make_frame("std", 0x5EED9000 + 100000 * rank + k, w, h)
+        ctx.batch_upload(gs, ds, repeat=reps)
+        ctx.batch_run(mask)
+        ssteps = max(1, min(steps, 5))
+        t1 = time.perf_counter()
+        for _ in range(ssteps):
+            ctx.batch_run(mask)
+        dts = time.perf_counter() - t1
+        rs = ctx.batch_download(mask, n=min(B, 64))
+        std_only = {"value": round(B * ssteps / dts, 2), "ms_per_step": round(dts / ssteps * 1e3, 4), "steps": ssteps, "frames_per_gpu": B,
+                    "mean_keypoints": round(float(np.mean([len(r["kp"]) for r in rs])), 1) if "orb" in stages else 0.0,
+                    "mean_lines": round(float(np.mean([len(r["kl"]) for r in rs])), 1) if "lsd" in stages else 0.0,
+                    "scene_mix": {"std": ndistinct}}
     ctx.close()
     parity = parity_sample(ge, np, stages, res, g0, d0, kinds, nfeat, scale=w / 640.0) if rank == 0 else None
 
@@ -594,9 +647,11 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": kroof[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kroof[dom]["frac"], "traffic": tr,
                     "traffic_source": (TRAFFIC_PROFILE + " (replayed: separate rocprofv3 --pmc passes of this command)") if tr is not None else None,
+                    "traffic_stale": profile_stale(TRAFFIC_PROFILE) if tr is not None else None,      # true: a kernel source changed after that profile was taken
                     "bytes_per_launch": int(table.get(dom, 0) * B), "ms_per_launch": round(groups[dom], 4),
                     "limiter": "dependent-latency chain (serial semantics), not HBM bandwidth: see valu_issue_frac / DESIGN.md section 4"}
             roof.update(sq_utilisation(value))
+            roof["counters_stale"] = profile_stale(SQ_PROFILE)
             vif = roof.get("valu_issue_frac")
             if vif is not None:
                 # what limits the STEP (all kernels overlapped): the vector ALUs' issue slots once they are more than half taken; the dominant
@@ -631,6 +686,8 @@ def main():
             out["gather"] = gather
         if world == 1 and not args.no_extras:
             out["latency_ms"] = latency_probe(hvo, args.config, g0, d0, mask, local_rank)
+            if std_only is not None:
+                out["value_std_only"] = std_only["value"]; out["std_only"] = std_only
             if e2e is not None:
                 # the end-to-end figure: host images in, host results (records + int8 label image) out, consecutive batches
                 out["value_end_to_end"] = e2e[0]

@@ -4,6 +4,17 @@
 import csv, glob, json, os, sys
 from collections import defaultdict
 
+
+def sources_sha16():
+    """as bench.py: sha256 of csrc/*.hip, *.inc, *.hpp (the sources the counters were measured on; run this right after the GPU pass)"""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hsh = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(root, "a-low-texture-robust-hybrid-feature-based-visual-odometry_amd", "csrc", "*"))):
+        if p.endswith((".hip", ".inc", ".hpp")):
+            hsh.update(os.path.basename(p).encode()); hsh.update(open(p, "rb").read())
+    return hsh.hexdigest()[:16]
+
 GROUPS = {"peac_cluster": ["k_peac_cluster"], "lsd_grow": ["k_lsd_grow", "k_lsd_grow_dense"], "peac_refine": ["k_peac_blkmap", "k_peac_flood", "k_peac_final", "k_peac_relabel"],
           "orb_levels": ["k_orb_level"], "orb_fast_cells": ["k_fast_cells"], "lsd_gradient": ["k_lsd_resize_grad"], "lsd_pre": ["k_lsd_pre"], "lbd_desc": ["k_lbd_desc"], "orb_pyramid": ["k_resize", "k_resize_dw"],
           "orb_blur": ["k_blur7"], "lsd_blur_scale": ["k_lsd_blur"], "lbd_sobel": ["k_lbd_blur5", "k_lbd_sobel", "k_lbd_blur_sobel"],
@@ -31,7 +42,7 @@ def main():
                  "summed over a group's kernels / frames per launch, x1024.  Calibration on kernels with a known byte count and the same access "
                  "width: k_blur7 (dword loads/stores, 950532 B each way + halo/pitch) reads 1:1, k_lsd_blur writes 2400 KiB fp64 -> WRITE 2400 KiB; "
                  "the x2 FETCH_SIZE correction of MI355X_MICROARCH.md applies to 16 B/lane reads: applied to k_orb_level, k_moments, k_brief (tile rows / patch rows as dwordx4), the other kernels use <= 8 B/lane.",
-         "frames_per_launch": B, "bytes_per_frame": {}}
+         "frames_per_launch": B, "sources_sha16": sources_sha16(), "bytes_per_frame": {}}
     for g, ks in GROUPS.items():
         j["bytes_per_frame"][g] = {"fetch": round(sum(fe.get(k, 0) * (2 if k in WIDE_READS else 1) for k in ks) / B * 1024), "write": round(sum(wr.get(k, 0) for k in ks) / B * 1024)}
     json.dump(j, open(out, "w"), indent=1)
