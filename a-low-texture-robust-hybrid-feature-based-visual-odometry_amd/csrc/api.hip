@@ -312,7 +312,7 @@ int hvo_batch_run(hvo_ctx *ctx, unsigned stages)
     // sched 3 / 4 (experiments): the plane stage is enqueued last, after LSD then ORB (3) or ORB then LSD (4)
     // measured (profiles/r02_sched_sweep.txt): policy 5 wins once the batch fills the wave slots (8192 frames: 207 against 218 ms,
     // 4096: 112 against 115), policy 1 below (2048 frames: 69 against 77 ms; 2048 frames of 1280x960: 344 against 387)
-    // round 3 (tools/knob_sweep*.sh): frames of 1280x960 prefer 7 -- their growing kernel is six times longer and loses more by waiting
+    // round 3 (tools/sweep.sh preset knobs1280): frames of 1280x960 prefer 7 -- their growing kernel is six times longer and loses more by waiting
     // for FAST than FAST loses beside it (3072 frames: 340 against 389 ms); 640x480 keeps 5 (188.8 against 191.3 ms at 8192 frames)
     const bool big_frames = (long long)ctx->batch_w * ctx->batch_h >= 2LL * 640 * 480;
     ctx->sched = ctx->sched_cfg >= 0 ? ctx->sched_cfg : (ctx->batch_n >= 3072 ? (big_frames ? 7 : 5) : 1);

@@ -281,7 +281,7 @@ def test_lines_async_1280(hvo, orc, synth, monkeypatch):
 def test_lbd_float_sqrt_is_correctly_rounded(hvo, orc, synth):
     """A 3-pixel vertical key line of this frame has a band deviation sqrt(0x1.b8a4d0p-5): `__fsqrt_rn` of this ROCm's headers is
     v_sqrt_f32 (0x1.dafbdap-3, one ulp low) and flipped one bit of the line's LBD descriptor; sqrtf() is correctly rounded
-    (tools/microbench/sqrt_check.hip).  Found by tools/soak_long.sh, frame 26 of its second run."""
+    (tools/microbench/sqrt_check.hip).  Found by tools/soak_suite.sh long, frame 26 of its second run."""
     g = synth.make_gray("lowtex", 0xE00E1000 + 26)
     kl_o, d_o, fn_o = orc.line_extract(g)
     ctx = hvo.Context()
