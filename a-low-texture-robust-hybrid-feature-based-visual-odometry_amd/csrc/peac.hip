@@ -1380,14 +1380,27 @@ __global__ __launch_bounds__(256) void k_peac_blkmap(const int *__restrict__ par
     __syncthreads();
     // phase 2: the frame's pixels in state order (tile by tile: coalesced stores, depth read in 8-byte row pieces);
     // pixels outside the block grid get -1, tile padding outside the image is never read
-    const int tw = FS_TW(w), nst = tw * FS_TH(h) * 32;
-    for (int i = slice * 256 + tid; i < nst; i += 256 * nslices) {
-        const int t = i >> 5, ty = t / tw, tx = t - ty * tw;
-        const int x = tx * 8 + (i & 7), y = ty * 4 + ((i >> 3) & 3);
-        if (x >= w || y >= h) continue;
-        const int by = y / WIN, bx = x / WIN;
-        const int lab = (by < Nh && bx < Nw) ? blkmap[by * Nw + bx] : -1;
-        state[i] = FS_MAKE(lab, lab >= 0, D[(size_t)y * pitch + x]);
+    // a thread forms one row of a tile: eight states = 32 bytes (two 16-byte stores), their depths one 16-byte load (pitch and x are
+    // multiples of 8; the frame's depth slab has a spare row behind it, and columns past the image are never read back); the row's
+    // eight pixels lie in at most two blocks of the block grid
+    const int tw = FS_TW(w), nrows = tw * FS_TH(h) * 4;
+    for (int i = slice * 256 + tid; i < nrows; i += 256 * nslices) {
+        const int t = i >> 2, ty = t / tw, tx = t - ty * tw;
+        const int x0 = tx * 8, y = ty * 4 + (i & 3);
+        if (y >= h) continue;
+        const int by = y / WIN, bx0 = x0 / WIN, xs = (bx0 + 1) * WIN;            // pixels x >= xs belong to block column bx0 + 1
+        const int l0 = (by < Nh && bx0 < Nw) ? blkmap[by * Nw + bx0] : -1, l1 = (by < Nh && bx0 + 1 < Nw) ? blkmap[by * Nw + bx0 + 1] : -1;
+        unsigned dd[4];
+        if (x0 + 8 <= pitch) { const uint4 q = *reinterpret_cast<const uint4 *>(D + (size_t)y * pitch + x0); dd[0] = q.x; dd[1] = q.y; dd[2] = q.z; dd[3] = q.w; }
+        else { for (int k = 0; k < 4; k++) { const int xa = x0 + 2 * k; dd[k] = (xa < w ? (unsigned)D[(size_t)y * pitch + xa] : 0u) | ((xa + 1 < w ? (unsigned)D[(size_t)y * pitch + xa + 1] : 0u) << 16); } }
+        unsigned st[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int lab = x0 + k < xs ? l0 : l1;
+            st[k] = FS_MAKE(lab, lab >= 0, (dd[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(state + (size_t)i * 8);
+        dst[0] = make_uint4(st[0], st[1], st[2], st[3]); dst[1] = make_uint4(st[4], st[5], st[6], st[7]);
     }
 }
 
