@@ -1460,12 +1460,17 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
     static_assert(NEV <= 2048, "the group lists hold 11-bit event indices");
     constexpr int IXB = NEV > 1024 ? 11 : 10;                     // bits of a compact event index; (plane << IXB) | index is 16 bits, or 17 in a 32-bit entry
     constexpr unsigned IXM = (1u << IXB) - 1u;
-    typedef typename std::conditional<(NEV > 1024), unsigned int, unsigned short>::type hl_t;
-    __shared__ double pl[MAX_PLANES][8];          // center[3], normal[3], mse, pad
+    // group lists: (plane << IXB) | compact index per entry; the one-wave form (256 events) stores the index alone, in a byte, and reads the plane
+    // from the event's record -- 1 KB instead of 2, which with the 8-byte records makes 16 workgroups per CU instead of 12 (the kernel is a chain of
+    // dependent instructions per wave: ~1000 of every kind per round at ~1.8 ns each, profiles/r05_valu_salu_issue.txt; frames in flight are its throughput)
+    constexpr bool HL8 = NEV <= 256;
+    typedef typename std::conditional<HL8, unsigned char, typename std::conditional<(NEV > 1024), unsigned int, unsigned short>::type>::type hl_t;
+    __shared__ double pl[MAX_PLANES][7];          // center[3], normal[3], mse
     __shared__ unsigned long long adj[MAX_PLANES], simok[MAX_PLANES];
-    __shared__ int hkeys[FLOOD_HS], hcnt[FLOOD_HS];
+    __shared__ int hkeys[FLOOD_HS], hcnt[FLOOD_HS];       // (a ranked round borrows both, by compact event index, once they are empty again: distances and push flags)
     __shared__ __attribute__((aligned(16))) hl_t hlist[FLOOD_HS * FLOOD_HL];
-    __shared__ uint4 rec[NEV];                    // the round's live events in event order: packed (plane, y, x) of the target pixel, its state word, its dist bits
+    __shared__ uint2 rec[NEV];                    // the round's live events in event order: packed (plane, y, x) of the target pixel, its state word
+    static_assert(FLOOD_HS >= NEV, "a ranked round indexes hkeys / hcnt by compact event index");
     __shared__ int wsum[EPL * NW], psum[FLOOD_NP * NW];
     __shared__ int s_nq, s_cx[2];
     const ClArgs &a = r.c;
@@ -1654,7 +1659,7 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                 const int px[4] = { sx - 1, sx + 1, sx, sx }, py[4] = { sy, sy, sy - 1, sy + 1 };
                 int c = off[e] + below[e];
 #pragma unroll
-                for (int j = 0; j < 4; j++) if (actm & (1u << (e * 4 + j))) { rec[c] = make_uint4((unsigned)FQ_PACK(px[j], py[j], plid), st[e][j], 0u, 0u); c++; }
+                for (int j = 0; j < 4; j++) if (actm & (1u << (e * 4 + j))) { rec[c] = make_uint2((unsigned)FQ_PACK(px[j], py[j], plid), st[e][j]); c++; }
             }
         }
         lds_barrier();
@@ -1673,7 +1678,7 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                 const int c = p * FLOOD_T + tid;
                 ev[p] = c < na;
                 if (ev[p]) {
-                    const uint4 R = rec[c];
+                    const uint2 R = rec[c];
                     eq[p] = R.x; es[p] = R.y;
                     const int ep = (int)(R.x >> 26), ex_ = (int)(R.x & 8191u), ey = (int)((R.x >> 13) & 8191u);
                     eix[p] = FS_IDX(ex_, ey, stw);
@@ -1685,7 +1690,7 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                         s = (s + 1) & (FLOOD_HS - 1);
                     }
                     const int pos = atomicAdd(&hcnt[s], 1);
-                    if (pos < FLOOD_HL) hlist[s * FLOOD_HL + pos] = (hl_t)((ep << IXB) | c);
+                    if (pos < FLOOD_HL) hlist[s * FLOOD_HL + pos] = HL8 ? (hl_t)c : (hl_t)((ep << IXB) | c);
                     hs[p] = s;
                 }
             }
@@ -1703,7 +1708,11 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                 else if (cnt[p] > 1) {
                     const unsigned me = ((eq[p] >> 26) << IXB) | (unsigned)(p * FLOOD_T + tid);
                     const hl_t *hp_ = &hlist[hs[p] * FLOOD_HL];
-                    const unsigned l[4] = { hp_[0], hp_[1], hp_[2], hp_[3] };
+                    unsigned l[4] = { hp_[0], hp_[1], hp_[2], hp_[3] };
+                    if (HL8) {
+#pragma unroll
+                        for (int t = 0; t < 4; t++) if (t < cnt[p]) l[t] |= (rec[l[t]].x >> 26) << IXB;
+                    }
 #pragma unroll
                     for (int t = 0; t < 4; t++) if (t < cnt[p]) {
                         if ((l[t] ^ me) >> IXB) multi[p] = true;                   // another plane on the same pixel
@@ -1744,13 +1753,17 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                 ft[6]++;
 #endif
 #pragma unroll
-                for (int p = 0; p < FLOOD_NP; p++) if (p < npass && multi[p]) rec[p * FLOOD_T + tid].w = eok[p] ? __float_as_uint(ecd[p]) : 0xFFFFFFFFu;
+                for (int p = 0; p < FLOOD_NP; p++) if (p < npass && multi[p]) hkeys[p * FLOOD_T + tid] = (int)(eok[p] ? __float_as_uint(ecd[p]) : 0xFFFFFFFFu);
                 lds_barrier();
 #pragma unroll
                 for (int p = 0; p < FLOOD_NP; p++) {
                     if (p < npass && first[p] && multi[p]) {
                         const hl_t *hp_ = &hlist[hs[p] * FLOOD_HL];
-                        const unsigned l[4] = { hp_[0], hp_[1], hp_[2], hp_[3] };
+                        unsigned l[4] = { hp_[0], hp_[1], hp_[2], hp_[3] };
+                        if (HL8) {
+#pragma unroll
+                            for (int t = 0; t < 4; t++) if (t < cnt[p]) l[t] |= (rec[l[t]].x >> 26) << IXB;
+                        }
                         int trail = FS_LABEL(es[p]); float dist = ed[p];
                         int last = -1;
                         for (int it = 0; it < cnt[p]; it++) {
@@ -1759,21 +1772,21 @@ __global__ __launch_bounds__(FLOOD_T) void k_peac_flood(RfArgs r, unsigned long 
                             for (int t = 0; t < 4; t++) { const int ct = (int)(l[t] & IXM); if (t < cnt[p] && ct > last && ct < c) { c = ct; best = l[t]; } }
                             const int ep = (int)(best >> IXB);
                             last = c;
-                            const unsigned okcd = rec[c].w;
+                            const unsigned okcd = (unsigned)hkeys[c];
                             const bool ok = okcd != 0xFFFFFFFFu; const float cd = __uint_as_float(okcd);
                             const bool live = !(trail <= -6 || trail == ep);
                             const bool closer = live && ok && cd < dist;
                             if (live && ok && trail >= 0 && ((simok[ep] >> trail) & 1ull)) { atomicOr(&adj[trail], 1ull << ep); atomicOr(&adj[ep], 1ull << trail); }
                             trail = closer ? ep : ((live && trail < 0) ? trail - 1 : trail);
                             dist = closer ? cd : dist;
-                            rec[c].z = closer ? 1u : 0u;
+                            hcnt[c] = closer ? 1 : 0;
                         }
                         state[eix[p]] = (es[p] & ~0xFFu) | ((unsigned)trail & 0xFFu);
                     }
                 }
                 lds_barrier();
 #pragma unroll
-                for (int p = 0; p < FLOOD_NP; p++) if (p < npass && multi[p]) push[p] = rec[p * FLOOD_T + tid].z != 0u;
+                for (int p = 0; p < FLOOD_NP; p++) if (p < npass && multi[p]) { push[p] = hcnt[p * FLOOD_T + tid] != 0; hkeys[p * FLOOD_T + tid] = -1; hcnt[p * FLOOD_T + tid] = 0; }     // (the table is empty again)
             }
             // ---- ordered append: exclusive scan of the pushes in compact (= event) order ----
             unsigned long long bm[FLOOD_NP]; int off[FLOOD_NP];

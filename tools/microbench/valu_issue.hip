@@ -31,8 +31,8 @@
         __syncthreads();                                                                                                 \
         const uint64_t t0 = __builtin_readcyclecounter();                                                                \
         for (int it = 0; it < iters; it++) {                                                                             \
-            if (DEP) { asm volatile(D16(INS) D16(INS) D16(INS) D16(INS) : ACC16 : "v"(s0), "v"(s1) : "vcc", "s20"); }                   \
-            else     { asm volatile(R16(INS) R16(INS) R16(INS) R16(INS) : ACC16 : "v"(s0), "v"(s1) : "vcc", "s20"); }                   \
+            if (DEP) { asm volatile(D16(INS) D16(INS) D16(INS) D16(INS) : ACC16 : "v"(s0), "v"(s1) : "vcc", "s20", "s21", "scc"); }                   \
+            else     { asm volatile(R16(INS) R16(INS) R16(INS) R16(INS) : ACC16 : "v"(s0), "v"(s1) : "vcc", "s20", "s21", "scc"); }                   \
         }                                                                                                                \
         const uint64_t t1 = __builtin_readcyclecounter();                                                                \
         T s = a[0]; for (int i = 1; i < 16; i++) s += a[i];                                                              \
@@ -92,6 +92,13 @@
 #define I_RCPF64(i)   "v_rcp_f64 %" #i ", %" #i "\n"
 #define I_READLANE(i) "v_readlane_b32 s20, %" #i ", 3\n"
 #define I_LDSRD(i)    "ds_read_b32 %" #i ", %16\n"
+// round 5: do SCALAR instructions take issue slots from the vector ones?  (the step's time matches (VALU + SALU) x 1.77 ns, not VALU alone)
+#define I_SADD(i)        "s_add_u32 s20, s20, 1\n"
+#define I_XOR_SADD(i)    "v_xor_b32 %" #i ", %" #i ", %16\n s_add_u32 s20, s20, 1\n"
+#define I_DOT4_SADD(i)   "v_dot4_u32_u8 %" #i ", %16, %17, %" #i "\n s_add_u32 s20, s20, 1\n"
+#define I_DOT4_SADD2(i)  "v_dot4_u32_u8 %" #i ", %16, %17, %" #i "\n s_add_u32 s20, s20, 1\n s_and_b32 s21, s20, 7\n"
+#define I_FMA64_SADD(i)  "v_fma_f64 %" #i ", %" #i ", %16, %17\n s_add_u32 s20, s20, 1\n"
+#define I_DOT4_NOP(i)    "v_dot4_u32_u8 %" #i ", %16, %17, %" #i "\n s_nop 0\n"
 
 DEF_KERNEL(add_u32, uint32_t, I_ADD)
 DEF_KERNEL(add3_u32, uint32_t, I_ADD3)
@@ -137,6 +144,12 @@ DEF_KERNEL(add_f64, double, I_ADDF64)
 DEF_KERNEL(fma_f64, double, I_FMAF64)
 DEF_KERNEL(sqrt_f64, double, I_SQRTF64)
 DEF_KERNEL(rcp_f64, double, I_RCPF64)
+DEF_KERNEL(s_add_only, uint32_t, I_SADD)
+DEF_KERNEL(xor_plus_sadd, uint32_t, I_XOR_SADD)
+DEF_KERNEL(dot4_plus_sadd, uint32_t, I_DOT4_SADD)
+DEF_KERNEL(dot4_plus_2salu, uint32_t, I_DOT4_SADD2)
+DEF_KERNEL(fma64_plus_sadd, double, I_FMA64_SADD)
+DEF_KERNEL(dot4_plus_snop, uint32_t, I_DOT4_NOP)
 
 struct Entry { const char *name; int per_copy; void (*run)(int, bool, int, uint32_t *, uint32_t *); };
 
@@ -175,6 +188,7 @@ int main(int argc, char **argv)
         ENTRY(mov_dpp, uint32_t, 1), ENTRY(add_u32_dpp, uint32_t, 1), ENTRY(cvt_f32_ubyte1, uint32_t, 1),
         ENTRY(fma_f32, float, 1), ENTRY(add_f32, float, 1), ENTRY(rcp_f32, float, 1), ENTRY(pk_fma_f32, double, 1),
         ENTRY(mul_f64, double, 1), ENTRY(add_f64, double, 1), ENTRY(fma_f64, double, 1), ENTRY(sqrt_f64, double, 1), ENTRY(rcp_f64, double, 1),
+        ENTRY(s_add_only, uint32_t, 1), ENTRY(xor_plus_sadd, uint32_t, 2), ENTRY(dot4_plus_sadd, uint32_t, 2), ENTRY(dot4_plus_2salu, uint32_t, 3), ENTRY(fma64_plus_sadd, double, 2), ENTRY(dot4_plus_snop, uint32_t, 2),
 
     };
     printf("# %s, %d CUs, clock attribute %d kHz; %d loop iterations x 64 instructions per wave\n", prop.gcnArchName, ncu, clk, iters);
