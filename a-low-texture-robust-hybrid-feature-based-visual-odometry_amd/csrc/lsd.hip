@@ -1215,34 +1215,45 @@ __global__ __launch_bounds__(64) void k_lbd_desc(const short2 *__restrict__ dxyI
         for (int q = 0; q < 8; q++) band[t][q] = s[q];
     }
     __syncthreads();
-    if (t == 0) {
-        const float invN2 = (float)(1.0 / 14.0), invN3 = (float)(1.0 / 21.0);
-        for (int b = 0; b < 9; b++) {
-            const float invN = (b == 0 || b == 8) ? invN2 : invN3;
-            float tmp = __fmul_rn(band[b][0], invN);
-            dv[8 * b] = tmp; dv[8 * b + 4] = sqrtf(__fsub_rn(__fmul_rn(band[b][2], invN), __fmul_rn(tmp, tmp)));
-            tmp = __fmul_rn(band[b][1], invN);
-            dv[8 * b + 1] = tmp; dv[8 * b + 5] = sqrtf(__fsub_rn(__fmul_rn(band[b][3], invN), __fmul_rn(tmp, tmp)));
-            tmp = __fmul_rn(band[b][4], invN);
-            dv[8 * b + 2] = tmp; dv[8 * b + 6] = sqrtf(__fsub_rn(__fmul_rn(band[b][6], invN), __fmul_rn(tmp, tmp)));
-            tmp = __fmul_rn(band[b][5], invN);
-            dv[8 * b + 3] = tmp; dv[8 * b + 7] = sqrtf(__fsub_rn(__fmul_rn(band[b][7], invN), __fmul_rn(tmp, tmp)));
-        }
+    // Mean / standard deviation of the nine bands, the three normalisations and the clip (binary_descriptor_custom.cpp:1256-1341).  One lane
+    // used to walk all 72 values four times (~1400 wave-instructions of a 3200-instruction kernel that is bound by issue); now lane b < 9 forms
+    // band b's eight values, every lane keeps one value (lanes 0..7 a second one: 64 + lane) and scales / clips it, and only the three sums --
+    // whose order of additions is the reference's -- are chains: every term is read from its lane (v_readlane, a uniform operand) and added by
+    // all lanes at once, so the totals need no broadcast.
+    if (t < 9) {
+        const float invN = (t == 0 || t == 8) ? (float)(1.0 / 14.0) : (float)(1.0 / 21.0);
+        float tmp = __fmul_rn(band[t][0], invN);
+        dv[8 * t] = tmp; dv[8 * t + 4] = sqrtf(__fsub_rn(__fmul_rn(band[t][2], invN), __fmul_rn(tmp, tmp)));
+        tmp = __fmul_rn(band[t][1], invN);
+        dv[8 * t + 1] = tmp; dv[8 * t + 5] = sqrtf(__fsub_rn(__fmul_rn(band[t][3], invN), __fmul_rn(tmp, tmp)));
+        tmp = __fmul_rn(band[t][4], invN);
+        dv[8 * t + 2] = tmp; dv[8 * t + 6] = sqrtf(__fsub_rn(__fmul_rn(band[t][6], invN), __fmul_rn(tmp, tmp)));
+        tmp = __fmul_rn(band[t][5], invN);
+        dv[8 * t + 3] = tmp; dv[8 * t + 7] = sqrtf(__fsub_rn(__fmul_rn(band[t][7], invN), __fmul_rn(tmp, tmp)));
+    }
+    __syncthreads();
+    {
+        float v0 = dv[t], v1 = t < 8 ? dv[64 + t] : 0.f;           // value t, and value 64 + t on lanes 0..7
+        auto lane_of = [](float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); };
+        float p0 = __fmul_rn(v0, v0), p1 = __fmul_rn(v1, v1);
         float tempM = 0, tempS = 0;
-        for (int b = 0; b < 9; b++) {
-            for (int q = 0; q < 4; q++) tempM = __fadd_rn(tempM, __fmul_rn(dv[8 * b + q], dv[8 * b + q]));
-            for (int q = 4; q < 8; q++) tempS = __fadd_rn(tempS, __fmul_rn(dv[8 * b + q], dv[8 * b + q]));
+#pragma unroll
+        for (int i = 0; i < 72; i++) {
+            const float term = i < 64 ? lane_of(p0, i & 63) : lane_of(p1, i & 7);
+            if ((i & 7) < 4) tempM = __fadd_rn(tempM, term); else tempS = __fadd_rn(tempS, term);
         }
         tempM = __fdiv_rn(1.f, sqrtf(tempM)); tempS = __fdiv_rn(1.f, sqrtf(tempS));
-        for (int b = 0; b < 9; b++) {
-            for (int q = 0; q < 4; q++) dv[8 * b + q] = __fmul_rn(dv[8 * b + q], tempM);
-            for (int q = 4; q < 8; q++) dv[8 * b + q] = __fmul_rn(dv[8 * b + q], tempS);
-        }
-        for (int i = 0; i < 72; i++) if ((double)dv[i] > 0.4) dv[i] = (float)0.4;
+        v0 = __fmul_rn(v0, (t & 7) < 4 ? tempM : tempS); v1 = __fmul_rn(v1, (t & 7) < 4 ? tempM : tempS);
+        if ((double)v0 > 0.4) v0 = (float)0.4;
+        if ((double)v1 > 0.4) v1 = (float)0.4;
+        p0 = __fmul_rn(v0, v0); p1 = __fmul_rn(v1, v1);
         float tmp = 0;
-        for (int i = 0; i < 72; i++) tmp = __fadd_rn(tmp, __fmul_rn(dv[i], dv[i]));
+#pragma unroll
+        for (int i = 0; i < 72; i++) tmp = __fadd_rn(tmp, i < 64 ? lane_of(p0, i & 63) : lane_of(p1, i & 7));
         tmp = __fdiv_rn(1.f, sqrtf(tmp));
-        for (int i = 0; i < 72; i++) dv[i] = __fmul_rn(dv[i], tmp);
+        __syncthreads();                                           // every lane has read its value(s)
+        dv[t] = __fmul_rn(v0, tmp);
+        if (t < 8) dv[64 + t] = __fmul_rn(v1, tmp);
     }
     __syncthreads();
     if (t < 32) {

@@ -83,14 +83,21 @@ def device_slabs(ctx, n, labels=False):
     return t
 
 
-def gather_device_slabs(ctx, n, reduce_device="cuda", labels=False):
-    """the path's one collective: all_gather of every rank's n result slabs.  With the nccl (= RCCL) backend the slabs go
-    from HBM to HBM over xGMI (all_gather_into_tensor on the packed tensor); with gloo (CPU rehearsal) they are staged
-    through the host.  Returns (ranks whose slabs arrived with results in them, slab bytes per frame)."""
+def max_shard(n_frames, world):
+    return max(shard_range(n_frames, world, r)[1] - shard_range(n_frames, world, r)[0] for r in range(world))
+
+
+def gather_padded(t, per, reduce_device="cuda"):
+    """all_gather of every rank's [n_r, slab_bytes] uint8 tensor where the n_r may differ (257 frames over 8 ranks: 33 + 7 x 32): every
+    rank pads to `per` rows -- zero slabs, whose header says that nothing arrived -- so that ONE all_gather_into_tensor of equal pieces
+    serves ragged shards on the device path too (round 5; before, only the host path gather_results took them).  -> [world, per, slab_bytes]"""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
-    t = device_slabs(ctx, n, labels)
+    if t.shape[0] != per:
+        pad = torch.zeros((per, t.shape[1]), dtype=torch.uint8, device=t.device)
+        pad[: t.shape[0]] = t
+        t = pad
     if reduce_device == "cuda":
         out = torch.empty((world,) + tuple(t.shape), dtype=torch.uint8, device="cuda")
         dist.all_gather_into_tensor(out, t)
@@ -100,9 +107,33 @@ def gather_device_slabs(ctx, n, reduce_device="cuda", labels=False):
         outs = [torch.empty_like(tc) for _ in range(world)]
         dist.all_gather(outs, tc)
         out = torch.stack(outs)
+    return out
+
+
+def unpack_gathered(pkg, out, n_frames, kp_cap, kl_cap, pl_cap=64, label_shape=None):
+    """[world, per, slab_bytes] as gather_padded returns it -> the results of all n_frames frames in global frame order"""
+    world = out.shape[0]
+    arr = out.cpu().numpy()
+    res = []
+    for r in range(world):
+        lo, hi = shard_range(n_frames, world, r)
+        res += unpack_results(pkg, arr[r][: hi - lo], kp_cap, kl_cap, pl_cap, label_shape)
+    return res
+
+
+def gather_device_slabs(ctx, n, reduce_device="cuda", labels=False, n_frames=None, want_tensor=False):
+    """the path's one collective: all_gather of every rank's n result slabs.  With the nccl (= RCCL) backend the slabs go
+    from HBM to HBM over xGMI (all_gather_into_tensor on the packed tensor); with gloo (CPU rehearsal) they are staged
+    through the host.  n_frames: the batch's total when the ranks' shards differ in size (shard_range): every rank pads to the largest.
+    Returns (ranks whose slabs arrived with results in them, slab bytes per frame[, the gathered tensor])."""
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    t = device_slabs(ctx, n, labels)
+    per = n if n_frames is None else max_shard(n_frames, world)
+    out = gather_padded(t, per, reduce_device)
     hdr = out[:, 0, :HDR].cpu().numpy().view(np.int32).reshape(world, 4)
     seen = int(((hdr[:, 0] > 0) | (hdr[:, 1] > 0) | (hdr[:, 2] > 0)).sum())
-    return seen, int(t.shape[1])
+    return (seen, int(t.shape[1]), out) if want_tensor else (seen, int(t.shape[1]))
 
 
 def gather_results(pkg, local_results, n_frames, kp_cap, kl_cap, pl_cap=64, device="cpu", label_shape=None):

@@ -545,11 +545,12 @@ def main():
     per_frame = BYTES_PER_FRAME_640 if w <= 640 else BYTES_PER_FRAME_1280
     if B <= 0:
         if args.config == "batch256":
-            B = max(1, 256 // world)                                 # BASELINE configs[3]: 256 frames over the ranks
+            lo_, hi_ = hdist.shard_range(256, world, rank)           # BASELINE configs[3]: 256 frames over the ranks, contiguous shards (ragged when 256 % N != 0)
+            B = max(1, hi_ - lo_)
         else:
             free_b, _ = torch.cuda.mem_get_info()
             B = next((c for c in (8192, 6144, 4096, 3072, 2048, 1024, 512, 256) if c * per_frame <= 0.85 * free_b), 128)
-        if dist is not None:                 # every rank must run the same workload
+        if dist is not None and args.config != "batch256":      # every rank must run the same workload (batch256: the shards of 256 frames)
             t = torch.tensor([B], dtype=torch.int64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             B = int(t.item())
@@ -592,10 +593,11 @@ def main():
     if dist is not None:
         barrier()
         tg = time.perf_counter()
-        ranks_seen, slab_bytes = hdist.gather_device_slabs(ctx, B, red_dev)
+        ragged = args.config == "batch256" and args.batch <= 0
+        ranks_seen, slab_bytes = hdist.gather_device_slabs(ctx, B, red_dev, n_frames=256 if ragged else None)
         barrier()
         gather = {"gather_ms": round((time.perf_counter() - tg) * 1e3, 3), "ranks_seen": ranks_seen, "slab_bytes_per_frame": slab_bytes,
-                  "frames_gathered": world * B}
+                  "frames_gathered": 256 if ragged else world * B}
 
     res = ctx.batch_download(mask, n=min(B, 256))     # a sample is enough for the workload statistics
     nkp = float(np.mean([len(r["kp"]) for r in res])) if "orb" in stages else 0.0
@@ -630,7 +632,7 @@ def main():
     parity = parity_sample(ge, np, stages, res, g0, d0, kinds, nfeat, scale=w / 640.0) if rank == 0 else None
 
     if rank == 0:
-        frames = world * B * steps
+        frames = (256 if (args.config == "batch256" and args.batch <= 0) else world * B) * steps      # (batch256: the ranks' shards of 256 frames may differ by one)
         value = frames / dt
         groups = {k: v / psteps for k, v in prof.items()}           # ms per launch group per step (serialised pass)
         if "lsd_gradient" in groups and "lsd_blur_scale" not in groups: groups["lsd_pre"] = groups.pop("lsd_gradient")      # the fused preamble reports under the second kernel's name

@@ -76,3 +76,46 @@ def test_gather_world2_gloo():
         p.join(180)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _worker_ragged(rank, world, port, n_frames, q):
+    """the DEVICE path's plumbing on CPU tensors: every rank packs its shard's slabs, pads to the largest shard, one all_gather of equal
+    pieces (gather_padded), rank 0 unpacks in global frame order (unpack_gathered)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_pkg(); orc = load_oracle(); synth = load_synth()
+    hd = importlib.import_module("hvo_amd.dist")
+    gray, depth = synth.make_batch("std", 0x5EED2100, n_frames, 320, 240)
+    lo, hi = hd.shard_range(n_frames, world, rank)
+    local = _oracle_results(orc, gray[lo:hi], depth[lo:hi])
+    t = torch.from_numpy(hd.pack_results(pkg, local, 1100, 200, 64, label_shape=(240, 320)))
+    out = hd.gather_padded(t, hd.max_shard(n_frames, world), reduce_device="cpu")
+    if rank == 0:
+        allres = hd.unpack_gathered(pkg, out, n_frames, 1100, 200, 64, label_shape=(240, 320))
+        ref = _oracle_results(orc, gray, depth)
+        ok = len(allres) == n_frames and tuple(out.shape[:2]) == (world, hd.max_shard(n_frames, world))
+        for a, b in zip(allres, ref):
+            for k in ("kp", "desc", "kl", "ldesc", "linefn", "planes", "labels"):
+                ok = ok and np.array_equal(a[k], b[k])
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_padded_world3_ragged_gloo():
+    """7 frames over 3 ranks (3 + 2 + 2): the padded all_gather of the device path, on CPU tensors"""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, 3, port, 7, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
