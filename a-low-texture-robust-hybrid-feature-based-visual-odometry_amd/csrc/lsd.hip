@@ -67,6 +67,7 @@ struct LsdPlan {
     bool pre_fused = true;             // k_lsd_pre instead of k_lsd_blur + k_lsd_resize_grad (HVO_LSD_PRE_SPLIT=1: the pair, with its fp64 image)
     // tuning variables, read when the plan is built (lsd_build_plan)
     struct { Knob dense, lat, async_w, async_early, async_lds, lat_lds, lbd_split, spin_max; } kn;
+    size_t async_w_cap = 0;            // (frame, worker) pairs the per-worker scratch holds
     int *d_redo = nullptr; int async_last_n = 0, async_last_w = 0;      // frames the one-wave kernel grew again after the async growing gave up; the last async launch
     int async_b = 0; unsigned *d_atags = nullptr; void *d_actl = nullptr; int *d_alists = nullptr, *d_ablk = nullptr, *d_afreg = nullptr; unsigned char *d_ainreg = nullptr; int ainreg_b = 0;
 };
@@ -1647,22 +1648,30 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     if (P->kn.lat.set) lat = P->kn.lat.v != 0 && (size_t)P->nwords * 4 <= 150 * 1024 && !P->compact;      // HVO_LSD_LAT
     // a handful of frames: W waves per frame grow regions side by side and commit them in seed order (lsd_async.inc); HVO_LSD_ASYNC = W, 0: off
     // (default: up to 16 frames; at 32 frames the one-wave kernel beside the plane chain is the faster whole, tools/latency.py)
+    // Workers per frame.  A handful of frames: as many as pay (32 / 16; 64 for a lone large frame).  Round 5 lifted the 16-frame limit of the
+    // scratch (allocated per (frames, W) now: HVO_LSD_ASYNC = W works for up to 1024 frames) and MEASURED 64-512 frames with W = 2-16
+    // (profiles/r05_async_midsize_batches.txt): slower than one wave per frame everywhere but at 128 frames (-7 %) -- batch256 26.5 -> 31.3 ms
+    // at W = 4, 33.5 at W = 8, 34.8 at W = 2 -- the workers that wait for their turn poll, and with a wave on every SIMD already their polling
+    // takes the issue slots the growing workers need.  The default stays: async up to 16 frames.
     int aw = n <= 8 ? 32 : n <= 16 ? 16 : 0;
     if (n <= 2 && (size_t)sw * sh >= 600000) aw = 64;          // a lone large frame (1280x960: 5.4 k seeds): more regions in flight
     if (P->kn.async_w.set) aw = std::min(std::max(P->kn.async_w.v, 0), LA_MAXW);
-    if (aw > 0 && n <= 64 && !P->compact) {
-        if (!P->d_atags) {
-            const size_t AB = (size_t)std::min(P->batch, 64);
+    if (aw > 0 && n <= 1024 && !P->compact) {
+        // scratch for (n frames, aw workers): owner tags and control block per frame; region list, held-pixel list and membership byte map per worker
+        const size_t need_f = (size_t)n, need_w = (size_t)n * aw;
+        if (need_f > (size_t)P->async_b || need_w > P->async_w_cap) {
+            const size_t AB = std::max(need_f, (size_t)P->async_b), AW = std::max(need_w, P->async_w_cap);
+            HVO_HIP(hipStreamSynchronize(st));
+            for (void *q : { (void *)P->d_atags, (void *)P->d_actl, (void *)P->d_alists, (void *)P->d_ablk, (void *)P->d_afreg, (void *)P->d_ainreg }) if (q) (void)hipFree(q);
+            P->d_atags = nullptr; P->d_actl = nullptr; P->d_alists = nullptr; P->d_ablk = nullptr; P->d_afreg = nullptr; P->d_ainreg = nullptr; P->async_b = 0; P->async_w_cap = 0;
             HVO_HIP(hipMalloc((void **)&P->d_atags, AB * P->nwords * 32 * 4)); HVO_HIP(hipMalloc((void **)&P->d_actl, AB * sizeof(LaCtl)));
-            HVO_HIP(hipMalloc((void **)&P->d_alists, AB * LA_MAXW * LA_CAP * 4)); HVO_HIP(hipMalloc((void **)&P->d_ablk, AB * LA_MAXW * 2 * LA_BCAP * 4));
+            HVO_HIP(hipMalloc((void **)&P->d_alists, AW * LA_CAP * 4)); HVO_HIP(hipMalloc((void **)&P->d_ablk, AW * 2 * LA_BCAP * 4));
             HVO_HIP(hipMalloc((void **)&P->d_afreg, AB * 2 * nsp * 4));
-            // a worker's map of its region, a byte per scaled pixel: for the 16 frames the growing is used for by default (a forced HVO_LSD_ASYNC on more falls back)
-            P->ainreg_b = (int)std::min(AB, (size_t)16);
-            HVO_HIP(hipMalloc((void **)&P->d_ainreg, (size_t)P->ainreg_b * LA_MAXW * P->nwords * 32));
-            HVO_HIP(hipMalloc((void **)&P->d_redo, 64));
-            P->async_b = (int)AB;
+            HVO_HIP(hipMalloc((void **)&P->d_ainreg, AW * P->nwords * 32));            // a worker's map of its region, a byte per scaled pixel
+            if (!P->d_redo) HVO_HIP(hipMalloc((void **)&P->d_redo, 64));
+            P->async_b = (int)AB; P->async_w_cap = AW; P->ainreg_b = (int)AB;
         }
-        if (n <= P->async_b && n <= P->ainreg_b) {
+        {
             HVO_HIP(hipMemsetAsync(P->d_actl, 0, (size_t)n * sizeof(LaCtl), st));
             HVO_HIP(hipMemsetAsync(P->d_redo, 0, 4, st)); P->async_last_n = n; P->async_last_w = aw;
             // tags and region bitmaps are all-free / all-zero after a launch that ran to its end; a launch that aborted (flag 4) may have
@@ -1674,7 +1683,7 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
             a.spin_max = P->kn.spin_max.set ? (unsigned)std::max(P->kn.spin_max.v, 0) : LA_SPIN_MAX;
             // (an LDS request keeps these one-wave workgroups off the CUs where a frame's AHC waves sit -- k_peac_cluster_heads takes 108 KB --:
             // both are bound by instruction issue and a shared SIMD slows both; HVO_LSD_ASYNC_LDS: bytes [0 for a lone frame's 32-64 workers, 56 K beside other frames])
-            size_t alds = n > 2 ? 56 * 1024 : 0;
+            size_t alds = (n > 2 && n <= 16) ? 56 * 1024 : 0;       // (more frames: the workers ARE the machine's load, nothing to keep them away from)
             if (P->kn.async_lds.set) alds = (size_t)std::min(std::max(P->kn.async_lds.v, 0), 150 * 1024);
             if (hvo_ensure_dyn_lds(reinterpret_cast<const void *>(k_lsd_grow_async), alds)) return HVO_ERR_HIP;
             hipLaunchKernelGGL(k_lsd_grow_async, dim3(((n + 7) / 8) * 8 * aw), dim3(64), alds, st, a);      // workgroups b, b + 8, ... of a frame: one XCD
@@ -1688,7 +1697,7 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
                 hipLaunchKernelGGL(k_lsd_resize_grad, dim3(gx, (sh + GRAD_ROWS - 1) / GRAD_ROWS, n), dim3(256), 0, st, P->d_blur, w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb,
                                    P->d_px, P->d_defined, P->nwords, P->rho);      // (the split preamble: n <= 16 <= chunk, the blurred images are still there; every frame is formed again)
             { GrowArgs g2 = g; g2.redo = 1; g2.redo_count = P->d_redo; g2.perm = nullptr; hipLaunchKernelGGL(k_lsd_grow, dim3(n), dim3(64), 0, st, g2); }
-        } else aw = 0;
+        }
     } else aw = 0;
     if (aw > 0) {
     } else if (lat) {

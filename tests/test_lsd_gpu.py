@@ -364,3 +364,24 @@ def test_lines_async_gives_up_and_the_frame_is_grown_again(hvo, orc, synth, monk
         assert ctx.lsd_async_report()[0] == 0
     finally:
         ctx.close()
+
+
+def test_lines_async_growing_on_a_mid_size_batch(hvo, orc, synth, monkeypatch):
+    """round 5: the async growing's scratch is allocated per (frames, workers), so HVO_LSD_ASYNC = W works beyond 16 frames (it is not the
+    default there: measured slower, profiles/r05_async_midsize_batches.txt).  40 frames x 3 workers, then the same context on 12 frames
+    x 3 (smaller: the scratch is kept), every frame against the oracle."""
+    monkeypatch.setenv("HVO_LSD_ASYNC", "3")
+    g = np.stack([synth.make_gray("std" if k % 5 else "lowtex", 0x5EED7400 + k) for k in range(40)])
+    ref = [orc.line_extract(g[b]) for b in range(40)]
+    ctx = hvo.Context(max_batch=40)
+    try:
+        for n in (40, 12):
+            ctx.batch_upload(g[:n], np.zeros((n, 480, 640), np.uint16))
+            ctx.batch_run(hvo.STAGE_LSD)
+            res = ctx.batch_download(hvo.STAGE_LSD)
+            assert ctx.lsd_async_report()[2] == 3
+            for b in range(n):
+                assert res[b]["status"] == 0
+                check(res[b]["kl"], res[b]["ldesc"], res[b]["linefn"], *ref[b])
+    finally:
+        ctx.close()
