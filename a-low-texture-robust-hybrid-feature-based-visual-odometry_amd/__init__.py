@@ -60,6 +60,8 @@ SURFACE_NORMAL_DT = np.dtype([("normal", "<f4", 3), ("position", "<f4", 3), ("fr
 assert KEYPOINT_DT.itemsize == 28 and KEYLINE_DT.itemsize == 68 and PLANE_DT.itemsize == 64 and LINE3D_DT.itemsize == 104
 assert PLANE_CLOUD_DT.itemsize == 40 and SURFACE_NORMAL_DT.itemsize == 32
 
+READING_BLUR_FLOAT, READING_LSD_8U = 1, 2
+
 EXPORTS = [
     "hvo_abi_version", "hvo_default_params", "hvo_create", "hvo_destroy", "hvo_strerror", "hvo_last_error",
     "hvo_extract_orb", "hvo_extract_lsd", "hvo_compute_planes",
@@ -67,7 +69,7 @@ EXPORTS = [
     "hvo_undistort_keypoints", "hvo_image_bounds", "hvo_assign_features_to_grid", "hvo_assign_lines_to_grid",
     "hvo_extract_lsd_culled", "hvo_set_line_culling", "hvo_lines_3d", "hvo_vanishing_points", "hvo_plane_clouds", "hvo_surface_normals", "hvo_search_by_projection_map", "hvo_frame_bf_match", "hvo_search_double",
     "hvo_batch_upload", "hvo_batch_run", "hvo_batch_download", "hvo_extract_batch", "hvo_batch_slab_layout", "hvo_batch_pack_results", "hvo_batch_slab_layout_ex", "hvo_batch_pack_results_ex", "hvo_batch_stage_upload", "hvo_batch_commit_staged", "hvo_batch_results_async", "hvo_batch_results_wait",
-    "hvo_profile_last", "hvo_profile_enable", "hvo_lsd_async_report", "hvo_pin_host", "hvo_unpin_host",
+    "hvo_profile_last", "hvo_profile_enable", "hvo_lsd_async_report", "hvo_set_readings", "hvo_stream_set_readings", "hvo_pin_host", "hvo_unpin_host",
     "hvo_stream_create", "hvo_stream_destroy", "hvo_stream_last_error", "hvo_stream_capacity", "hvo_stream_image_bounds",
     "hvo_stream_submit", "hvo_stream_poll", "hvo_stream_collect", "hvo_stream_stage_ms",
     "hvo_stream_search_by_projection", "hvo_stream_match_lines", "hvo_stream_project_last", "hvo_search_by_projection_tracked",
@@ -452,6 +454,11 @@ class Context:
         self._chk(lib().hvo_search_lines_by_projection(self.h, nq, _p(q_xyxy), _p(q_kl), _p(q_desc), _p(q_blocks), _p(t_kl), _p(t_linefn), _p(t_desc), _p(t_occupied), nt,
                                                        _p(cs), _p(ci), _p(b), th, _p(mi), _p(md), C.byref(n)), "search_lines_by_projection")
         return n.value, mi[:nq], md[:nq]
+
+    def set_readings(self, blur_float=False, lsd_8u=False):
+        """the alternative readings of cv::GaussianBlur / cv::LineSegmentDetector (include/hvo.h HVO_READING_*); the next extraction uses them"""
+        lib().hvo_set_readings.argtypes = [C.c_void_p, C.c_uint]
+        self._chk(lib().hvo_set_readings(self.h, (READING_BLUR_FLOAT if blur_float else 0) | (READING_LSD_8U if lsd_8u else 0)), "set_readings")
 
     def lsd_async_report(self):
         """(frames grown again by the one-wave kernel, workers that sat on a foreign XCD, workers per frame) of the last async line growing"""
@@ -856,6 +863,10 @@ class Stream:
                                                         _p(q_max_level), pp(q_ur), _p(q_blocks), pp(t_occupied), th_high, 1 if check_orientation else 0,
                                                         _p(mi), _p(md), C.byref(n)), "stream_search_by_projection")
         return n.value, mi[:nq], md[:nq]
+
+    def set_readings(self, blur_float=False, lsd_8u=False):
+        lib().hvo_stream_set_readings.argtypes = [C.c_void_p, C.c_uint]
+        self._chk(lib().hvo_stream_set_readings(self.h, (READING_BLUR_FLOAT if blur_float else 0) | (READING_LSD_8U if lsd_8u else 0)), "stream_set_readings")
 
     def match_lines_geom(self, cur, last, desc_th=0.9, last_has_mapline=None):
         """LSDmatcher::SearchByGeomNApearance(Cur, Last) between two resident frames -> (lmatches, matches12, accepted)"""

@@ -152,6 +152,14 @@ void hvo_destroy(hvo_ctx *ctx)
     delete ctx;
 }
 
+// alternative readings of two OpenCV calls (readings.hip); takes effect with the next extraction
+int hvo_set_readings(hvo_ctx *ctx, unsigned mask)
+{
+    if (!ctx || (mask & ~(unsigned)(HVO_READING_BLUR_FLOAT | HVO_READING_LSD_8U))) return HVO_ERR_INVALID_ARG;
+    ctx->readings = mask;
+    return HVO_OK;
+}
+
 int hvo_profile_enable(hvo_ctx *ctx, int on)
 {
     if (!ctx) return HVO_ERR_INVALID_ARG;

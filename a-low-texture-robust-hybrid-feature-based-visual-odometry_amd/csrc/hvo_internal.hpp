@@ -100,6 +100,7 @@ int hvo_ensure_dyn_lds(const void *kernel, size_t bytes);
 struct hvo_ctx {
     hvo_params p;
     Knob kn_frame_perm, kn_upload_single;  // HVO_FRAME_PERM, HVO_UPLOAD_SINGLE (read by hvo_create)
+    unsigned readings = 0;                 // HVO_READING_* (hvo_set_readings): alternative readings of two OpenCV calls, readings.hip
     int device = 0;
     hipStream_t stream = nullptr;          // ORB + matching + uploads
     hipStream_t s_lsd = nullptr;           // LSD/LBD kernels   } the three subsystems are independent and run
@@ -214,6 +215,24 @@ static __device__ __forceinline__ double hvo_div_const(double a, double b, doubl
     return fma(fma(-q1, b, a), y, q1);
 }
 
+// cv::fastAtan2, float, evaluated without contraction (the same text as lsd.hip's and orb.hip's own copies)
+static __device__ __forceinline__ float hvo_fatan2_deg(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const bool hi = ax >= ay;
+    const float c = __fdiv_rn(hi ? ay : ax, __fadd_rn(hi ? ax : ay, eps)), c2 = __fmul_rn(c, c);
+    float r = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    if (!hi) r = __fsub_rn(90.f, r);
+    if (x < 0) r = __fsub_rn(180.f, r);
+    if (y < 0) r = __fsub_rn(360.f, r);
+    return r;
+}
+
 static inline int hvo_grid(long long items, int wg_per_cu) {
     const long long cap = 256LL * wg_per_cu;
     return (int)(items < cap ? (items < 1 ? 1 : items) : cap);
@@ -247,6 +266,7 @@ int orb_download(hvo_ctx *ctx, int n, hvo_frame_out *out);
 // orb_level.hip
 bool orb_level_build(OrbPlan &P, const std::vector<CellDesc> &cells, const std::vector<int> &xofs, const std::vector<int> &yofs, std::vector<OrbTile> &tiles);
 int orb_level_run(hvo_ctx *ctx, int c0, int n, hipStream_t st, int k0, int k1, int k2, int k3);   // frames [c0, c0 + n) = one chunk
+int orb_blur_float_run(hvo_ctx *ctx, int c0, int m, hipStream_t st);
 // orb_describe.hip
 int orb_describe_build(hvo_ctx *ctx);
 int orb_describe_run(hvo_ctx *ctx, int c0, int n, hipStream_t st);
@@ -316,6 +336,14 @@ int match_stereo_enqueue(hipStream_t st, const hvo_keypoint *d_kp, const hvo_key
                          int w, int h, float dfac, float bf, float *d_uright, float *d_zdepth);
 int match_stereo_from_rgbd(hvo_ctx *ctx, const hvo_keypoint *kp, const hvo_keypoint *kpun, int n, const uint16_t *depth, int w, int h, int stride,
                            float bf, float *uright, float *zdepth);
+
+// readings.hip: the alternative readings of cv::GaussianBlur / cv::LineSegmentDetector (hvo_set_readings)
+int readings_gblur_enqueue(hipStream_t st, const uint8_t *src, size_t sframe, int spitch, int w, int h, uint8_t *dst, size_t dframe, int dpitch,
+                           int nframes, int ksize, double sigma, bool float_reading);
+int readings_resize_tables(hipStream_t st, int sw, int sh, int dw, int dh, double factor, int *d_tab);
+int readings_resize_enqueue(hipStream_t st, const uint8_t *src, size_t sframe, int spitch, int sw, uint8_t *dst, size_t dframe, int dpitch, int dw, int dh,
+                            int nframes, const int *d_tab);
+int readings_lsd_grad8_enqueue(hipStream_t st, const uint8_t *s8, size_t sframe, int sw, int sh, double4 *px4, unsigned *defined, int nwords, double rho, int nframes);
 
 // frame.hip
 int frame_undistort(hvo_ctx *ctx, const hvo_keypoint *kp, int n, const float *dist5, hvo_keypoint *kp_un);

@@ -67,6 +67,7 @@ struct LsdPlan {
     bool pre_fused = true;             // k_lsd_pre instead of k_lsd_blur + k_lsd_resize_grad (HVO_LSD_PRE_SPLIT=1: the pair, with its fp64 image)
     // tuning variables, read when the plan is built (lsd_build_plan)
     struct { Knob dense, lat, async_w, async_early, async_lds, lat_lds, lbd_split, spin_max; } kn;
+    uint8_t *d_b8 = nullptr, *d_s8 = nullptr; int *d_rs8tab = nullptr;      // HVO_READING_LSD_8U: the u8 blurred image and the u8 scaled image of a chunk, the resize tables (readings.hip)
     size_t async_w_cap = 0;            // (frame, worker) pairs the per-worker scratch holds
     int *d_redo = nullptr; int async_last_n = 0, async_last_w = 0;      // frames the one-wave kernel grew again after the async growing gave up; the last async launch
     int async_b = 0; unsigned *d_atags = nullptr; void *d_actl = nullptr; int *d_alists = nullptr, *d_ablk = nullptr, *d_afreg = nullptr; unsigned char *d_ainreg = nullptr; int ainreg_b = 0;
@@ -1432,7 +1433,7 @@ void lsd_free(hvo_ctx *ctx)
     if (!P) return;
     void *ptrs[] = { P->d_kl2, P->d_desc2, P->d_fn2, P->d_nkl2, P->d_blur, P->d_px, P->d_defined, P->d_reg, P->d_segs, P->d_kl_all, P->d_kl,
                      P->d_desc, P->d_fn, P->d_nkl, P->d_flags, P->d_b5, P->d_dxy, P->d_xofs, P->d_yofs, P->d_xa, P->d_yb, P->d_gL, P->d_gG, P->d_stats,
-                     P->d_pool, P->d_defmask, P->d_wprefix, P->d_fbase, P->d_fcount, P->d_pooltop, P->d_atags, P->d_actl, P->d_alists, P->d_ablk, P->d_afreg, P->d_ainreg, P->d_redo };
+                     P->d_pool, P->d_defmask, P->d_wprefix, P->d_fbase, P->d_fcount, P->d_pooltop, P->d_atags, P->d_actl, P->d_alists, P->d_ablk, P->d_afreg, P->d_ainreg, P->d_redo, P->d_b8, P->d_s8, P->d_rs8tab };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
     ctx->lsd = nullptr;
@@ -1592,6 +1593,19 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
         if (P->compact) HVO_HIP(hipMemsetAsync(P->d_pooltop, 0, 16, st));
         for (int c0 = 0; c0 < n; c0 += P->chunk) {
             const int m = std::min(P->chunk, n - c0);
+            if (ctx->readings & HVO_READING_LSD_8U) {
+                // the detector on CV_8U (readings.hip): u8 GaussianBlur 7 x 7 sigma 0.75, u8 resize 0.8x, gradients of the rounded bytes
+                id = hvo_prof_begin(ctx, "lsd_gradient", st);
+                const size_t npix_ = (size_t)w * h;
+                if (!P->d_b8) {
+                    HVO_HIP(hipMalloc((void **)&P->d_b8, (size_t)P->chunk * npix_)); HVO_HIP(hipMalloc((void **)&P->d_s8, (size_t)P->chunk * nsp));
+                    HVO_HIP(hipMalloc((void **)&P->d_rs8tab, (2 * (size_t)sw + 2 * (size_t)sh) * sizeof(int)));
+                    if ((rc = readings_resize_tables(st, w, h, sw, sh, 0.8, P->d_rs8tab))) return rc;
+                }
+                if ((rc = readings_gblur_enqueue(st, gray + (size_t)c0 * O.pyr_bytes, O.pyr_bytes, gpitch, w, h, P->d_b8, npix_, w, m, 7, 0.6 / 0.8, (ctx->readings & HVO_READING_BLUR_FLOAT) != 0))) return rc;
+                if ((rc = readings_resize_enqueue(st, P->d_b8, npix_, w, w, P->d_s8, nsp, sw, sw, sh, m, P->d_rs8tab))) return rc;
+                if ((rc = readings_lsd_grad8_enqueue(st, P->d_s8, nsp, sw, sh, P->d_px + (P->compact ? 0 : (size_t)c0 * nsp), P->d_defined + (size_t)c0 * P->nwords, P->nwords, P->rho, m))) return rc;
+            } else
             if (P->pre_fused) {
                 // one kernel from the u8 image to the records (k_lsd_pre); the fp64 blurred image is never written
                 id = hvo_prof_begin(ctx, "lsd_gradient", st);
@@ -1656,6 +1670,7 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
     int aw = n <= 8 ? 32 : n <= 16 ? 16 : 0;
     if (n <= 2 && (size_t)sw * sh >= 600000) aw = 64;          // a lone large frame (1280x960: 5.4 k seeds): more regions in flight
     if (P->kn.async_w.set) aw = std::min(std::max(P->kn.async_w.v, 0), LA_MAXW);
+    if (ctx->readings & HVO_READING_LSD_8U) aw = 0;             // (the async growing's fall-back forms a frame again with the default preamble)
     if (aw > 0 && n <= 1024 && !P->compact) {
         // scratch for (n frames, aw workers): owner tags and control block per frame; region list, held-pixel list and membership byte map per worker
         const size_t need_f = (size_t)n, need_w = (size_t)n * aw;
@@ -1720,6 +1735,11 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
         const uint8_t *gc = gray + (size_t)c0 * O.pyr_bytes;
         const size_t ko = (size_t)c0 * P->nfeat;
         id = hvo_prof_begin(ctx, "lbd_sobel", st);
+        if (ctx->readings & HVO_READING_BLUR_FLOAT) {  // GaussianBlur(5 x 5, sigma 1) in the float-kernel reading (readings.hip), then the Sobel pair
+            if (!P->d_b5) HVO_HIP(hipMalloc((void **)&P->d_b5, (size_t)P->chunk * w * h));
+            if ((rc = readings_gblur_enqueue(st, gc, O.pyr_bytes, gpitch, w, h, P->d_b5, (size_t)w * h, w, m, 5, 1.0, true))) return rc;
+            hipLaunchKernelGGL(k_lbd_sobel, dim3((w + 255) / 256, (h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS, m), dim3(256), 0, st, P->d_b5, P->d_dxy, w, h);
+        } else
         if (P->d_b5) {                                  // the two-kernel formulation (blurred u8 image materialised), kept for A/B runs (HVO_LBD_SPLIT)
             hipLaunchKernelGGL(k_lbd_blur5, dim3((w + 255) / 256, (h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS, m), dim3(256), 0, st, gc, O.pyr_bytes, gpitch, P->d_b5, w, h, P->k5[0], P->k5[1], P->k5[2]);
             hipLaunchKernelGGL(k_lbd_sobel, dim3((w + 255) / 256, (h + LBD_BLUR_ROWS - 1) / LBD_BLUR_ROWS, m), dim3(256), 0, st, P->d_b5, P->d_dxy, w, h);

@@ -850,6 +850,19 @@ template <class T> static int dev_upload(hvo_ctx *ctx, T **p, const std::vector<
     return HVO_OK;
 }
 
+// GaussianBlur(7 x 7, sigma 2) of every level of the chunk's frames in the float-kernel reading (HVO_READING_BLUR_FLOAT, readings.hip)
+int orb_blur_float_run(hvo_ctx *ctx, int c0, int m, hipStream_t st)
+{
+    OrbPlan &P = ctx->orb;
+    for (int l = 0; l < P.nlevels; l++) {
+        const LevelGeom &L = P.lev[l];
+        const uint8_t *src = l == 0 ? P.d_pyr + (size_t)c0 * P.pyr_bytes : P.d_lvl + L.lvl_off;
+        const int rc = readings_gblur_enqueue(st, src, l == 0 ? P.pyr_bytes : P.lvl_bytes, L.pitch, L.w, L.h, P.d_blur + L.img_off, P.blur_bytes, L.pitch, m, 7, 2.0, true);
+        if (rc) return rc;
+    }
+    return HVO_OK;
+}
+
 static int orb_build_plan(hvo_ctx *ctx, int w, int h, int batch);
 // The cache key (w, h, batch) stays valid only if every table and slab behind it exists: a geometry that is rejected
 // half-way (a level below 38 pixels, a cell larger than the LDS tile, an allocation failure) frees the partial plan,
@@ -1093,7 +1106,8 @@ int orb_run(hvo_ctx *ctx, int n)
     if (P.fused) {
         // one launch per level: level l is read once into LDS tiles and gives its FAST corners, its blurred image and level l+1
         id = hvo_prof_begin(ctx, "orb_levels", st);
-        const int rl = orb_level_run(ctx, c0, m, st, k7[0], k7[1], k7[2], k7[3]);
+        int rl = orb_level_run(ctx, c0, m, st, k7[0], k7[1], k7[2], k7[3]);
+        if (!rl && (ctx->readings & HVO_READING_BLUR_FLOAT)) rl = orb_blur_float_run(ctx, c0, m, st);
         hvo_prof_end(ctx, id);
         if (rl) return rl;
         if (last && ctx->ev_fast && !ctx->serialize) { HVO_HIP(hipEventRecord(ctx->ev_fast, st)); ctx->fast_recorded = true; }
@@ -1116,9 +1130,11 @@ int orb_run(hvo_ctx *ctx, int n)
     const bool blur_late = ctx->orb_blur_late;
     auto run_blur = [&]() -> int {
         id = hvo_prof_begin(ctx, "orb_blur", st);
-        hipLaunchKernelGGL(k_blur7, dim3(P.ntiles, m), dim3(256), 0, st, pyr0, P.pyr_bytes, P.d_lvl, P.lvl_bytes, P.d_blur, P.blur_bytes, P.d_lev, P.d_tiles, k7[0], k7[1], k7[2], k7[3]);
+        int rb_ = HVO_OK;
+        if (ctx->readings & HVO_READING_BLUR_FLOAT) rb_ = orb_blur_float_run(ctx, c0, m, st);
+        else hipLaunchKernelGGL(k_blur7, dim3(P.ntiles, m), dim3(256), 0, st, pyr0, P.pyr_bytes, P.d_lvl, P.lvl_bytes, P.d_blur, P.blur_bytes, P.d_lev, P.d_tiles, k7[0], k7[1], k7[2], k7[3]);
         hvo_prof_end(ctx, id);
-        return HVO_OK;
+        return rb_;
     };
     if (!blur_late) { const int rb = run_blur(); if (rb) return rb; }
     id = hvo_prof_begin(ctx, "orb_fast_cells", st);

@@ -573,6 +573,7 @@ int orb_level_run(hvo_ctx *ctx, int c0, int n, hipStream_t st, int k0, int k1, i
 #else
         A.skip = 0;                                        // (the phase-skip mask exists in -DHVO_TIMING_KNOBS builds only: a stray variable must not corrupt ORB output)
 #endif
+        if (ctx->readings & HVO_READING_BLUR_FLOAT) A.skip |= 2;      // the float-kernel reading of GaussianBlur: the blurred levels come from readings.hip (orb_blur_float_run)
         A.flags = P.d_flags + c0; A.k0 = k0; A.k1 = k1; A.k2 = k2; A.k3 = k3;
         if (A.ntiles < 1) continue;
         const int n8 = (n + 7) / 8 * 8;

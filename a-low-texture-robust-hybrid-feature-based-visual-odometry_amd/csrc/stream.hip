@@ -691,4 +691,11 @@ int hvo_stream_search_lines_by_projection(hvo_stream *s, int64_t cur, int64_t la
     return HVO_OK;
 }
 
+int hvo_stream_set_readings(hvo_stream *s, unsigned mask)
+{
+    if (!s) return HVO_ERR_INVALID_ARG;
+    for (int i = 0; i < s->depth; i++) { const int rc = hvo_set_readings(s->slot[i].ctx, mask); if (rc) return rc; }
+    return HVO_OK;
+}
+
 }  // extern "C"

@@ -474,6 +474,15 @@ int hvo_unpin_host(void *p);
  * workgroups b, b + 8, ... to one XCD on this system: set HVO_LSD_ASYNC=0), and the workers per frame of that launch (0: it was not async). */
 int hvo_lsd_async_report(hvo_ctx *ctx, int *frames_regrown, int *foreign_workers, int *workers_per_frame);
 
+/* ---- alternative readings of two un-vendored OpenCV calls (SURVEY.md Appendix A "(?)"; csrc/readings.hip) ----
+ * The defaults (mask 0) are what the golden vectors pin.  A maintainer with the author's OpenCV 3.2 decides by running one
+ * cv::GaussianBlur(ramp image, 7 x 7, sigma 2) and comparing it with both readings; the oracle has the same
+ * switches (oracle.h orc_set_reading), and the parity tests run with both sides flipped. */
+#define HVO_READING_BLUR_FLOAT 1u   /* cv::GaussianBlur on CV_8U served by IPP: float kernel, one rounding (ORB's 7x7 blur, LBD's 5x5 blur; with LSD_8U the detector's too) */
+#define HVO_READING_LSD_8U     2u   /* cv::LineSegmentDetector working on CV_8U: u8 blur and u8 0.8x resize, gradients of the rounded bytes */
+int hvo_set_readings(hvo_ctx *ctx, unsigned mask);            /* takes effect with the next extraction; HVO_ERR_INVALID_ARG for unknown bits */
+int hvo_stream_set_readings(hvo_stream *s, unsigned mask);     /* every frame submitted afterwards */
+
 /* ---- measurement hooks (bench.py) ---- */
 /* Per-kernel-group device time of the last hvo_batch_run, measured with hipEvents on the ctx
  * stream.  names[i] points at static strings.  Returns the number of groups written (<= cap). */
