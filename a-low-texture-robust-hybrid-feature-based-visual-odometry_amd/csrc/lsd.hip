@@ -1159,13 +1159,68 @@ __global__ __launch_bounds__(64) void k_lbd_desc(const short2 *__restrict__ dxyI
     const float midY = (float)(0.5 * (double)__fadd_rn(kl.soy, kl.eoy));
     const float dL0 = (float)cos((double)kl.angle), dL1 = (float)sin((double)kl.angle);
     const float dO0 = -dL1, dO1 = dL0;
+    // The samples of row t at positions w0 .. : a sequential chain of float additions per row (lane = row carries it).  What the gathers cost
+    // is the number of distinct cache lines a load instruction touches (the texture addresser takes a line per cycle): with lane = row the 63
+    // samples of one position lie ACROSS the segment -- in 63 image rows for a segment that runs along the image rows, i.e. 63 lines per load.
+    // Such segments (|dL0| > |dL1|) go through an LDS tile (round 5): lane = row forms 32 positions' addresses, the tile is read back with
+    // lane = position (two band rows per instruction: 32 consecutive samples ALONG the segment share one or two lines), the values return
+    // through the tile and lane = row accumulates them in the reference's order.  Steep segments keep the direct form (their 63 rows lie
+    // along an image row already).
+    __shared__ int tile[63 * 33];
+    const bool along_rows = fabsf(dL0) > fabsf(dL1);
+    float sCorX = 0, sCorY = 0, pL = 0, nL = 0, pO = 0, nO = 0;
     if (t < 63) {
         // sCorX0/sCorY0 of row hID are reached by hID sequential updates in the reference
         float sCorX0 = __fadd_rn(__fadd_rn(__fmul_rn(-dL0, (float)halfWidth), __fmul_rn(dL1, (float)halfHeight)), midX);
         float sCorY0 = __fadd_rn(__fsub_rn(__fmul_rn(-dL1, (float)halfWidth), __fmul_rn(dL0, (float)halfHeight)), midY);
         for (int q = 0; q < t; q++) { sCorX0 = __fsub_rn(sCorX0, dL1); sCorY0 = __fadd_rn(sCorY0, dL0); }
-        float sCorX = sCorX0, sCorY = sCorY0;
-        float pL = 0, nL = 0, pO = 0, nO = 0;
+        sCorX = sCorX0; sCorY = sCorY0;
+    }
+    auto accumulate = [&](short gx, short gy) {
+        const float ddx = (float)gx, ddy = (float)gy;
+        const float gDL = __fadd_rn(__fmul_rn(ddx, dL0), __fmul_rn(ddy, dL1));
+        const float gDO = __fadd_rn(__fmul_rn(ddx, dO0), __fmul_rn(ddy, dO1));
+        if (gDL > 0) pL = __fadd_rn(pL, gDL); else nL = __fsub_rn(nL, gDL);
+        if (gDO > 0) pO = __fadd_rn(pO, gDO); else nO = __fsub_rn(nO, gDO);
+    };
+    if (along_rows) {
+        for (int w0 = 0; w0 < lengthOfLSP; w0 += 32) {
+            if (t < 63) {
+#pragma unroll 4
+                for (int u = 0; u < 32; u++) {
+                    int a = -1;
+                    if (w0 + u < lengthOfLSP) {
+                        short tc = (short)roundf(sCorX);
+                        const short xCor = (tc < 0) ? 0 : (tc > imageWidth) ? imageWidth : tc;
+                        tc = (short)roundf(sCorY);
+                        const short yCor = (tc < 0) ? 0 : (tc > imageHeight) ? imageHeight : tc;
+                        a = (int)yCor * w + xCor;
+                        sCorX = __fadd_rn(sCorX, dL0); sCorY = __fadd_rn(sCorY, dL1);
+                    }
+                    tile[t * 33 + u] = a;
+                }
+            }
+            __syncthreads();
+            {
+                const int u = t & 31, rh = t >> 5;
+                for (int r0 = 0; r0 < 64; r0 += 16) {              // eight instructions' loads in flight
+                    int av[8]; short2 gv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { const int r = r0 + 2 * k + rh; av[k] = r < 63 ? tile[r * 33 + u] : -1; }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { gv[k] = make_short2(0, 0); if (av[k] >= 0) gv[k] = DXY[av[k]]; }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { const int r = r0 + 2 * k + rh; if (r < 63) tile[r * 33 + u] = (int)(((unsigned)(unsigned short)gv[k].x) | ((unsigned)(unsigned short)gv[k].y << 16)); }
+                }
+            }
+            __syncthreads();
+            if (t < 63) {
+                const int nu = min(32, (int)lengthOfLSP - w0);
+                for (int u = 0; u < nu; u++) { const unsigned b = (unsigned)tile[t * 33 + u]; accumulate((short)(b & 0xFFFFu), (short)(b >> 16)); }
+            }
+            __syncthreads();
+        }
+    } else if (t < 63) {
         // Samples are taken LBD_UNR at a time: the sample coordinates form a cheap sequential chain, the gathers that
         // depend on them are all issued before the first one is consumed, and the signed sums are then accumulated in
         // the reference's order.
@@ -1186,16 +1241,10 @@ __global__ __launch_bounds__(64) void k_lbd_desc(const short2 *__restrict__ dxyI
                 }
             }
 #pragma unroll
-            for (int u = 0; u < LBD_UNR; u++) {
-                if (w0 + u < lengthOfLSP) {
-                    const float ddx = (float)g2[u].x, ddy = (float)g2[u].y;
-                    const float gDL = __fadd_rn(__fmul_rn(ddx, dL0), __fmul_rn(ddy, dL1));
-                    const float gDO = __fadd_rn(__fmul_rn(ddx, dO0), __fmul_rn(ddy, dO1));
-                    if (gDL > 0) pL = __fadd_rn(pL, gDL); else nL = __fsub_rn(nL, gDL);
-                    if (gDO > 0) pO = __fadd_rn(pO, gDO); else nO = __fsub_rn(nO, gDO);
-                }
-            }
+            for (int u = 0; u < LBD_UNR; u++) if (w0 + u < lengthOfLSP) accumulate(g2[u].x, g2[u].y);
         }
+    }
+    if (t < 63) {
         const float coef = gG[t];
         rows[t][0] = __fmul_rn(coef, pL); rows[t][1] = __fmul_rn(coef, nL); rows[t][2] = __fmul_rn(coef, pO); rows[t][3] = __fmul_rn(coef, nO);
     }
