@@ -1324,7 +1324,7 @@ __global__ __launch_bounds__(64) void k_lbd_desc(const short2 *__restrict__ dxyI
 //   step 3 (1062-1092): new KeyLines, stable rank sort by response, class_id = rank, line functions
 // The second LBD pass (1094-1096) is a k_lbd_desc launch on the result.
 // ------------------------------------------------------------------------------------------------
-#define CULL_MAXL 512
+#define CULL_MAXL 2048         // lines per frame cullingLine holds in LDS (round 5: carved from dynamic LDS by the plan's line quota; 512 and static before)
 struct CullArgs {
     const hvo_keyline *kl; const double *fn; const int *nkl; hvo_keyline *tmp; hvo_keyline *kl_out; double *fn_out; int *nkl_out;
     int cap, tmp_stride, w, h; double dis, cos_th, endpoint_dis;
@@ -1365,16 +1365,20 @@ static __device__ void cull_merge_two_lines(const float *l1, const float *l2, fl
     const double d1 = fmin(axg, fmin(bxg, fmin(cxg, dxg))), d2 = fmax(axg, fmax(bxg, fmax(cxg, dxg)));
     out[0] = (float)(d1 * c + xg); out[1] = (float)(d1 * s + yg); out[2] = (float)(d2 * c + xg); out[3] = (float)(d2 * s + yg);
 }
-__global__ __launch_bounds__(64) void k_cull_lines(CullArgs a)
+static size_t cull_lds_bytes(int maxl) { return (size_t)maxl * (24 + 16 + 16 + 4 + 2 + 2 + 1) + 64; }
+__global__ __launch_bounds__(64) void k_cull_lines(CullArgs a, int maxl)
 {
-    __shared__ float ep[CULL_MAXL][4];            // end points of the input lines
-    __shared__ double fnl[CULL_MAXL][3];
-    __shared__ unsigned char tag[CULL_MAXL];
-    __shared__ short grp[CULL_MAXL]; __shared__ short gstart[CULL_MAXL + 1];
-    __shared__ float nl[CULL_MAXL][4];            // merged / surviving segments
-    __shared__ float resp[CULL_MAXL];
+    // 65 bytes of LDS per line, for `maxl` lines (the plan's quota rounded up to 64): doubles first
+    extern __shared__ __attribute__((aligned(16))) unsigned char cull_lds[];
+    double (*fnl)[3] = reinterpret_cast<double (*)[3]>(cull_lds);
+    float (*ep)[4] = reinterpret_cast<float (*)[4]>(cull_lds + (size_t)maxl * 24);              // end points of the input lines
+    float (*nl)[4] = reinterpret_cast<float (*)[4]>(cull_lds + (size_t)maxl * 40);              // merged / surviving segments
+    float *resp = reinterpret_cast<float *>(cull_lds + (size_t)maxl * 56);
+    short *grp = reinterpret_cast<short *>(cull_lds + (size_t)maxl * 60);
+    short *gstart = reinterpret_cast<short *>(cull_lds + (size_t)maxl * 62);                    // maxl + 1 entries (the slack behind the last array holds the last one)
+    unsigned char *tag = cull_lds + (size_t)maxl * 64 + 8;
     const int f = blockIdx.x, lane = threadIdx.x;
-    const int n = min(a.nkl[f], CULL_MAXL);
+    const int n = min(a.nkl[f], maxl);
     const hvo_keyline *kl = a.kl + (size_t)f * a.cap;
     const double *fn = a.fn + (size_t)f * a.cap * 3;
     for (int i = lane; i < n; i += 64) {
@@ -1805,7 +1809,9 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
             c.kl = P->d_kl + ko; c.fn = P->d_fn + ko * 3; c.nkl = P->d_nkl + c0; c.tmp = P->d_kl_all + (size_t)c0 * P->maxseg; c.tmp_stride = P->maxseg;
             c.kl_out = P->d_kl2 + ko; c.fn_out = P->d_fn2 + ko * 3; c.nkl_out = P->d_nkl2 + c0;
             c.cap = P->nfeat; c.w = w; c.h = h; c.dis = ctx->cull_dis; c.cos_th = cos(ctx->cull_angle * 0.0174533); c.endpoint_dis = ctx->cull_endpoint;
-            hipLaunchKernelGGL(k_cull_lines, dim3(m), dim3(64), 0, st, c);
+            const int maxl = (P->nfeat + 63) & ~63;
+            if (hvo_ensure_dyn_lds(reinterpret_cast<const void *>(k_cull_lines), cull_lds_bytes(maxl))) return HVO_ERR_HIP;
+            hipLaunchKernelGGL(k_cull_lines, dim3(m), dim3(64), cull_lds_bytes(maxl), st, c, maxl);
             hipLaunchKernelGGL(k_lbd_desc, dim3(P->nfeat, m), dim3(64), 0, st, P->d_dxy, w, h, P->d_kl2 + ko, P->d_nkl2 + c0, P->nfeat, P->d_gL, P->d_gG, P->d_desc2 + ko * 32);
             hvo_prof_end(ctx, id);
         }

@@ -385,3 +385,21 @@ def test_lines_async_growing_on_a_mid_size_batch(hvo, orc, synth, monkeypatch):
                 check(res[b]["kl"], res[b]["ldesc"], res[b]["linefn"], *ref[b])
     finally:
         ctx.close()
+
+
+def test_culling_with_a_large_line_quota(hvo, orc, synth):
+    """round 5: Frame::cullingLine holds its lines in dynamic LDS sized by the plan's quota (up to 2048; 512 and an error before).  nLSDFeature = 1500
+    on a dense periodic pattern (thousands of segments before the quota): the culled lines against the oracle."""
+    yy, xx = np.mgrid[0:480, 0:640]
+    g = (((xx + yy) // 13 + (xx - yy) // 13) % 2 * 90 + 60).astype(np.uint8)             # a diagonal checkerboard of period 13
+    g = np.clip(g.astype(np.int32) + (synth.make_gray("std", 0x5EED7500).astype(np.int32) - 120) // 8, 0, 255).astype(np.uint8)
+    ctx = hvo.Context(lsd_nfeatures=1500)
+    try:
+        kl, ld, fn = ctx.extract_lsd(g, culled=True)
+    finally:
+        ctx.close()
+    klo, ldo, fno = orc.line_extract(g, nfeatures=1500)
+    assert len(klo) > 600                                          # beyond the old 512-line limit
+    klc, ldc, fnc = orc.cull_lines(g, klo, fno)
+    assert len(kl) == len(klc) and np.array_equal(ld, ldc)
+    for k in ("sx", "sy", "ex", "ey"): assert np.array_equal(kl[k], klc[k]), k
