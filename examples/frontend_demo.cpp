@@ -67,6 +67,17 @@ int main(int argc, char **argv)
         printf("l3d %d vp %d %d %d %d best %d clouds %d cloudpts %zu normals %zu stream %d %016llx\n", good, vc[0], vc[1], vc[2], vc[3], vp.best, valid, xyz.size() / 3,
                sn.size(), fo.n_kp, (unsigned long long)fnv(sdesc.data(), (size_t)fo.n_kp * 32));
         printf("tail l3d %d vpbest %d clouds %d cloudpts %d normals %d ptitems %d lnitems %d\n", tgood, tail.vp.best, tvalid, tail.c.n_cloud, tail.c.n_normals, tail.c.n_pt_items, tail.c.n_ln_items);
+        // round 5: the line tracker's own calls (LSDmatcher::SearchByGeomNApearance, SearchByProjection(Cur, Last, th)): the frame against itself
+        {
+            std::vector<int> m12g; std::vector<uint8_t> acc;
+            const int ng = lm.SearchByGeomNApearance(ldesc.data(), kls.data(), nullptr, (int)kls.size(), ldesc.data(), kls.data(), (int)kls.size(), 0.9f, b, m12g, acc);
+            std::vector<float> q; for (const hvo::KeyLine &k : kls) { q.push_back(k.sx + 1.5f); q.push_back(k.sy - 0.5f); q.push_back(k.ex + 1.5f); q.push_back(k.ey - 0.5f); }
+            std::vector<uint8_t> blocks(kls.size(), 1), occ(kls.size(), 0);
+            std::vector<int32_t> mi;
+            const int ns = lm.SearchByProjection((int)kls.size(), q.data(), kls.data(), ldesc.data(), blocks.data(), kls.data(), fn.data(), ldesc.data(), occ.data(), (int)kls.size(),
+                                                 lstart.data(), litems.data(), b, 15.f, mi);
+            printf("linetrack geom %d %016llx sbp %d %016llx\n", ng, (unsigned long long)fnv(m12g.data(), m12g.size() * 4), ns, (unsigned long long)fnv(mi.data(), mi.size() * 4));
+        }
     } catch (const hvo::Error &e) { fprintf(stderr, "hvo error: %s\n", e.what()); return 1; }
     return 0;
 }

@@ -335,6 +335,32 @@ public:
         check(hvo_match_nnr(ctx_, desc1, n1, desc2, n2, nnr, matches_12.data(), &m), "hvo_match_nnr");
         return m;
     }
+    // int SearchByGeomNApearance(CurrentFrame, LastFrame, desc_th, matches_12) (LSDmatcher.cpp:36-108) on host arrays: the descriptor match and the
+    // angle / end-point gates; accepted[i1] != 0 where the reference assigns CurrentFrame.mvpMapLines[matches_12[i1]] = LastFrame.mvpMapLines[i1]
+    int SearchByGeomNApearance(const uint8_t *ldescLast, const hvo_keyline *klLast, const uint8_t *lastHasMapLine, int nLast,
+                               const uint8_t *ldescCur, const hvo_keyline *klCur, int nCur, float desc_th, const float bounds4[4],
+                               std::vector<int> &matches_12, std::vector<uint8_t> &accepted) const
+    {
+        matches_12.assign(nLast > 0 ? nLast : 1, -1); accepted.assign(nLast > 0 ? nLast : 1, 0);
+        int n = 0;
+        check(hvo_match_lines_geom(ctx_, ldescLast, klLast, lastHasMapLine, nLast, ldescCur, klCur, nCur, desc_th, bounds4, matches_12.data(), accepted.data(), &n), "hvo_match_lines_geom");
+        matches_12.resize(nLast); accepted.resize(nLast);
+        return n;
+    }
+    // int SearchByProjection(CurrentFrame, LastFrame, th) core (LSDmatcher.cpp:561-662 over Frame::GetFeaturesInAreaForLine, Frame.cc:1557-1627): one query per
+    // last-frame map line in view (its projected end points, its key line, its descriptor, whether it has observations); the current frame's key lines, line
+    // functions, descriptors, occupied flags and line grid (hvo::FrameGrid / hvo_assign_lines_to_grid)
+    int SearchByProjection(int nq, const float *q_xyxy, const hvo_keyline *q_kl, const uint8_t *q_desc, const uint8_t *q_blocks,
+                           const hvo_keyline *t_kl, const double *t_linefn, const uint8_t *t_desc, const uint8_t *t_occupied, int nt,
+                           const int32_t *cell_start, const int32_t *cell_items, const float bounds4[4], float th, std::vector<int32_t> &match_idx) const
+    {
+        match_idx.assign(nq > 0 ? nq : 1, -1); std::vector<int32_t> dist(nq > 0 ? nq : 1, 256);
+        int n = 0;
+        check(hvo_search_lines_by_projection(ctx_, nq, q_xyxy, q_kl, q_desc, q_blocks, t_kl, t_linefn, t_desc, t_occupied, nt, cell_start, cell_items, bounds4, th,
+                                             match_idx.data(), dist.data(), &n), "hvo_search_lines_by_projection");
+        match_idx.resize(nq);
+        return n;
+    }
 private:
     hvo_ctx *ctx_;
 };
@@ -409,6 +435,28 @@ public:
         matches12.resize(nfrom);
         return nm;
     }
+    // LSDmatcher::SearchByGeomNApearance(Cur, Last, desc_th, matches_12) whole between two resident frames (LSDmatcher.cpp:36-108)
+    int searchByGeomNApearance(int64_t cur, int64_t last, float desc_th, const uint8_t *lastHasMapLine, std::vector<int32_t> &matches12, std::vector<uint8_t> &accepted)
+    {
+        matches12.assign(kl_cap_, -1); accepted.assign(kl_cap_, 0);
+        int nlast = 0, nm = 0;
+        check(hvo_stream_match_lines_geom(s_, cur, last, desc_th, lastHasMapLine, matches12.data(), accepted.data(), &nlast, &nm), "hvo_stream_match_lines_geom");
+        matches12.resize(nlast); accepted.resize(nlast);
+        return nm;
+    }
+    // LSDmatcher::SearchByProjection(Cur, Last, th) core between two resident frames (LSDmatcher.cpp:561-662); the stream must run HVO_STAGE_GRIDS
+    int searchLinesByProjection(int64_t cur, int64_t last, const std::vector<int32_t> &q_index, const std::vector<float> &q_xyxy, const uint8_t *q_desc,
+                                const uint8_t *q_blocks, const uint8_t *t_occupied, float th, std::vector<int32_t> &match_idx)
+    {
+        const int nq = (int)q_index.size();
+        match_idx.assign(nq > 0 ? nq : 1, -1); std::vector<int32_t> dist(nq > 0 ? nq : 1, 256);
+        int n = 0;
+        check(hvo_stream_search_lines_by_projection(s_, cur, last, nq, q_index.data(), q_xyxy.data(), q_desc, q_blocks, t_occupied, th, match_idx.data(), dist.data(), &n),
+              "hvo_stream_search_lines_by_projection");
+        match_idx.resize(nq);
+        return n;
+    }
+    void setReadings(unsigned mask) { check(hvo_stream_set_readings(s_, mask), "hvo_stream_set_readings"); }
     hvo_stream *get() const { return s_; }
     int kpCap() const { return kp_cap_; } int klCap() const { return kl_cap_; } int plCap() const { return pl_cap_; }
 private:

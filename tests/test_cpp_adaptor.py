@@ -63,3 +63,12 @@ def test_cpp_demo_matches_oracle(tmp_path, orc, synth):
     out = out[18:]
     assert out[0] == "tail" and int(out[2]) == int(l3["good"].sum()) and int(out[6]) == int(pcs["valid"].sum()) and int(out[8]) == len(cloud) and int(out[10]) == len(sn)
     assert int(out[12]) == len(gi) and int(out[14]) == len(li)
+    # fourth line (round 5): "linetrack geom N HASH sbp N HASH" -- LSDmatcher::SearchByGeomNApearance / SearchByProjection of the frame against itself
+    out = out[15:]
+    fn_o = orc.line_extract(g)[2]
+    ng, m12, _ = orc.lines_geom_match(ld_o, kl_o, ld_o, kl_o, b, desc_th=0.9)
+    cs, ci, _ = orc.assign_lines_to_grid(kl_o, b)
+    q = np.stack([kl_o["sx"] + np.float32(1.5), kl_o["sy"] - np.float32(0.5), kl_o["ex"] + np.float32(1.5), kl_o["ey"] - np.float32(0.5)], axis=1).astype(np.float32)
+    ns, mi, _ = orc.search_lines_by_projection(q, kl_o, ld_o, np.ones(len(kl_o), np.uint8), kl_o, fn_o, ld_o, np.zeros(len(kl_o), np.uint8), cs, ci, b, 15.0)
+    assert out[0] == "linetrack" and int(out[2]) == ng and int(out[3], 16) == _fnv(m12.astype(np.int32).tobytes())
+    assert int(out[5]) == ns and int(out[6], 16) == _fnv(mi.astype(np.int32).tobytes()) and ns > 50
