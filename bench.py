@@ -32,11 +32,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
-TRAFFIC_PROFILE = "profiles/r04_hbm_traffic.json"
-SQ_PROFILE = "profiles/r04_sq_utilisation.json"
-VALU_ISSUE_PROFILE = "profiles/r04_valu_issue.txt"
+TRAFFIC_PROFILE = "profiles/r05_hbm_traffic.json"
+SQ_PROFILE = "profiles/r05_sq_utilisation.json"
+VALU_ISSUE_PROFILE = "profiles/r05_valu_salu_issue.txt"
 VALU_ISSUE_NS = 1.77           # ns per wave64 instruction per SIMD, the integer / fp64 classes at 8 waves per SIMD (that profile)
-BYTES_PER_FRAME_640 = 23.0e6      # resident footprint of one 640x480 frame incl. its share of the chunk scratch (profiles/r03_hbm_footprint.txt)
+BYTES_PER_FRAME_640 = 21.1e6      # resident footprint of one 640x480 frame incl. its share of the chunk scratch (profiles/r05_hbm_footprint.txt)
 BYTES_PER_FRAME_1280 = 80.0e6     # 1280x960, 2000 ORB: 63 MB per frame + 32 GB of chunk scratch
 
 
