@@ -50,7 +50,7 @@ struct PeacPlan {
     double c15 = 0, c60 = 0, c30 = 0;   // cos thresholds evaluated on the host (glibc), like the oracle
     double ang_factor = 0, ang_near = 0;
     // tuning variables, read when the plan is built (peac_build_plan)
-    struct { Knob edges, gl, perm, heads_maxn, heads, heads_big, poolcap, ldsq, flood_t, flood_epl, flood_perm; } kn;
+    struct { Knob edges, gl, perm, lend, heads_maxn, heads, heads_big, poolcap, ldsq, flood_t, flood_epl, flood_perm; } kn;
 };
 
 static PeacPlan *plan_of(hvo_ctx *ctx) { return (PeacPlan *)ctx->peac; }
@@ -1017,6 +1017,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
             if (keep) pool[moff + mcnt + __popcll(km & lt_mask)] = vB;
             mcnt += __popcll(km);
         }
+        PT(5)
         for (int base = GL; __any(base < ncnt); base += GL) {    // partner lists longer than a chunk (rare)
             const int k = base + gl;
             int v = -1; bool keep = false;
@@ -1033,6 +1034,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
             if (keep) pool[moff + mcnt + __popcll(km & lt_mask)] = v;
             mcnt += __popcll(km);
         }
+        PT(6)
         // ... then A: the first of {p, nb} found becomes the new id, the second is dropped (merge); p is dropped (no merge)
 #pragma unroll
         for (int u = 0; u < ACH; u++) {
@@ -1051,6 +1053,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
                 mcnt += __popcll(km);
             }
         }
+        PT(5)
         for (int base = ACH * GL; __any(live && base < pcnt); base += GL) {   // p's list beyond ACH chunks (rare)
             const int k = base + gl;
             int v = -1; bool keep = false;
@@ -1075,7 +1078,7 @@ static __device__ void ah_cluster_grouped(const ClArgs &a, int frame, const TQue
             if (keep) pool[moff + mcnt + __popcll(km & lt_mask)] = v;
             mcnt += __popcll(km);
         }
-        PT(5)
+        PT(6)
         if (do_merge && is_w) {
             HotNode *M = hot + id;
             const HotNode *W = hot + bid;                                                 // sums of the merge = p's + the partner's
@@ -1198,10 +1201,12 @@ __global__ __launch_bounds__(512) void k_peac_edges(ClArgs a, int nframes)
     for (int b = tid; b < nblk; b += 512) eflag[b] = ef[b];
 }
 
+#include "peac_lend.inc"
+
 // ------------------------------------------------------------------------------------------------
-// k_peac_cluster: initGraph edges + main ahCluster, 64/GL frames per wave
+// k_peac_cluster: initGraph edges + main ahCluster, 64/GL frames per wave; LEND (GL = 16): idle lanes work for the other frames of the wave
 // ------------------------------------------------------------------------------------------------
-template <int GL>
+template <int GL, bool LEND>
 #ifdef HVO_CLUSTER_WPE
 __attribute__((amdgpu_waves_per_eu(HVO_CLUSTER_WPE, HVO_CLUSTER_WPE)))
 #endif
@@ -1212,7 +1217,8 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
     asm volatile("v_mov_b32 v231, 0" ::: "v231");
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char tq_lds[];          // NG groups x n0 x (double + int)
-    __shared__ double ps_lds[NG][12];
+    __shared__ __attribute__((aligned(16))) unsigned char cl_lds[LEND ? sizeof(LendLds) : sizeof(double) * NG * 12];
+    static_assert(!LEND || GL == 16, "lanes are lent between the four frames of a wave");
     const int lane = threadIdx.x, gl = Grp<GL>::gl(), gid = lane / GL;
     int frame = (a.perm ? a.perm[blockIdx.x] : (int)blockIdx.x) * NG + gid;
     const bool galive = frame < nframes;
@@ -1312,7 +1318,8 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
     int nseg = nblk, pooltop = nblk * 4, next = 0, flags = 0;
     int *ext = a.extracted + (size_t)frame * 2 * MAX_PLANES;
     __syncthreads();
-    ah_cluster_grouped<GL>(a, frame, Q, ps_lds[gid], hn, nseg, pooltop, pool, pool2, ext, next, flags);
+    if constexpr (LEND) ah_cluster_lend(a, frame, Q, *reinterpret_cast<LendLds *>(cl_lds), hn, nseg, pooltop, pool, pool2, ext, next, flags);
+    else ah_cluster_grouped<GL>(a, frame, Q, reinterpret_cast<double *>(cl_lds) + gid * 12, hn, nseg, pooltop, pool, pool2, ext, next, flags);
     if (galive && gl == 0) {
         int *meta = a.meta + (size_t)frame * 16;
         meta[0] = nseg; meta[1] = 0; meta[2] = next; meta[3] = flags; meta[6] = 0;      // the lists are dead: k_peac_final starts an empty pool
@@ -1981,7 +1988,7 @@ static int peac_build_plan(hvo_ctx *ctx, int w, int h, int batch)
 {
     PeacPlan *P = new PeacPlan();
     ctx->peac = P;
-    P->kn.edges.read("HVO_PEAC_EDGES"); P->kn.gl.read("HVO_PEAC_GL"); P->kn.perm.read("HVO_PEAC_PERM"); P->kn.heads_maxn.read("HVO_PEAC_HEADS_MAXN");
+    P->kn.edges.read("HVO_PEAC_EDGES"); P->kn.gl.read("HVO_PEAC_GL"); P->kn.perm.read("HVO_PEAC_PERM"); P->kn.lend.read("HVO_PEAC_LEND"); P->kn.heads_maxn.read("HVO_PEAC_HEADS_MAXN");
     P->kn.heads.read("HVO_PEAC_HEADS"); P->kn.heads_big.read("HVO_PEAC_HEADS_BIG"); P->kn.poolcap.read("HVO_PEAC_POOLCAP"); P->kn.ldsq.read("HVO_PEAC_LDSQ");
     P->kn.flood_t.read("HVO_FLOOD_T"); P->kn.flood_epl.read("HVO_FLOOD_EPL"); P->kn.flood_perm.read("HVO_FLOOD_PERM");
     P->w = w; P->h = h; P->pitch = (w + 31) & ~31; P->Nw = w / WIN; P->Nh = h / WIN; P->nblk = P->Nw * P->Nh;
@@ -2147,12 +2154,13 @@ int peac_run(hvo_ctx *ctx, int n)
             const size_t full = ((lq + 15) & ~(size_t)15) + (size_t)a.tq_n0 * (256 * 8 + 16 * 12);
             if (ldsq && full <= 150 * 1024) {
                 a.tq_lds_keys = 1; lds = full;
-                if (hvo_ensure_dyn_lds(reinterpret_cast<const void *>(k_peac_cluster<64>), lds)) return HVO_ERR_HIP;
+                if (hvo_ensure_dyn_lds(reinterpret_cast<const void *>(k_peac_cluster<64, false>), lds)) return HVO_ERR_HIP;
             }
-            hipLaunchKernelGGL(k_peac_cluster<64>, dim3(n), dim3(64), lds, st, a, n);
+            hipLaunchKernelGGL((k_peac_cluster<64, false>), dim3(n), dim3(64), lds, st, a, n);
         }
-        else if (use == 32) hipLaunchKernelGGL(k_peac_cluster<32>, dim3((n + 1) / 2), dim3(64), 2 * lq, st, a, n);
-        else hipLaunchKernelGGL(k_peac_cluster<16>, dim3((n + 3) / 4), dim3(64), 4 * lq, st, a, n);
+        else if (use == 32) hipLaunchKernelGGL((k_peac_cluster<32, false>), dim3((n + 1) / 2), dim3(64), 2 * lq, st, a, n);
+        else if (P->kn.lend.off()) hipLaunchKernelGGL((k_peac_cluster<16, false>), dim3((n + 3) / 4), dim3(64), 4 * lq, st, a, n);
+        else hipLaunchKernelGGL((k_peac_cluster<16, true>), dim3((n + 3) / 4), dim3(64), 4 * lq, st, a, n);   // HVO_PEAC_LEND=0: the lanes of a frame stay with it
     }
     hvo_prof_end(ctx, id);
     id = hvo_prof_begin(ctx, "peac_refine", st);
