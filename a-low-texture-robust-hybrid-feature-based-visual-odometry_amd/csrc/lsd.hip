@@ -730,6 +730,67 @@ static __device__ __forceinline__ double rect_density(const Rect &r, int reg_siz
     return (double)reg_size / (d * r.width);
 }
 
+// reduce_region_radius's removal loop (OpenCV 3.2 lsd.cpp: `if (dist > radSq) { used = NOTUSED; swap(reg[i], reg[reg_size - 1]); --reg_size; --i; }`)
+// walks i upwards; an element outside the radius is swapped with the last one and the element swapped in is examined next.  It was one
+// lane walking the list -- a dependent load per element, 517 ns apiece: 3.1 of a frame's 22 ms in the batch kernel, and pure waiting for a
+// lone frame.  What the walk leaves in [0, K) (K = the elements inside the radius) has a closed form: the inside elements of [0, K) stay
+// where they are, and the r-th hole of [0, K) in ascending order receives the r-th inside element of [K, n) counted from the END; the
+// elements outside end up in [K, n) (as a set: nothing reads their order).  So: one pass for the keep masks of the 64-element chunks and
+// the count of kept elements before each (LDS), then every hole finds its partner by rank -- a binary search over the chunk counts and a
+// select within the chunk's mask -- and the two are swapped.  `mask` (64 entries) and `pre` (65) are LDS; n <= 4096 (the caller keeps
+// the walk for longer lists).  Returns K.  release(a) is called once per removed element (order does not matter: bit clears / releases).
+static __device__ __forceinline__ int lsd_nth_set_bit(unsigned long long m, int t)
+{
+    unsigned x = (unsigned)m; int pos = 0;
+    { const int c = __popc(x); if (t >= c) { t -= c; pos = 32; x = (unsigned)(m >> 32); } }
+#pragma unroll
+    for (int w = 16; w >= 1; w >>= 1) {
+        const unsigned low = x & ((1u << w) - 1u); const int pc = __popc(low);
+        if (t >= pc) { t -= pc; x >>= w; pos += w; } else x = low;
+    }
+    return pos;
+}
+template <class Rel>
+static __device__ int reduce_radius_wave(int *reg, int n, double xc, double yc, double radSq, unsigned long long *mask, int *pre, Rel release)
+{
+    const int lane = threadIdx.x & 63, nc = (n + 63) >> 6;
+    int K = 0;
+    for (int c = 0; c < nc; c++) {
+        const int i = c * 64 + lane;
+        bool keep = false;
+        if (i < n) {
+            const int a = reg[i];
+            const double ddx = (double)(a & 0xFFFF) - xc, ddy = (double)(a >> 16) - yc;
+            keep = !(ddx * ddx + ddy * ddy > radSq);
+            if (!keep) release(a);
+        }
+        const unsigned long long km = __ballot(keep);
+        if (lane == 0) { mask[c] = km; pre[c] = K; }
+        K += __popcll(km);
+    }
+    if (lane == 0) pre[nc] = K;
+    __syncthreads();
+    if (K == n || K == 0) return K;
+    const int cK = K >> 6, bK = K & 63;
+    const int keptFront = pre[cK] + __popcll(mask[cK] & ((1ull << bK) - 1ull));       // cK < nc because K < n
+    const int H = K - keptFront;
+    for (int c = 0; c * 64 < K; c++) {
+        const int i = c * 64 + lane;
+        const unsigned long long km = mask[c];
+        const unsigned long long holes = ~km & (c == cK ? ((1ull << bK) - 1ull) : ~0ull);
+        if ((holes >> lane) & 1ull) {
+            const int r = (c * 64 - pre[c]) + __popcll(holes & ((1ull << lane) - 1ull));
+            const int g = keptFront + (H - 1 - r);                 // my partner: the g-th kept element of the list (it lies in [K, n))
+            int lo = cK, hi = nc - 1;                              // the chunk with pre[c2] <= g < pre[c2 + 1]
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pre[mid] <= g) lo = mid; else hi = mid - 1; }
+            const int j = lo * 64 + lsd_nth_set_bit(mask[lo], g - pre[lo]);
+            const int ah = reg[i], aj = reg[j];
+            reg[i] = aj; reg[j] = ah;
+        }
+    }
+    return K;
+}
+
 // refine + reduce_region_radius (LSD_REFINE_STD).  Returns false when the region is rejected.
 template <bool CP>
 static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle, double prec, Rect &rec, double density_th,
@@ -782,21 +843,26 @@ static __device__ bool refine_wave(GrowState &S, int &reg_size, double reg_angle
         radSq *= 0.75 * 0.75;
         // swap-with-last removal is order dependent: lane 0 walks the region
         __syncthreads();
-        if (lane == 0) {
-            int rs = reg_size;
-            for (int i = 0; i < rs; ++i) {
-                const int a = S.reg[i];
-                const double ddx = (double)(a & 0xFFFF) - xc, ddy = (double)(a >> 16) - yc;
-                if (ddx * ddx + ddy * ddy > radSq) {
-                    used_clr(S, a & 0xFFFF, a >> 16);
-                    const int last = S.reg[rs - 1];
-                    S.reg[i] = last; S.reg[rs - 1] = a;
-                    --rs; --i;
+        if (reg_size <= 4096) {
+            reg_size = reduce_radius_wave(S.reg, reg_size, xc, yc, radSq, reinterpret_cast<unsigned long long *>(b0), reinterpret_cast<int *>(b1),
+                                          [&](int a) { used_clr(S, a & 0xFFFF, a >> 16); });
+        } else {
+            if (lane == 0) {                                  // a list longer than the chunk table: the walk as written
+                int rs = reg_size;
+                for (int i = 0; i < rs; ++i) {
+                    const int a = S.reg[i];
+                    const double ddx = (double)(a & 0xFFFF) - xc, ddy = (double)(a >> 16) - yc;
+                    if (ddx * ddx + ddy * ddy > radSq) {
+                        used_clr(S, a & 0xFFFF, a >> 16);
+                        const int last = S.reg[rs - 1];
+                        S.reg[i] = last; S.reg[rs - 1] = a;
+                        --rs; --i;
+                    }
                 }
+                reg_size = rs;
             }
-            reg_size = rs;
+            reg_size = __shfl(reg_size, 0);
         }
-        reg_size = __shfl(reg_size, 0);
         __syncthreads();
         if (reg_size < 2) return false;
         region2rect_wave<CP>(S, reg_size, reg_angle, prec, rec, b0, b1, b2);
