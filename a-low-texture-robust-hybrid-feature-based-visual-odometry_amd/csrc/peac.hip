@@ -542,16 +542,18 @@ static __device__ __forceinline__ double readlane_f64(double v, int l)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
-// Butterfly partner inside a 16-lane row through DPP (a VALU move) instead of a permute through LDS.
+// Butterfly partner inside a 16-lane row through DPP (a VALU move) instead of a permute through LDS.  `old` = 0 with bound_ctrl: every lane
+// of these permutations has its source inside the row, so the old value is never used -- and without it the compiler folds the DPP into the
+// consuming v_min_i32 / v_max_i32 (one instruction per step instead of copy + move + op) and drops the copies in front of the 64-bit moves.
 // STEP 1,2: quad_perm xor; STEP 4: row_half_mirror; STEP 8: row_mirror.  The mirrors pair lane i with
 // 7-i / 15-i rather than i^4 / i^8, which is the same for an all-reduce of a commutative operation whose
 // earlier steps made each quad / half-row uniform.  Steps >= 16 (wider groups) fall back to ds_bpermute.
 template <int STEP> static __device__ __forceinline__ int row_partner(int v)
 {
-    if (STEP == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);
-    if (STEP == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);
-    if (STEP == 4) return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);
-    if (STEP == 8) return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false);
+    if (STEP == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+    if (STEP == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    if (STEP == 4) return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+    if (STEP == 8) return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
     return __shfl_xor(v, STEP);
 }
 template <int STEP> static __device__ __forceinline__ double row_partner(double v)
@@ -579,29 +581,31 @@ struct TQueue { double *K, *M1k; int *M1i; double *M0k; int *M0i; int n0; };
 static __device__ __forceinline__ double dpp_f64(double v, double old, const int ctrl_sel)
 {
     int lo, hi;
-    if (ctrl_sel == 0) { lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0xB1, 0xF, 0xF, false); }
-    else if (ctrl_sel == 1) { lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x4E, 0xF, 0xF, false); }
-    else if (ctrl_sel == 2) { lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x141, 0xF, 0xF, false); }
-    else if (ctrl_sel == 3) { lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x140, 0xF, 0xF, false); }
+    if (ctrl_sel == 0) { lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, true); }
+    else if (ctrl_sel == 1) { lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x4E, 0xF, 0xF, true); }
+    else if (ctrl_sel == 2) { lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x141, 0xF, 0xF, true); }
+    else if (ctrl_sel == 3) { lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x140, 0xF, 0xF, true); }
     else if (ctrl_sel == 4) { lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x142, 0xA, 0xF, false); hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x142, 0xA, 0xF, false); }
     else { lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x143, 0xC, 0xF, false); hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x143, 0xC, 0xF, false); }
     return __hiloint2double(hi, lo);
 }
 static __device__ __forceinline__ int dpp_i32(int v, int old, const int ctrl_sel)
 {
-    if (ctrl_sel == 0) return __builtin_amdgcn_update_dpp(old, v, 0xB1, 0xF, 0xF, false);
-    if (ctrl_sel == 1) return __builtin_amdgcn_update_dpp(old, v, 0x4E, 0xF, 0xF, false);
-    if (ctrl_sel == 2) return __builtin_amdgcn_update_dpp(old, v, 0x141, 0xF, 0xF, false);
-    if (ctrl_sel == 3) return __builtin_amdgcn_update_dpp(old, v, 0x140, 0xF, 0xF, false);
+    if (ctrl_sel == 0) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+    if (ctrl_sel == 1) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    if (ctrl_sel == 2) return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+    if (ctrl_sel == 3) return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
     if (ctrl_sel == 4) return __builtin_amdgcn_update_dpp(old, v, 0x142, 0xA, 0xF, false);
     return __builtin_amdgcn_update_dpp(old, v, 0x143, 0xC, 0xF, false);
 }
+// min of two keys that are never NaN (an mse or TQ_INF): one v_min_f64 where `t < g ? t : g` costs a compare and two selects
+static __device__ __forceinline__ double key_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 template <int STEPS>                               // 4: within the 16-lane row (every lane of the row gets the result); 6: the wave (uniform result)
 static __device__ __forceinline__ void min_key_id(double &k, int &i)
 {
     double g = k;
 #pragma unroll
-    for (int s_ = 0; s_ < STEPS; s_++) { const double t = dpp_f64(g, g, s_); g = t < g ? t : g; }
+    for (int s_ = 0; s_ < STEPS; s_++) { const double t = dpp_f64(g, g, s_); g = key_min(t, g); }
     if (STEPS == 6) g = readlane_f64(g, 63);
     int c = (k == g) ? i : 0x7FFFFFFF;
 #pragma unroll
