@@ -39,6 +39,16 @@
 #define LSD_RING 256              // pending region points mirrored in LDS (older ones are read back from reg[])
 #endif
 
+// the largest double x with sqrt(x) <= rho, sqrt correctly rounded (host libm and the device's fp64 sqrt both are): ll_angle's
+// `norm <= threshold` on the squared norm
+static double lsd_sqrt_threshold(double rho)
+{
+    double c = rho * rho;
+    while (sqrt(nextafter(c, INFINITY)) <= rho) c = nextafter(c, INFINITY);
+    while (sqrt(c) > rho) c = nextafter(c, 0.0);
+    return c;
+}
+
 struct LsdPlan {
     int w = 0, h = 0, sw = 0, sh = 0, batch = 0, nfeat = 0, nwords = 0;
     double *d_blur = nullptr;                               // w*h doubles per frame of a chunk
@@ -62,6 +72,7 @@ struct LsdPlan {
     double gL[21], gG[63];
     float *d_gL = nullptr, *d_gG = nullptr;
     double rho = 0, prec = 0, p = 0; unsigned min_reg = 0;
+    double rhoT = 0;                   // the largest x with sqrt(x) <= rho (k_lsd_pre tests the squared magnitude)
     long long *d_stats = nullptr;      // per frame 8 counters (diagnostics: hvo_debug_lsd_stats)
     // k_lsd_grow_async (lsd_async.inc), allocated at its first launch for the first `async_b` frames of the plan
     bool pre_fused = true;             // k_lsd_pre instead of k_lsd_blur + k_lsd_resize_grad (HVO_LSD_PRE_SPLIT=1: the pair, with its fp64 image)
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(256) void k_lsd_resize_grad(const double *__restric
 #define PRE_SEG 96                                    // scaled rows a workgroup walks
 __global__ __launch_bounds__(256) void k_lsd_pre(const uint8_t *__restrict__ gray, size_t gframe, int gpitch, int w, int h, int sw, int sh,
                                                  const int *__restrict__ xofs, const float *__restrict__ xa, const int *__restrict__ yofs, const float *__restrict__ yb,
-                                                 double4 *__restrict__ px4, unsigned *__restrict__ defined, int nwords, double rho,
+                                                 double4 *__restrict__ px4, unsigned *__restrict__ defined, int nwords, double rhoT,
                                                  double k0, double k1, double k2, double k3, const int *__restrict__ redo_flags)
 {
     // redo_flags: only the frames whose growing gave up (flag 4: k_lsd_grow_async's bounded wait) are formed again -- their availability mask was consumed
@@ -264,7 +275,8 @@ __global__ __launch_bounds__(256) void k_lsd_pre(const uint8_t *__restrict__ gra
     const int sya = yofs[y0] & 0xFFFF, syb = yofs[ye] >> 16;
     const bool colt = tid < ncols;
     const int x = min(cA + tid, w - 1);
-    const int xm3 = refl(x - 3, w), xm2 = refl(x - 2, w), xm1 = refl(x - 1, w), xp1 = refl(x + 1, w), xp2 = refl(x + 2, w), xp3 = refl(x + 3, w);
+    // unsigned column offsets: a row's seven byte loads take the row pointer as a scalar base and the column as a 32-bit lane offset
+    unsigned xm3 = (unsigned)refl(x - 3, w), xm2 = (unsigned)refl(x - 2, w), xm1 = (unsigned)refl(x - 1, w), x00 = (unsigned)x, xp1 = (unsigned)refl(x + 1, w), xp2 = (unsigned)refl(x + 2, w), xp3 = (unsigned)refl(x + 3, w);
     // my scaled column's taps (threads < nsc) -- fixed over the rows
     const int sxq = x0 + min(tid, nsc - 1);
     const int tx0 = xofs[sxq] - cA, tx1 = min(xofs[sxq] + 1, w - 1) - cA;
@@ -272,23 +284,34 @@ __global__ __launch_bounds__(256) void k_lsd_pre(const uint8_t *__restrict__ gra
     double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0;
     int ys = y0;                                        // next scaled row to form
     int npend = 0;
+    // What a pixel WITH an angle needs beyond the test -- the square root of its squared gradient magnitude, the arctangent, the double
+    // cos / sin -- is computed here, on the compacted queue (full workgroups of the ~15 % of the pixels that have one), not on every pixel:
+    // the queue holds (float gx, float gy) and the squared magnitude.
     auto emit = [&](int i) {
+        const float2 gq = reinterpret_cast<const float2 *>(la)[i];
+        const double m = sqrt(lm[i]);
+        const double aa = (double)fatan2_deg(gq.x, -gq.y) * (LSD_PI / 180);
         // region_grow accumulates cos(float(angle)) / sin(float(angle)) evaluated in double
-        const double aa = la[i], af = (double)(float)aa;
+        const double af = (double)(float)aa;
         double sn, cs; sincos(af, &sn, &cs);
-        PX[lpos[i]] = make_double4(aa, cs, sn, lm[i]);
+        PX[lpos[i]] = make_double4(aa, cs, sn, m);
     };
     for (int j = sya - 3; j <= syb + 3; j++) {
         // ---- row pass of source row j (reflected), the window of seven, the column pass of row j - 3 ----
         {
             const uint8_t *S = G + (size_t)refl(min(j, h + 2), h) * gpitch;
-            double s = k0 * (double)S[xm3];
-            s += k1 * (double)S[xm2];
-            s += k2 * (double)S[xm1];
-            s += k3 * (double)S[x];
-            s += k2 * (double)S[xp1];
-            s += k1 * (double)S[xp2];
-            s += k0 * (double)S[xp3];
+            // (the empty asm keeps the zero-extension of a lane offset in this block: the loads then take scalar base + 32-bit lane offset
+            // instead of seven 64-bit address additions per row)
+            asm("" : "+v"(xm3), "+v"(xm2), "+v"(xm1), "+v"(x00), "+v"(xp1), "+v"(xp2), "+v"(xp3));
+            const unsigned q0 = S[xm3], q1 = S[xm2], q2 = S[xm1], q3 = S[x00], q4 = S[xp1], q5 = S[xp2], q6 = S[xp3];
+            __builtin_amdgcn_sched_barrier(0);                 // all seven in flight before the first is converted
+            double s = k0 * (double)q0;
+            s += k1 * (double)q1;
+            s += k2 * (double)q2;
+            s += k3 * (double)q3;
+            s += k2 * (double)q4;
+            s += k1 * (double)q5;
+            s += k0 * (double)q6;
             v0 = v1; v1 = v2; v2 = v3; v3 = v4; v4 = v5; v5 = v6; v6 = s;
         }
         const int rb = j - 3;                           // the blurred row that is complete now
@@ -316,14 +339,17 @@ __global__ __launch_bounds__(256) void k_lsd_pre(const uint8_t *__restrict__ gra
             if (ys > y0) {
                 // ---- ll_angle of scaled row ys - 1 (its lower neighbours are row ys) ----
                 const int y = ys - 1, xg = x0 + tid;
+                // ll_angle's test `sqrt(x) <= rho` (x = (gx^2 + gy^2) / 4) is taken on x: rhoT is the largest double whose correctly rounded
+                // square root is <= rho (lsd_sqrt_threshold, host), so the two tests agree on every x
                 bool def = false;
-                double a = LSD_NOTDEF, m = 0;
+                double xq = 0; float fgx = 0, fgy = 0;
                 if (tid < PRE_TW && xg < sw - 1 && y < sh - 1) {
                     const double vprev = sc[y & 1][tid], vprev_r = sc[y & 1][tid + 1], vcur = sc[ys & 1][tid], vcur_r = sc[ys & 1][tid + 1];
                     const double DA = vcur_r - vprev, BC = vprev_r - vcur;
                     const double gx = DA + BC, gy = DA - BC;
-                    m = sqrt((gx * gx + gy * gy) / 4);
-                    if (!(m <= rho)) { a = (double)fatan2_deg((float)gx, (float)-gy) * (LSD_PI / 180); def = true; }
+                    xq = (gx * gx + gy * gy) / 4;
+                    def = !(xq <= rhoT);
+                    fgx = (float)gx; fgy = (float)gy;
                 }
                 const unsigned long long bal = __ballot(def);
                 if (tid < PRE_TW && xg < ((sw + 31) & ~31)) {
@@ -336,7 +362,7 @@ __global__ __launch_bounds__(256) void k_lsd_pre(const uint8_t *__restrict__ gra
                 __syncthreads();
                 int base = 0, total = 0;
                 for (int i = 0; i < 4; i++) { const int cn = wcnt[i]; if (i < wv) base += cn; total += cn; }
-                if (def) { const int p = npend + base + __popcll(bal & ((1ull << lane) - 1)); la[p] = a; lm[p] = m; lpos[p] = y * sw + xg; }
+                if (def) { const int p = npend + base + __popcll(bal & ((1ull << lane) - 1)); reinterpret_cast<float2 *>(la)[p] = make_float2(fgx, fgy); lm[p] = xq; lpos[p] = y * sw + xg; }
                 npend += total;
                 __syncthreads();
                 if (npend >= 256) {                       // a full workgroup of queued pixels
@@ -1582,7 +1608,7 @@ static int lsd_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     P->nwords = ((P->sw + 31) / 32) * P->sh;
     // LSD constants (OpenCV defaults, LSD_REFINE_STD)
     const double SCALE = 0.8, ANG_TH = 22.5;
-    P->prec = LSD_PI * ANG_TH / 180; P->p = ANG_TH / 180; P->rho = 2.0 / sin(P->prec);
+    P->prec = LSD_PI * ANG_TH / 180; P->p = ANG_TH / 180; P->rho = 2.0 / sin(P->prec); P->rhoT = lsd_sqrt_threshold(P->rho);
     const double LOG_NT = 5 * (log10((double)P->sw) + log10((double)P->sh)) / 2 + log10(11.0);
     P->min_reg = (unsigned)(-LOG_NT / log10(P->p));
     P->maxseg = (int)(((size_t)P->sw * P->sh) / std::max(P->min_reg, 1u)) + 64;     // every segment is a region of at least min_reg pixels of its own
@@ -1730,7 +1756,7 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
                 id = hvo_prof_begin(ctx, "lsd_gradient", st);
                 hipLaunchKernelGGL(k_lsd_pre, dim3((sw + PRE_TW - 1) / PRE_TW, (sh - 1 + PRE_SEG - 1) / PRE_SEG, m), dim3(256), 0, st, gray + (size_t)c0 * O.pyr_bytes, O.pyr_bytes, gpitch,
                                    w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb, P->d_px + (P->compact ? 0 : (size_t)c0 * nsp),
-                                   P->d_defined + (size_t)c0 * P->nwords, P->nwords, P->rho, P->k7[0], P->k7[1], P->k7[2], P->k7[3], (const int *)nullptr);
+                                   P->d_defined + (size_t)c0 * P->nwords, P->nwords, P->rhoT, P->k7[0], P->k7[1], P->k7[2], P->k7[3], (const int *)nullptr);
             } else {
             id = hvo_prof_begin(ctx, "lsd_blur_scale", st);
             hipLaunchKernelGGL(k_lsd_blur, dim3((w + 255) / 256, (h + LSD_BLUR_ROWS - 1) / LSD_BLUR_ROWS, m), dim3(256), 0, st, gray + (size_t)c0 * O.pyr_bytes, O.pyr_bytes, gpitch, P->d_blur, w, h,
@@ -1826,7 +1852,7 @@ int lsd_run(hvo_ctx *ctx, int n, bool cull)
             // the deterministic one-wave kernel grows it; both launches return at once for every other frame (~10 us per call when nothing failed)
             if (P->pre_fused)
                 hipLaunchKernelGGL(k_lsd_pre, dim3((sw + PRE_TW - 1) / PRE_TW, (sh - 1 + PRE_SEG - 1) / PRE_SEG, n), dim3(256), 0, st, gray, O.pyr_bytes, gpitch,
-                                   w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb, P->d_px, P->d_defined, P->nwords, P->rho, P->k7[0], P->k7[1], P->k7[2], P->k7[3], (const int *)P->d_flags);
+                                   w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb, P->d_px, P->d_defined, P->nwords, P->rhoT, P->k7[0], P->k7[1], P->k7[2], P->k7[3], (const int *)P->d_flags);
             else
                 hipLaunchKernelGGL(k_lsd_resize_grad, dim3(gx, (sh + GRAD_ROWS - 1) / GRAD_ROWS, n), dim3(256), 0, st, P->d_blur, w, h, sw, sh, P->d_xofs, P->d_xa, P->d_yofs, P->d_yb,
                                    P->d_px, P->d_defined, P->nwords, P->rho);      // (the split preamble: n <= 16 <= chunk, the blurred images are still there; every frame is formed again)
