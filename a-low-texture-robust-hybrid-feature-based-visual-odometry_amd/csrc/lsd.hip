@@ -364,8 +364,8 @@ __global__ __launch_bounds__(256) void k_lsd_pre(const uint8_t *__restrict__ gra
                 for (int i = 0; i < 4; i++) { const int cn = wcnt[i]; if (i < wv) base += cn; total += cn; }
                 if (def) { const int p = npend + base + __popcll(bal & ((1ull << lane) - 1)); reinterpret_cast<float2 *>(la)[p] = make_float2(fgx, fgy); lm[p] = xq; lpos[p] = y * sw + xg; }
                 npend += total;
-                __syncthreads();
-                if (npend >= 256) {                       // a full workgroup of queued pixels
+                if (npend >= 256) {                       // a full workgroup of queued pixels (npend is the same in every thread)
+                    __syncthreads();
                     emit(tid);
                     const int rem = npend - 256;
                     double ta = 0, tm = 0; int tp = 0;

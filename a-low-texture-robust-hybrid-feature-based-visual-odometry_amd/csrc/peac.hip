@@ -616,6 +616,30 @@ static __device__ __forceinline__ void min_key_id(double &k, int &i)
 
 // all-reduce of (k, i) under hless over the 16-lane DPP row (every lane ends up with the minimum)
 static __device__ __forceinline__ void row_min16(double &k, int &i) { min_key_id<4>(k, i); }
+// three independent reductions, their steps interleaved: a DPP instruction may not read a register the instruction before it wrote (two wait
+// states), and one reduction is a chain of exactly such pairs -- side by side the three fill each other's gaps instead of s_nop
+static __device__ __forceinline__ void row_min16x3(double (&k)[3], int (&i)[3])
+{
+    double g[3] = { k[0], k[1], k[2] };
+#pragma unroll
+    for (int s_ = 0; s_ < 4; s_++) {
+        double t[3];
+#pragma unroll
+        for (int n = 0; n < 3; n++) t[n] = dpp_f64(g[n], g[n], s_);
+#pragma unroll
+        for (int n = 0; n < 3; n++) g[n] = key_min(t[n], g[n]);
+    }
+    int c[3];
+#pragma unroll
+    for (int n = 0; n < 3; n++) c[n] = (k[n] == g[n]) ? i[n] : 0x7FFFFFFF;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; s_++) {
+#pragma unroll
+        for (int n = 0; n < 3; n++) { const int t = dpp_i32(c[n], c[n], s_); c[n] = min(c[n], t); }
+    }
+#pragma unroll
+    for (int n = 0; n < 3; n++) { k[n] = g[n]; i[n] = c[n]; }
+}
 static __device__ __forceinline__ int tq_top(const TQueue &Q, int rl)
 {
     double k = TQ_INF; int i = 0x7FFFFFFF;
@@ -647,9 +671,9 @@ struct TQUpdate {
 #pragma unroll
             for (int u = 0; u < 3; u++) if (u < nx && ((x[u] ^ x[t]) >> 4) == 0 && (x[u] & 15) == rl) k = kn[u];
             if (t >= nx) { k = TQ_INF; i = 0x7FFFFFFF; }
-            row_min16(k, i);
             bk[t] = k; bi[t] = i;
         }
+        row_min16x3(bk, bi);
 #pragma unroll
         for (int t = 0; t < 3; t++) if (writer && t < nx) { Q.M1k[x[t] >> 4] = bk[t]; Q.M1i[x[t] >> 4] = bi[t]; }
         double sk[3]; int si[3];
@@ -659,9 +683,9 @@ struct TQUpdate {
 #pragma unroll
             for (int u = 0; u < 3; u++) if (u < nx && ((x[u] ^ x[t]) >> 8) == 0 && ((x[u] >> 4) & 15) == rl) { k = bk[u]; i = bi[u]; }
             if (t >= nx) { k = TQ_INF; i = 0x7FFFFFFF; }
-            row_min16(k, i);
             sk[t] = k; si[t] = i;
         }
+        row_min16x3(sk, si);
         double k = TQ_INF; int i = 0x7FFFFFFF;
         for (int j = rl; j < Q.n0; j += 16) {
             double a = Q.M0k[j]; int b = Q.M0i[j];
@@ -2009,8 +2033,8 @@ static int peac_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_depth, B * P->pitch * (h + 1) * sizeof(uint16_t));
     PA(P->d_segD, B * P->segcap * SEG_D * sizeof(double));
     PA(P->d_segI, B * P->segcap * SEG_I * sizeof(int));
-    PA(P->d_pool, B * P->poolcap * sizeof(int));
-    PA(P->d_pool2, B * P->poolcap * sizeof(int));
+    PA(P->d_pool, B * P->poolcap * sizeof(int) + 64);          // + 64: the list searches fetch eight entries at a time (peac_lend.inc)
+    PA(P->d_pool2, B * P->poolcap * sizeof(int) + 64);
     PA(P->d_parent, B * P->nblk * sizeof(int)); PA(P->d_dsize, B * P->nblk * sizeof(int)); PA(P->d_eflag, B * P->nblk * sizeof(int));
     PA(P->d_meta, B * 16 * sizeof(int)); PA(P->d_extracted, B * 2 * MAX_PLANES * sizeof(int));
     PA(P->d_blkmap, B * P->nblk * sizeof(int)); PA(P->d_labels, B * ((npix + 3) & ~(size_t)3)); PA(P->d_state, B * FS_FRAME(w, h) * sizeof(uint32_t));
