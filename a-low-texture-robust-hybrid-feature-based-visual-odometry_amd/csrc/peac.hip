@@ -47,10 +47,11 @@ struct PeacPlan {
     unsigned long long *d_adj = nullptr;
     void *d_hot = nullptr;                                                 // HotNode records of the grouped AHC kernel
     double *d_hkey = nullptr, *d_m1k = nullptr; int *d_hid = nullptr;      // TQueue: keys, bucket minima, their ids
+    int *d_lq = nullptr;                                                   // k_peac_cluster_slots: (label << 16 | slot) of every slot
     double c15 = 0, c60 = 0, c30 = 0;   // cos thresholds evaluated on the host (glibc), like the oracle
     double ang_factor = 0, ang_near = 0;
     // tuning variables, read when the plan is built (peac_build_plan)
-    struct { Knob edges, gl, perm, lend, heads_maxn, heads, heads_big, poolcap, ldsq, flood_t, flood_epl, flood_perm; } kn;
+    struct { Knob edges, gl, perm, lend, slots, heads_maxn, heads, heads_big, poolcap, ldsq, flood_t, flood_epl, flood_perm; } kn;
 };
 
 static PeacPlan *plan_of(hvo_ctx *ctx) { return (PeacPlan *)ctx->peac; }
@@ -213,7 +214,7 @@ struct ClArgs {
     double *segD; int *segI; int *pool; int *pool2; int *parent; int *dsize; int *eflag; int *meta; int *extracted;
     struct HotNode *hot;                            // the grouped kernel's node records (one 128-byte line each)
     const int *perm;                                // wave b works on frames NG * perm[b] .. (hvo_frame_perm over the waves), or nullptr
-    double *tqK, *tqM1k; int *tqM1i; int tq_n0;      // the grouped kernel's min-MSE queue (TQueue): n0 * 256 keys, n0 * 16 bucket minima per frame
+    double *tqK, *tqM1k; int *tqM1i; int *tqLq; int tq_n0;      // the grouped kernel's min-MSE queue (TQueue): n0 * 256 keys, n0 * 16 bucket minima per frame
     int tq_lds_keys;                                 // GL = 64, a handful of frames: the keys and bucket minima live in LDS too (54 KB per frame)
     int segcap, poolcap, nblk, Nw, Nh;
     int edges_done;                                  // k_peac_edges has written eflag (initGraph's edges); the clustering kernels skip their own passes
@@ -1357,6 +1358,7 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClArgs a, int nframes)
 }
 
 #include "peac_heads.inc"
+#include "peac_slots.inc"
 
 // ------------------------------------------------------------------------------------------------
 // k_peac_blkmap: findBlockMembership (block erosion) + coarse membership image
@@ -1993,7 +1995,7 @@ void peac_free(hvo_ctx *ctx)
     PeacPlan *P = plan_of(ctx);
     if (!P) return;
     void *ptrs[] = { P->d_depth, P->d_segD, P->d_segI, P->d_pool, P->d_pool2, P->d_parent, P->d_dsize, P->d_eflag, P->d_meta, P->d_extracted,
-                     P->d_blkmap, P->d_labels, P->d_state, P->d_queue, P->d_plidmap, P->d_isvalid, P->d_planes, P->d_adj, P->d_hkey, P->d_m1k, P->d_hid, P->d_hot };
+                     P->d_blkmap, P->d_labels, P->d_state, P->d_queue, P->d_plidmap, P->d_isvalid, P->d_planes, P->d_adj, P->d_hkey, P->d_m1k, P->d_hid, P->d_hot, P->d_lq };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete P;
     ctx->peac = nullptr;
@@ -2016,7 +2018,7 @@ static int peac_build_plan(hvo_ctx *ctx, int w, int h, int batch)
 {
     PeacPlan *P = new PeacPlan();
     ctx->peac = P;
-    P->kn.edges.read("HVO_PEAC_EDGES"); P->kn.gl.read("HVO_PEAC_GL"); P->kn.perm.read("HVO_PEAC_PERM"); P->kn.lend.read("HVO_PEAC_LEND"); P->kn.heads_maxn.read("HVO_PEAC_HEADS_MAXN");
+    P->kn.edges.read("HVO_PEAC_EDGES"); P->kn.gl.read("HVO_PEAC_GL"); P->kn.perm.read("HVO_PEAC_PERM"); P->kn.lend.read("HVO_PEAC_LEND"); P->kn.slots.read("HVO_PEAC_SLOTS"); P->kn.heads_maxn.read("HVO_PEAC_HEADS_MAXN");
     P->kn.heads.read("HVO_PEAC_HEADS"); P->kn.heads_big.read("HVO_PEAC_HEADS_BIG"); P->kn.poolcap.read("HVO_PEAC_POOLCAP"); P->kn.ldsq.read("HVO_PEAC_LDSQ");
     P->kn.flood_t.read("HVO_FLOOD_T"); P->kn.flood_epl.read("HVO_FLOOD_EPL"); P->kn.flood_perm.read("HVO_FLOOD_PERM");
     P->w = w; P->h = h; P->pitch = (w + 31) & ~31; P->Nw = w / WIN; P->Nh = h / WIN; P->nblk = P->Nw * P->Nh;
@@ -2043,7 +2045,7 @@ static int peac_build_plan(hvo_ctx *ctx, int w, int h, int batch)
     PA(P->d_planes, B * MAX_PLANES * sizeof(hvo_plane));
     PA(P->d_adj, B * MAX_PLANES * sizeof(unsigned long long));
     PA(P->d_hot, B * P->segcap * 128);
-    { const size_t n0 = (P->segcap + 255) / 256; PA(P->d_hkey, B * n0 * 256 * sizeof(double)); PA(P->d_m1k, B * n0 * 16 * sizeof(double)); PA(P->d_hid, B * n0 * 16 * sizeof(int)); }   // TQueue
+    { const size_t n0 = (P->segcap + 255) / 256; PA(P->d_hkey, B * n0 * 256 * sizeof(double)); PA(P->d_m1k, B * n0 * 16 * sizeof(double)); PA(P->d_hid, B * n0 * 16 * sizeof(int)); PA(P->d_lq, B * n0 * 256 * sizeof(int)); }   // TQueue
 #undef PA
     // stream-ordered fill: a null-stream hipMemset is not ordered against the non-blocking ctx stream
     HVO_HIP(hipMemsetAsync(P->d_depth, 0, B * P->pitch * (h + 1) * sizeof(uint16_t), ctx->s_peac));
@@ -2112,7 +2114,7 @@ int peac_run(hvo_ctx *ctx, int n)
     ClArgs a;
     a.segD = P->d_segD; a.segI = P->d_segI; a.pool = P->d_pool; a.pool2 = P->d_pool2; a.parent = P->d_parent; a.dsize = P->d_dsize; a.eflag = P->d_eflag;
     a.meta = P->d_meta; a.extracted = P->d_extracted; a.segcap = P->segcap; a.poolcap = P->poolcap; a.nblk = P->nblk; a.Nw = P->Nw; a.Nh = P->Nh;
-    a.c15 = P->c15; a.c60 = P->c60; a.hot = (HotNode *)P->d_hot; a.perm = nullptr; a.tqK = P->d_hkey; a.tqM1k = P->d_m1k; a.tqM1i = P->d_hid; a.tq_n0 = (P->segcap + 255) / 256;
+    a.c15 = P->c15; a.c60 = P->c60; a.hot = (HotNode *)P->d_hot; a.perm = nullptr; a.tqK = P->d_hkey; a.tqM1k = P->d_m1k; a.tqM1i = P->d_hid; a.tqLq = P->d_lq; a.tq_n0 = (P->segcap + 255) / 256;
     a.ang_factor = P->ang_factor; a.ang_near = P->ang_near;
     if (ctx->sched == 6 && !ctx->serialize) {               // experiment: the streaming kernels of the other stages first, then the serial ones together
         if (ctx->fast_recorded) HVO_HIP(hipStreamWaitEvent(st, ctx->ev_fast, 0));
@@ -2187,6 +2189,7 @@ int peac_run(hvo_ctx *ctx, int n)
             hipLaunchKernelGGL((k_peac_cluster<64, false>), dim3(n), dim3(64), lds, st, a, n);
         }
         else if (use == 32) hipLaunchKernelGGL((k_peac_cluster<32, false>), dim3((n + 1) / 2), dim3(64), 2 * lq, st, a, n);
+        else if (!P->kn.slots.off() && !P->kn.lend.off() && a.edges_done && a.nblk < 32768 && P->d_lq) hipLaunchKernelGGL(k_peac_cluster_slots, dim3((n + 3) / 4), dim3(64), 4 * lq, st, a, n);   // HVO_PEAC_SLOTS=0: a new record per merge
         else if (P->kn.lend.off()) hipLaunchKernelGGL((k_peac_cluster<16, false>), dim3((n + 3) / 4), dim3(64), 4 * lq, st, a, n);
         else hipLaunchKernelGGL((k_peac_cluster<16, true>), dim3((n + 3) / 4), dim3(64), 4 * lq, st, a, n);   // HVO_PEAC_LEND=0: the lanes of a frame stay with it
     }
