@@ -702,7 +702,7 @@ int sn_enqueue(hvo_ctx *ctx, hipStream_t st, const uint16_t *d_depth, int pitch,
     {
         const size_t lds = (size_t)9 * 3 * (a.W + 2) * sizeof(double);
         if (lds > 160 * 1024) return HVO_ERR_UNSUPPORTED;
-        if (lds > 64 * 1024) HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sn_serial), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (hvo_ensure_dyn_lds(reinterpret_cast<const void *>(k_sn_serial), lds)) return HVO_ERR_HIP;
         hipLaunchKernelGGL(k_sn_serial, dim3(1), dim3(576), lds, st, a);
     }
     if (nout > 0) hipLaunchKernelGGL(k_sn_normals, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, a);

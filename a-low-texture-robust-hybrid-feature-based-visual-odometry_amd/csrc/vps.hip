@@ -308,8 +308,7 @@ int vp_enqueue(hvo_ctx *ctx, hipStream_t st, const hvo_keyline *d_kl, const int 
     if (nmax > 1) hipLaunchKernelGGL(k_vp_pairs, dim3((nmax + 255) / 256, nmax - 1), dim3(256), 0, st, para, len, ori, d_n, nmax, fx, cx, cy, dcell, val);
     {
         const size_t lds = (VP_CPT * 1024 + 16) * sizeof(int);            // 131 KB: one workgroup owns the CU
-        static bool attr = false;
-        if (!attr) { HVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_vp_grid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        if (hvo_ensure_dyn_lds(reinterpret_cast<const void *>(k_vp_grid), lds)) return HVO_ERR_HIP;      // per device, under the library's lock
         hipLaunchKernelGGL(k_vp_grid, dim3(1), dim3(1024), lds, st, dcell, val, d_n, nmax, raw, dorder, dorder2);
     }
     hipLaunchKernelGGL(k_vp_smooth, dim3((VP_CELLS + 255) / 256), dim3(256), 0, st, raw, grid);

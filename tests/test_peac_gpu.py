@@ -207,6 +207,32 @@ def test_peac_batch(hvo, orc, synth):
         check(res[b]["labels"], res[b]["planes"], lo, po)
 
 
+@pytest.mark.parametrize("slots,lend,poolcap", [("1", "1", None), ("0", "1", None), ("0", "0", None), ("1", "1", "22000"), ("0", "1", "22000"), ("0", "0", "22000")])
+def test_peac_four_frames_per_wave_variants(hvo, orc, synth, monkeypatch, slots, lend, poolcap):
+    """the three forms of the four-frames-per-wave AHC -- k_peac_cluster_slots (round 5: the merged node keeps the slot of the longer
+    neighbour list; default), ah_cluster_lend (idle lanes lent between the frames, a new record per merge) and ah_cluster_grouped --
+    each also with a list pool small enough to be compacted on the way; 10 frames = two full waves and a half-empty one, with an exact
+    plane (every candidate ties: labels decide), a three-plane corner and an empty frame among them"""
+    monkeypatch.setenv("HVO_PEAC_GL", "16"); monkeypatch.setenv("HVO_PEAC_SLOTS", slots); monkeypatch.setenv("HVO_PEAC_LEND", lend)
+    if poolcap: monkeypatch.setenv("HVO_PEAC_POOLCAP", poolcap)
+    j = np.arange(640)[None, :]; i = np.arange(480)[:, None]
+    exact = np.rint(2.0 / (0.1 * (j - 320.1) / 535.4 + 0.2 * (i - 247.6) / 539.2 + 1.0) * 5000).astype(np.uint16)
+    depth = [synth.make_depth(s) for s in (0x5EED0002, 0x5EED1000, 0x5EED1003, 77, 0x5EED1001, 0x5EED1002, 0x5EED2001)] + [exact, corner_depth(3, 25, cu=323.0, cv=236.0), np.zeros((480, 640), np.uint16)]
+    depth = np.stack(depth)
+    ctx = hvo.Context(max_batch=len(depth))
+    try:
+        ctx.batch_upload(np.zeros((len(depth), 480, 640), np.uint8), depth)
+        ctx.batch_run(hvo.STAGE_PLANES)
+        res = ctx.batch_download(hvo.STAGE_PLANES)
+        stats = ctx.peac_stats(1)
+    finally:
+        ctx.close()
+    for b in range(len(depth)):
+        lo, po = orc.peac(depth[b])
+        assert res[b]["status"] == 0
+        check(res[b]["labels"], res[b]["planes"], lo, po)
+
+
 @pytest.mark.parametrize("gl,flood_t", [(16, 64), (16, 128), (32, 128), (64, 256)])
 def test_peac_batch_grouped_paths(hvo, orc, synth, monkeypatch, gl, flood_t):
     """the configurations large batches select (several frames per wave in lockstep, smaller flood
