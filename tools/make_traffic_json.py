@@ -15,7 +15,7 @@ def sources_sha16():
             hsh.update(os.path.basename(p).encode()); hsh.update(open(p, "rb").read())
     return hsh.hexdigest()[:16]
 
-GROUPS = {"peac_cluster": ["k_peac_cluster"], "lsd_grow": ["k_lsd_grow", "k_lsd_grow_dense"], "peac_refine": ["k_peac_blkmap", "k_peac_flood", "k_peac_final", "k_peac_relabel"],
+GROUPS = {"peac_cluster": ["k_peac_cluster", "k_peac_cluster_slots", "k_peac_cluster_heads", "k_peac_edges"], "lsd_grow": ["k_lsd_grow", "k_lsd_grow_dense"], "peac_refine": ["k_peac_blkmap", "k_peac_flood", "k_peac_final", "k_peac_relabel"],
           "orb_levels": ["k_orb_level"], "orb_fast_cells": ["k_fast_cells"], "lsd_gradient": ["k_lsd_resize_grad"], "lsd_pre": ["k_lsd_pre"], "lbd_desc": ["k_lbd_desc"], "orb_pyramid": ["k_resize", "k_resize_dw"],
           "orb_blur": ["k_blur7"], "lsd_blur_scale": ["k_lsd_blur"], "lbd_sobel": ["k_lbd_blur5", "k_lbd_sobel", "k_lbd_blur_sobel"],
           "orb_octree": ["k_octree"], "peac_blocks": ["k_peac_blocks"], "orb_orient": ["k_moments", "k_kpfinish"], "orb_brief": ["k_brief"]}
