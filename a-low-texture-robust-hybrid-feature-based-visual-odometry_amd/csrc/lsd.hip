@@ -1999,6 +1999,30 @@ extern "C" int hvo_set_line_culling(hvo_ctx *ctx, double dis, double angle_deg, 
 }
 
 // diagnostics (not part of include/hvo.h): per-frame counters of the last k_lsd_grow launch:
+// reduce_radius_wave on a list of packed points (y << 16 | x), for the test that compares it with the reference's loop
+// (tests/test_lsd_gpu.py::test_reduce_region_radius_closed_form): the list is reordered in place, *n_out = the elements kept,
+// released[i] = 1 for every element the radius let go (the reference clears its used flag).
+static __global__ __launch_bounds__(64) void k_debug_reduce_radius(int *reg, int n, double xc, double yc, double radSq, int *n_out, unsigned char *released, int w)
+{
+    __shared__ unsigned long long mask[64]; __shared__ int pre[66];
+    const int k = reduce_radius_wave(reg, n, xc, yc, radSq, mask, pre, [&](int a) { released[(a >> 16) * w + (a & 0xFFFF)] = 1; });
+    if (threadIdx.x == 0) *n_out = k;
+}
+extern "C" int hvo_debug_reduce_radius(int *list, int n, double xc, double yc, double rad_sq, int width, int height, unsigned char *released, int *n_kept)
+{
+    if (!list || n < 1 || n > 4096 || width < 1 || height < 1 || !released || !n_kept) return HVO_ERR_INVALID_ARG;
+    int *d = nullptr, *dn = nullptr; unsigned char *dr = nullptr;
+    bool ok = hipMalloc((void **)&d, (size_t)n * 4) == hipSuccess && hipMalloc((void **)&dn, 4) == hipSuccess && hipMalloc((void **)&dr, (size_t)width * height) == hipSuccess;
+    ok = ok && hipMemcpy(d, list, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemset(dr, 0, (size_t)width * height) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_debug_reduce_radius, dim3(1), dim3(64), 0, 0, d, n, xc, yc, rad_sq, dn, dr, width);
+        ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(list, d, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(n_kept, dn, 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(released, dr, (size_t)width * height, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d); (void)hipFree(dn); (void)hipFree(dr);
+    return ok ? HVO_OK : HVO_ERR_HIP;
+}
+
 // [0] seeds [1] region points grown [2] regions >= min size [3] ticks in region_grow [4] region2rect
 // [5] refine [6] whole kernel [7] segments; ticks are 100 MHz wall-clock ticks.
 extern "C" int hvo_debug_lsd_stats(hvo_ctx *ctx, int frame, long long *out8)

@@ -403,3 +403,43 @@ def test_culling_with_a_large_line_quota(hvo, orc, synth):
     klc, ldc, fnc = orc.cull_lines(g, klo, fno)
     assert len(kl) == len(klc) and np.array_equal(ld, ldc)
     for k in ("sx", "sy", "ex", "ey"): assert np.array_equal(kl[k], klc[k]), k
+
+
+def test_reduce_region_radius_closed_form(hvo):
+    """reduce_region_radius (OpenCV 3.2 lsd.cpp) removes the points outside a radius with `swap(reg[i], reg[size - 1]); --size; --i`: the
+    order it leaves behind feeds the ordered fp64 sums of region2rect.  csrc/lsd.hip evaluates that loop in closed form on 64 lanes
+    (reduce_radius_wave); here: random lists of every length class (chunk boundaries of 64, the 4096-entry limit, nothing / everything
+    removed) against the loop itself -- the kept prefix in the loop's order, the released set, the tail as a set."""
+    import ctypes as C
+    L = hvo.lib()
+    L.hvo_debug_reduce_radius.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.hvo_debug_reduce_radius.restype = C.c_int
+    rng = np.random.RandomState(0xC105ED)
+    W, H = 512, 384
+    def loop(reg, xc, yc, rad):
+        reg = list(reg); n = len(reg); i = 0; rel = []
+        while i < n:
+            a = reg[i]; dx = (a & 0xFFFF) - xc; dy = (a >> 16) - yc
+            if dx * dx + dy * dy > rad:
+                rel.append(a); reg[i], reg[n - 1] = reg[n - 1], reg[i]; n -= 1
+            else: i += 1
+        return reg[:n], set(rel), set(reg[n:])
+    sizes = [1, 2, 3, 63, 64, 65, 127, 128, 129, 500, 1000, 2047, 2048, 2049, 4095, 4096] + [int(x) for x in rng.randint(2, 4096, 40)]
+    for n in sizes:
+        for frac in (0.0, 0.1, 0.5, 0.9, 1.0, None):
+            pts = rng.choice(W * H, n, replace=False)
+            reg = ((pts // W) << 16 | (pts % W)).astype(np.int32)
+            xc, yc = float(rng.randint(0, W)), float(rng.randint(0, H))
+            d2 = ((reg & 0xFFFF) - xc) ** 2 + ((reg >> 16) - yc) ** 2
+            if frac is None: rad = float(rng.choice(d2))                                   # ties at the boundary: `>` keeps them
+            elif frac == 0.0: rad = -1.0
+            elif frac == 1.0: rad = float(d2.max())
+            else: rad = float(np.quantile(d2, frac))
+            kept_o, rel_o, tail_o = loop(reg.tolist(), xc, yc, rad)
+            out = reg.copy(); released = np.zeros(W * H, np.uint8); nk = C.c_int(0)
+            assert L.hvo_debug_reduce_radius(out.ctypes.data_as(C.c_void_p), n, xc, yc, rad, W, H, released.ctypes.data_as(C.c_void_p), C.byref(nk)) == 0
+            assert nk.value == len(kept_o), (n, frac)
+            assert out[:nk.value].tolist() == kept_o, (n, frac)
+            assert set(out[nk.value:].tolist()) == tail_o
+            r = np.nonzero(released)[0]
+            assert set(((r // W) << 16 | (r % W)).tolist()) == rel_o

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
-NAMES = ["round boundary: sync + next top's list", "stage 0 (partner list, queue lines) + queue update", "eval: loads", "eval: reduce+bcast", "eval: eigen-solve (+decision)", "stages 1-3 (member headers, lists, edits) + both tail loops", "A edits of chunk 0 (after the tails)", "record write",
+NAMES = ["round boundary: sync + next top's list", "stage 0 (partner list, queue lines) + queue update", "eval: loads", "eval: reduce+bcast", "eval: eigen-solve (+decision)", "stages 1-3 (member headers, lists, edits)", "list tails (entries beyond the first pass)", "record write",
          "#iters", "#eval passes", "#merge iters", "#nomerge iters", "init edges+lists", "heapify", "#waves"]
 
 
