@@ -2191,11 +2191,11 @@ int peac_run(hvo_ctx *ctx, int n)
         else if (use == 32) hipLaunchKernelGGL((k_peac_cluster<32, false>), dim3((n + 1) / 2), dim3(64), 2 * lq, st, a, n);
         else if (use == 16 && P->kn.poolcap.set && P->kn.poolcap.v >= 7 * a.nblk && P->kn.poolcap.v < a.poolcap) {   // tests: force the pool's compaction in the four-frames-per-wave kernels
             ClArgs b = a; b.poolcap = P->kn.poolcap.v;
-            if (!P->kn.slots.off() && !P->kn.lend.off() && a.edges_done && a.nblk < 32768 && P->d_lq) hipLaunchKernelGGL(k_peac_cluster_slots, dim3((n + 3) / 4), dim3(64), 4 * lq, st, b, n);
+            if (!P->kn.slots.off() && !P->kn.lend.off() && a.nblk < 32768 && P->d_lq) hipLaunchKernelGGL(k_peac_cluster_slots, dim3((n + 3) / 4), dim3(64), 4 * lq, st, b, n);
             else if (P->kn.lend.off()) hipLaunchKernelGGL((k_peac_cluster<16, false>), dim3((n + 3) / 4), dim3(64), 4 * lq, st, b, n);
             else hipLaunchKernelGGL((k_peac_cluster<16, true>), dim3((n + 3) / 4), dim3(64), 4 * lq, st, b, n);
         }
-        else if (!P->kn.slots.off() && !P->kn.lend.off() && a.edges_done && a.nblk < 32768 && P->d_lq) hipLaunchKernelGGL(k_peac_cluster_slots, dim3((n + 3) / 4), dim3(64), 4 * lq, st, a, n);   // HVO_PEAC_SLOTS=0: a new record per merge
+        else if (!P->kn.slots.off() && !P->kn.lend.off() && a.nblk < 32768 && P->d_lq) hipLaunchKernelGGL(k_peac_cluster_slots, dim3((n + 3) / 4), dim3(64), 4 * lq, st, a, n);   // HVO_PEAC_SLOTS=0: a new record per merge
         else if (P->kn.lend.off()) hipLaunchKernelGGL((k_peac_cluster<16, false>), dim3((n + 3) / 4), dim3(64), 4 * lq, st, a, n);
         else hipLaunchKernelGGL((k_peac_cluster<16, true>), dim3((n + 3) / 4), dim3(64), 4 * lq, st, a, n);   // HVO_PEAC_LEND=0: the lanes of a frame stay with it
     }

@@ -207,14 +207,16 @@ def test_peac_batch(hvo, orc, synth):
         check(res[b]["labels"], res[b]["planes"], lo, po)
 
 
-@pytest.mark.parametrize("slots,lend,poolcap", [("1", "1", None), ("0", "1", None), ("0", "0", None), ("1", "1", "22000"), ("0", "1", "22000"), ("0", "0", "22000")])
-def test_peac_four_frames_per_wave_variants(hvo, orc, synth, monkeypatch, slots, lend, poolcap):
+@pytest.mark.parametrize("slots,lend,poolcap,edges", [("1", "1", None, None), ("0", "1", None, None), ("0", "0", None, None), ("1", "1", "22000", None), ("0", "1", "22000", None),
+                                                     ("0", "0", "22000", None), ("1", "1", None, "0"), ("0", "1", None, "0")])
+def test_peac_four_frames_per_wave_variants(hvo, orc, synth, monkeypatch, slots, lend, poolcap, edges):
     """the three forms of the four-frames-per-wave AHC -- k_peac_cluster_slots (round 5: the merged node keeps the slot of the longer
     neighbour list; default), ah_cluster_lend (idle lanes lent between the frames, a new record per merge) and ah_cluster_grouped --
     each also with a list pool small enough to be compacted on the way; 10 frames = two full waves and a half-empty one, with an exact
     plane (every candidate ties: labels decide), a three-plane corner and an empty frame among them"""
     monkeypatch.setenv("HVO_PEAC_GL", "16"); monkeypatch.setenv("HVO_PEAC_SLOTS", slots); monkeypatch.setenv("HVO_PEAC_LEND", lend)
     if poolcap: monkeypatch.setenv("HVO_PEAC_POOLCAP", poolcap)
+    if edges: monkeypatch.setenv("HVO_PEAC_EDGES", edges)       # initGraph's edges inside the clustering kernel (what 1280x960 frames get)
     j = np.arange(640)[None, :]; i = np.arange(480)[:, None]
     exact = np.rint(2.0 / (0.1 * (j - 320.1) / 535.4 + 0.2 * (i - 247.6) / 539.2 + 1.0) * 5000).astype(np.uint16)
     depth = [synth.make_depth(s) for s in (0x5EED0002, 0x5EED1000, 0x5EED1003, 77, 0x5EED1001, 0x5EED1002, 0x5EED2001)] + [exact, corner_depth(3, 25, cu=323.0, cv=236.0), np.zeros((480, 640), np.uint16)]
@@ -312,3 +314,23 @@ def test_peac_queue_heads(hvo, orc, synth, monkeypatch, heads, poolcap, big):
     if heads == "4": assert 0 < stats["ahc_rounds"] < 0.55 * merges, stats
     if heads == "3": assert 0 < stats["ahc_rounds"] < 0.6 * merges, stats
     if heads == "2": assert 0 < stats["ahc_rounds"] < 0.75 * merges, stats
+
+
+def test_peac_four_frames_per_wave_1280(hvo, orc, synth, monkeypatch):
+    """the slot AHC at 1280x960 (12 288 blocks: initGraph's edges inside the kernel, 15-bit labels, a queue of 48 super-buckets), forced onto six frames"""
+    monkeypatch.setenv("HVO_PEAC_GL", "16")
+    w, h = 1280, 960
+    g, d = synth.make_batch("std", 0x5EED4400, 5, w, h)
+    g2, d2 = synth.make_batch("lowtex", 0x5EED4500, 1, w, h)
+    d = np.concatenate([d, d2])
+    ctx = hvo.Context(max_batch=len(d))
+    try:
+        ctx.batch_upload(np.zeros((len(d), h, w), np.uint8), d)
+        ctx.batch_run(hvo.STAGE_PLANES)
+        res = ctx.batch_download(hvo.STAGE_PLANES)
+    finally:
+        ctx.close()
+    for b in range(len(d)):
+        lo, po = orc.peac(d[b])
+        assert res[b]["status"] == 0
+        check(res[b]["labels"], res[b]["planes"], lo, po)
