@@ -1065,8 +1065,10 @@ static __device__ __forceinline__ void lsd_grow_body(const GrowArgs &g)
 __global__ __launch_bounds__(64) void k_lsd_grow(GrowArgs g) { lsd_grow_body<false, false>(g); }
 __global__ __launch_bounds__(64) void k_lsd_grow_lat(GrowArgs g) { lsd_grow_body<true, false>(g); }
 __global__ __launch_bounds__(64) void k_lsd_grow_c(GrowArgs g) { lsd_grow_body<false, true>(g); }       // compact records
+// (round 5, after the radius walk left the kernel: seven waves per SIMD with 72 registers beat eight with 64 and their spills -- 34.2 -> 32.6 ms
+// alone, the step 154.1 -> 153.2 ms on one box; six: 31.4 ms alone but 154.3 for the step, five: 38.9 / 154.0)
 #ifndef HVO_WPE_GROW
-#define HVO_WPE_GROW 8
+#define HVO_WPE_GROW 7
 #endif
 __attribute__((amdgpu_waves_per_eu(HVO_WPE_GROW)))
 __global__ __launch_bounds__(64) void k_lsd_grow_dense(GrowArgs g) { lsd_grow_body<false, false>(g); }
